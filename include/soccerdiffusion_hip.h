@@ -1,0 +1,175 @@
+/*
+ * soccerdiffusion_hip.h — C ABI of the MI355X (gfx950) denoiser hot path.
+ *
+ * Drop-in boundary for the diffusion-policy denoising path of bit-bots/SoccerDiffusion.
+ * The reference is pure Python/PyTorch and has no FFI of its own; each entry point below
+ * replaces the ATen work behind one reference method (file:line relative to the
+ * reference checkout) and is what a ctypes binding on the reference side would call
+ * (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); no entry point
+ *     allocates, frees or synchronises, so all of them can be captured into a hipGraph;
+ *   - scratch memory comes from the caller: ask sd_workspace_floats() and pass a buffer of
+ *     at least that many floats;
+ *   - return value: 0 = ok, negative = invalid argument (SD_E_*), positive = hipError_t
+ *     of the failing launch.  sd_last_error() returns a static description.
+ *   - inputs are never modified unless the argument is documented as in/out.
+ *
+ * Numerics: all arithmetic is fp32.  GEMMs run on v_mfma_f32_32x32x2_f32 (exact fp32
+ * fma chain), LayerNorm eps = 1e-5 biased variance, GELU = exact erf form, softmax in
+ * fp32.  Parity bar: <= 1e-4 relative L2 vs the fp32 CPU path (BASELINE.json).
+ */
+#ifndef SOCCERDIFFUSION_HIP_H
+#define SOCCERDIFFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_ABI_VERSION 1
+
+#define SD_E_BADARG (-1)   /* null pointer / non-positive size                       */
+#define SD_E_BADDIM (-2)   /* hidden_dim not in {64,128,256,512} or not /heads        */
+#define SD_E_TOOBIG (-3)   /* sequence longer than the kernels support               */
+
+/* One pre-norm transformer layer (torch nn.TransformerDecoderLayer / EncoderLayer with
+ * norm_first=True, activation="gelu", dim_feedforward=d — reference
+ * soccer_diffusion/ml/model/decoder.py:25-35, encoder/base.py:29-40).  Pointer names are
+ * the checkpoint keys.  Encoder layers leave ca_* and n3_* NULL and
+ * use n2_* as the FFN norm. */
+typedef struct sd_layer_weights {
+    const float *sa_in_w;   /* self_attn.in_proj_weight      (3d, d) */
+    const float *sa_in_b;   /* self_attn.in_proj_bias        (3d)    */
+    const float *sa_out_w;  /* self_attn.out_proj.weight     (d, d)  */
+    const float *sa_out_b;  /* self_attn.out_proj.bias       (d)     */
+    const float *ca_in_w;   /* multihead_attn.in_proj_weight (3d, d) */
+    const float *ca_in_b;   /* multihead_attn.in_proj_bias   (3d)    */
+    const float *ca_out_w;  /* multihead_attn.out_proj.weight (d, d) */
+    const float *ca_out_b;  /* multihead_attn.out_proj.bias  (d)     */
+    const float *lin1_w;    /* linear1.weight (d, d) */
+    const float *lin1_b;    /* linear1.bias   (d)    */
+    const float *lin2_w;    /* linear2.weight (d, d) */
+    const float *lin2_b;    /* linear2.bias   (d)    */
+    const float *n1_w, *n1_b;  /* norm1 */
+    const float *n2_w, *n2_b;  /* norm2 */
+    const float *n3_w, *n3_b;  /* norm3 (decoder only) */
+} sd_layer_weights;
+
+/* DiffusionActionGenerator parameters — reference soccer_diffusion/ml/model/decoder.py:23-36. */
+typedef struct sd_denoiser_weights {
+    int32_t d;       /* hidden_dim                     */
+    int32_t J;       /* num_joints                     */
+    int32_t L;       /* num_decoder_layers             */
+    int32_t heads;   /* 4 (model.py:115)               */
+    const float *emb_w;  /* embedding.weight (d, J)    */
+    const float *emb_b;  /* embedding.bias   (d)       */
+    const float *out_w;  /* fc_out.weight    (J, d)    */
+    const float *out_b;  /* fc_out.bias      (J)       */
+    const float *pe;     /* positional table (T_max, d): PositionalEncoding.pe, misc.py:43-56 */
+    int32_t T_max;       /* rows of pe (= trajectory_prediction_length) */
+    int32_t _pad;
+    const sd_layer_weights *layers;  /* HOST array of L entries (device pointers inside) */
+} sd_denoiser_weights;
+
+/* BaseEncoder parameters — reference soccer_diffusion/ml/model/encoder/base.py:27-40. */
+typedef struct sd_encoder_weights {
+    int32_t d;       /* hidden_dim                                  */
+    int32_t C;       /* input_dim                                   */
+    int32_t p;       /* patch_size (Conv1d kernel = stride)         */
+    int32_t L;       /* num_layers                                  */
+    int32_t heads;   /* 4 (8 for the image sequence encoder)        */
+    int32_t S_max;   /* rows of pe                                  */
+    const float *emb_w;  /* embedding.weight (d, C, p)  Conv1d      */
+    const float *emb_b;  /* embedding.bias   (d)                    */
+    const float *pe;     /* positional table (S_max, d)             */
+    const sd_layer_weights *layers;  /* HOST array of L entries     */
+} sd_encoder_weights;
+
+int sd_abi_version(void);
+const char *sd_last_error(void);
+
+/* Floats of caller-provided scratch for the calls below (upper bound over all of them)
+ * for batch B, horizon T (decoder tokens or encoder patches), memory tokens M. */
+size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
+
+/* StepToken.forward — soccer_diffusion/ml/model/misc.py:25-35.
+ * steps: B values, int64 if steps_is_i64 else fp32.  freq: d/4 host-built frequencies
+ * (built in fp32 exactly as misc.py:32 does).  token: learned (d/2).  Writes row b of the
+ * step token to out + b*out_row_stride (d floats), so the caller can aim it at the last
+ * row of each sample's memory block (model.py:176). */
+int sd_step_token(const void *steps, int steps_is_i64, const float *freq, const float *token,
+                  float *out, long out_row_stride, int B, int d, void *stream);
+
+/* DiffusionActionGenerator.forward — soccer_diffusion/ml/model/decoder.py:38-54.
+ * x (B,T,J), memory (B,M,d) [context tokens + step token], eps_out (B,T,J). */
+int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x, const float *memory,
+                        float *eps_out, float *workspace, int B, int T, int M, void *stream);
+
+/* BaseEncoder.forward — soccer_diffusion/ml/model/encoder/base.py:41-53.
+ * x (B,S,C) -> out (B,S/p,d). */
+int sd_encoder_forward(const sd_encoder_weights *w, const float *x, float *out,
+                       float *workspace, int B, int S, void *stream);
+
+/* GameStateEncoder.forward — soccer_diffusion/ml/model/encoder/game_state.py:19-27.
+ * idx: B int64 indices; table (n_states,d); writes row b to out + b*out_row_stride. */
+int sd_game_state_embed(const int64_t *idx, const float *table, float *out, long out_row_stride,
+                        int B, int d, int n_states, void *stream);
+
+/* DDIMScheduler.add_noise — call site soccer_diffusion/ml/training/train.py:218.
+ * t: B int64 timesteps; acp: device table alphas_cumprod (n_train). rows = T*J per sample. */
+int sd_ddim_add_noise(const float *x0, const float *noise, const int64_t *t, const float *acp,
+                      float *out, int B, int per_sample, void *stream);
+
+/* DDIMScheduler.step(...).prev_sample (eta = 0, epsilon prediction, no clipping) — call
+ * site soccer_diffusion/ml/inference/plot.py:131.  In place on x is allowed.
+ * sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev are the four fp32 scalars. */
+int sd_ddim_step(const float *eps, const float *x, float *x_prev, float sqrt_a_t, float sqrt_1m_a_t,
+                 float sqrt_a_prev, float sqrt_1m_a_prev, long n, void *stream);
+
+/* The iterated sampler — reference loops soccer_diffusion/ml/inference/plot.py:122-131,
+ * ml/training/distill.py:179-189, ml/inference/ros.py:301-310: for every t in timesteps:
+ * eps = forward_with_context(ctx, x, t); x = scheduler.step(eps, t, x).prev_sample.
+ *   ctx (B,Mc,d) context tokens WITHOUT the step token (may be NULL when Mc = 0);
+ *   step_tokens (n_steps,d): row i = StepToken(timesteps[i]) (same for the whole batch);
+ *   coef (HOST pointer, n_steps*4 floats): per step sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev);
+ *   x (B,T,J) in/out: x_T on entry, the sample on return;
+ *   trace (n_steps,B,T,J) or NULL: x after every step (parity tests).
+ * Context keys/values are projected once per rollout and the n_steps step-token
+ * keys/values once per call (memory is not layer-normed before the K/V projection). */
+int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                   const float *coef, float *x, float *trace, float *workspace,
+                   int B, int T, int Mc, int n_steps, void *stream);
+
+/* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
+
+/* out[R,N] = act(LN?(A)[R,d] @ W[N,d]^T + bias) (+ res).  ln_w/ln_b NULL = no LayerNorm;
+ * act: 0 none, 1 gelu(erf); res NULL or [R,N] (may alias out).  N % d == 0. */
+int sd_op_linear(const float *A, const float *W, const float *bias, const float *ln_w,
+                 const float *ln_b, const float *res, float *out, int R, int N, int d, int act,
+                 void *stream);
+
+/* Multi-head attention core, unmasked: out[b,i,h*hd:(h+1)*hd] = softmax(q k^T / sqrt(hd)) v.
+ * q rows (B*Tq) with row stride ldq; k, v rows (B*S) with row stride ldkv; optional extra
+ * key/value row shared by the whole batch (k_extra/v_extra, d floats each, NULL = none). */
+int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv,
+                    const float *k_extra, const float *v_extra, float *out, int ldo,
+                    int B, int Tq, int S, int d, int heads, void *stream);
+
+/* out (B,S/p,d) = Conv1d(k=s=p)(x (B,S,C)) + bias + pe[:S/p]; p = 1 is nn.Linear + PE. */
+int sd_op_patch_embed(const float *x, const float *w, const float *b, const float *pe,
+                      float *out, int B, int S, int C, int p, int d, void *stream);
+
+/* eps[R,J] = h[R,d] @ W[J,d]^T + b.  If x_io != NULL also applies the DDIM update to it in
+ * place using coef[4] (see sd_ddim_step).  eps may be NULL when x_io is given. */
+int sd_op_fc_out(const float *h, const float *W, const float *b, float *eps, float *x_io,
+                 const float *coef4_host, int R, int d, int J, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCCERDIFFUSION_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of include/soccerdiffusion_hip.h.
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails,
+this module raises.  (The CPU oracle lives in oracle/ and is test infrastructure.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libsoccerdiffusion_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class LayerWeights(C.Structure):
+    """sd_layer_weights (field order = header order)."""
+
+    FIELDS = (
+        "sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b",
+        "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
+        "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+        "n1_w", "n1_b", "n2_w", "n2_b", "n3_w", "n3_b",
+    )
+    _fields_ = [(n, C.c_void_p) for n in FIELDS]
+
+
+class DenoiserWeights(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("J", C.c_int32), ("L", C.c_int32), ("heads", C.c_int32),
+        ("emb_w", C.c_void_p), ("emb_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+        ("pe", C.c_void_p), ("T_max", C.c_int32), ("_pad", C.c_int32),
+        ("layers", C.POINTER(LayerWeights)),
+    ]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("C", C.c_int32), ("p", C.c_int32), ("L", C.c_int32),
+        ("heads", C.c_int32), ("S_max", C.c_int32),
+        ("emb_w", C.c_void_p), ("emb_b", C.c_void_p), ("pe", C.c_void_p),
+        ("layers", C.POINTER(LayerWeights)),
+    ]
+
+
+# name -> (restype, argtypes); mirrors the header one to one (tests check the export list)
+SIGNATURES = {
+    "sd_abi_version": (C.c_int, []),
+    "sd_last_error": (C.c_char_p, []),
+    "sd_workspace_floats": (C.c_size_t, [C.c_int] * 6),
+    "sd_step_token": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "sd_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_encoder_forward": (C.c_int, [C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sd_game_state_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_ddim_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sd_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_long, C.c_void_p]),
+    "sd_ddim_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_op_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_op_patch_embed": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "sd_op_fc_out": (C.c_int, [C.c_void_p] * 5 + [c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m soccerdiffusion_amd.build` "
+            "(hipcc, gfx950).  soccerdiffusion_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sd_abi_version() != 1:
+        raise RuntimeError("libsoccerdiffusion_hip.so ABI version mismatch: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sd_last_error().decode()
+        kind = "invalid argument" if rc < 0 else "HIP error"
+        raise RuntimeError(f"{what}: {kind} {rc}: {msg}")

@@ -1,0 +1,863 @@
+// MI355X (gfx950 / CDNA4) kernels + C ABI for the SoccerDiffusion denoiser hot path.
+// Interface and reference citations: include/soccerdiffusion_hip.h.  Design: DESIGN.md.
+//
+// Everything is fp32.  Contractions run on v_mfma_f32_32x32x2_f32 (exact fp32 fma
+// chain, 64 FLOP/clk/SIMD).  Fragment maps used throughout (wave = 64 lanes):
+//   A operand: lane l holds A[i = l & 31][k = l >> 5]
+//   B operand: lane l holds B[k = l >> 5][j = l & 31]
+//   C/D:       lane l, reg r holds D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31]
+// The k order inside a K-loop is free as long as A and B agree, so each lane fetches 4
+// consecutive k (one 16-byte load) at k0 + 4 * (l >> 5) and feeds them to 4 MFMAs:
+// together the two lane halves cover k0 .. k0 + 7.  Weights are torch-layout W[N][K]
+// (K contiguous), which is exactly that B-fragment shape.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/soccerdiffusion_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SD_LN_EPS 1e-5f
+
+static thread_local const char *g_last_error = "ok";
+static int fail(int code, const char *msg) {
+    g_last_error = msg;
+    return code;
+}
+#define SD_CHECK_LAUNCH(name)                                 \
+    do {                                                      \
+        hipError_t e_ = hipGetLastError();                    \
+        if (e_ != hipSuccess) return fail((int)e_, name);     \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+
+// ======================================================================================
+// Row-panel GEMM:  out[R,N] = act(LN?(A)[R,D] @ W[N,D]^T + bias) (+ res)
+//
+// One workgroup (4 waves) owns a panel of BM = 64 rows.  The panel (64 x D fp32) is read
+// from HBM once, kept in LDS for all N/D output passes, and LayerNorm is applied to it in
+// place (the whole row is resident, so the statistics need no extra pass over memory).
+// Waves split the D output columns of a pass, so B fragments (weights) are private to a
+// wave and go global -> registers directly (L2/L1 resident, 16 B per lane); the K loop
+// has no barrier at all.  LDS rows are padded by 4 floats: 16 consecutive rows then hit
+// 16 distinct 4-bank groups for ds_read_b128.
+// ======================================================================================
+template <int D>
+struct PanelCfg {
+    static constexpr int BM = 64;
+    static constexpr int WAVES_N = (D / 32 >= 4) ? 4 : D / 32;
+    static constexpr int WAVES_M = 4 / WAVES_N;
+    static constexpr int WM = BM / WAVES_M;  // rows per wave
+    static constexpr int WN = D / WAVES_N;   // output columns per wave per pass
+    static constexpr int TM = WM / 32;
+    static constexpr int TN = WN / 32;
+    static constexpr int LDA = D + 4;
+    static constexpr size_t LDS_BYTES = (size_t)BM * LDA * sizeof(float);
+};
+
+template <int D, bool HAS_LN, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ ln_w,
+                                                          const float *__restrict__ ln_b, const float *res,
+                                                          float *out, int R, int N) {
+    using C = PanelCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const long r0 = (long)blockIdx.x * C::BM;
+
+    // ---- panel load: rows are consecutive in memory, 16 B per lane, zero-fill the tail --
+    constexpr int VEC_PER_ROW = D / 4;
+    for (int i = tid; i < C::BM * VEC_PER_ROW; i += 256) {
+        const int row = i / VEC_PER_ROW;
+        const int c4 = i - row * VEC_PER_ROW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < R) v = *reinterpret_cast<const f32x4 *>(A + (r0 + row) * D + c4 * 4);
+        *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    if constexpr (HAS_LN) {
+        // each wave normalises 16 rows; two-pass mean / biased variance in fp32
+        constexpr int PER_LANE = D / 64;
+        for (int row = wave; row < C::BM; row += 4) {
+            float v[PER_LANE];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                v[j] = sA[row * C::LDA + lane + 64 * j];
+                s += v[j];
+            }
+            const float mean = wave_sum(s) * (1.0f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                v[j] -= mean;
+                q += v[j] * v[j];
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + SD_LN_EPS);
+#pragma unroll
+            for (int j = 0; j < PER_LANE; ++j) {
+                const int c = lane + 64 * j;
+                sA[row * C::LDA + c] = v[j] * rstd * ln_w[c] + ln_b[c];
+            }
+        }
+        __syncthreads();
+    }
+
+    const int wm = wave / C::WAVES_N;
+    const int wn = wave % C::WAVES_N;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const float *aBase = sA + (wm * C::WM + l31) * C::LDA + 4 * half;
+
+    for (int n0 = 0; n0 < N; n0 += D) {
+        f32x16 acc[C::TM][C::TN];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+        const float *wBase = W + (long)(n0 + wn * C::WN + l31) * D + 4 * half;
+        f32x4 bcur[C::TN], bnext[C::TN];
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) bcur[tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
+
+#pragma unroll 4
+        for (int k0 = 0; k0 < D; k0 += 8) {
+            const int kn = (k0 + 8 < D) ? k0 + 8 : k0;  // last iteration re-reads (harmless)
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bnext[tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + kn);
+            f32x4 a[C::TM];
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) a[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], bcur[tn][j], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) bcur[tn] = bnext[tn];
+        }
+
+        // ---- epilogue: bias, activation, residual; each store covers 2 rows x 128 B ------
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int col = n0 + wn * C::WN + tn * 32 + l31;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = r0 + wm * C::WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < R) {
+                        float v = acc[tm][tn][r] + bv;
+                        if constexpr (ACT == 1) v = gelu_erf(v);
+                        if constexpr (HAS_RES) v += res[row * N + col];
+                        out[row * N + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+static int launch_panel(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
+                        const float *res, float *out, int R, int N, int act, hipStream_t s) {
+    using C = PanelCfg<D>;
+    dim3 grid((R + C::BM - 1) / C::BM), block(256);
+    const size_t lds = C::LDS_BYTES;
+#define SD_PANEL(LN_, ACT_, RES_)                                                                              \
+    do {                                                                                                       \
+        auto kfn = panel_gemm_kernel<D, LN_, ACT_, RES_>;                                                      \
+        static bool attr_set = false;                                                                          \
+        if (lds > 64 * 1024 && !attr_set) {                                                                    \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N);                  \
+    } while (0)
+    const bool ln = ln_w != nullptr;
+    const bool rs = res != nullptr;
+    if (ln && act == 0 && !rs) SD_PANEL(true, 0, false);
+    else if (ln && act == 1 && !rs) SD_PANEL(true, 1, false);
+    else if (!ln && act == 0 && !rs) SD_PANEL(false, 0, false);
+    else if (!ln && act == 0 && rs) SD_PANEL(false, 0, true);
+    else if (!ln && act == 1 && !rs) SD_PANEL(false, 1, false);
+    else if (ln && act == 0 && rs) SD_PANEL(true, 0, true);
+    else return fail(SD_E_BADARG, "sd_op_linear: unsupported LN/act/res combination");
+#undef SD_PANEL
+    SD_CHECK_LAUNCH("panel_gemm_kernel");
+    return 0;
+}
+
+static int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
+                  const float *res, float *out, int R, int N, int d, int act, hipStream_t s) {
+    if (!A || !W || !out || R <= 0 || N <= 0) return fail(SD_E_BADARG, "linear: null pointer or empty shape");
+    if (N % d != 0) return fail(SD_E_BADDIM, "linear: N must be a multiple of d");
+    switch (d) {
+        case 64: return launch_panel<64>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 128: return launch_panel<128>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 256: return launch_panel<256>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 512: return launch_panel<512>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+    }
+    return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+}
+
+// ======================================================================================
+// Attention core (self- and cross-attention), unmasked, one workgroup per (sample, head).
+//
+// Computed transposed: S^T = K Q^T (keys x queries) so that a query is a lane column.
+// The softmax statistics of a query are then in-lane reductions plus one lane^32 exchange,
+// and the probabilities, still sitting in the accumulator registers, are directly the
+// B operand of O^T = V^T P^T (the contraction runs over the accumulator's row index), so
+// P never touches LDS.  Keys are streamed through LDS in chunks of KC with an online
+// softmax, so any S is supported; each wave owns 32 queries (128 per workgroup pass).
+// ======================================================================================
+template <int HD>
+struct AttnCfg {
+    static constexpr int KC = (HD >= 128) ? 64 : 128;      // keys per LDS chunk
+    static constexpr int FT = (HD + 31) / 32;              // 32-feature tiles of O^T
+    static constexpr int LDK = HD + 4;                     // ds_read_b128 conflict-free
+    static constexpr int LDV = FT * 32;                    // zero-padded feature columns
+    static constexpr int KSTEPS = HD / 8;
+    static constexpr size_t LDS_BYTES = (size_t)KC * (LDK + LDV) * sizeof(float);
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, int ldq,
+                                                         const float *__restrict__ k, const float *__restrict__ v,
+                                                         int ldkv, const float *__restrict__ k_extra,
+                                                         const float *__restrict__ v_extra, float *__restrict__ out,
+                                                         int ldo, int Tq, int S, int heads, float scale_log2e) {
+    using C = AttnCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sK = smem;
+    float *sV = smem + C::KC * C::LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int S_all = S + (k_extra ? 1 : 0);
+    const float *qb = q + (long)b * Tq * ldq + h * HD;
+    const float *kb = k + (long)b * S * ldkv + h * HD;
+    const float *vb = v + (long)b * S * ldkv + h * HD;
+
+    for (int qpass = 0; qpass < Tq; qpass += 128) {
+        const int q0 = qpass + wave * 32;
+        const bool wave_active = q0 < Tq;  // wave-uniform
+        // Q fragments stay in registers for the whole pass: B[k = feature][j = query]
+        f32x4 qf[C::KSTEPS];
+        {
+            const int qi = q0 + l31;
+            const bool ok = qi < Tq;
+#pragma unroll
+            for (int st = 0; st < C::KSTEPS; ++st) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (ok) t = *reinterpret_cast<const f32x4 *>(qb + (long)qi * ldq + st * 8 + 4 * half);
+                qf[st] = t;
+            }
+        }
+        f32x16 o[C::FT];
+#pragma unroll
+        for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
+        float m_run = -INFINITY, l_part = 0.f;
+
+        for (int kc0 = 0; kc0 < S_all; kc0 += C::KC) {
+            __syncthreads();  // previous chunk fully consumed
+            // ---- stage K and V chunk (zero-filled past S_all; V feature pad zeroed) -----
+            constexpr int KV4 = HD / 4;
+            for (int i = tid; i < C::KC * KV4; i += 256) {
+                const int row = i / KV4, c4 = i - row * KV4;
+                const int key = kc0 + row;
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (key < S) {
+                    kv = *reinterpret_cast<const f32x4 *>(kb + (long)key * ldkv + c4 * 4);
+                    vv = *reinterpret_cast<const f32x4 *>(vb + (long)key * ldkv + c4 * 4);
+                } else if (key < S_all) {
+                    kv = *reinterpret_cast<const f32x4 *>(k_extra + h * HD + c4 * 4);
+                    vv = *reinterpret_cast<const f32x4 *>(v_extra + h * HD + c4 * 4);
+                }
+                *reinterpret_cast<f32x4 *>(sK + row * C::LDK + c4 * 4) = kv;
+                *reinterpret_cast<f32x4 *>(sV + row * C::LDV + c4 * 4) = vv;
+            }
+            if constexpr (C::LDV > HD) {
+                constexpr int PADW = C::LDV - HD;
+                for (int i = tid; i < C::KC * PADW; i += 256) sV[(i / PADW) * C::LDV + HD + (i % PADW)] = 0.f;
+            }
+            __syncthreads();
+            if (!wave_active) continue;
+
+            // ---- S^T chunk = K Q^T : KC/32 tiles of (32 keys x 32 queries) ---------------
+            constexpr int KT = C::KC / 32;
+            f32x16 sc[KT];
+            const int kt_valid = (min(S_all - kc0, C::KC) + 31) / 32;  // wave-uniform
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+                if (kt < kt_valid) {
+                    const float *kp = sK + (kt * 32 + l31) * C::LDK + 4 * half;
+#pragma unroll
+                    for (int st = 0; st < C::KSTEPS; ++st) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + st * 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[st][j], sc[kt], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- online softmax for this lane's query (column l31) -----------------------
+            float m_c = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kc0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float sv = (key < S_all) ? sc[kt][r] : -INFINITY;
+                    sc[kt][r] = sv;
+                    m_c = fmaxf(m_c, sv);
+                }
+            m_c = fmaxf(m_c, __shfl_xor(m_c, 32, 64));
+            const float m_new = fmaxf(m_run, m_c);  // finite: every chunk holds >= 1 valid key
+            const float alpha = exp2f((m_run - m_new) * scale_log2e);
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f((sc[kt][r] - m_new) * scale_log2e);
+                    sc[kt][r] = p;
+                    psum += p;
+                }
+            l_part = l_part * alpha + psum;
+#pragma unroll
+            for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+            // ---- O^T += V^T P^T : A = V^T[feature l31][key], B = P^T straight from sc ------
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < kt_valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int krow = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                        for (int ft = 0; ft < C::FT; ++ft) {
+                            const float a = sV[krow * C::LDV + ft * 32 + l31];
+                            o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (wave_active) {
+            const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+            const float inv = 1.0f / l_tot;
+            const int qi = q0 + l31;
+            if (qi < Tq) {
+                float *op = out + ((long)b * Tq + qi) * ldo + h * HD;
+#pragma unroll
+                for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int f = ft * 32 + 8 * g + 4 * half;  // 4 consecutive features
+                        if (f < HD) {
+                            f32x4 t = {o[ft][4 * g] * inv, o[ft][4 * g + 1] * inv, o[ft][4 * g + 2] * inv,
+                                       o[ft][4 * g + 3] * inv};
+                            *reinterpret_cast<f32x4 *>(op + f) = t;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+static int attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
+                     const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
+                     hipStream_t s) {
+    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || S < 0 || heads <= 0)
+        return fail(SD_E_BADARG, "attention: null pointer or empty shape");
+    if ((k_extra == nullptr) != (v_extra == nullptr)) return fail(SD_E_BADARG, "attention: k_extra/v_extra mismatch");
+    if (S + (k_extra ? 1 : 0) <= 0) return fail(SD_E_BADARG, "attention: no keys");
+    if (d % heads != 0) return fail(SD_E_BADDIM, "attention: d not divisible by heads");
+    const int hd = d / heads;
+    const float sl2e = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
+    dim3 grid(B * heads), block(256);
+#define SD_ATTN(HD_)                                                                                             \
+    do {                                                                                                         \
+        auto kfn = attention_kernel<HD_>;                                                                        \
+        const size_t lds = AttnCfg<HD_>::LDS_BYTES;                                                              \
+        static bool attr_set = false;                                                                            \
+        if (lds > 64 * 1024 && !attr_set) {                                                                      \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e); \
+    } while (0)
+    switch (hd) {
+        case 16: SD_ATTN(16); break;
+        case 32: SD_ATTN(32); break;
+        case 64: SD_ATTN(64); break;
+        case 128: SD_ATTN(128); break;
+        default: return fail(SD_E_BADDIM, "attention: head dim must be 16, 32, 64 or 128");
+    }
+#undef SD_ATTN
+    SD_CHECK_LAUNCH("attention_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// Patch embedding (+ bias + positional table):  Conv1d(kernel = stride = p) == a GEMM with
+// K = C*p <= a few hundred; 0.4 % of the step's FLOPs, done on the VALU.  p = 1 is the
+// decoder's nn.Linear(J -> d).  One workgroup = 64 output rows; W^T and the 64 input
+// patches are staged in LDS ([k][c] and [row][k+1]: conflict-free reads).
+// ======================================================================================
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                           const float *__restrict__ bias,
+                                                           const float *__restrict__ pe, float *__restrict__ out,
+                                                           long rows, int n_per_sample, int S, int C, int p, int d,
+                                                           int RB, int DC) {
+    extern __shared__ float sm[];
+    const int K = C * p;
+    float *sX = sm;                          // [RB][K+1]
+    float *sW = sm + (size_t)RB * (K + 1);   // [K][DC]  (column chunk of W^T)
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * RB;
+    for (int i = tid; i < RB * K; i += 256) {
+        const int row = i / K, kk = i - row * K;
+        const long r = r0 + row;
+        float v = 0.f;
+        if (r < rows) {
+            const long bidx = r / n_per_sample;
+            const int n = (int)(r - bidx * n_per_sample);
+            const int c = kk / p, t = kk - c * p;  // w is (d, C, p): kk = c*p + t
+            v = x[((bidx * S) + (long)n * p + t) * C + c];
+        }
+        sX[row * (K + 1) + kk] = v;
+    }
+    for (int c0 = 0; c0 < d; c0 += DC) {
+        __syncthreads();
+        for (int i = tid; i < DC * K; i += 256) {
+            const int cc = i / K, kk = i - cc * K;
+            sW[kk * DC + cc] = (c0 + cc < d) ? w[(long)(c0 + cc) * K + kk] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < RB * DC; i += 256) {
+            const int row = i / DC, cc = i - row * DC;
+            const long r = r0 + row;
+            const int c = c0 + cc;
+            if (r >= rows || c >= d) continue;
+            float acc = 0.f;
+            for (int kk = 0; kk < K; ++kk) acc = fmaf(sX[row * (K + 1) + kk], sW[kk * DC + cc], acc);
+            const int n = (int)(r % n_per_sample);
+            out[r * d + c] = acc + bias[c] + pe[(long)n * d + c];
+        }
+    }
+}
+
+static int patch_embed(const float *x, const float *w, const float *b, const float *pe, float *out, int B, int S,
+                       int C, int p, int d, hipStream_t s) {
+    if (!x || !w || !b || !pe || !out || B <= 0 || S <= 0 || C <= 0 || p <= 0 || d <= 0)
+        return fail(SD_E_BADARG, "patch_embed: null pointer or empty shape");
+    const int n = S / p;
+    if (n <= 0) return fail(SD_E_BADARG, "patch_embed: sequence shorter than one patch");
+    const long rows = (long)B * n;
+    const int K = C * p;
+    const int RB = (K <= 64) ? 64 : 16;
+    const long budget = 15360 - (long)RB * (K + 1);  // floats (60 KB total)
+    long DC = budget > 0 ? (budget / K) / 32 * 32 : 0;
+    if (DC > d) DC = (d + 31) / 32 * 32;
+    if (DC < 32) return fail(SD_E_TOOBIG, "patch_embed: C*p too large for LDS staging");
+    const size_t lds = ((size_t)RB * (K + 1) + (size_t)K * DC) * sizeof(float);
+    hipLaunchKernelGGL(patch_embed_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, s, x, w, b, pe, out,
+                       rows, n, S, C, p, d, RB, (int)DC);
+    SD_CHECK_LAUNCH("patch_embed_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// fc_out (d -> J) fused with the DDIM update of x.  N = J = 20 is far too narrow for a
+// 32-wide MFMA tile (0.4 % of FLOPs): VALU, one workgroup per 64 rows, each thread owns one
+// row and a quarter of the joints, h rows and W staged in LDS with +1 padding.
+// coef = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}.
+// ======================================================================================
+#define SD_MAX_J 64
+__global__ __launch_bounds__(256) void fc_out_kernel(const float *__restrict__ h, const float *__restrict__ W,
+                                                      const float *__restrict__ b, float *__restrict__ eps,
+                                                      float *x_io, float c0, float c1, float c2, float c3, long R,
+                                                      int d, int J, int RB) {
+    extern __shared__ float sm[];
+    float *sH = sm;                          // [RB][d+1]
+    float *sW = sm + (size_t)RB * (d + 1);   // [J][d+1]
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * RB;
+    for (int i = tid; i < RB * d; i += 256) {
+        const int row = i / d, c = i - row * d;
+        sH[row * (d + 1) + c] = (r0 + row < R) ? h[(r0 + row) * d + c] : 0.f;
+    }
+    for (int i = tid; i < J * d; i += 256) sW[(i / d) * (d + 1) + (i % d)] = W[i];
+    __syncthreads();
+    const int TPR = 256 / RB;  // threads per row: 4 (RB = 64) or 8 (RB = 32)
+    const int row = tid / TPR, jq = tid % TPR;
+    const long r = r0 + row;
+    constexpr int JPT = SD_MAX_J / 4;
+    float acc[JPT];
+#pragma unroll
+    for (int i = 0; i < JPT; ++i) acc[i] = 0.f;
+    const float *hp = sH + row * (d + 1);
+    for (int kk = 0; kk < d; ++kk) {
+        const float hv = hp[kk];
+#pragma unroll
+        for (int i = 0; i < JPT; ++i) {
+            const int j = jq + TPR * i;
+            if (j < J) acc[i] = fmaf(hv, sW[j * (d + 1) + kk], acc[i]);
+        }
+    }
+    if (r >= R) return;
+#pragma unroll
+    for (int i = 0; i < JPT; ++i) {
+        const int j = jq + TPR * i;
+        if (j < J) {
+            const float e = acc[i] + b[j];
+            if (eps) eps[r * J + j] = e;
+            if (x_io) {
+                const float xv = x_io[r * J + j];
+                const float x0 = (xv - c1 * e) / c0;
+                x_io[r * J + j] = c2 * x0 + c3 * e;
+            }
+        }
+    }
+}
+
+static int fc_out(const float *h, const float *W, const float *b, float *eps, float *x_io, const float *coef, long R,
+                  int d, int J, hipStream_t s) {
+    if (!h || !W || !b || (!eps && !x_io) || R <= 0) return fail(SD_E_BADARG, "fc_out: null pointer or empty shape");
+    if (x_io && !coef) return fail(SD_E_BADARG, "fc_out: DDIM update needs coefficients");
+    if (J > SD_MAX_J) return fail(SD_E_TOOBIG, "fc_out: more than 64 joints");
+    const int RB = (d <= 256) ? 64 : 32;
+    const size_t lds = (size_t)(RB + J) * (d + 1) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)fc_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
+    const float c0 = coef ? coef[0] : 1.f, c1 = coef ? coef[1] : 0.f, c2 = coef ? coef[2] : 1.f, c3 = coef ? coef[3] : 0.f;
+    hipLaunchKernelGGL(fc_out_kernel, dim3((unsigned)((R + RB - 1) / RB)), dim3(256), lds, s, h, W, b, eps, x_io, c0, c1,
+                       c2, c3, R, d, J, RB);
+    SD_CHECK_LAUNCH("fc_out_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// small elementwise kernels
+// ======================================================================================
+__global__ void step_token_kernel(const void *steps, int is_i64, const float *__restrict__ freq,
+                                  const float *__restrict__ token, float *out, long stride, int B, int d) {
+    const int b = blockIdx.x;
+    const int n = d / 4;
+    const float t = is_i64 ? (float)reinterpret_cast<const int64_t *>(steps)[b] : reinterpret_cast<const float *>(steps)[b];
+    float *o = out + (long)b * stride;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float v;
+        if (i < n) v = sinf(t * freq[i]);
+        else if (i < 2 * n) v = cosf(t * freq[i - n]);
+        else v = token[i - 2 * n];
+        o[i] = v;
+    }
+}
+
+__global__ void gather_rows_kernel(const int64_t *__restrict__ idx, const float *__restrict__ table, float *out,
+                                   long stride, int B, int d, int n_states) {
+    const int b = blockIdx.x;
+    int64_t i = idx[b];
+    if (i < 0) i = 0;
+    if (i >= n_states) i = n_states - 1;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(long)b * stride + c] = table[i * d + c];
+}
+
+__global__ void add_noise_kernel(const float *__restrict__ x0, const float *__restrict__ noise,
+                                 const int64_t *__restrict__ t, const float *__restrict__ acp, float *out, int B,
+                                 int per_sample) {
+    const long n = (long)B * per_sample;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = acp[t[i / per_sample]];
+        out[i] = sqrtf(a) * x0[i] + sqrtf(1.0f - a) * noise[i];
+    }
+}
+
+__global__ void ddim_step_kernel(const float *__restrict__ eps, const float *x, float *x_prev, float c0, float c1,
+                                 float c2, float c3, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float e = eps[i];
+        const float x0 = (x[i] - c1 * e) / c0;
+        x_prev[i] = c2 * x0 + c3 * e;
+    }
+}
+
+__global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride, float *dst, long dst_stride,
+                                 long rows, int width) {
+    const long n = rows * width;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / width;
+        const int c = (int)(i - r * width);
+        dst[r * dst_stride + c] = src[r * src_stride + c];
+    }
+}
+
+static inline unsigned grid_for(long n, int block = 256) {
+    long g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ======================================================================================
+// Layer drivers
+// ======================================================================================
+struct Scratch {  // carve-up of the caller's workspace (floats)
+    float *h, *qkv, *a, *u, *kv, *kvstep;
+};
+
+static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps) {
+    Scratch s;
+    size_t off = 0;
+    s.h = ws + off; off += align64((size_t)R * d);
+    s.qkv = ws + off; off += align64((size_t)R * 3 * d);
+    s.a = ws + off; off += align64((size_t)R * d);
+    s.u = ws + off; off += align64((size_t)R * d);
+    s.kv = ws + off; off += align64((size_t)L * RM * 2 * d);
+    s.kvstep = ws + off; off += align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d);
+    return s;
+}
+
+extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps) {
+    const size_t R = (size_t)B * T, RM = (size_t)B * (M > 0 ? M : 1);
+    return align64(R * d) * 3 + align64(R * 3 * d) + align64((size_t)L * RM * 2 * d) +
+           align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
+}
+
+// self-attention block: h += out_proj(attn(LN1(h) Wqkv))
+static int self_attn_block(const sd_layer_weights &w, const Scratch &s, int B, int T, int d, int heads,
+                           hipStream_t st) {
+    const int R = B * T;
+    int rc = linear(s.h, w.sa_in_w, w.sa_in_b, w.n1_w, w.n1_b, nullptr, s.qkv, R, 3 * d, d, 0, st);
+    if (rc) return rc;
+    rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
+    if (rc) return rc;
+    return linear(s.a, w.sa_out_w, w.sa_out_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
+}
+
+// feed-forward block: h += W2 gelu(W1 LN(h))
+static int ffn_block(const sd_layer_weights &w, const float *nw, const float *nb, const Scratch &s, int R, int d,
+                     hipStream_t st) {
+    int rc = linear(s.h, w.lin1_w, w.lin1_b, nw, nb, nullptr, s.u, R, d, d, 1, st);
+    if (rc) return rc;
+    return linear(s.u, w.lin2_w, w.lin2_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
+}
+
+// cross-attention block given projected memory keys/values kv (B*Mk rows of 2d: K | V)
+static int cross_attn_block(const sd_layer_weights &w, const Scratch &s, const float *kv, int Mk,
+                            const float *kv_extra, int B, int T, int d, int heads, hipStream_t st) {
+    const int R = B * T;
+    int rc = linear(s.h, w.ca_in_w, w.ca_in_b, w.n2_w, w.n2_b, nullptr, s.u, R, d, d, 0, st);  // Q rows [0:d)
+    if (rc) return rc;
+    rc = attention(s.u, d, kv, kv + d, 2 * d, kv_extra, kv_extra ? kv_extra + d : nullptr, s.a, d, B, T, Mk, d, heads,
+                   st);
+    if (rc) return rc;
+    return linear(s.a, w.ca_out_w, w.ca_out_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
+}
+
+static int check_denoiser(const sd_denoiser_weights *w) {
+    if (!w || !w->layers || !w->emb_w || !w->emb_b || !w->out_w || !w->out_b || !w->pe)
+        return fail(SD_E_BADARG, "denoiser weights: null pointer");
+    if (w->d != 64 && w->d != 128 && w->d != 256 && w->d != 512)
+        return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    if (w->heads <= 0 || w->d % w->heads != 0) return fail(SD_E_BADDIM, "hidden_dim not divisible by heads");
+    if (w->L <= 0 || w->J <= 0 || w->J > SD_MAX_J) return fail(SD_E_BADARG, "denoiser weights: bad L or J");
+    return 0;
+}
+
+extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x, const float *memory,
+                                   float *eps_out, float *workspace, int B, int T, int M, void *stream) {
+    int rc = check_denoiser(w);
+    if (rc) return rc;
+    if (!x || !memory || !eps_out || !workspace || B <= 0 || T <= 0 || M <= 0)
+        return fail(SD_E_BADARG, "sd_denoiser_forward: null pointer or empty shape");
+    if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_denoiser_forward: horizon exceeds positional table");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = w->d, R = B * T;
+    Scratch s = carve(workspace, R, (long)B * M, d, w->L, 0);
+    rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
+    if (rc) return rc;
+    for (int l = 0; l < w->L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        float *kv = s.kv + (size_t)l * B * M * 2 * d;
+        // memory is NOT layer-normed: K = mem Wk^T + bk, V = mem Wv^T + bv (rows [d:3d) of in_proj)
+        rc = linear(memory, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, kv, B * M, 2 * d, d,
+                    0, st);
+        if (rc) return rc;
+        if ((rc = self_attn_block(lw, s, B, T, d, w->heads, st))) return rc;
+        if ((rc = cross_attn_block(lw, s, kv, M, nullptr, B, T, d, w->heads, st))) return rc;
+        if ((rc = ffn_block(lw, lw.n3_w, lw.n3_b, s, R, d, st))) return rc;
+    }
+    return fc_out(s.h, w->out_w, w->out_b, eps_out, nullptr, nullptr, R, d, w->J, st);
+}
+
+extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, float *out, float *workspace, int B,
+                                  int S, void *stream) {
+    if (!w || !w->layers || !w->emb_w || !w->emb_b || !w->pe || !x || !out || !workspace || B <= 0 || S <= 0)
+        return fail(SD_E_BADARG, "sd_encoder_forward: null pointer or empty shape");
+    if (w->d != 64 && w->d != 128 && w->d != 256 && w->d != 512)
+        return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    if (w->p <= 0 || S / w->p <= 0 || S / w->p > w->S_max)
+        return fail(SD_E_TOOBIG, "sd_encoder_forward: sequence exceeds positional table");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = w->d, n = S / w->p, R = B * n;
+    Scratch s = carve(workspace, R, 1, d, 1, 0);
+    int rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, S, w->C, w->p, d, st);
+    if (rc) return rc;
+    for (int l = 0; l < w->L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        if ((rc = self_attn_block(lw, s, B, n, d, w->heads, st))) return rc;
+        if ((rc = ffn_block(lw, lw.n2_w, lw.n2_b, s, R, d, st))) return rc;
+    }
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long)R * d)), dim3(256), 0, st, s.h, (long)d, out, (long)d,
+                       (long)R, d);
+    SD_CHECK_LAUNCH("copy_rows_kernel");
+    return 0;
+}
+
+extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                              const float *coef, float *x, float *trace, float *workspace, int B, int T, int Mc,
+                              int n_steps, void *stream) {
+    int rc = check_denoiser(w);
+    if (rc) return rc;
+    if (!step_tokens || !coef || !x || !workspace || B <= 0 || T <= 0 || Mc < 0 || n_steps <= 0 || (Mc > 0 && !ctx))
+        return fail(SD_E_BADARG, "sd_ddim_sample: null pointer or empty shape");
+    if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = w->d, R = B * T, L = w->L;
+    Scratch s = carve(workspace, R, (long)B * Mc, d, L, n_steps);
+    // once per rollout: K/V of the context rows and of all n_steps step tokens, per layer
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
+        if (Mc > 0) {
+            rc = linear(ctx, wkv, bkv, nullptr, nullptr, nullptr, s.kv + (size_t)l * B * Mc * 2 * d, B * Mc, 2 * d, d, 0, st);
+            if (rc) return rc;
+        }
+        rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * n_steps * 2 * d, n_steps,
+                    2 * d, d, 0, st);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
+        if (rc) return rc;
+        for (int l = 0; l < L; ++l) {
+            const sd_layer_weights &lw = w->layers[l];
+            const float *kv = s.kv + (size_t)l * B * Mc * 2 * d;
+            const float *kvs = s.kvstep + ((size_t)l * n_steps + i) * 2 * d;
+            if ((rc = self_attn_block(lw, s, B, T, d, w->heads, st))) return rc;
+            if ((rc = cross_attn_block(lw, s, kv, Mc, kvs, B, T, d, w->heads, st))) return rc;
+            if ((rc = ffn_block(lw, lw.n3_w, lw.n3_b, s, R, d, st))) return rc;
+        }
+        rc = fc_out(s.h, w->out_w, w->out_b, nullptr, x, coef + 4 * i, R, d, w->J, st);
+        if (rc) return rc;
+        if (trace) {
+            const long n = (long)R * w->J;
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, trace + (size_t)i * n, n,
+                               1L, (int)n);
+            SD_CHECK_LAUNCH("copy_rows_kernel");
+        }
+    }
+    return 0;
+}
+
+// ======================================================================================
+// thin C-ABI wrappers
+// ======================================================================================
+extern "C" int sd_abi_version(void) { return SD_ABI_VERSION; }
+extern "C" const char *sd_last_error(void) { return g_last_error; }
+
+extern "C" int sd_step_token(const void *steps, int steps_is_i64, const float *freq, const float *token, float *out,
+                             long out_row_stride, int B, int d, void *stream) {
+    if (!steps || !freq || !token || !out || B <= 0 || d < 8 || d % 4) return fail(SD_E_BADARG, "sd_step_token: bad argument");
+    hipLaunchKernelGGL(step_token_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, steps,
+                       steps_is_i64, freq, token, out, out_row_stride, B, d);
+    SD_CHECK_LAUNCH("step_token_kernel");
+    return 0;
+}
+
+extern "C" int sd_game_state_embed(const int64_t *idx, const float *table, float *out, long out_row_stride, int B,
+                                   int d, int n_states, void *stream) {
+    if (!idx || !table || !out || B <= 0 || d <= 0 || n_states <= 0) return fail(SD_E_BADARG, "sd_game_state_embed: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, idx, table, out,
+                       out_row_stride, B, d, n_states);
+    SD_CHECK_LAUNCH("gather_rows_kernel");
+    return 0;
+}
+
+extern "C" int sd_ddim_add_noise(const float *x0, const float *noise, const int64_t *t, const float *acp, float *out,
+                                 int B, int per_sample, void *stream) {
+    if (!x0 || !noise || !t || !acp || !out || B <= 0 || per_sample <= 0) return fail(SD_E_BADARG, "sd_ddim_add_noise: bad argument");
+    hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for((long)B * per_sample)), dim3(256), 0, (hipStream_t)stream, x0,
+                       noise, t, acp, out, B, per_sample);
+    SD_CHECK_LAUNCH("add_noise_kernel");
+    return 0;
+}
+
+extern "C" int sd_ddim_step(const float *eps, const float *x, float *x_prev, float sqrt_a_t, float sqrt_1m_a_t,
+                            float sqrt_a_prev, float sqrt_1m_a_prev, long n, void *stream) {
+    if (!eps || !x || !x_prev || n <= 0) return fail(SD_E_BADARG, "sd_ddim_step: bad argument");
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, x_prev, sqrt_a_t,
+                       sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, n);
+    SD_CHECK_LAUNCH("ddim_step_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
+                            const float *res, float *out, int R, int N, int d, int act, void *stream) {
+    if ((ln_w == nullptr) != (ln_b == nullptr)) return fail(SD_E_BADARG, "sd_op_linear: ln_w/ln_b mismatch");
+    return linear(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
+                               const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
+                               void *stream) {
+    return attention(q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_patch_embed(const float *x, const float *w, const float *b, const float *pe, float *out, int B,
+                                 int S, int C, int p, int d, void *stream) {
+    return patch_embed(x, w, b, pe, out, B, S, C, p, d, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_fc_out(const float *h, const float *W, const float *b, float *eps, float *x_io,
+                            const float *coef4_host, int R, int d, int J, void *stream) {
+    return fc_out(h, W, b, eps, x_io, coef4_host, R, d, J, (hipStream_t)stream);
+}

@@ -1,0 +1,368 @@
+"""Tensor-level wrappers over the C ABI (include/soccerdiffusion_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation is a
+HIP kernel behind ``libsoccerdiffusion_hip.so``.  All functions require contiguous fp32
+CUDA(HIP) tensors and raise otherwise — there is no CPU path in this package.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DenoiserWeights, EncoderWeights, LayerWeights, check
+
+Tensor = torch.Tensor
+NUM_TRAIN_TIMESTEPS = 1000
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda) device, got {t.device}; "
+                           "soccerdiffusion_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------------------
+# host-side tables, built exactly as the reference builds them (fp32 CPU ops)
+# --------------------------------------------------------------------------------------
+def positional_table(d_model: int, max_len: int) -> Tensor:
+    """The ``pe`` buffer of PositionalEncoding (reference ml/model/misc.py:43-56), CPU fp32."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def step_frequencies(dim: int) -> Tensor:
+    """Frequency table of StepToken (reference ml/model/misc.py:31-32), CPU fp32."""
+    half_dim = dim // 4
+    return torch.exp(torch.arange(half_dim) * -math.log(10000) / (half_dim - 1))
+
+
+def alphas_cumprod(num_train_timesteps: int = NUM_TRAIN_TIMESTEPS) -> Tensor:
+    """squaredcos_cap_v2 schedule of the scheduler the reference constructs at
+    ml/training/train.py:185 (diffusers DDIMScheduler defaults)."""
+    def alpha_bar(s):
+        return math.cos((s + 0.008) / 1.008 * math.pi / 2) ** 2
+
+    n = num_train_timesteps
+    betas = torch.tensor([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), 0.999) for i in range(n)],
+                         dtype=torch.float32)
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def ddim_timesteps(num_inference_steps: int, num_train_timesteps: int = NUM_TRAIN_TIMESTEPS) -> list[int]:
+    """``set_timesteps`` (leading spacing, offset 0): e.g. 50 -> 980, 960, ..., 0."""
+    ratio = num_train_timesteps // num_inference_steps
+    return [int(round(i * ratio)) for i in range(num_inference_steps)][::-1]
+
+
+def ddim_coefficients(timesteps: Sequence[int], acp: Tensor, num_inference_steps: int,
+                      num_train_timesteps: int = NUM_TRAIN_TIMESTEPS) -> np.ndarray:
+    """Per step (sqrt a_t, sqrt(1-a_t), sqrt a_prev, sqrt(1-a_prev)) as fp32 (eta = 0,
+    final_alpha_cumprod = 1).  Computed with fp32 tensor ops like the scheduler does."""
+    acp = acp.detach().cpu().float()
+    ratio = num_train_timesteps // num_inference_steps
+    out = np.zeros((len(timesteps), 4), dtype=np.float32)
+    one = torch.tensor(1.0)
+    for i, t in enumerate(timesteps):
+        prev = t - ratio
+        a_t = acp[t]
+        a_p = acp[prev] if prev >= 0 else one
+        out[i] = [float(a_t.sqrt()), float((1 - a_t).sqrt()), float(a_p.sqrt()), float((1 - a_p).sqrt())]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# weight descriptors
+# --------------------------------------------------------------------------------------
+_DEC_KEYS = {
+    "sa_in_w": "self_attn.in_proj_weight", "sa_in_b": "self_attn.in_proj_bias",
+    "sa_out_w": "self_attn.out_proj.weight", "sa_out_b": "self_attn.out_proj.bias",
+    "ca_in_w": "multihead_attn.in_proj_weight", "ca_in_b": "multihead_attn.in_proj_bias",
+    "ca_out_w": "multihead_attn.out_proj.weight", "ca_out_b": "multihead_attn.out_proj.bias",
+    "lin1_w": "linear1.weight", "lin1_b": "linear1.bias", "lin2_w": "linear2.weight", "lin2_b": "linear2.bias",
+    "n1_w": "norm1.weight", "n1_b": "norm1.bias", "n2_w": "norm2.weight", "n2_b": "norm2.bias",
+    "n3_w": "norm3.weight", "n3_b": "norm3.bias",
+}
+
+
+class _Packed:
+    """Keeps the ctypes structs and every tensor they point at alive together."""
+
+    def __init__(self):
+        self.keep: list[Tensor] = []
+        self.layers = None
+        self.struct = None
+
+    def dev(self, t: Tensor, device) -> Tensor:
+        t = t.detach()
+        if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device=device, dtype=torch.float32).contiguous()
+        self.keep.append(t)
+        return t
+
+    def fill_layers(self, sd: Mapping[str, Tensor], stem: str, n_layers: int, device, decoder: bool):
+        arr = (LayerWeights * n_layers)()
+        for l in range(n_layers):
+            for field, key in _DEC_KEYS.items():
+                full = f"{stem}{l}.{key}"
+                if full in sd:
+                    setattr(arr[l], field, self.dev(sd[full], device).data_ptr())
+                elif decoder or not (field.startswith("ca_") or field.startswith("n3_")):
+                    raise KeyError(f"missing weight {full}")
+        self.layers = arr
+
+
+def _count_layers(sd: Mapping[str, Tensor], stem: str) -> int:
+    n = 0
+    while f"{stem}{n}.norm1.weight" in sd:
+        n += 1
+    return n
+
+
+def pack_denoiser(sd: Mapping[str, Tensor], device, prefix: str = "diffusion_action_generator.",
+                  heads: int = 4, max_len: Optional[int] = None) -> _Packed:
+    """Builds the ``sd_denoiser_weights`` descriptor from checkpoint-keyed tensors
+    (zero-copy for tensors already on ``device``)."""
+    device = torch.device(device)
+    p = _Packed()
+    emb_w = p.dev(sd[prefix + "embedding.weight"], device)
+    d, J = emb_w.shape
+    stem = prefix + "transformer_decoder.layers."
+    L = _count_layers(sd, stem)
+    p.fill_layers(sd, stem, L, device, decoder=True)
+    T_max = int(max_len) if max_len is not None else 512
+    pe = p.dev(positional_table(d, T_max), device)
+    w = DenoiserWeights()
+    w.d, w.J, w.L, w.heads = d, J, L, heads
+    w.emb_w = emb_w.data_ptr()
+    w.emb_b = p.dev(sd[prefix + "embedding.bias"], device).data_ptr()
+    w.out_w = p.dev(sd[prefix + "fc_out.weight"], device).data_ptr()
+    w.out_b = p.dev(sd[prefix + "fc_out.bias"], device).data_ptr()
+    w.pe = pe.data_ptr()
+    w.T_max = T_max
+    w.layers = C.cast(p.layers, C.POINTER(LayerWeights))
+    p.struct = w
+    p.d, p.J, p.L, p.heads, p.T_max = d, J, L, heads, T_max
+    return p
+
+
+def pack_encoder(sd: Mapping[str, Tensor], device, prefix: str, heads: int = 4, max_len: Optional[int] = None) -> _Packed:
+    """Builds the ``sd_encoder_weights`` descriptor for a BaseEncoder (``prefix`` ends with '.')."""
+    device = torch.device(device)
+    p = _Packed()
+    emb_w = p.dev(sd[prefix + "embedding.weight"], device)
+    d, Cin, patch = emb_w.shape
+    stem = prefix + "transformer_encoder.layers."
+    L = _count_layers(sd, stem)
+    p.fill_layers(sd, stem, L, device, decoder=False)
+    S_max = int(max_len) if max_len is not None else 512
+    pe = p.dev(positional_table(d, S_max), device)
+    w = EncoderWeights()
+    w.d, w.C, w.p, w.L, w.heads, w.S_max = d, Cin, patch, L, heads, S_max
+    w.emb_w = emb_w.data_ptr()
+    w.emb_b = p.dev(sd[prefix + "embedding.bias"], device).data_ptr()
+    w.pe = pe.data_ptr()
+    w.layers = C.cast(p.layers, C.POINTER(LayerWeights))
+    p.struct = w
+    p.d, p.C, p.p, p.L, p.heads, p.S_max = d, Cin, patch, L, heads, S_max
+    return p
+
+
+_ws_cache: dict = {}
+
+
+def workspace(n_floats: int, device) -> Tensor:
+    """Grow-only scratch buffer per (device, stream)."""
+    key = (torch.device(device), _stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------
+# calls
+# --------------------------------------------------------------------------------------
+def denoiser_forward(packed: _Packed, x: Tensor, memory: Tensor) -> Tensor:
+    """DiffusionActionGenerator.forward (reference ml/model/decoder.py:38-54)."""
+    lib = _lib.load()
+    _req(x, "x"); _req(memory, "memory")
+    B, T, J = x.shape
+    Bm, M, d = memory.shape
+    if Bm != B or d != packed.d or J != packed.J:
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)}, memory {tuple(memory.shape)}, model d={packed.d} J={packed.J}")
+    out = torch.empty_like(x)
+    ws = workspace(lib.sd_workspace_floats(B, T, M, d, packed.L, 0), x.device)
+    check(lib.sd_denoiser_forward(C.byref(packed.struct), x.data_ptr(), memory.data_ptr(), out.data_ptr(),
+                                  ws.data_ptr(), B, T, M, _stream()), "sd_denoiser_forward")
+    return out
+
+
+def encoder_forward(packed: _Packed, x: Tensor) -> Tensor:
+    """BaseEncoder.forward (reference ml/model/encoder/base.py:41-53)."""
+    lib = _lib.load()
+    _req(x, "x")
+    B, S, Cin = x.shape
+    if Cin != packed.C:
+        raise ValueError(f"encoder expects {packed.C} input features, got {Cin}")
+    n = S // packed.p
+    out = torch.empty(B, n, packed.d, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.sd_workspace_floats(B, n, 1, packed.d, 1, 0), x.device)
+    check(lib.sd_encoder_forward(C.byref(packed.struct), x.data_ptr(), out.data_ptr(), ws.data_ptr(), B, S, _stream()),
+          "sd_encoder_forward")
+    return out
+
+
+def step_token(steps: Tensor, freq: Tensor, token: Tensor, out: Optional[Tensor] = None, row_stride: Optional[int] = None) -> Tensor:
+    """StepToken.forward (reference ml/model/misc.py:25-35) -> (B, 1, d)."""
+    lib = _lib.load()
+    if steps.dtype not in (torch.int64, torch.float32):
+        steps = steps.to(torch.int64 if not steps.is_floating_point() else torch.float32)
+    _req(steps, "steps", steps.dtype); _req(freq, "freq"); _req(token, "token")
+    B = steps.shape[0]
+    d = token.numel() * 2
+    if out is None:
+        out = torch.empty(B, 1, d, dtype=torch.float32, device=steps.device)
+        row_stride = d
+    check(lib.sd_step_token(steps.data_ptr(), int(steps.dtype == torch.int64), freq.data_ptr(), token.data_ptr(),
+                            out.data_ptr(), int(row_stride), B, d, _stream()), "sd_step_token")
+    return out
+
+
+def game_state_embed(idx: Tensor, table: Tensor) -> Tensor:
+    """GameStateEncoder.forward (reference ml/model/encoder/game_state.py:19-27) -> (B, 1, d)."""
+    lib = _lib.load()
+    _req(idx, "game_state", torch.int64); _req(table, "embedding.weight")
+    B = idx.shape[0]
+    n, d = table.shape
+    out = torch.empty(B, 1, d, dtype=torch.float32, device=idx.device)
+    check(lib.sd_game_state_embed(idx.data_ptr(), table.data_ptr(), out.data_ptr(), d, B, d, n, _stream()),
+          "sd_game_state_embed")
+    return out
+
+
+def ddim_add_noise(x0: Tensor, noise: Tensor, t: Tensor, acp: Tensor) -> Tensor:
+    """scheduler.add_noise (reference call site ml/training/train.py:218)."""
+    lib = _lib.load()
+    _req(x0, "x0"); _req(noise, "noise"); _req(t, "timesteps", torch.int64); _req(acp, "alphas_cumprod")
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    check(lib.sd_ddim_add_noise(x0.data_ptr(), noise.data_ptr(), t.data_ptr(), acp.data_ptr(), out.data_ptr(), B,
+                                x0.numel() // B, _stream()), "sd_ddim_add_noise")
+    return out
+
+
+def ddim_step(eps: Tensor, x: Tensor, coef4) -> Tensor:
+    """scheduler.step(...).prev_sample (reference call site ml/inference/plot.py:131)."""
+    lib = _lib.load()
+    _req(eps, "eps"); _req(x, "x")
+    out = torch.empty_like(x)
+    c = [float(v) for v in coef4]
+    check(lib.sd_ddim_step(eps.data_ptr(), x.data_ptr(), out.data_ptr(), c[0], c[1], c[2], c[3], x.numel(), _stream()),
+          "sd_ddim_step")
+    return out
+
+
+def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
+                trace: bool = False, inplace: bool = False):
+    """The reference's sampling loop (ml/inference/plot.py:122-131, ml/training/distill.py:179-189)
+    as ONE native call.  Returns the sample, or (sample, per-step trace) when ``trace``."""
+    lib = _lib.load()
+    _req(x_T, "x_T"); _req(step_tokens, "step_tokens")
+    B, T, J = x_T.shape
+    n_steps = step_tokens.shape[0]
+    Mc = 0
+    if ctx is not None:
+        _req(ctx, "context")
+        Mc = ctx.shape[1]
+        if ctx.shape[0] != B or ctx.shape[2] != packed.d:
+            raise ValueError("context shape mismatch")
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    if coef.shape != (n_steps, 4):
+        raise ValueError("coef must be (n_steps, 4)")
+    x = x_T if inplace else x_T.clone()
+    tr = torch.empty(n_steps, B, T, J, dtype=torch.float32, device=x.device) if trace else None
+    ws = workspace(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, n_steps), x.device)
+    check(lib.sd_ddim_sample(C.byref(packed.struct), _ptr(ctx), step_tokens.data_ptr(),
+                             coef.ctypes.data_as(_lib.c_float_p), x.data_ptr(), _ptr(tr), ws.data_ptr(),
+                             B, T, Mc, n_steps, _stream()), "sd_ddim_sample")
+    return (x, tr) if trace else x
+
+
+# ---- single ops (unit parity tests) ----------------------------------------------------
+def linear(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, ln: Optional[tuple] = None, act: str = "none",
+           res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    _req(A, "A"); _req(W, "W")
+    R, d = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(R, N, dtype=torch.float32, device=A.device)
+    check(lib.sd_op_linear(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(ln[0]) if ln else None,
+                           _ptr(ln[1]) if ln else None, _ptr(res), out.data_ptr(), R, N, d,
+                           {"none": 0, "gelu": 1}[act], _stream()), "sd_op_linear")
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, extra: Optional[tuple] = None) -> Tensor:
+    """q (B,Tq,d), k/v (B,S,d) contiguous; extra = (k_row (d,), v_row (d,)) shared by the batch."""
+    lib = _lib.load()
+    _req(q, "q"); _req(k, "k"); _req(v, "v")
+    B, Tq, d = q.shape
+    S = k.shape[1]
+    out = torch.empty_like(q)
+    check(lib.sd_op_attention(q.data_ptr(), d, k.data_ptr(), v.data_ptr(), d, _ptr(extra[0]) if extra else None,
+                              _ptr(extra[1]) if extra else None, out.data_ptr(), d, B, Tq, S, d, heads, _stream()),
+          "sd_op_attention")
+    return out
+
+
+def patch_embed(x: Tensor, w: Tensor, b: Tensor, pe: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(x, "x"); _req(w, "w"); _req(b, "b"); _req(pe, "pe")
+    B, S, Cin = x.shape
+    if w.dim() == 2:
+        d, p = w.shape[0], 1
+    else:
+        d, _, p = w.shape
+    out = torch.empty(B, S // p, d, dtype=torch.float32, device=x.device)
+    check(lib.sd_op_patch_embed(x.data_ptr(), w.data_ptr(), b.data_ptr(), pe.data_ptr(), out.data_ptr(), B, S, Cin, p, d,
+                                _stream()), "sd_op_patch_embed")
+    return out
+
+
+def fc_out(h: Tensor, W: Tensor, b: Tensor, x_io: Optional[Tensor] = None, coef4=None, want_eps: bool = True):
+    lib = _lib.load()
+    _req(h, "h"); _req(W, "W"); _req(b, "b")
+    R, d = h.shape
+    J = W.shape[0]
+    eps = torch.empty(R, J, dtype=torch.float32, device=h.device) if want_eps else None
+    cbuf = None
+    if coef4 is not None:
+        cbuf = (C.c_float * 4)(*[float(v) for v in coef4])
+    check(lib.sd_op_fc_out(h.data_ptr(), W.data_ptr(), b.data_ptr(), _ptr(eps), _ptr(x_io),
+                           C.cast(cbuf, _lib.c_float_p) if cbuf is not None else None, R, d, J, _stream()), "sd_op_fc_out")
+    return eps
