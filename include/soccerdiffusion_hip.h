@@ -169,6 +169,19 @@ int sd_op_patch_embed(const float *x, const float *w, const float *b, const floa
 int sd_op_fc_out(const float *h, const float *W, const float *b, float *eps, float *x_io,
                  const float *coef4_host, int R, int d, int J, void *stream);
 
+/* ---- measurement hooks (bench.py roofline leg; not part of the reference's surface) ----
+ * While enabled, every kernel launch made by this library is bracketed by a hipEvent pair
+ * on the launch stream.  sd_profile_collect waits for them, returns the summed device
+ * milliseconds and launch counts per kernel class, and clears the records.  Do not
+ * enable during hipGraph capture. */
+#define SD_KCLASS_PANEL_GEMM 0   /* panel_gemm_kernel<...>  (all LN/act/res variants)  */
+#define SD_KCLASS_ATTENTION 1    /* attention_kernel<HD>                                */
+#define SD_KCLASS_PATCH_EMBED 2  /* patch_embed_kernel                                  */
+#define SD_KCLASS_FC_OUT 3       /* fc_out_kernel (+ fused DDIM update)                 */
+#define SD_KCLASS_COUNT 4
+int sd_profile_enable(int on);
+int sd_profile_collect(double *ms_by_class, long *launches_by_class, int n_classes);
+
 #ifdef __cplusplus
 }
 #endif

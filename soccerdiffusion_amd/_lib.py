@@ -61,7 +61,11 @@ SIGNATURES = {
     "sd_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_patch_embed": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "sd_op_fc_out": (C.c_int, [C.c_void_p] * 5 + [c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_profile_enable": (C.c_int, [C.c_int]),
+    "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }
+
+KERNEL_CLASSES = ("panel_gemm_kernel", "attention_kernel", "patch_embed_kernel", "fc_out_kernel")
 
 _lib = None
 

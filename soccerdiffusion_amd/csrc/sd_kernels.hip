@@ -33,6 +33,46 @@ static int fail(int code, const char *msg) {
         if (e_ != hipSuccess) return fail((int)e_, name);     \
     } while (0)
 
+// --------------------------------------------------------------------------------------
+// Optional per-launch timing (bench.py's roofline leg): when enabled, every kernel launch
+// is bracketed by a hipEvent pair on the launch stream, tagged with its kernel class.
+// Off by default; never enable while capturing a graph (events are created lazily).
+// --------------------------------------------------------------------------------------
+#include <vector>
+struct ProfRec { int cls; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    bool on;
+    ProfRec rec;
+    hipStream_t st;
+    ProfScope(int cls, hipStream_t s) : on(g_prof_on), st(s) {
+        if (on) {
+            rec.cls = cls;
+            rec.a = prof_event();
+            rec.b = prof_event();
+            (void)hipEventRecord(rec.a, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(rec.b, st);
+            g_prof_recs.push_back(rec);
+        }
+    }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -183,6 +223,7 @@ template <int D>
 static int launch_panel(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
                         const float *res, float *out, int R, int N, int act, hipStream_t s) {
     using C = PanelCfg<D>;
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
     dim3 grid((R + C::BM - 1) / C::BM), block(256);
     const size_t lds = C::LDS_BYTES;
 #define SD_PANEL(LN_, ACT_, RES_)                                                                              \
@@ -402,6 +443,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     if (S + (k_extra ? 1 : 0) <= 0) return fail(SD_E_BADARG, "attention: no keys");
     if (d % heads != 0) return fail(SD_E_BADDIM, "attention: d not divisible by heads");
     const int hd = d / heads;
+    ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     dim3 grid(B * heads), block(256);
 #define SD_ATTN(HD_)                                                                                             \
@@ -490,6 +532,7 @@ static int patch_embed(const float *x, const float *w, const float *b, const flo
     if (DC > d) DC = (d + 31) / 32 * 32;
     if (DC < 32) return fail(SD_E_TOOBIG, "patch_embed: C*p too large for LDS staging");
     const size_t lds = ((size_t)RB * (K + 1) + (size_t)K * DC) * sizeof(float);
+    ProfScope prof(SD_KCLASS_PATCH_EMBED, s);
     hipLaunchKernelGGL(patch_embed_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, s, x, w, b, pe, out,
                        rows, n, S, C, p, d, RB, (int)DC);
     SD_CHECK_LAUNCH("patch_embed_kernel");
@@ -565,6 +608,7 @@ static int fc_out(const float *h, const float *W, const float *b, float *eps, fl
         }
     }
     const float c0 = coef ? coef[0] : 1.f, c1 = coef ? coef[1] : 0.f, c2 = coef ? coef[2] : 1.f, c3 = coef ? coef[3] : 0.f;
+    ProfScope prof(SD_KCLASS_FC_OUT, s);
     hipLaunchKernelGGL(fc_out_kernel, dim3((unsigned)((R + RB - 1) / RB)), dim3(256), lds, s, h, W, b, eps, x_io, c0, c1,
                        c2, c3, R, d, J, RB);
     SD_CHECK_LAUNCH("fc_out_kernel");
@@ -802,6 +846,32 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
 // thin C-ABI wrappers
 // ======================================================================================
 extern "C" int sd_abi_version(void) { return SD_ABI_VERSION; }
+
+extern "C" int sd_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int sd_profile_collect(double *ms_by_class, long *launches_by_class, int n_classes) {
+    if (!ms_by_class || !launches_by_class || n_classes < SD_KCLASS_COUNT) return fail(SD_E_BADARG, "sd_profile_collect: bad argument");
+    for (int i = 0; i < n_classes; ++i) {
+        ms_by_class[i] = 0.0;
+        launches_by_class[i] = 0;
+    }
+    for (const ProfRec &r : g_prof_recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return fail((int)e, "sd_profile_collect: hipEventSynchronize");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return fail((int)e, "sd_profile_collect: hipEventElapsedTime");
+        ms_by_class[r.cls] += ms;
+        launches_by_class[r.cls] += 1;
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return 0;
+}
 extern "C" const char *sd_last_error(void) { return g_last_error; }
 
 extern "C" int sd_step_token(const void *steps, int steps_is_i64, const float *freq, const float *token, float *out,
