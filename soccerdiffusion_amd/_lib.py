@@ -9,6 +9,13 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch MUST be imported before the HIP library is dlopen'ed: the torch wheel bundles its own
+# libamdhip64.so.7 / libhsa-runtime64.so.1, and the dynamic loader binds our NEEDED entry to
+# whichever copy with that SONAME is already mapped.  Loading ours first would map the
+# system ROCm runtime instead and leave the process with a runtime torch did not initialise
+# (launches then fail with hipErrorNoDevice).  One process, one HIP runtime: torch's.
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libsoccerdiffusion_hip.so")
 

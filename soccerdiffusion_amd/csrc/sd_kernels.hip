@@ -27,10 +27,18 @@ static int fail(int code, const char *msg) {
     g_last_error = msg;
     return code;
 }
+// hipGetLastError() is sticky per thread and also reports errors left behind by other
+// users of the runtime in this process (e.g. a probe made by the host framework), so
+// every launch first clears it and then checks only its own result.
 #define SD_CHECK_LAUNCH(name)                                 \
     do {                                                      \
         hipError_t e_ = hipGetLastError();                    \
         if (e_ != hipSuccess) return fail((int)e_, name);     \
+    } while (0)
+#define SD_LAUNCH(...)                    \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
     } while (0)
 
 // --------------------------------------------------------------------------------------
@@ -234,7 +242,7 @@ static int launch_panel(const float *A, const float *W, const float *bias, const
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N);                  \
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N);                  \
     } while (0)
     const bool ln = ln_w != nullptr;
     const bool rs = res != nullptr;
@@ -455,7 +463,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e); \
+        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e); \
     } while (0)
     switch (hd) {
         case 16: SD_ATTN(16); break;
@@ -533,7 +541,7 @@ static int patch_embed(const float *x, const float *w, const float *b, const flo
     if (DC < 32) return fail(SD_E_TOOBIG, "patch_embed: C*p too large for LDS staging");
     const size_t lds = ((size_t)RB * (K + 1) + (size_t)K * DC) * sizeof(float);
     ProfScope prof(SD_KCLASS_PATCH_EMBED, s);
-    hipLaunchKernelGGL(patch_embed_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, s, x, w, b, pe, out,
+    SD_LAUNCH(patch_embed_kernel, dim3((unsigned)((rows + RB - 1) / RB)), dim3(256), lds, s, x, w, b, pe, out,
                        rows, n, S, C, p, d, RB, (int)DC);
     SD_CHECK_LAUNCH("patch_embed_kernel");
     return 0;
@@ -609,7 +617,7 @@ static int fc_out(const float *h, const float *W, const float *b, float *eps, fl
     }
     const float c0 = coef ? coef[0] : 1.f, c1 = coef ? coef[1] : 0.f, c2 = coef ? coef[2] : 1.f, c3 = coef ? coef[3] : 0.f;
     ProfScope prof(SD_KCLASS_FC_OUT, s);
-    hipLaunchKernelGGL(fc_out_kernel, dim3((unsigned)((R + RB - 1) / RB)), dim3(256), lds, s, h, W, b, eps, x_io, c0, c1,
+    SD_LAUNCH(fc_out_kernel, dim3((unsigned)((R + RB - 1) / RB)), dim3(256), lds, s, h, W, b, eps, x_io, c0, c1,
                        c2, c3, R, d, J, RB);
     SD_CHECK_LAUNCH("fc_out_kernel");
     return 0;
@@ -790,7 +798,7 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
         if ((rc = self_attn_block(lw, s, B, n, d, w->heads, st))) return rc;
         if ((rc = ffn_block(lw, lw.n2_w, lw.n2_b, s, R, d, st))) return rc;
     }
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long)R * d)), dim3(256), 0, st, s.h, (long)d, out, (long)d,
+    SD_LAUNCH(copy_rows_kernel, dim3(grid_for((long)R * d)), dim3(256), 0, st, s.h, (long)d, out, (long)d,
                        (long)R, d);
     SD_CHECK_LAUNCH("copy_rows_kernel");
     return 0;
@@ -834,7 +842,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         if (rc) return rc;
         if (trace) {
             const long n = (long)R * w->J;
-            hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, trace + (size_t)i * n, n,
+            SD_LAUNCH(copy_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, trace + (size_t)i * n, n,
                                1L, (int)n);
             SD_CHECK_LAUNCH("copy_rows_kernel");
         }
@@ -877,7 +885,7 @@ extern "C" const char *sd_last_error(void) { return g_last_error; }
 extern "C" int sd_step_token(const void *steps, int steps_is_i64, const float *freq, const float *token, float *out,
                              long out_row_stride, int B, int d, void *stream) {
     if (!steps || !freq || !token || !out || B <= 0 || d < 8 || d % 4) return fail(SD_E_BADARG, "sd_step_token: bad argument");
-    hipLaunchKernelGGL(step_token_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, steps,
+    SD_LAUNCH(step_token_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, steps,
                        steps_is_i64, freq, token, out, out_row_stride, B, d);
     SD_CHECK_LAUNCH("step_token_kernel");
     return 0;
@@ -886,7 +894,7 @@ extern "C" int sd_step_token(const void *steps, int steps_is_i64, const float *f
 extern "C" int sd_game_state_embed(const int64_t *idx, const float *table, float *out, long out_row_stride, int B,
                                    int d, int n_states, void *stream) {
     if (!idx || !table || !out || B <= 0 || d <= 0 || n_states <= 0) return fail(SD_E_BADARG, "sd_game_state_embed: bad argument");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, idx, table, out,
+    SD_LAUNCH(gather_rows_kernel, dim3(B), dim3(d < 256 ? 64 : 256), 0, (hipStream_t)stream, idx, table, out,
                        out_row_stride, B, d, n_states);
     SD_CHECK_LAUNCH("gather_rows_kernel");
     return 0;
@@ -895,7 +903,7 @@ extern "C" int sd_game_state_embed(const int64_t *idx, const float *table, float
 extern "C" int sd_ddim_add_noise(const float *x0, const float *noise, const int64_t *t, const float *acp, float *out,
                                  int B, int per_sample, void *stream) {
     if (!x0 || !noise || !t || !acp || !out || B <= 0 || per_sample <= 0) return fail(SD_E_BADARG, "sd_ddim_add_noise: bad argument");
-    hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for((long)B * per_sample)), dim3(256), 0, (hipStream_t)stream, x0,
+    SD_LAUNCH(add_noise_kernel, dim3(grid_for((long)B * per_sample)), dim3(256), 0, (hipStream_t)stream, x0,
                        noise, t, acp, out, B, per_sample);
     SD_CHECK_LAUNCH("add_noise_kernel");
     return 0;
@@ -904,7 +912,7 @@ extern "C" int sd_ddim_add_noise(const float *x0, const float *noise, const int6
 extern "C" int sd_ddim_step(const float *eps, const float *x, float *x_prev, float sqrt_a_t, float sqrt_1m_a_t,
                             float sqrt_a_prev, float sqrt_1m_a_prev, long n, void *stream) {
     if (!eps || !x || !x_prev || n <= 0) return fail(SD_E_BADARG, "sd_ddim_step: bad argument");
-    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, x_prev, sqrt_a_t,
+    SD_LAUNCH(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, x_prev, sqrt_a_t,
                        sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, n);
     SD_CHECK_LAUNCH("ddim_step_kernel");
     return 0;
