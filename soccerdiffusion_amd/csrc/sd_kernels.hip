@@ -170,56 +170,89 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const float *aBase = sA + (wm * C::WM + l31) * C::LDA + 4 * half;
+    const bool full_panel = r0 + C::BM <= R;  // workgroup-uniform
 
     for (int n0 = 0; n0 < N; n0 += D) {
         f32x16 acc[C::TM][C::TN];
+        if constexpr (HAS_RES) {
+            // the residual is the accumulator's initial value: its loads are in flight while
+            // the first weight fragments arrive, and the add costs nothing
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm)
+            for (int tn = 0; tn < C::TN; ++tn) {
+                const int col = n0 + wn * C::WN + tn * 32 + l31;
 #pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
+                for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const long row = r0 + wm * C::WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        acc[tm][tn][r] = (full_panel || row < R) ? res[row * N + col] : 0.f;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+        }
 
+        // ---- K loop: weight fragments prefetched one k-step (1024 MFMA cycles) ahead and A
+        // fragments double-buffered; sched_barriers pin "issue next loads, then 16 MFMAs" so
+        // the compiler cannot sink a load next to its use (it does otherwise: -40 %).
         const float *wBase = W + (long)(n0 + wn * C::WN + l31) * D + 4 * half;
-        f32x4 bcur[C::TN], bnext[C::TN];
+        constexpr int NK = D / 8;
+        f32x4 bf[2][C::TN], af[2][C::TM];
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) bcur[tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
-
-#pragma unroll 4
-        for (int k0 = 0; k0 < D; k0 += 8) {
-            const int kn = (k0 + 8 < D) ? k0 + 8 : k0;  // last iteration re-reads (harmless)
+        for (int tn = 0; tn < C::TN; ++tn) bf[0][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
 #pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
-                bnext[tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + kn);
-            f32x4 a[C::TM];
+        for (int tm = 0; tm < C::TM; ++tm) af[0][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA);
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) a[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + k0);
+        for (int ks = 0; ks < NK; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < NK) {
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    bf[nxt][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 8);
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+                    af[nxt][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + (ks + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < C::TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], bcur[tn][j], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn) bcur[tn] = bnext[tn];
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][tm][j], bf[cur][tn][j], acc[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- epilogue: bias, activation, residual; each store covers 2 rows x 128 B ------
+        // ---- epilogue: bias, activation; each store instruction covers 2 rows x 128 B -----
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
             const int col = n0 + wn * C::WN + tn * 32 + l31;
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm) {
+                float *op = out + (r0 + wm * C::WM + tm * 32 + 4 * half) * N + col;
+                if (full_panel) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = r0 + wm * C::WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < R) {
+                    for (int r = 0; r < 16; ++r) {
                         float v = acc[tm][tn][r] + bv;
                         if constexpr (ACT == 1) v = gelu_erf(v);
-                        if constexpr (HAS_RES) v += res[row * N + col];
-                        out[row * N + col] = v;
+                        op[(long)((r & 3) + 8 * (r >> 2)) * N] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        if (r0 + wm * C::WM + tm * 32 + 4 * half + rr < R) {
+                            float v = acc[tm][tn][r] + bv;
+                            if constexpr (ACT == 1) v = gelu_erf(v);
+                            op[(long)rr * N] = v;
+                        }
                     }
                 }
             }
