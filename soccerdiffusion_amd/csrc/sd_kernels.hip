@@ -581,54 +581,79 @@ static int patch_embed(const float *x, const float *w, const float *b, const flo
 }
 
 // ======================================================================================
-// fc_out (d -> J) fused with the DDIM update of x.  N = J = 20 is far too narrow for a
-// 32-wide MFMA tile (0.4 % of FLOPs): VALU, one workgroup per 64 rows, each thread owns one
-// row and a quarter of the joints, h rows and W staged in LDS with +1 padding.
+// fc_out (d -> J) fused with the DDIM update of x:  eps = h W^T + b;  x <- ddim(x, eps).
+// J = 20 pads to one 32-wide MFMA tile.  Same row-panel skeleton as panel_gemm (64 rows of
+// h in LDS); the 4 waves take (row tile, K half) and the two K halves are summed through
+// LDS.  Weight rows >= J read as zero.  The kernel is HBM-bound (one read of h).
 // coef = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}.
 // ======================================================================================
 #define SD_MAX_J 64
+template <int D>
 __global__ __launch_bounds__(256) void fc_out_kernel(const float *__restrict__ h, const float *__restrict__ W,
                                                       const float *__restrict__ b, float *__restrict__ eps,
                                                       float *x_io, float c0, float c1, float c2, float c3, long R,
-                                                      int d, int J, int RB) {
-    extern __shared__ float sm[];
-    float *sH = sm;                          // [RB][d+1]
-    float *sW = sm + (size_t)RB * (d + 1);   // [J][d+1]
-    const int tid = threadIdx.x;
-    const long r0 = (long)blockIdx.x * RB;
-    for (int i = tid; i < RB * d; i += 256) {
-        const int row = i / d, c = i - row * d;
-        sH[row * (d + 1) + c] = (r0 + row < R) ? h[(r0 + row) * d + c] : 0.f;
+                                                      int J) {
+    constexpr int BM = 64, LDA = D + 4, KH = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const long r0 = (long)blockIdx.x * BM;
+    constexpr int VEC_PER_ROW = D / 4;
+    for (int i = tid; i < BM * VEC_PER_ROW; i += 256) {
+        const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < R) v = *reinterpret_cast<const f32x4 *>(h + (r0 + row) * D + c4 * 4);
+        *reinterpret_cast<f32x4 *>(sA + row * LDA + c4 * 4) = v;
     }
-    for (int i = tid; i < J * d; i += 256) sW[(i / d) * (d + 1) + (i % d)] = W[i];
     __syncthreads();
-    const int TPR = 256 / RB;  // threads per row: 4 (RB = 64) or 8 (RB = 32)
-    const int row = tid / TPR, jq = tid % TPR;
-    const long r = r0 + row;
-    constexpr int JPT = SD_MAX_J / 4;
-    float acc[JPT];
+    const int tm = wave & 1, kh = wave >> 1;
+    const float *aBase = sA + (tm * 32 + l31) * LDA + kh * KH + 4 * half;
+    const int n_tiles = (J + 31) / 32;  // 1 or 2
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < JPT; ++i) acc[i] = 0.f;
-    const float *hp = sH + row * (d + 1);
-    for (int kk = 0; kk < d; ++kk) {
-        const float hv = hp[kk];
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int i = 0; i < JPT; ++i) {
-            const int j = jq + TPR * i;
-            if (j < J) acc[i] = fmaf(hv, sW[j * (d + 1) + kk], acc[i]);
+        for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+    for (int tn = 0; tn < n_tiles; ++tn) {
+        const int j = tn * 32 + l31;
+        const float *wp = W + (long)(j < J ? j : 0) * D + kh * KH + 4 * half;
+        const float wmask = j < J ? 1.f : 0.f;
+#pragma unroll 4
+        for (int k0 = 0; k0 < KH; k0 += 8) {
+            f32x4 bf = *reinterpret_cast<const f32x4 *>(wp + k0);
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(aBase + k0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (tn == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[0], 0, 0, 0);
+                else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[1], 0, 0, 0);
+            }
         }
     }
-    if (r >= R) return;
+    __syncthreads();  // panel no longer needed: reuse it for the K-half exchange
+    float *sX = sA;   // [2 row tiles][2 n tiles][16 regs][64 lanes]
+    if (kh == 1) {
 #pragma unroll
-    for (int i = 0; i < JPT; ++i) {
-        const int j = jq + TPR * i;
-        if (j < J) {
-            const float e = acc[i] + b[j];
-            if (eps) eps[r * J + j] = e;
-            if (x_io) {
-                const float xv = x_io[r * J + j];
-                const float x0 = (xv - c1 * e) / c0;
-                x_io[r * J + j] = c2 * x0 + c3 * e;
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sX[((tm * 2 + tn) * 16 + r) * 64 + lane] = acc[tn][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        for (int tn = 0; tn < n_tiles; ++tn) {
+            const int j = tn * 32 + l31;
+            if (j >= J) continue;
+            const float bv = b[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = r0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= R) continue;
+                const float e = (tn == 0 ? acc[0][r] : acc[1][r]) + sX[((tm * 2 + tn) * 16 + r) * 64 + lane] + bv;
+                if (eps) eps[row * J + j] = e;
+                if (x_io) {
+                    const float xv = x_io[row * J + j];
+                    const float x0 = (xv - c1 * e) / c0;
+                    x_io[row * J + j] = c2 * x0 + c3 * e;
+                }
             }
         }
     }
@@ -638,20 +663,29 @@ static int fc_out(const float *h, const float *W, const float *b, float *eps, fl
                   int d, int J, hipStream_t s) {
     if (!h || !W || !b || (!eps && !x_io) || R <= 0) return fail(SD_E_BADARG, "fc_out: null pointer or empty shape");
     if (x_io && !coef) return fail(SD_E_BADARG, "fc_out: DDIM update needs coefficients");
-    if (J > SD_MAX_J) return fail(SD_E_TOOBIG, "fc_out: more than 64 joints");
-    const int RB = (d <= 256) ? 64 : 32;
-    const size_t lds = (size_t)(RB + J) * (d + 1) * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)fc_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-    }
+    if (J <= 0 || J > SD_MAX_J) return fail(SD_E_TOOBIG, "fc_out: joints must be in 1..64");
     const float c0 = coef ? coef[0] : 1.f, c1 = coef ? coef[1] : 0.f, c2 = coef ? coef[2] : 1.f, c3 = coef ? coef[3] : 0.f;
     ProfScope prof(SD_KCLASS_FC_OUT, s);
-    SD_LAUNCH(fc_out_kernel, dim3((unsigned)((R + RB - 1) / RB)), dim3(256), lds, s, h, W, b, eps, x_io, c0, c1,
-                       c2, c3, R, d, J, RB);
+    dim3 grid((unsigned)((R + 63) / 64)), block(256);
+#define SD_FCOUT(D_)                                                                                            \
+    do {                                                                                                        \
+        auto kfn = fc_out_kernel<D_>;                                                                           \
+        const size_t lds = (size_t)64 * (D_ + 4) * sizeof(float);                                               \
+        static bool attr_set = false;                                                                           \
+        if (lds > 64 * 1024 && !attr_set) {                                                                     \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        SD_LAUNCH(kfn, grid, block, lds, s, h, W, b, eps, x_io, c0, c1, c2, c3, R, J);                          \
+    } while (0)
+    switch (d) {
+        case 64: SD_FCOUT(64); break;
+        case 128: SD_FCOUT(128); break;
+        case 256: SD_FCOUT(256); break;
+        case 512: SD_FCOUT(512); break;
+        default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    }
+#undef SD_FCOUT
     SD_CHECK_LAUNCH("fc_out_kernel");
     return 0;
 }

@@ -85,7 +85,7 @@ def test_patch_embed(ops, d, C, p, S):
     assert rel_err(ops.patch_embed(x.cuda(), wd, b.cuda(), pe.cuda()), want) < TOL
 
 
-@pytest.mark.parametrize("d,J,R", [(64, 20, 32), (256, 20, 1000), (256, 22, 65), (512, 22, 100), (128, 1, 5)])
+@pytest.mark.parametrize("d,J,R", [(64, 20, 32), (256, 20, 1000), (256, 22, 65), (512, 22, 100), (128, 1, 5), (256, 33, 130), (64, 64, 7)])
 def test_fc_out_and_fused_ddim(ops, d, J, R):
     from oracle import ddim_ref
 
