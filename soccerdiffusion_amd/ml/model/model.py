@@ -1,0 +1,143 @@
+"""End2EndDiffusionTransformer — the boundary class of the hot path
+(reference: soccer_diffusion/ml/model/model.py:16-179).
+
+Same keyword constructor, same three methods, same buffers (``mean``, ``std``) and the
+same ``state_dict`` keys, so reference checkpoints load unchanged.  Extra (not in the
+reference class): ``sample`` runs the whole DDIM loop natively."""
+
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from ... import ops
+from .decoder import DiffusionActionGenerator
+from .encoder.encoders import GameStateEncoder, IMUEncoder, JointEncoder
+from .encoder.image import ImageEncoderType, SequenceEncoderType, image_sequence_encoder_factory
+from .misc import StepToken
+
+NUM_HEADS = 4  # fixed by the reference (model.py:57,71,85,115)
+
+
+class End2EndDiffusionTransformer(nn.Module):
+    def __init__(
+        self,
+        num_joints: int,
+        hidden_dim: int,
+        use_action_history: bool,
+        num_action_history_encoder_layers: int,
+        max_action_context_length: int,
+        encoder_patch_size: int,
+        use_imu: bool,
+        imu_orientation_embedding_method,
+        num_imu_encoder_layers: int,
+        imu_context_length: int,
+        use_joint_states: bool,
+        joint_state_encoder_layers: int,
+        joint_state_context_length: int,
+        use_images: bool,
+        image_encoder_type: ImageEncoderType,
+        image_sequence_encoder_type: SequenceEncoderType,
+        num_image_sequence_encoder_layers: int,
+        image_context_length: int,
+        image_use_final_avgpool: bool,
+        image_resolution: int,
+        use_gamestate: bool,
+        num_decoder_layers: int,
+        trajectory_prediction_length: int,
+    ):
+        super().__init__()
+        d = hidden_dim
+        self.hidden_dim, self.num_joints = d, num_joints
+        self.trajectory_prediction_length = trajectory_prediction_length
+        self.step_encoding = StepToken(d)
+
+        def seq(kind, enabled, *args):
+            return kind(*args) if enabled else None
+
+        self.action_history_encoder = seq(JointEncoder, use_action_history, num_joints, encoder_patch_size, d,
+                                          num_action_history_encoder_layers, NUM_HEADS, max_action_context_length)
+        self.imu_encoder = seq(IMUEncoder, use_imu, imu_orientation_embedding_method, encoder_patch_size, d,
+                               num_imu_encoder_layers, NUM_HEADS, imu_context_length)
+        self.joint_states_encoder = seq(JointEncoder, use_joint_states, num_joints, encoder_patch_size, d,
+                                        joint_state_encoder_layers, NUM_HEADS, joint_state_context_length)
+        self.image_sequence_encoder = (
+            image_sequence_encoder_factory(
+                encoder_type=image_sequence_encoder_type, image_encoder_type=image_encoder_type, hidden_dim=d,
+                num_layers=num_image_sequence_encoder_layers, max_seq_len=image_context_length,
+                use_final_avgpool=image_use_final_avgpool, resolution=image_resolution)
+            if use_images else None
+        )
+        self.game_state_encoder = GameStateEncoder(d) if use_gamestate else None
+        self.diffusion_action_generator = DiffusionActionGenerator(
+            num_joints=num_joints, hidden_dim=d, num_layers=num_decoder_layers, num_heads=NUM_HEADS,
+            max_seq_len=trajectory_prediction_length)
+        self.register_buffer("mean", torch.zeros(num_joints))
+        self.register_buffer("std", torch.ones(num_joints))
+
+    # ---- reference API -----------------------------------------------------------------
+    def encode_input_data(self, input_data: dict[str, torch.Tensor]) -> list[torch.Tensor]:
+        """Context tokens per enabled modality, in the reference's fixed order
+        [action history, IMU, joint state, images, game state] (model.py:135-144)."""
+        pairs = ((self.action_history_encoder, "joint_command_history"), (self.imu_encoder, "rotation"),
+                 (self.joint_states_encoder, "joint_state"), (self.image_sequence_encoder, "image_data"),
+                 (self.game_state_encoder, "game_state"))
+        return [enc(input_data[key]) for enc, key in pairs if enc is not None]
+
+    def forward(self, input_data: dict[str, torch.Tensor], noisy_action_predictions: torch.Tensor,
+                step: torch.Tensor) -> torch.Tensor:
+        return self.forward_with_context(self.encode_input_data(input_data), noisy_action_predictions, step)
+
+    def forward_with_context(self, context: Sequence[torch.Tensor], noisy_action_predictions: torch.Tensor,
+                             step: torch.Tensor) -> torch.Tensor:
+        """Predicted noise for x_t given precomputed context tokens; the step token is the
+        LAST memory row (model.py:176).  ``step`` is int64 or float, shape (B,) (or (1,) at B=1)."""
+        x = noisy_action_predictions
+        B = x.shape[0]
+        if step.dim() == 0:
+            step = step.reshape(1)
+        if step.shape[0] != B:
+            if step.shape[0] != 1:
+                raise RuntimeError(f"step has {step.shape[0]} entries for a batch of {B}")  # torch.cat would fail too
+            step = step.expand(B)
+        step = step.to(x.device)
+        memory = self._assemble_memory(context, step, B, x.device)
+        return self.diffusion_action_generator(x, memory)
+
+    # ---- extras ------------------------------------------------------------------------
+    def _assemble_memory(self, context, step, B, device) -> torch.Tensor:
+        grad_path = torch.is_grad_enabled() and any(c.requires_grad for c in context)
+        if grad_path or (torch.is_grad_enabled() and self.step_encoding.token.requires_grad):
+            from ...training import step_token_autograd
+
+            return torch.cat(list(context) + [step_token_autograd(self.step_encoding, step)], dim=1)
+        d = self.hidden_dim
+        M = sum(int(c.shape[1]) for c in context) + 1
+        memory = torch.empty(B, M, d, dtype=torch.float32, device=device)
+        at = 0
+        for c in context:
+            n = c.shape[1]
+            memory[:, at : at + n].copy_(c)
+            at += n
+        step = step.contiguous()
+        if step.dtype not in (torch.int64, torch.float32):
+            step = step.to(torch.float32 if step.is_floating_point() else torch.int64)
+        # the kernel writes sample b's token straight into row M-1 of its memory block
+        ops.step_token(step, self.step_encoding._freq, self.step_encoding.token.detach(),
+                       out=memory.view(-1)[(M - 1) * d :], row_stride=M * d)
+        return memory
+
+    @torch.no_grad()
+    def sample(self, context: Sequence[torch.Tensor], x_T: torch.Tensor, num_inference_steps: int,
+               return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None):
+        """The reference's denoising loop (plot.py:122-131 / distill.py:179-189 / ros.py:301-310)
+        as one native call: 50x (denoiser forward + DDIM update) with the context K/V cached."""
+        ts = ops.ddim_timesteps(num_inference_steps)
+        acp = ops.alphas_cumprod() if alphas_cumprod is None else alphas_cumprod
+        coef = ops.ddim_coefficients(ts, acp, num_inference_steps)
+        tokens = self.step_encoding.table(ts, x_T.device)
+        ctx = torch.cat(list(context), dim=1).contiguous() if len(context) else None
+        return ops.ddim_sample(self.diffusion_action_generator.packed(), ctx, tokens, coef, x_T.contiguous(),
+                               trace=return_trace)

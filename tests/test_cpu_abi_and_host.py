@@ -1,0 +1,149 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares,
+the ctypes signatures cover the header, host-side tables equal the oracle's, the module
+mirror has the reference's state_dict keys, and the product path refuses to run on CPU."""
+
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import REPO
+from oracle import ddim_ref
+from oracle import denoiser_ref as ref
+
+HEADER = os.path.join(REPO, "include", "soccerdiffusion_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from soccerdiffusion_amd import build
+
+    build.build()
+    from soccerdiffusion_amd import _lib
+
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sd_[a-z0-9_]+)", out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert exported == set(declared), "exported symbol missing from the header: %s" % sorted(exported - set(declared))
+
+
+def test_ctypes_signatures_cover_header(lib):
+    assert sorted(lib.SIGNATURES) == _declared_symbols()
+    h = lib.load()
+    assert h.sd_abi_version() == 1
+    assert h.sd_workspace_floats(2, 16, 11, 64, 2, 10) > 0
+    assert h.sd_last_error() == b"ok"
+
+
+def test_struct_layout_matches_header(lib):
+    import ctypes as C
+
+    assert C.sizeof(lib.LayerWeights) == 18 * 8
+    assert C.sizeof(lib.DenoiserWeights) == 4 * 4 + 5 * 8 + 2 * 4 + 8
+    assert C.sizeof(lib.EncoderWeights) == 6 * 4 + 4 * 8
+    hdr = open(HEADER).read()
+    block = hdr[hdr.index("typedef struct sd_layer_weights") : hdr.index("} sd_layer_weights;")]
+    fields = re.findall(r"\*\s*([a-z0-9_]+)\s*[;,]", block)
+    assert tuple(fields) == lib.LayerWeights.FIELDS
+
+
+def test_argument_errors_without_gpu(lib):
+    h = lib.load()
+    assert h.sd_ddim_step(None, None, None, 1.0, 0.0, 1.0, 0.0, 10, None) == -1
+    assert b"sd_ddim_step" in h.sd_last_error()
+    assert h.sd_op_linear(None, None, None, None, None, None, None, 4, 64, 64, 0, None) == -1
+    with pytest.raises(RuntimeError, match="invalid argument -1"):
+        lib.check(-1, "x")
+
+
+def test_host_tables_equal_oracle():
+    from soccerdiffusion_amd import ops
+
+    assert torch.equal(ops.alphas_cumprod(), ddim_ref.alphas_cumprod())
+    for n in (10, 30, 50, 1000):
+        assert ops.ddim_timesteps(n) == ddim_ref.timesteps(n).tolist()
+    for d, T in ((64, 16), (256, 100)):
+        assert torch.equal(ops.positional_table(d, T), ref.positional_table(d, T))
+    acp = ops.alphas_cumprod()
+    ts = ops.ddim_timesteps(50)
+    coef = ops.ddim_coefficients(ts, acp, 50)
+    for i, t in enumerate(ts):
+        a_t, a_p = ddim_ref.step_coefficients(t, 50, acp)
+        want = [a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()]
+        assert [float(c) for c in coef[i]] == [float(w) for w in want]
+    assert float(coef[-1][2]) == 1.0 and float(coef[-1][3]) == 0.0  # final_alpha_cumprod = 1
+    # step frequencies: the values StepToken multiplies t with (misc.py:32)
+    tok = ref.step_token(torch.tensor([1.0]), torch.zeros(1, 32), 64)
+    assert torch.allclose(tok[0, 0, :16], torch.sin(ops.step_frequencies(64)))
+
+
+def test_module_state_dict_keys_match_reference_checkpoints(g1, g2):
+    from soccerdiffusion_amd.ml.model import End2EndDiffusionTransformer
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from soccerdiffusion_amd.ml.model.encoder.imu import IMUEncoder
+
+    def build(c, full):
+        return End2EndDiffusionTransformer(
+            num_joints=c["J"], hidden_dim=c["d"], use_action_history=full, num_action_history_encoder_layers=c.get("enc_layers", 1),
+            max_action_context_length=20, encoder_patch_size=5, use_imu=full,
+            imu_orientation_embedding_method=IMUEncoder.OrientationEmbeddingMethod("quaternion"), num_imu_encoder_layers=c.get("enc_layers", 1),
+            imu_context_length=20, use_joint_states=full, joint_state_encoder_layers=c.get("enc_layers", 1), joint_state_context_length=20,
+            use_images=False, image_encoder_type=ImageEncoderType("resnet18"), image_sequence_encoder_type=SequenceEncoderType("transformer"),
+            num_image_sequence_encoder_layers=1, image_context_length=0, image_use_final_avgpool=True, image_resolution=480,
+            use_gamestate=full, num_decoder_layers=c["L"], trajectory_prediction_length=c["T"])
+
+    for g, full in ((g1, False), (g2, True)):
+        m = build(g["config"], full)
+        want = g["state_dict"]
+        have = m.state_dict()
+        assert set(have) == set(want)
+        for k in want:
+            assert have[k].shape == want[k].shape, k
+        m.load_state_dict(want)  # strict
+        assert not any(k.endswith(".pe") or "_freq" in k for k in have)  # tables are non-persistent
+
+
+def test_product_path_has_no_cpu_fallback(g1):
+    from soccerdiffusion_amd import ops
+
+    sd = g1["state_dict"]
+    packed = ops.pack_denoiser(sd, "cpu", max_len=16)  # descriptors can be built anywhere ...
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.denoiser_forward(packed, g1["x"], torch.cat([g1["ctx"], g1["step_token_int"]], 1))  # ... compute cannot
+
+
+def test_product_package_does_not_import_oracle():
+    pkg = os.path.join(REPO, "soccerdiffusion_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(root, f)
+
+
+def test_scheduler_rejects_unsupported_configs():
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    s = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    assert s.config["num_train_timesteps"] == 1000
+    s.set_timesteps(30)
+    assert s.timesteps.tolist() == ddim_ref.timesteps(30).tolist()
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(beta_schedule="linear")
+    s.config["num_train_timesteps"] = 500  # the reference's post-construction override (train.py:186)
+    with pytest.raises(ValueError):
+        s.set_timesteps(10)

@@ -1,0 +1,110 @@
+"""GPU parity through the host-side mirror of the reference API
+(End2EndDiffusionTransformer + DDIMScheduler) against golden vectors from the reference."""
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ddim_ref
+from oracle import denoiser_ref as ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _build(c, full):
+    from soccerdiffusion_amd.ml.model import End2EndDiffusionTransformer
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from soccerdiffusion_amd.ml.model.encoder.imu import IMUEncoder
+
+    return End2EndDiffusionTransformer(
+        num_joints=c["J"], hidden_dim=c["d"], use_action_history=full,
+        num_action_history_encoder_layers=c.get("enc_layers", 1), max_action_context_length=c.get("ctx_len", 20),
+        encoder_patch_size=c.get("patch", 5), use_imu=full,
+        imu_orientation_embedding_method=IMUEncoder.OrientationEmbeddingMethod.QUATERNION,
+        num_imu_encoder_layers=c.get("enc_layers", 1), imu_context_length=c.get("ctx_len", 20),
+        use_joint_states=full, joint_state_encoder_layers=c.get("enc_layers", 1),
+        joint_state_context_length=c.get("ctx_len", 20), use_images=False,
+        image_encoder_type=ImageEncoderType.RESNET18, image_sequence_encoder_type=SequenceEncoderType.TRANSFORMER,
+        num_image_sequence_encoder_layers=1, image_context_length=0, image_use_final_avgpool=True,
+        image_resolution=480, use_gamestate=full, num_decoder_layers=c["L"], trajectory_prediction_length=c["T"])
+
+
+def test_forward_with_context_golden(g1):
+    m = _build(g1["config"], full=False).cuda()
+    mean_before = m.mean
+    m.load_state_dict(g1["state_dict"])
+    assert m.mean is mean_before and torch.equal(m.mean.cpu(), g1["state_dict"]["mean"])  # in-place load (plot.py:65-66)
+    m.eval()
+    ctx = [g1["ctx"].cuda()]
+    x = g1["x"].cuda()
+    x_copy = x.clone()
+    with torch.no_grad():
+        assert rel_err(m.step_encoding(g1["steps_int"].cuda()), g1["step_token_int"]) < 1e-6
+        assert rel_err(m.forward_with_context(ctx, x, g1["steps_int"].cuda()), g1["eps_int"]) < TOL
+        assert rel_err(m.forward_with_context(ctx, x, g1["steps_float"].cuda()), g1["eps_float"]) < TOL
+        assert rel_err(m.forward_with_context(ctx, x[:, :7], g1["steps_int"].cuda()), g1["eps_short"]) < TOL
+    assert torch.equal(x, x_copy), "inputs must not be modified (distill.py reuses them)"
+
+
+def test_full_model_forward_golden(g2):
+    m = _build(g2["config"], full=True).cuda()
+    m.load_state_dict(g2["state_dict"])
+    m.eval()
+    inp = {k: v.cuda() for k, v in g2["input_data"].items()}
+    with torch.no_grad():
+        enc = m.encode_input_data(inp)
+        assert [tuple(e.shape) for e in enc] == [tuple(e.shape) for e in g2["encoded"]]
+        for got, want in zip(enc, g2["encoded"]):
+            assert rel_err(got, want) < TOL
+        assert rel_err(m(inp, g2["x"].cuda(), g2["steps"].cuda()), g2["eps"]) < TOL
+
+
+def test_step_broadcast_and_mismatch(g1):
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    with torch.no_grad():
+        one = m.forward_with_context([g1["ctx"][:1].cuda()], g1["x"][:1].cuda(), torch.tensor([900], device="cuda"))
+        assert rel_err(one, g1["eps_int"][:1]) < TOL  # (1,) step at B=1 as ros.py:306 passes it
+        with pytest.raises(RuntimeError):
+            m.forward_with_context([g1["ctx"].cuda()], g1["x"].cuda(), torch.tensor([1, 2, 3], device="cuda"))
+
+
+def test_scheduler_loop_equals_native_sampler(g1):
+    """plot.py-style python loop (model + scheduler.step) == model.sample == CPU oracle."""
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    m.eval()
+    sched = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    sched.config["num_train_timesteps"] = 1000
+    sched.set_timesteps(10)
+    ctx = [g1["ctx"].cuda()]
+    x = g1["x"].cuda()
+    traj = x
+    with torch.no_grad():
+        for t in sched.timesteps:
+            eps = m.forward_with_context(ctx, traj, torch.full((x.shape[0],), int(t), device="cuda"))
+            traj = sched.step(eps, t, traj).prev_sample
+    native = m.sample(ctx, x, 10)
+    assert rel_err(native, traj) < 1e-5
+    sd = g1["state_dict"]
+    want = ddim_ref.sample(lambda xx, t: ref.forward_with_context(sd, [g1["ctx"]], xx, torch.full((2,), t, dtype=torch.int64)),
+                           g1["x"], 10)[-1]
+    assert rel_err(native, want) < TOL
+    # add_noise
+    noise = torch.randn_like(g1["x"])
+    tt = torch.tensor([3, 999])
+    assert rel_err(sched.add_noise(x, noise.cuda(), tt.cuda()), ddim_ref.add_noise(g1["x"], noise, tt, ddim_ref.alphas_cumprod())) < 1e-6
+
+
+def test_use_images_is_rejected_loudly(g1):
+    from soccerdiffusion_amd.ml.model import End2EndDiffusionTransformer
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from soccerdiffusion_amd.ml.model.encoder.imu import IMUEncoder
+
+    with pytest.raises(NotImplementedError):
+        End2EndDiffusionTransformer(20, 64, False, 1, 20, 5, False, IMUEncoder.OrientationEmbeddingMethod.QUATERNION, 1, 20,
+                                    False, 1, 20, True, ImageEncoderType.RESNET18, SequenceEncoderType.TRANSFORMER, 1, 10,
+                                    True, 480, False, 2, 16)
