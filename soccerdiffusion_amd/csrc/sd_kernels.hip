@@ -305,6 +305,315 @@ static int linear(const float *A, const float *W, const float *bias, const float
 }
 
 // ======================================================================================
+// Row-chain kernels: the row-wise part of a transformer layer fused over one 64-row panel.
+//
+// Between two attention cores everything is row-local: out-projection + residual,
+// LayerNorm, projections, GELU feed-forward, the next layer's LayerNorm + QKV.  A
+// workgroup keeps the residual stream of its 64 rows in the MFMA accumulator registers
+// (wave w owns columns [w*D/4, (w+1)*D/4) of every row: the same tile map for every GEMM,
+// so "h += ..." is simply C-in = h) and the current GEMM input in the LDS panel.  Between
+// GEMMs the accumulator is written back into the panel, LayerNorm runs in place, and the
+// next GEMM starts: no HBM round trip, no launch, one HBM read (attention output + h) and
+// one write (h, next q/qkv) per chain.
+//   chain A (decoder):        h += a Wo^T + bo ;            q  = LN2(h) Wq^T + bq
+//   chain B (decoder/encoder): h += a Wo^T + bo ; h += W2 gelu(W1 LN(h) + b1) + b2 ;
+//                             qkv' = LN1'(h) Wqkv'^T + b'   (next layer, optional)
+// ======================================================================================
+template <int D>
+struct ChainCfg : PanelCfg<D> {};
+
+template <int D>
+__device__ __forceinline__ void chain_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *aBase,
+                                           const float *wBase) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 8;
+    f32x4 bf[2][C::TN], af[2][C::TM];
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) bf[0][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) af[0][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bf[nxt][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 8);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                af[nxt][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + (ks + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][tm][j], bf[cur][tn][j], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// per-thread geometry of the accumulator tile map
+template <int D>
+struct ChainPos {
+    using C = PanelCfg<D>;
+    int lane, wave, l31, half, wm, wn;
+    long r0;
+    int R_left;  // valid rows in this panel (<= 64)
+    __device__ ChainPos(long R) {
+        lane = threadIdx.x & 63;
+        wave = threadIdx.x >> 6;
+        l31 = lane & 31;
+        half = lane >> 5;
+        wm = wave / C::WAVES_N;
+        wn = wave % C::WAVES_N;
+        r0 = (long)blockIdx.x * C::BM;
+        const long left = R - r0;
+        R_left = left < C::BM ? (int)left : C::BM;
+    }
+    __device__ __forceinline__ int row(int tm, int r) const { return wm * C::WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
+    __device__ __forceinline__ int col(int tn) const { return wn * C::WN + tn * 32 + l31; }
+};
+
+template <int D>
+__device__ __forceinline__ void chain_load_panel(float *sA, const float *src, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    constexpr int VEC_PER_ROW = D / 4;
+    for (int i = threadIdx.x; i < C::BM * VEC_PER_ROW; i += 256) {
+        const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < p.R_left) v = *reinterpret_cast<const f32x4 *>(src + (p.r0 + row) * D + c4 * 4);
+        *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void chain_load_acc(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *src,
+                                               const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p.row(tm, r);
+                acc[tm][tn][r] = (row < p.R_left) ? src[(p.r0 + row) * D + p.col(tn)] : 0.f;
+            }
+}
+
+template <int D, int ACT>
+__device__ __forceinline__ void chain_bias_act(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *bias,
+                                               const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const float bv = bias[p.col(tn)];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[tm][tn][r] + bv;
+                if constexpr (ACT == 1) v = gelu_erf(v);
+                acc[tm][tn][r] = v;
+            }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void chain_zero(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN]) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+}
+
+template <int D>
+__device__ __forceinline__ void chain_acc_to_lds(float *sA, const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                                 const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[p.row(tm, r) * C::LDA + p.col(tn)] = acc[tm][tn][r];
+}
+
+template <int D>
+__device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
+                                                const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                                const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p.row(tm, r);
+                if (row < p.R_left) dst[(p.r0 + row) * ld + col0 + p.col(tn)] = acc[tm][tn][r];
+            }
+}
+
+// LayerNorm of the LDS panel in place (each wave 16 rows; two-pass, fp32)
+template <int D>
+__device__ __forceinline__ void chain_layer_norm(float *sA, const float *ln_w, const float *ln_b, int lane, int wave) {
+    using C = PanelCfg<D>;
+    constexpr int PER_LANE = D / 64;
+    for (int row = wave; row < C::BM; row += 4) {
+        float v[PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            v[j] = sA[row * C::LDA + lane + 64 * j];
+            s += v[j];
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            v[j] -= mean;
+            q += v[j] * v[j];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + SD_LN_EPS);
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int c = lane + 64 * j;
+            sA[row * C::LDA + c] = v[j] * rstd * ln_w[c] + ln_b[c];
+        }
+    }
+}
+
+struct ChainAArgs {
+    const float *a;              // attention output rows [R, D]
+    float *h;                    // residual stream [R, D] in/out
+    const float *wo, *bo;        // out projection
+    const float *ln_w, *ln_b;    // norm2
+    const float *wq, *bq;        // cross-attention Q projection (rows [0:D) of in_proj)
+    float *q;                    // [R, D]
+    long R;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_a_kernel(ChainAArgs g) {
+    using C = PanelCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.R);
+    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    f32x16 H[C::TM][C::TN];
+    chain_load_acc<D>(H, g.h, p);   // issued first: in flight while the panel lands
+    chain_load_panel<D>(sA, g.a, p);
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.wo + (long)(p.wn * C::WN + p.l31) * D + 4 * p.half);
+    chain_bias_act<D, 0>(H, g.bo, p);
+    chain_store_acc<D>(g.h, D, 0, H, p);
+    __syncthreads();  // every wave is done reading the panel
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
+    __syncthreads();
+    chain_zero<D>(H);
+    chain_gemm<D>(H, aBase, g.wq + (long)(p.wn * C::WN + p.l31) * D + 4 * p.half);
+    chain_bias_act<D, 0>(H, g.bq, p);
+    chain_store_acc<D>(g.q, D, 0, H, p);
+}
+
+struct ChainBArgs {
+    const float *a;              // attention output rows [R, D]
+    float *h;                    // residual stream [R, D] in/out
+    const float *wo, *bo;        // out projection of that attention
+    const float *ln_w, *ln_b;    // FFN norm (norm3 decoder / norm2 encoder)
+    const float *w1, *b1, *w2, *b2;
+    const float *nln_w, *nln_b;  // next layer's norm1 (NULL: no next layer)
+    const float *wqkv, *bqkv;    // next layer's in_proj (3D, D)
+    float *qkv;                  // [R, 3D]
+    long R;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_b_kernel(ChainBArgs g) {
+    using C = PanelCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.R);
+    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    const long wOff = (long)(p.wn * C::WN + p.l31) * D + 4 * p.half;
+    f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
+    chain_load_acc<D>(H, g.h, p);
+    chain_load_panel<D>(sA, g.a, p);
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.wo + wOff);          // h += a Wo^T
+    chain_bias_act<D, 0>(H, g.bo, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
+    __syncthreads();
+    chain_zero<D>(U);
+    chain_gemm<D>(U, aBase, g.w1 + wOff);          // u = gelu(LN(h) W1^T + b1)
+    chain_bias_act<D, 1>(U, g.b1, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, U, p);
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.w2 + wOff);          // h += u W2^T + b2
+    chain_bias_act<D, 0>(H, g.b2, p);
+    chain_store_acc<D>(g.h, D, 0, H, p);
+    if (g.nln_w == nullptr) return;
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.nln_w, g.nln_b, p.lane, p.wave);
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {          // next layer's q | k | v
+        chain_zero<D>(U);
+        chain_gemm<D>(U, aBase, g.wqkv + (long)pass * D * D + wOff);
+        chain_bias_act<D, 0>(U, g.bqkv + pass * D, p);
+        chain_store_acc<D>(g.qkv, 3 * D, pass * D, U, p);
+    }
+}
+
+template <typename Args, typename KA, typename KB, typename KC, typename KD>
+static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512, const char *name, hipStream_t s) {
+    if (g.R <= 0) return fail(SD_E_BADARG, "chain: empty shape");
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    dim3 grid((unsigned)((g.R + 63) / 64)), block(256);
+#define SD_CHAIN(D_, K_)                                                                                        \
+    do {                                                                                                        \
+        const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                             \
+        static bool attr_set = false;                                                                           \
+        if (lds > 64 * 1024 && !attr_set) {                                                                     \
+            (void)hipFuncSetAttribute((const void *)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        SD_LAUNCH(K_, grid, block, lds, s, g);                                                                  \
+    } while (0)
+    switch (d) {
+        case 64: SD_CHAIN(64, k64); break;
+        case 128: SD_CHAIN(128, k128); break;
+        case 256: SD_CHAIN(256, k256); break;
+        case 512: SD_CHAIN(512, k512); break;
+        default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    }
+#undef SD_CHAIN
+    SD_CHECK_LAUNCH(name);
+    return 0;
+}
+
+static int chain_a(const ChainAArgs &g, int d, hipStream_t s) {
+    return launch_chain(g, d, chain_a_kernel<64>, chain_a_kernel<128>, chain_a_kernel<256>, chain_a_kernel<512>,
+                        "chain_a_kernel", s);
+}
+static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
+    return launch_chain(g, d, chain_b_kernel<64>, chain_b_kernel<128>, chain_b_kernel<256>, chain_b_kernel<512>,
+                        "chain_b_kernel", s);
+}
+
+// ======================================================================================
 // Attention core (self- and cross-attention), unmasked, one workgroup per (sample, head).
 //
 // Computed transposed: S^T = K Q^T (keys x queries) so that a query is a lane column.
@@ -780,35 +1089,58 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
            align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
 }
 
-// self-attention block: h += out_proj(attn(LN1(h) Wqkv))
-static int self_attn_block(const sd_layer_weights &w, const Scratch &s, int B, int T, int d, int heads,
-                           hipStream_t st) {
-    const int R = B * T;
-    int rc = linear(s.h, w.sa_in_w, w.sa_in_b, w.n1_w, w.n1_b, nullptr, s.qkv, R, 3 * d, d, 0, st);
+// Decoder stack on the fused row chains.  On entry s.h holds the embedded trajectory rows.
+//   head:      qkv = LN1_0(h) Wqkv_0^T + b
+//   per layer: a = self-attention(qkv);  chain A: h += a Wo^T + bo, q = LN2(h) Wq^T + bq;
+//              a = cross-attention(q, memory K/V);  chain B: h += a Woc^T + boc,
+//              h += FFN(LN3(h)), qkv = LN1_{l+1}(h) Wqkv_{l+1}^T + b (if any)
+// kv(l): projected memory keys/values of layer l (B*Mk rows of 2d), kvx(l): optional extra
+// key/value row shared by the batch (the sampler's step token), or nullptr.
+template <typename KV, typename KVX>
+static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, KVX kvx,
+                         hipStream_t st) {
+    const int d = w->d, heads = w->heads;
+    const long R = (long)B * T;
+    const sd_layer_weights &l0 = w->layers[0];
+    int rc = linear(s.h, l0.sa_in_w, l0.sa_in_b, l0.n1_w, l0.n1_b, nullptr, s.qkv, (int)R, 3 * d, d, 0, st);
     if (rc) return rc;
-    rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
-    if (rc) return rc;
-    return linear(s.a, w.sa_out_w, w.sa_out_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
+    for (int l = 0; l < w->L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
+        if (rc) return rc;
+        ChainAArgs ga{s.a, s.h, lw.sa_out_w, lw.sa_out_b, lw.n2_w, lw.n2_b, lw.ca_in_w, lw.ca_in_b, s.u, R};
+        if ((rc = chain_a(ga, d, st))) return rc;
+        const float *kvl = kv(l), *kvxl = kvx(l);
+        rc = attention(s.u, d, kvl, kvl + d, 2 * d, kvxl, kvxl ? kvxl + d : nullptr, s.a, d, B, T, Mk, d, heads, st);
+        if (rc) return rc;
+        const bool last = l + 1 == w->L;
+        const sd_layer_weights *nx = last ? nullptr : &w->layers[l + 1];
+        ChainBArgs gb{s.a, s.h, lw.ca_out_w, lw.ca_out_b, lw.n3_w, lw.n3_b, lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b,
+                      nx ? nx->n1_w : nullptr, nx ? nx->n1_b : nullptr, nx ? nx->sa_in_w : nullptr,
+                      nx ? nx->sa_in_b : nullptr, s.qkv, R};
+        if ((rc = chain_b(gb, d, st))) return rc;
+    }
+    return 0;
 }
 
-// feed-forward block: h += W2 gelu(W1 LN(h))
-static int ffn_block(const sd_layer_weights &w, const float *nw, const float *nb, const Scratch &s, int R, int d,
-                     hipStream_t st) {
-    int rc = linear(s.h, w.lin1_w, w.lin1_b, nw, nb, nullptr, s.u, R, d, d, 1, st);
+// Encoder stack (self-attention + FFN layers): chain B with norm2 as the FFN norm.
+static int encoder_stack(const sd_layer_weights *layers, int L, const Scratch &s, int B, int n, int d, int heads,
+                         hipStream_t st) {
+    const long R = (long)B * n;
+    int rc = linear(s.h, layers[0].sa_in_w, layers[0].sa_in_b, layers[0].n1_w, layers[0].n1_b, nullptr, s.qkv, (int)R,
+                    3 * d, d, 0, st);
     if (rc) return rc;
-    return linear(s.u, w.lin2_w, w.lin2_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
-}
-
-// cross-attention block given projected memory keys/values kv (B*Mk rows of 2d: K | V)
-static int cross_attn_block(const sd_layer_weights &w, const Scratch &s, const float *kv, int Mk,
-                            const float *kv_extra, int B, int T, int d, int heads, hipStream_t st) {
-    const int R = B * T;
-    int rc = linear(s.h, w.ca_in_w, w.ca_in_b, w.n2_w, w.n2_b, nullptr, s.u, R, d, d, 0, st);  // Q rows [0:d)
-    if (rc) return rc;
-    rc = attention(s.u, d, kv, kv + d, 2 * d, kv_extra, kv_extra ? kv_extra + d : nullptr, s.a, d, B, T, Mk, d, heads,
-                   st);
-    if (rc) return rc;
-    return linear(s.a, w.ca_out_w, w.ca_out_b, nullptr, nullptr, s.h, s.h, R, d, d, 0, st);
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = layers[l];
+        rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, n, n, d, heads, st);
+        if (rc) return rc;
+        const sd_layer_weights *nx = (l + 1 == L) ? nullptr : &layers[l + 1];
+        ChainBArgs gb{s.a, s.h, lw.sa_out_w, lw.sa_out_b, lw.n2_w, lw.n2_b, lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b,
+                      nx ? nx->n1_w : nullptr, nx ? nx->n1_b : nullptr, nx ? nx->sa_in_w : nullptr,
+                      nx ? nx->sa_in_b : nullptr, s.qkv, R};
+        if ((rc = chain_b(gb, d, st))) return rc;
+    }
+    return 0;
 }
 
 static int check_denoiser(const sd_denoiser_weights *w) {
@@ -834,16 +1166,17 @@ extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x,
     rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
     if (rc) return rc;
     for (int l = 0; l < w->L; ++l) {
-        const sd_layer_weights &lw = w->layers[l];
-        float *kv = s.kv + (size_t)l * B * M * 2 * d;
         // memory is NOT layer-normed: K = mem Wk^T + bk, V = mem Wv^T + bv (rows [d:3d) of in_proj)
-        rc = linear(memory, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, kv, B * M, 2 * d, d,
-                    0, st);
+        const sd_layer_weights &lw = w->layers[l];
+        rc = linear(memory, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr,
+                    s.kv + (size_t)l * B * M * 2 * d, B * M, 2 * d, d, 0, st);
         if (rc) return rc;
-        if ((rc = self_attn_block(lw, s, B, T, d, w->heads, st))) return rc;
-        if ((rc = cross_attn_block(lw, s, kv, M, nullptr, B, T, d, w->heads, st))) return rc;
-        if ((rc = ffn_block(lw, lw.n3_w, lw.n3_b, s, R, d, st))) return rc;
     }
+    const float *kvbase = s.kv;
+    const size_t kvstride = (size_t)B * M * 2 * d;
+    rc = decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; },
+                       [](int) { return (const float *)nullptr; }, st);
+    if (rc) return rc;
     return fc_out(s.h, w->out_w, w->out_b, eps_out, nullptr, nullptr, R, d, w->J, st);
 }
 
@@ -860,11 +1193,7 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
     Scratch s = carve(workspace, R, 1, d, 1, 0);
     int rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, S, w->C, w->p, d, st);
     if (rc) return rc;
-    for (int l = 0; l < w->L; ++l) {
-        const sd_layer_weights &lw = w->layers[l];
-        if ((rc = self_attn_block(lw, s, B, n, d, w->heads, st))) return rc;
-        if ((rc = ffn_block(lw, lw.n2_w, lw.n2_b, s, R, d, st))) return rc;
-    }
+    if ((rc = encoder_stack(w->layers, w->L, s, B, n, d, w->heads, st))) return rc;
     SD_LAUNCH(copy_rows_kernel, dim3(grid_for((long)R * d)), dim3(256), 0, st, s.h, (long)d, out, (long)d,
                        (long)R, d);
     SD_CHECK_LAUNCH("copy_rows_kernel");
@@ -897,13 +1226,12 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     for (int i = 0; i < n_steps; ++i) {
         rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
         if (rc) return rc;
-        for (int l = 0; l < L; ++l) {
-            const sd_layer_weights &lw = w->layers[l];
-            const float *kv = s.kv + (size_t)l * B * Mc * 2 * d;
-            const float *kvs = s.kvstep + ((size_t)l * n_steps + i) * 2 * d;
-            if ((rc = self_attn_block(lw, s, B, T, d, w->heads, st))) return rc;
-            if ((rc = cross_attn_block(lw, s, kv, Mc, kvs, B, T, d, w->heads, st))) return rc;
-            if ((rc = ffn_block(lw, lw.n3_w, lw.n3_b, s, R, d, st))) return rc;
+        {
+            const float *kvbase = s.kv, *kvsbase = s.kvstep;
+            const size_t kvstride = (size_t)B * Mc * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
+            rc = decoder_stack(w, s, B, T, Mc, [=](int l) { return kvbase + l * kvstride; },
+                               [=](int l) { return kvsbase + l * kvsstride + (size_t)i * 2 * d; }, st);
+            if (rc) return rc;
         }
         rc = fc_out(s.h, w->out_w, w->out_b, nullptr, x, coef + 4 * i, R, d, w->J, st);
         if (rc) return rc;
