@@ -445,6 +445,22 @@ __device__ __forceinline__ void chain_acc_to_lds(float *sA, const f32x16 (&acc)[
             for (int r = 0; r < 16; ++r) sA[p.row(tm, r) * C::LDA + p.col(tn)] = acc[tm][tn][r];
 }
 
+// bias + GELU applied on the way into the panel, one element at a time: the activated
+// tile is never live in registers as a whole (64 erf temporaries would spill)
+template <int D>
+__device__ __forceinline__ void chain_gelu_to_lds(float *sA, const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                                  const float *bias, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const float bv = bias[p.col(tn)];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[p.row(tm, r) * C::LDA + p.col(tn)] = gelu_erf(acc[tm][tn][r] + bv);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
                                                 const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
@@ -556,9 +572,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_b_kernel(ChainB
     __syncthreads();
     chain_zero<D>(U);
     chain_gemm<D>(U, aBase, g.w1 + wOff);          // u = gelu(LN(h) W1^T + b1)
-    chain_bias_act<D, 1>(U, g.b1, p);
     __syncthreads();
-    chain_acc_to_lds<D>(sA, U, p);
+    chain_gelu_to_lds<D>(sA, U, g.b1, p);
     __syncthreads();
     chain_gemm<D>(H, aBase, g.w2 + wOff);          // h += u W2^T + b2
     chain_bias_act<D, 0>(H, g.b2, p);
@@ -677,7 +692,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             __syncthreads();  // previous chunk fully consumed
             // ---- stage K and V chunk (zero-filled past S_all; V feature pad zeroed) -----
             constexpr int KV4 = HD / 4;
-            for (int i = tid; i < C::KC * KV4; i += 256) {
+            const int rows_staged = ((min(S_all - kc0, C::KC) + 31) / 32) * 32;  // only the tiles that are read
+            for (int i = tid; i < rows_staged * KV4; i += 256) {
                 const int row = i / KV4, c4 = i - row * KV4;
                 const int key = kc0 + row;
                 f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -693,7 +709,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             }
             if constexpr (C::LDV > HD) {
                 constexpr int PADW = C::LDV - HD;
-                for (int i = tid; i < C::KC * PADW; i += 256) sV[(i / PADW) * C::LDV + HD + (i % PADW)] = 0.f;
+                for (int i = tid; i < rows_staged * PADW; i += 256) sV[(i / PADW) * C::LDV + HD + (i % PADW)] = 0.f;
             }
             __syncthreads();
             if (!wave_active) continue;
@@ -751,12 +767,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             for (int kt = 0; kt < KT; ++kt) {
                 if (kt < kt_valid) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int krow = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    for (int g = 0; g < 4; ++g) {
+                        // registers 4g..4g+3 contract keys 8g..8g+7 of the tile: skip the group when
+                        // all of them are past the end (their p is 0); one wave-uniform test per 8 keys
+                        if (kc0 + kt * 32 + 8 * g < S_all) {
 #pragma unroll
-                        for (int ft = 0; ft < C::FT; ++ft) {
-                            const float a = sV[krow * C::LDV + ft * 32 + l31];
-                            o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
+                            for (int ri = 0; ri < 4; ++ri) {
+                                const int r = 4 * g + ri;
+                                const int krow = kt * 32 + ri + 8 * g + 4 * half;
+#pragma unroll
+                                for (int ft = 0; ft < C::FT; ++ft) {
+                                    const float a = sV[krow * C::LDV + ft * 32 + l31];
+                                    o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                 }
