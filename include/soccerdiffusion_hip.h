@@ -169,6 +169,56 @@ int sd_op_patch_embed(const float *x, const float *w, const float *b, const floa
 int sd_op_fc_out(const float *h, const float *W, const float *b, float *eps, float *x_io,
                  const float *coef4_host, int R, int d, int J, void *stream);
 
+/* ---- training: backward of the blocks, loss, optimizer -------------------------------
+ * One training step of the reference (soccer_diffusion/ml/training/train.py:204-240:
+ * add_noise, forward, F.mse_loss, backward, AdamW.step) at dropout p = 0 is composed from
+ * these entry points by soccerdiffusion_amd/training.py (autograd nodes per block). */
+
+/* sd_op_linear with a row stride on A (lda >= d, multiple of 4): lets dX = dY[:, slice] W^T-slices
+ * accumulate through `res` without copying the slice. */
+int sd_op_linear_strided(const float *A, int lda, const float *W, const float *bias, const float *ln_w,
+                         const float *ln_b, const float *res, float *out, int R, int N, int d, int act,
+                         void *stream);
+
+/* sd_op_attention that also writes lse2[b, head, q] = log2-sum-exp of the scaled scores
+ * (log2 domain), which the backward uses to recompute the probabilities. */
+int sd_op_attention_lse(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                        int ldo, float *lse2, int B, int Tq, int S, int d, int heads, void *stream);
+
+/* dq, dk, dv of softmax(q k^T / sqrt(hd)) v given dO.  dk/dv rows are fully overwritten. */
+int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
+                        int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
+                        float *dv, int lddkv, int B, int Tq, int S, int d, int heads, void *stream);
+
+/* dW[N,K] += dY[R,N]^T X[R,K];  db[N] += column sums of dY (db may be NULL).  Accumulates
+ * with fp32 atomics: zero dW/db first (summation order is not fixed). */
+int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,
+                  int N, int K, void *stream);
+
+/* y = LayerNorm(x) * g + b (eps 1e-5, biased variance); mean/rstd (R) may be NULL. */
+int sd_op_layernorm_fwd(const float *x, const float *g, const float *b, float *y, float *mean, float *rstd,
+                        long R, int d, void *stream);
+/* dx = LN backward of dy (+ dres if not NULL; dx may alias dres); dg/db accumulate (atomics). */
+int sd_op_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *g,
+                        const float *dres, float *dx, float *dg, float *db, long R, int d, void *stream);
+
+int sd_op_gelu_fwd(const float *pre, float *out, long n, void *stream);
+int sd_op_gelu_bwd(const float *dy, const float *pre, float *dpre, long n, void *stream);
+
+/* out[c] += sum over rows of src[r*row_stride + c], c < width. */
+int sd_op_colsum(const float *src, long row_stride, long rows, int width, float *out, void *stream);
+/* out[R,N] = A[R,K] B[K,N] for K <= 64 (input gradient of fc_out). */
+int sd_op_small_k_matmul(const float *A, const float *Bm, float *out, long R, int K, int N, void *stream);
+
+/* F.mse_loss(pred, target) -> loss[0]; grad (may be NULL) = 2 (pred - target) / n.
+ * scratch256d: 256 doubles of device scratch.  Deterministic. (train.py:229) */
+int sd_mse_loss(const float *pred, const float *target, float *loss, float *grad, void *scratch256d, long n,
+                void *stream);
+
+/* torch.optim.AdamW update on flat buffers (train.py:162,239), `step` = 1-based step count. */
+int sd_adamw_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, long step, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference's surface) ----
  * While enabled, every kernel launch made by this library is bracketed by a hipEvent pair
  * on the launch stream.  sd_profile_collect waits for them, returns the summed device

@@ -68,6 +68,19 @@ SIGNATURES = {
     "sd_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_patch_embed": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "sd_op_fc_out": (C.c_int, [C.c_void_p] * 5 + [c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_op_linear_strided": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+    "sd_op_attention_lse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "sd_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]),
+    "sd_op_gemm_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "sd_op_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_long, C.c_int, C.c_void_p]),
+    "sd_op_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_long, C.c_int, C.c_void_p]),
+    "sd_op_gelu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "sd_op_gelu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "sd_op_colsum": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "sd_op_small_k_matmul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "sd_mse_loss": (C.c_int, [C.c_void_p] * 5 + [C.c_long, C.c_void_p]),
+    "sd_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_double] * 5 + [C.c_long, C.c_void_p]),
     "sd_profile_enable": (C.c_int, [C.c_int]),
     "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }

@@ -1,0 +1,64 @@
+// Shared by the translation units of libsoccerdiffusion_hip.so (not part of the public ABI).
+#ifndef SD_COMMON_H
+#define SD_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SD_LN_EPS 1e-5f
+
+// error reporting (definitions in sd_kernels.hip)
+int fail(int code, const char *msg);
+
+// hipGetLastError() is sticky per thread and also reports errors left behind by other
+// users of the runtime in this process (e.g. a probe made by the host framework), so
+// every launch first clears it and then checks only its own result.
+#define SD_CHECK_LAUNCH(name)                                 \
+    do {                                                      \
+        hipError_t e_ = hipGetLastError();                    \
+        if (e_ != hipSuccess) return fail((int)e_, name);     \
+    } while (0)
+#define SD_LAUNCH(...)                    \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+
+// --------------------------------------------------------------------------------------
+// Optional per-launch timing (bench.py's roofline leg): when enabled, every kernel launch
+// is bracketed by a hipEvent pair on the launch stream, tagged with its kernel class.
+// Off by default; never enable while capturing a graph (events are created lazily).
+// --------------------------------------------------------------------------------------
+struct ProfRec { int cls; hipEvent_t a, b; };
+struct ProfScope {
+    bool on;
+    ProfRec rec;
+    hipStream_t st;
+    ProfScope(int cls, hipStream_t s);
+    ~ProfScope();
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+
+static inline unsigned grid_for(long n, int block = 256) {
+    long g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// row-panel linear layer (sd_kernels.hip): out[R,N] = act(LN?(A) W^T + bias) (+res)
+int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+           float *out, int R, int N, int d, int act, hipStream_t s, int lda = 0);
+
+#endif

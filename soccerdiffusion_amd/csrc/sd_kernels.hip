@@ -17,37 +17,14 @@
 
 #include "../../include/soccerdiffusion_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define SD_LN_EPS 1e-5f
+#include "sd_common.h"
 
 static thread_local const char *g_last_error = "ok";
-static int fail(int code, const char *msg) {
+int fail(int code, const char *msg) {
     g_last_error = msg;
     return code;
 }
-// hipGetLastError() is sticky per thread and also reports errors left behind by other
-// users of the runtime in this process (e.g. a probe made by the host framework), so
-// every launch first clears it and then checks only its own result.
-#define SD_CHECK_LAUNCH(name)                                 \
-    do {                                                      \
-        hipError_t e_ = hipGetLastError();                    \
-        if (e_ != hipSuccess) return fail((int)e_, name);     \
-    } while (0)
-#define SD_LAUNCH(...)                    \
-    do {                                  \
-        (void)hipGetLastError();          \
-        hipLaunchKernelGGL(__VA_ARGS__);  \
-    } while (0)
 
-// --------------------------------------------------------------------------------------
-// Optional per-launch timing (bench.py's roofline leg): when enabled, every kernel launch
-// is bracketed by a hipEvent pair on the launch stream, tagged with its kernel class.
-// Off by default; never enable while capturing a graph (events are created lazily).
-// --------------------------------------------------------------------------------------
-#include <vector>
-struct ProfRec { int cls; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -61,33 +38,20 @@ static hipEvent_t prof_event() {
     (void)hipEventCreate(&e);
     return e;
 }
-struct ProfScope {
-    bool on;
-    ProfRec rec;
-    hipStream_t st;
-    ProfScope(int cls, hipStream_t s) : on(g_prof_on), st(s) {
-        if (on) {
-            rec.cls = cls;
-            rec.a = prof_event();
-            rec.b = prof_event();
-            (void)hipEventRecord(rec.a, st);
-        }
+ProfScope::ProfScope(int cls, hipStream_t s) : on(g_prof_on), st(s) {
+    if (on) {
+        rec.cls = cls;
+        rec.a = prof_event();
+        rec.b = prof_event();
+        (void)hipEventRecord(rec.a, st);
     }
-    ~ProfScope() {
-        if (on) {
-            (void)hipEventRecord(rec.b, st);
-            g_prof_recs.push_back(rec);
-        }
-    }
-};
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
-
-__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(rec.b, st);
+        g_prof_recs.push_back(rec);
+    }
+}
 
 // ======================================================================================
 // Row-panel GEMM:  out[R,N] = act(LN?(A)[R,D] @ W[N,D]^T + bias) (+ res)
@@ -118,7 +82,7 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
                                                           const float *__restrict__ bias,
                                                           const float *__restrict__ ln_w,
                                                           const float *__restrict__ ln_b, const float *res,
-                                                          float *out, int R, int N) {
+                                                          float *out, int R, int N, int lda) {
     using C = PanelCfg<D>;
     extern __shared__ __attribute__((aligned(16))) float sA[];
     const int tid = threadIdx.x;
@@ -132,7 +96,7 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
         const int row = i / VEC_PER_ROW;
         const int c4 = i - row * VEC_PER_ROW;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r0 + row < R) v = *reinterpret_cast<const f32x4 *>(A + (r0 + row) * D + c4 * 4);
+        if (r0 + row < R) v = *reinterpret_cast<const f32x4 *>(A + (r0 + row) * lda + c4 * 4);
         *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v;
     }
     __syncthreads();
@@ -261,7 +225,7 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
 }
 
 template <int D>
-static int launch_panel(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
+static int launch_panel(const float *A, int lda, const float *W, const float *bias, const float *ln_w, const float *ln_b,
                         const float *res, float *out, int R, int N, int act, hipStream_t s) {
     using C = PanelCfg<D>;
     ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
@@ -275,7 +239,7 @@ static int launch_panel(const float *A, const float *W, const float *bias, const
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N);                  \
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda);                  \
     } while (0)
     const bool ln = ln_w != nullptr;
     const bool rs = res != nullptr;
@@ -291,15 +255,17 @@ static int launch_panel(const float *A, const float *W, const float *bias, const
     return 0;
 }
 
-static int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b,
-                  const float *res, float *out, int R, int N, int d, int act, hipStream_t s) {
+int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+           float *out, int R, int N, int d, int act, hipStream_t s, int lda) {
+    if (lda == 0) lda = d;
+    if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "linear: row stride must be >= d and a multiple of 4");
     if (!A || !W || !out || R <= 0 || N <= 0) return fail(SD_E_BADARG, "linear: null pointer or empty shape");
     if (N % d != 0) return fail(SD_E_BADDIM, "linear: N must be a multiple of d");
     switch (d) {
-        case 64: return launch_panel<64>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
-        case 128: return launch_panel<128>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
-        case 256: return launch_panel<256>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
-        case 512: return launch_panel<512>(A, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 64: return launch_panel<64>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 128: return launch_panel<128>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 256: return launch_panel<256>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 512: return launch_panel<512>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
     }
     return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
 }
@@ -653,7 +619,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                          const float *__restrict__ k, const float *__restrict__ v,
                                                          int ldkv, const float *__restrict__ k_extra,
                                                          const float *__restrict__ v_extra, float *__restrict__ out,
-                                                         int ldo, int Tq, int S, int heads, float scale_log2e) {
+                                                         int ldo, int Tq, int S, int heads, float scale_log2e,
+                                                         float *__restrict__ lse2) {
     using C = AttnCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sK = smem;
@@ -790,6 +757,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
             const float inv = 1.0f / l_tot;
             const int qi = q0 + l31;
+            // log2-domain log-sum-exp of the scaled scores, for the backward's P recompute
+            if (lse2 && qi < Tq && half == 0) lse2[((long)b * heads + h) * Tq + qi] = m_run * scale_log2e + log2f(l_tot);
             if (qi < Tq) {
                 float *op = out + ((long)b * Tq + qi) * ldo + h * HD;
 #pragma unroll
@@ -810,7 +779,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
 static int attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
                      const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
-                     hipStream_t s) {
+                     hipStream_t s, float *lse2 = nullptr) {
     if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || S < 0 || heads <= 0)
         return fail(SD_E_BADARG, "attention: null pointer or empty shape");
     if ((k_extra == nullptr) != (v_extra == nullptr)) return fail(SD_E_BADARG, "attention: k_extra/v_extra mismatch");
@@ -829,7 +798,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e); \
+        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e, lse2); \
     } while (0)
     switch (hd) {
         case 16: SD_ATTN(16); break;
@@ -1079,12 +1048,6 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride,
     }
 }
 
-static inline unsigned grid_for(long n, int block = 256) {
-    long g = (n + block - 1) / block;
-    if (g > 256 * 8) g = 256 * 8;
-    if (g < 1) g = 1;
-    return (unsigned)g;
-}
 
 // ======================================================================================
 // Layer drivers
@@ -1341,6 +1304,19 @@ extern "C" int sd_op_linear(const float *A, const float *W, const float *bias, c
                             const float *res, float *out, int R, int N, int d, int act, void *stream) {
     if ((ln_w == nullptr) != (ln_b == nullptr)) return fail(SD_E_BADARG, "sd_op_linear: ln_w/ln_b mismatch");
     return linear(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, (hipStream_t)stream);
+}
+
+extern "C" int sd_op_linear_strided(const float *A, int lda, const float *W, const float *bias, const float *ln_w,
+                                    const float *ln_b, const float *res, float *out, int R, int N, int d, int act,
+                                    void *stream) {
+    if ((ln_w == nullptr) != (ln_b == nullptr)) return fail(SD_E_BADARG, "sd_op_linear_strided: ln_w/ln_b mismatch");
+    return linear(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, (hipStream_t)stream, lda);
+}
+
+extern "C" int sd_op_attention_lse(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                                   int ldo, float *lse2, int B, int Tq, int S, int d, int heads, void *stream) {
+    if (!lse2) return fail(SD_E_BADARG, "sd_op_attention_lse: lse2 is required");
+    return attention(q, ldq, k, v, ldkv, nullptr, nullptr, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream, lse2);
 }
 
 extern "C" int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,

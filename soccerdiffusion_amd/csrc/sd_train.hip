@@ -1,0 +1,659 @@
+// Training-side kernels (backward of the denoiser blocks, loss, optimizer) for gfx950.
+// Interface: include/soccerdiffusion_hip.h ("training" section).  Same fragment maps and
+// conventions as sd_kernels.hip; all arithmetic fp32.
+//
+// Reference semantics: one training step of soccer_diffusion/ml/training/train.py:204-240
+// (add_noise, forward, F.mse_loss, backward, AdamW.step, OneCycleLR.step) at dropout p=0.
+
+#include <math.h>
+
+#include "../../include/soccerdiffusion_hip.h"
+#include "sd_common.h"
+
+// ======================================================================================
+// gemm_tn:  dW[N,K] += dY[R,N]^T X[R,K]   and   db[N] += sum_r dY[r,:]
+//
+// The contraction runs over the R rows, so both MFMA operands are read exactly as they lie
+// in memory (row-major, 32 consecutive columns per half-wave = one 128-B segment):
+//   A[i = n][k = row] = dY[row][n0 + lane&31],  B[k = row][j = col] = X[row][k0 + lane&31],
+// two rows per MFMA.  A workgroup owns a 128 x 128 tile of dW for a chunk of RC rows (4
+// waves, each 64 x 64), keeps the partial tile in the accumulators and adds it to dW with
+// fp32 atomics (each instruction = two 128-B row segments).  Columns past N / K and rows
+// past R read as zero.  The bias gradient falls out of the A fragments.
+// ======================================================================================
+#define TN_RC 256
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ dY, int ldy,
+                                                       const float *__restrict__ X, int ldx, float *dW, int ldw,
+                                                       float *db, long R, int N, int K) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = (K + 127) / 128;
+    const int n0 = (blockIdx.x / tiles_k) * 128 + wm * 64;
+    const int k0 = (blockIdx.x % tiles_k) * 128 + wn * 64;
+    const long rbeg = (long)blockIdx.y * TN_RC;
+    long rend = rbeg + TN_RC;
+    if (rend > R) rend = R;
+    if (n0 >= N || k0 >= K) return;  // wave-uniform: this wave's 64 x 64 block is empty
+
+    int ncol[2], kcol[2];
+    float nmask[2], kmask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 32 + l31, k = k0 + t * 32 + l31;
+        nmask[t] = n < N ? 1.f : 0.f;
+        kmask[t] = k < K ? 1.f : 0.f;
+        ncol[t] = n < N ? n : 0;
+        kcol[t] = k < K ? k : 0;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    auto load = [&](long r, float (&a)[2][4], float (&b)[2][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long row = r + 2 * j + half;
+            const bool ok = row < rend;
+            const long rr = ok ? row : rbeg;
+            const float m = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t][j] = dY[rr * ldy + ncol[t]] * (m * nmask[t]);
+                b[t][j] = X[rr * ldx + kcol[t]] * (m * kmask[t]);
+            }
+        }
+    };
+    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    load(rbeg, a0, b0);
+    for (long r = rbeg; r < rend; r += 16) {
+        load(r + 8, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                bsum[tm] += a0[tm][j];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[tm][j], b0[tn][j], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load(r + 16, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                bsum[tm] += a1[tm][j];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tm][j], b1[tn][j], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int k = k0 + tn * 32 + l31;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < N) atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r]);
+            }
+        }
+    if (db && (blockIdx.x % tiles_k) == 0 && wn == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const float v = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);
+            const int n = n0 + tm * 32 + l31;
+            if (half == 0 && n < N) atomicAdd(db + n, v);
+        }
+    }
+}
+
+extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,
+                             int N, int K, void *stream) {
+    if (!dY || !X || !dW || R <= 0 || N <= 0 || K <= 0 || ldy < N || ldx < K || ldw < K)
+        return fail(SD_E_BADARG, "sd_op_gemm_tn: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    dim3 grid(((N + 127) / 128) * ((K + 127) / 128), (unsigned)((R + TN_RC - 1) / TN_RC));
+    SD_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    SD_CHECK_LAUNCH("gemm_tn_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// LayerNorm forward (materialised, saves mean / rstd) and backward.  One wave per row.
+//   y = (x - mean) * rstd * g + b
+//   dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat))   [+ dres]
+//   dg += sum_r dy * xhat ; db += sum_r dy    (per-workgroup partials -> fp32 atomics)
+// ======================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                             const float *__restrict__ b, float *__restrict__ y,
+                                                             float *__restrict__ mean, float *__restrict__ rstd,
+                                                             long R) {
+    constexpr int PL = D / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+        float v[PL], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            v[j] = x[row * D + lane + 64 * j];
+            s += v[j];
+        }
+        const float mu = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            v[j] -= mu;
+            q += v[j] * v[j];
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + SD_LN_EPS);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            const int c = lane + 64 * j;
+            y[row * D + c] = v[j] * rs * g[c] + b[c];
+        }
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd,
+                                                             const float *__restrict__ g, const float *dres, float *dx,
+                                                             float *dg, float *db, long R) {
+    constexpr int PL = D / 64;
+    __shared__ float red[2][4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gw[PL], pg[PL], pb[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        gw[j] = g[lane + 64 * j];
+        pg[j] = 0.f;
+        pb[j] = 0.f;
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[PL], gd[PL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            const int c = lane + 64 * j;
+            const float d = dy[row * D + c];
+            xh[j] = (x[row * D + c] - mu) * rs;
+            gd[j] = d * gw[j];
+            s1 += gd[j];
+            s2 += gd[j] * xh[j];
+            pg[j] += d * xh[j];
+            pb[j] += d;
+        }
+        s1 = wave_sum(s1) * (1.0f / D);
+        s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            const int c = lane + 64 * j;
+            float v = rs * (gd[j] - s1 - xh[j] * s2);
+            if (dres) v += dres[row * D + c];
+            dx[row * D + c] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        red[0][wave][lane + 64 * j] = pg[j];
+        red[1][wave][lane + 64 * j] = pb[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dg + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(db + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+extern "C" int sd_op_layernorm_fwd(const float *x, const float *g, const float *b, float *y, float *mean, float *rstd,
+                                   long R, int d, void *stream) {
+    if (!x || !g || !b || !y || R <= 0) return fail(SD_E_BADARG, "sd_op_layernorm_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((R + 3) / 4 > 4096 ? 4096 : (R + 3) / 4)), block(256);
+    switch (d) {
+        case 64: SD_LAUNCH(layernorm_fwd_kernel<64>, grid, block, 0, s, x, g, b, y, mean, rstd, R); break;
+        case 128: SD_LAUNCH(layernorm_fwd_kernel<128>, grid, block, 0, s, x, g, b, y, mean, rstd, R); break;
+        case 256: SD_LAUNCH(layernorm_fwd_kernel<256>, grid, block, 0, s, x, g, b, y, mean, rstd, R); break;
+        case 512: SD_LAUNCH(layernorm_fwd_kernel<512>, grid, block, 0, s, x, g, b, y, mean, rstd, R); break;
+        default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    }
+    SD_CHECK_LAUNCH("layernorm_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *g,
+                                   const float *dres, float *dx, float *dg, float *db, long R, int d, void *stream) {
+    if (!dy || !x || !mean || !rstd || !g || !dx || !dg || !db || R <= 0)
+        return fail(SD_E_BADARG, "sd_op_layernorm_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((R + 3) / 4 > 1024 ? 1024 : (R + 3) / 4)), block(256);
+    switch (d) {
+        case 64: SD_LAUNCH(layernorm_bwd_kernel<64>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
+        case 128: SD_LAUNCH(layernorm_bwd_kernel<128>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
+        case 256: SD_LAUNCH(layernorm_bwd_kernel<256>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
+        case 512: SD_LAUNCH(layernorm_bwd_kernel<512>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
+        default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    }
+    SD_CHECK_LAUNCH("layernorm_bwd_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// elementwise: GELU forward / backward, MSE loss, AdamW, column sums, small-K linear
+// ======================================================================================
+__global__ void gelu_fwd_kernel(const float *__restrict__ pre, float *__restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = gelu_erf(pre[i]);
+}
+
+__global__ void gelu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ pre, float *__restrict__ dpre, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float u = pre[i];
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+        dpre[i] = dy[i] * (cdf + u * pdf);
+    }
+}
+
+extern "C" int sd_op_gelu_fwd(const float *pre, float *out, long n, void *stream) {
+    if (!pre || !out || n <= 0) return fail(SD_E_BADARG, "sd_op_gelu_fwd: bad argument");
+    SD_LAUNCH(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pre, out, n);
+    SD_CHECK_LAUNCH("gelu_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_gelu_bwd(const float *dy, const float *pre, float *dpre, long n, void *stream) {
+    if (!dy || !pre || !dpre || n <= 0) return fail(SD_E_BADARG, "sd_op_gelu_bwd: bad argument");
+    SD_LAUNCH(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, pre, dpre, n);
+    SD_CHECK_LAUNCH("gelu_bwd_kernel");
+    return 0;
+}
+
+// F.mse_loss(pred, target) (mean) and its gradient 2 (pred - target) / n  (train.py:229)
+__global__ void mse_kernel(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ grad,
+                           double *partial, long n, float scale) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        s += (double)d * d;
+        if (grad) grad[i] = d * scale;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_finish_kernel(const double *partial, int nblocks, float *loss, double inv_n) {
+    double s = 0.0;
+    for (int i = 0; i < nblocks; ++i) s += partial[i];  // fixed order: deterministic
+    loss[0] = (float)(s * inv_n);
+}
+
+extern "C" int sd_mse_loss(const float *pred, const float *target, float *loss, float *grad, void *scratch256d, long n,
+                           void *stream) {
+    if (!pred || !target || !loss || !scratch256d || n <= 0) return fail(SD_E_BADARG, "sd_mse_loss: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = grid_for(n) > 256 ? 256 : grid_for(n);
+    SD_LAUNCH(mse_kernel, dim3(nb), dim3(256), 0, s, pred, target, grad, (double *)scratch256d, n, 2.0f / (float)n);
+    SD_CHECK_LAUNCH("mse_kernel");
+    SD_LAUNCH(mse_finish_kernel, dim3(1), dim3(1), 0, s, (const double *)scratch256d, (int)nb, loss, 1.0 / (double)n);
+    SD_CHECK_LAUNCH("mse_finish_kernel");
+    return 0;
+}
+
+// torch.optim.AdamW single-tensor update order (decoupled weight decay, bias-corrected):
+//   p *= 1 - lr*wd ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2) g^2
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                             float *__restrict__ v, long n, float decay, float one_minus_b1, float b2,
+                             float one_minus_b2, float step_size, float bc2_sqrt, float eps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * decay;
+        float mi = m[i];
+        mi = mi + one_minus_b1 * (gi - mi);
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int sd_adamw_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, long step, void *stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return fail(SD_E_BADARG, "sd_adamw_step: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    SD_LAUNCH(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+              (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+              (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+    SD_CHECK_LAUNCH("adamw_kernel");
+    return 0;
+}
+
+// out[c] += sum_r src[r*row_stride + c]   (bias-like gradients over strided rows)
+__global__ void colsum_kernel(const float *__restrict__ src, long row_stride, long rows, int width, float *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) s += src[r * row_stride + c];
+    atomicAdd(out + c, s);
+}
+
+extern "C" int sd_op_colsum(const float *src, long row_stride, long rows, int width, float *out, void *stream) {
+    if (!src || !out || rows <= 0 || width <= 0) return fail(SD_E_BADARG, "sd_op_colsum: bad argument");
+    dim3 grid((width + 255) / 256, (unsigned)(rows < 64 ? rows : 64));
+    SD_LAUNCH(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, row_stride, rows, width, out);
+    SD_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+
+// out[R,N] = A[R,K] @ B[K,N] for a small contraction (K <= 64: joints): backward of fc_out
+// w.r.t. its input.  One thread per output element, A row cached in LDS.
+__global__ __launch_bounds__(256) void small_k_matmul_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
+                                                              float *__restrict__ out, long R, int K, int N) {
+    extern __shared__ float sAB[];  // [16][K] rows of A, then B [K][N]
+    float *sArow = sAB;
+    float *sB = sAB + 16 * K;
+    for (int i = threadIdx.x; i < K * N; i += 256) sB[i] = Bm[i];
+    const long r0 = (long)blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * K; i += 256) {
+        const long r = r0 + i / K;
+        sArow[i] = r < R ? A[r * K + i % K] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * N; i += 256) {
+        const int row = i / N, c = i - row * N;
+        if (r0 + row >= R) continue;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(sArow[row * K + k], sB[k * N + c], acc);
+        out[(r0 + row) * N + c] = acc;
+    }
+}
+
+extern "C" int sd_op_small_k_matmul(const float *A, const float *Bm, float *out, long R, int K, int N, void *stream) {
+    if (!A || !Bm || !out || R <= 0 || K <= 0 || K > 64 || N <= 0 || N > 512)
+        return fail(SD_E_BADARG, "sd_op_small_k_matmul: bad argument (K <= 64, N <= 512)");
+    const size_t lds = ((size_t)16 * K + (size_t)K * N) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)small_k_matmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
+    SD_LAUNCH(small_k_matmul_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), lds, (hipStream_t)stream, A, Bm, out, R, K, N);
+    SD_CHECK_LAUNCH("small_k_matmul_kernel");
+    return 0;
+}
+
+// ======================================================================================
+// Attention backward, one workgroup per (sample, head).
+//
+// Same transposed orientation as the forward: with keys on the accumulator rows and a
+// query per lane column,  P^T = exp2(K Q^T * c - lse),  dP^T = V dO^T,
+// dS^T = P^T o (dP^T - delta_q) / sqrt(hd)  are all in-lane, and  dQ^T += K^T dS^T  takes dS^T
+// straight from the accumulator as its B operand.  dV = P^T dO and dK = dS^T Q contract over
+// queries (the lane index), so the P^T / dS^T tiles of the 4 waves make one trip through
+// LDS ([32 keys][QP queries]) and each wave then owns one (dV | dK, feature tile) job.
+// Q and dO of the query pass sit in LDS row-major and serve both as B fragments of the
+// first two products (16-B reads) and of the last two (4-B reads).
+// ======================================================================================
+template <int HD>
+struct AttnBwdCfg {
+    static constexpr int QP = (HD >= 128) ? 64 : 128;   // queries per pass
+    static constexpr int KC = 64;                       // keys per LDS chunk
+    static constexpr int FT = (HD + 31) / 32;
+    static constexpr int FW = FT * 32;                  // feature width incl. zero padding
+    static constexpr int LDF = FW + 4;                  // row stride of Q / dO / K / V images
+    static constexpr int LDP = QP + 4;                  // row stride of P^T / dS^T tiles
+    static constexpr int KSTEPS = HD / 8;
+    static constexpr size_t LDS_FLOATS = (size_t)2 * QP * LDF + 2 * KC * LDF + 2 * 32 * LDP;
+    static constexpr size_t LDS_BYTES = LDS_FLOATS * sizeof(float);
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restrict__ q, int ldq,
+                                                             const float *__restrict__ k,
+                                                             const float *__restrict__ v, int ldkv,
+                                                             const float *__restrict__ o, int ldo,
+                                                             const float *__restrict__ dO, int lddo,
+                                                             const float *__restrict__ lse2, float *dq, int lddq,
+                                                             float *dk, float *dv, int lddkv, int Tq, int S, int heads,
+                                                             float scale) {
+    using C = AttnBwdCfg<HD>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sQ = smem;
+    float *sdO = sQ + C::QP * C::LDF;
+    float *sK = sdO + C::QP * C::LDF;
+    float *sV = sK + C::KC * C::LDF;
+    float *sP = sV + C::KC * C::LDF;
+    float *sdS = sP + 32 * C::LDP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const float sl2e = scale * 1.44269504088896340736f;
+    const float *qb = q + (long)b * Tq * ldq + h * HD;
+    const float *ob = o + (long)b * Tq * ldo + h * HD;
+    const float *dob = dO + (long)b * Tq * lddo + h * HD;
+    const float *kb = k + (long)b * S * ldkv + h * HD;
+    const float *vb = v + (long)b * S * ldkv + h * HD;
+    float *dqb = dq + (long)b * Tq * lddq + h * HD;
+    float *dkb = dk + (long)b * S * lddkv + h * HD;
+    float *dvb = dv + (long)b * S * lddkv + h * HD;
+    constexpr int F4 = C::FW / 4;
+
+    for (int qpass = 0; qpass < Tq; qpass += C::QP) {
+        __syncthreads();
+        // ---- stage Q and dO rows of this pass (zero rows past Tq, zero feature padding) ---
+        for (int i = tid; i < C::QP * F4; i += 256) {
+            const int row = i / F4, c4 = i - row * F4;
+            const int qi = qpass + row;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+            if (qi < Tq && c4 * 4 < HD) {
+                a = *reinterpret_cast<const f32x4 *>(qb + (long)qi * ldq + c4 * 4);
+                d = *reinterpret_cast<const f32x4 *>(dob + (long)qi * lddo + c4 * 4);
+            }
+            *reinterpret_cast<f32x4 *>(sQ + row * C::LDF + c4 * 4) = a;
+            *reinterpret_cast<f32x4 *>(sdO + row * C::LDF + c4 * 4) = d;
+        }
+        const int q0 = wave * 32;                 // this wave's queries inside the pass
+        const int qi = qpass + q0 + l31;
+        const bool wave_active = q0 < C::QP && qpass + q0 < Tq;  // wave-uniform
+        const bool q_ok = wave_active && qi < Tq;
+        // delta_q = sum_f dO[q,f] O[q,f]; lse of the query
+        float delta = 0.f, lse = 0.f;
+        if (q_ok) {
+            for (int f = half * (HD / 2); f < (half + 1) * (HD / 2); f += 4) {
+                const f32x4 ov = *reinterpret_cast<const f32x4 *>(ob + (long)qi * ldo + f);
+                const f32x4 dv4 = *reinterpret_cast<const f32x4 *>(dob + (long)qi * lddo + f);
+                delta += ov[0] * dv4[0] + ov[1] * dv4[1] + ov[2] * dv4[2] + ov[3] * dv4[3];
+            }
+            lse = lse2[((long)b * heads + h) * Tq + qi];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        f32x16 dqT[C::FT];
+#pragma unroll
+        for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqT[ft][r] = 0.f;
+        __syncthreads();
+        // Q / dO fragments of this wave's queries: B[k = feature][j = query]
+        f32x4 qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+        for (int st = 0; st < C::KSTEPS; ++st) {
+            const int row = wave_active ? q0 + l31 : 0;
+            qf[st] = *reinterpret_cast<const f32x4 *>(sQ + row * C::LDF + st * 8 + 4 * half);
+            dof[st] = *reinterpret_cast<const f32x4 *>(sdO + row * C::LDF + st * 8 + 4 * half);
+        }
+
+        for (int kc0 = 0; kc0 < S; kc0 += C::KC) {
+            __syncthreads();
+            for (int i = tid; i < C::KC * F4; i += 256) {
+                const int row = i / F4, c4 = i - row * F4;
+                const int key = kc0 + row;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+                if (key < S && c4 * 4 < HD) {
+                    a = *reinterpret_cast<const f32x4 *>(kb + (long)key * ldkv + c4 * 4);
+                    d = *reinterpret_cast<const f32x4 *>(vb + (long)key * ldkv + c4 * 4);
+                }
+                *reinterpret_cast<f32x4 *>(sK + row * C::LDF + c4 * 4) = a;
+                *reinterpret_cast<f32x4 *>(sV + row * C::LDF + c4 * 4) = d;
+            }
+            __syncthreads();
+            const int tiles = (min(S - kc0, C::KC) + 31) / 32;
+            for (int kt = 0; kt < tiles; ++kt) {
+                f32x16 pT, dsT;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pT[r] = 0.f;
+                    dsT[r] = 0.f;
+                }
+                if (wave_active) {
+                    const float *kp = sK + (kt * 32 + l31) * C::LDF + 4 * half;
+                    const float *vp = sV + (kt * 32 + l31) * C::LDF + 4 * half;
+#pragma unroll
+                    for (int st = 0; st < C::KSTEPS; ++st) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + st * 8);
+                        const f32x4 vf = *reinterpret_cast<const f32x4 *>(vp + st * 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            pT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[st][j], pT, 0, 0, 0);     // S^T
+                            dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[st][j], dsT, 0, 0, 0);  // dP^T
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kc0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const float p = (key < S && q_ok) ? exp2f(pT[r] * sl2e - lse) : 0.f;
+                        pT[r] = p;
+                        dsT[r] = p * (dsT[r] - delta) * scale;
+                    }
+                    // dQ^T += K^T dS^T : A = K^T[feature l31][key] read as K[key][feature]
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int krow = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                        for (int ft = 0; ft < C::FT; ++ft) {
+                            const float a = sK[krow * C::LDF + ft * 32 + l31];
+                            dqT[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dsT[r], dqT[ft], 0, 0, 0);
+                        }
+                    }
+                }
+                // P^T / dS^T tiles -> LDS [32 keys][QP queries]
+                if (q0 < C::QP) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int krow = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        sP[krow * C::LDP + q0 + l31] = pT[r];
+                        sdS[krow * C::LDP + q0 + l31] = dsT[r];
+                    }
+                }
+                __syncthreads();
+                // dV tile (32 keys x 32 features) = P^T dO ; dK tile = dS^T Q ; 2*FT jobs over 4 waves
+                for (int job = wave; job < 2 * C::FT; job += 4) {
+                    const bool is_dk = job >= C::FT;
+                    const int ft = is_dk ? job - C::FT : job;
+                    const float *aT = is_dk ? sdS : sP;
+                    const float *bM = is_dk ? sQ : sdO;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+                    for (int kq = 0; kq < C::QP; kq += 8) {
+                        const f32x4 af = *reinterpret_cast<const f32x4 *>(aT + l31 * C::LDP + kq + 4 * half);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float bf = bM[(kq + 4 * half + j) * C::LDF + ft * 32 + l31];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf, acc, 0, 0, 0);
+                        }
+                    }
+                    float *dst = is_dk ? dkb : dvb;
+                    const int f = ft * 32 + l31;
+                    if (f < HD) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kc0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (key < S) {
+                                float *pd = dst + (long)key * lddkv + f;
+                                // one workgroup owns this (sample, head): later query passes add in program order
+                                *pd = (qpass == 0) ? acc[r] : *pd + acc[r];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (q_ok) {
+            float *op = dqb + (long)qi * lddq;
+#pragma unroll
+            for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = ft * 32 + 8 * g + 4 * half;
+                    if (f < HD) {
+                        f32x4 t = {dqT[ft][4 * g], dqT[ft][4 * g + 1], dqT[ft][4 * g + 2], dqT[ft][4 * g + 3]};
+                        *reinterpret_cast<f32x4 *>(op + f) = t;
+                    }
+                }
+        }
+    }
+}
+
+extern "C" int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
+                                   int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
+                                   float *dv, int lddkv, int B, int Tq, int S, int d, int heads, void *stream) {
+    if (!q || !k || !v || !o || !dO || !lse2 || !dq || !dk || !dv || B <= 0 || Tq <= 0 || S <= 0 || heads <= 0)
+        return fail(SD_E_BADARG, "sd_op_attention_bwd: bad argument");
+    if (d % heads != 0) return fail(SD_E_BADDIM, "attention: d not divisible by heads");
+    const int hd = d / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(SD_KCLASS_ATTENTION, s);
+    dim3 grid(B * heads), block(256);
+#define SD_ATTNB(HD_)                                                                                            \
+    do {                                                                                                         \
+        auto kfn = attention_bwd_kernel<HD_>;                                                                    \
+        const size_t lds = AttnBwdCfg<HD_>::LDS_BYTES;                                                           \
+        static bool attr_set = false;                                                                            \
+        if (lds > 64 * 1024 && !attr_set) {                                                                      \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, o, ldo, dO, lddo, lse2, dq, lddq, dk, dv, lddkv, Tq, S, \
+                  heads, scale);                                                                                 \
+    } while (0)
+    switch (hd) {
+        case 16: SD_ATTNB(16); break;
+        case 32: SD_ATTNB(32); break;
+        case 64: SD_ATTNB(64); break;
+        case 128: SD_ATTNB(128); break;
+        default: return fail(SD_E_BADDIM, "attention: head dim must be 16, 32, 64 or 128");
+    }
+#undef SD_ATTNB
+    SD_CHECK_LAUNCH("attention_bwd_kernel");
+    return 0;
+}

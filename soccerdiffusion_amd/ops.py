@@ -366,3 +366,158 @@ def fc_out(h: Tensor, W: Tensor, b: Tensor, x_io: Optional[Tensor] = None, coef4
     check(lib.sd_op_fc_out(h.data_ptr(), W.data_ptr(), b.data_ptr(), _ptr(eps), _ptr(x_io),
                            C.cast(cbuf, _lib.c_float_p) if cbuf is not None else None, R, d, J, _stream()), "sd_op_fc_out")
     return eps
+
+
+# ---- training ops (backward of the blocks, loss, optimizer) ------------------------------
+def _rows(t: Tensor, name: str):
+    """(data_ptr, row stride) of a tensor viewed as rows of its last dim; the last dim must
+    be contiguous and all leading dims must collapse to one uniform row stride (true for
+    column slices of a packed [.., 3d] buffer)."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected a float32 tensor on the MI355X; soccerdiffusion_amd has no CPU path")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    for i in range(t.dim() - 2):
+        if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            raise ValueError(f"{name}: rows are not uniformly strided")
+    return t.data_ptr(), int(ld)
+
+
+def linear_strided(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
+                   out: Optional[Tensor] = None) -> Tensor:
+    """out[R,N] = A W^T + bias (+res) where A may be a column slice (row stride > d)."""
+    lib = _lib.load()
+    ap, lda = _rows(A, "A")
+    _req(W, "W")
+    R = A.numel() // A.shape[-1]
+    d = A.shape[-1]
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(R, N, dtype=torch.float32, device=A.device)
+    check(lib.sd_op_linear_strided(ap, lda, W.data_ptr(), _ptr(bias), None, None, _ptr(res), out.data_ptr(), R, N, d, 0,
+                                   _stream()), "sd_op_linear_strided")
+    return out
+
+
+def attention_lse(q: Tensor, k: Tensor, v: Tensor, heads: int):
+    """Forward attention that also returns lse2 (B, heads, Tq).  q (B,Tq,d), k/v (B,S,d) may be
+    column-slice views of packed buffers."""
+    lib = _lib.load()
+    qp, ldq = _rows(q, "q"); kp, ldk = _rows(k, "k"); vp, ldv = _rows(v, "v")
+    if ldk != ldv:
+        raise ValueError("k and v must share a row stride")
+    B, Tq, d = q.shape
+    S = k.shape[1]
+    out = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
+    lse = torch.empty(B, heads, Tq, dtype=torch.float32, device=q.device)
+    check(lib.sd_op_attention_lse(qp, ldq, kp, vp, ldk, out.data_ptr(), d, lse.data_ptr(), B, Tq, S, d, heads, _stream()),
+          "sd_op_attention_lse")
+    return out, lse
+
+
+def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, dO: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
+                  heads: int) -> None:
+    lib = _lib.load()
+    qp, ldq = _rows(q, "q"); kp, ldk = _rows(k, "k"); vp, ldv = _rows(v, "v")
+    op, ldo = _rows(o, "o"); dop, lddo = _rows(dO, "dO")
+    dqp, lddq = _rows(dq, "dq"); dkp, lddk = _rows(dk, "dk"); dvp, lddv = _rows(dv, "dv")
+    if ldk != ldv or lddk != lddv:
+        raise ValueError("k/v (and dk/dv) must share a row stride")
+    B, Tq, d = q.shape
+    S = k.shape[1]
+    check(lib.sd_op_attention_bwd(qp, ldq, kp, vp, ldk, op, ldo, dop, lddo, lse.data_ptr(), dqp, lddq, dkp, dvp, lddk,
+                                  B, Tq, S, d, heads, _stream()), "sd_op_attention_bwd")
+
+
+def gemm_tn(dY: Tensor, X: Tensor, dW: Tensor, db: Optional[Tensor] = None) -> None:
+    """dW[N,K] += dY[R,N]^T X[R,K]; db[N] += colsum(dY).  dY / X may be column slices."""
+    lib = _lib.load()
+    yp, ldy = _rows(dY, "dY"); xp, ldx = _rows(X, "X")
+    _req(dW, "dW")
+    N, K = dY.shape[-1], X.shape[-1]
+    R = dY.numel() // N
+    if X.numel() // K != R or tuple(dW.shape) != (N, K):
+        raise ValueError("gemm_tn: shape mismatch")
+    check(lib.sd_op_gemm_tn(yp, ldy, xp, ldx, dW.data_ptr(), K, _ptr(db), R, N, K, _stream()), "sd_op_gemm_tn")
+
+
+def layernorm_fwd(x: Tensor, g: Tensor, b: Tensor, want_stats: bool = True):
+    lib = _lib.load()
+    _req(x, "x")
+    d = x.shape[-1]
+    R = x.numel() // d
+    y = torch.empty_like(x)
+    mean = torch.empty(R, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(R, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.sd_op_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), _ptr(mean), _ptr(rstd), R, d,
+                                  _stream()), "sd_op_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, dres: Optional[Tensor] = None):
+    lib = _lib.load()
+    _req(dy, "dy"); _req(x, "x")
+    d = x.shape[-1]
+    R = x.numel() // d
+    dx = torch.empty_like(x)
+    dg = torch.zeros(d, dtype=torch.float32, device=x.device)
+    db = torch.zeros(d, dtype=torch.float32, device=x.device)
+    check(lib.sd_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), _ptr(dres),
+                                  dx.data_ptr(), dg.data_ptr(), db.data_ptr(), R, d, _stream()), "sd_op_layernorm_bwd")
+    return dx, dg, db
+
+
+def gelu_fwd(pre: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(pre, "pre")
+    out = torch.empty_like(pre)
+    check(lib.sd_op_gelu_fwd(pre.data_ptr(), out.data_ptr(), pre.numel(), _stream()), "sd_op_gelu_fwd")
+    return out
+
+
+def gelu_bwd(dy: Tensor, pre: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(dy, "dy"); _req(pre, "pre")
+    out = torch.empty_like(pre)
+    check(lib.sd_op_gelu_bwd(dy.data_ptr(), pre.data_ptr(), out.data_ptr(), pre.numel(), _stream()), "sd_op_gelu_bwd")
+    return out
+
+
+def colsum(src: Tensor, out: Tensor) -> None:
+    """out[c] += sum_r src[r, c] for a (possibly column-sliced) 2-D / 3-D src."""
+    lib = _lib.load()
+    sp, ld = _rows(src, "src")
+    width = src.shape[-1]
+    check(lib.sd_op_colsum(sp, ld, src.numel() // width, width, out.data_ptr(), _stream()), "sd_op_colsum")
+
+
+def small_k_matmul(A: Tensor, Bm: Tensor) -> Tensor:
+    lib = _lib.load()
+    _req(A, "A"); _req(Bm, "B")
+    K, N = Bm.shape
+    R = A.numel() // K
+    out = torch.empty(R, N, dtype=torch.float32, device=A.device)
+    check(lib.sd_op_small_k_matmul(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), R, K, N, _stream()), "sd_op_small_k_matmul")
+    return out
+
+
+def mse_loss(pred: Tensor, target: Tensor, want_grad: bool = True):
+    """(loss (1,), grad or None): F.mse_loss mean reduction and 2 (pred - target) / n."""
+    lib = _lib.load()
+    _req(pred, "pred"); _req(target, "target")
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    scratch = torch.empty(256, dtype=torch.float64, device=pred.device)
+    check(lib.sd_mse_loss(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _ptr(grad), scratch.data_ptr(), pred.numel(),
+                          _stream()), "sd_mse_loss")
+    return loss, grad
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+               weight_decay: float, step: int) -> None:
+    lib = _lib.load()
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, n)
+    check(lib.sd_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                            weight_decay, step, _stream()), "sd_adamw_step")

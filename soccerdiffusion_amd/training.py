@@ -1,0 +1,370 @@
+"""Training side of the hot path: forward/backward of the denoiser and the context encoders
+as autograd nodes whose every computation is a HIP kernel, the fused AdamW step on flat
+buffers, and the data-parallel gradient all-reduce.
+
+Reference semantics: one iteration of soccer_diffusion/ml/training/train.py:204-240
+(normalise, t ~ randint, eps ~ randn, add_noise, forward, F.mse_loss, backward,
+AdamW(lr).step, OneCycleLR.step) with dropout p = 0 — the reference trains with torch's
+default dropout 0.1; parity is only defined without it, and this
+implementation has no dropout.
+
+torch.autograd is used as the tape only (plumbing): each node below is one reference
+block, its forward and backward are calls into libsoccerdiffusion_hip.so.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _zeros_like_param(p: Tensor) -> Tensor:
+    return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+
+
+def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
+    """dX[R,d] = dY[R,N] @ W[N,d]: the forward panel kernel on W^T, one pass per d-wide
+    column slice of dY (N = d, 2d or 3d), accumulated through the residual input."""
+    N, d = W.shape
+    out = None
+    for p in range(N // d):
+        Wt = W[p * d : (p + 1) * d].t().contiguous()
+        out = ops.linear_strided(dy2d[:, p * d : (p + 1) * d], Wt, res=out, out=out)
+    return out
+
+
+class _LNLinear(Function):
+    """y = act(LayerNorm(x) W^T + b) — LN1+QKV, LN2+Q, LN3+FFN1(+GELU)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool):
+        x2 = x.reshape(-1, x.shape[-1])
+        pre = ops.linear(x2, W, b, ln=(ln_w, ln_b))
+        y = ops.gelu_fwd(pre) if gelu else pre
+        ctx.save_for_backward(x2, ln_w, ln_b, W, pre if gelu else None)
+        ctx.gelu = gelu
+        ctx.shape = x.shape
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ln_w, ln_b, W, pre = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dpre = ops.gelu_bwd(dy2, pre) if ctx.gelu else dy2
+        n, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b)  # recomputed, not stored
+        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        ops.gemm_tn(dpre, n, dW, db)
+        dn = _dx_through_weight(dpre, W)
+        dx, dg, dbeta = ops.layernorm_bwd(dn, x2, mean, rstd, ln_w)
+        return dx.view(ctx.shape), dg, dbeta, dW, db, None
+
+
+class _LinearRes(Function):
+    """y = res + a W^T + b — attention out-projection and FFN2 with the residual add."""
+
+    @staticmethod
+    def forward(ctx, a, W, b, res):
+        a2 = a.reshape(-1, a.shape[-1])
+        ctx.save_for_backward(a2, W)
+        ctx.shape = a.shape
+        y = ops.linear(a2, W, b, res=res.reshape(-1, W.shape[0]).contiguous())
+        return y.view(*a.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, W = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        ops.gemm_tn(dy2, a2, dW, db)
+        da = _dx_through_weight(dy2, W)
+        return da.view(ctx.shape), dW, db, dy
+
+
+class _Linear(Function):
+    """y = a W^T + b (no norm) — K/V projection of the un-normalised memory rows."""
+
+    @staticmethod
+    def forward(ctx, a, W, b):
+        a2 = a.reshape(-1, a.shape[-1]).contiguous()
+        ctx.save_for_backward(a2, W)
+        ctx.shape = a.shape
+        return ops.linear(a2, W, b).view(*a.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, W = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        ops.gemm_tn(dy2, a2, dW, db)
+        da = _dx_through_weight(dy2, W) if ctx.needs_input_grad[0] else None
+        return (da.view(ctx.shape) if da is not None else None), dW, db
+
+
+class _SelfAttention(Function):
+    """softmax(q k^T / sqrt(hd)) v on a packed (B, T, 3d) q|k|v buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads: int):
+        d = qkv.shape[-1] // 3
+        out, lse = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, out, lse = ctx.saved_tensors
+        d = qkv.shape[-1] // 3
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], out, dO.contiguous(), lse,
+                          dqkv[..., :d], dqkv[..., d : 2 * d], dqkv[..., 2 * d :], ctx.heads)
+        return dqkv, None
+
+
+class _CrossAttention(Function):
+    """Queries (B, T, d) against packed memory keys|values (B, M, 2d)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads: int):
+        d = q.shape[-1]
+        out, lse = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads)
+        ctx.save_for_backward(q, kv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, kv, out, lse = ctx.saved_tensors
+        d = q.shape[-1]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attention_bwd(q, kv[..., :d], kv[..., d:], out, dO.contiguous(), lse, dq, dkv[..., :d], dkv[..., d:], ctx.heads)
+        return dq, dkv, None
+
+
+class _PatchEmbed(Function):
+    """Conv1d(kernel = stride = p) (+ bias + positional table); p = 1 is nn.Linear(J -> d).
+    The input is data (noisy trajectory / sensor history): no input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pe):
+        ctx.save_for_backward(x, W)
+        return ops.patch_embed(x.contiguous(), W, b, pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        d = W.shape[0]
+        if W.dim() == 2:
+            patches = x.reshape(-1, x.shape[-1])
+        else:  # (d, C, p): patch rows in (c, k) order, a layout copy
+            _, C, p = W.shape
+            B, S, _ = x.shape
+            n = S // p
+            patches = x[:, : n * p].reshape(B, n, p, C).permute(0, 1, 3, 2).reshape(B * n, C * p).contiguous()
+        dW = torch.zeros(d, patches.shape[1], dtype=torch.float32, device=W.device)
+        db = torch.zeros(d, dtype=torch.float32, device=W.device)
+        ops.gemm_tn(dy.contiguous().view(-1, d), patches, dW, db)
+        return None, dW.view(W.shape), db, None
+
+
+class _FcOut(Function):
+    """eps = h W^T + b with W (J, d)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        h2 = h.reshape(-1, h.shape[-1])
+        ctx.save_for_backward(h2, W)
+        ctx.shape = h.shape
+        return ops.fc_out(h2, W, b).view(*h.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, W = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        ops.gemm_tn(dy2, h2, dW, db)
+        dh = ops.small_k_matmul(dy2, W)
+        return dh.view(ctx.shape), dW, db
+
+
+class _StepTokenFn(Function):
+    @staticmethod
+    def forward(ctx, steps, freq, token):
+        ctx.half = token.shape[-1]
+        return ops.step_token(steps, freq, token)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        dtoken = torch.zeros(1, ctx.half, dtype=torch.float32, device=dtok.device)
+        ops.colsum(dtok.contiguous()[:, 0, ctx.half :], dtoken.view(-1))  # the learned half is expanded over the batch
+        return None, None, dtoken
+
+
+class _MSELoss(Function):
+    """F.mse_loss(pred, target) with mean reduction (train.py:229)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, grad = ops.mse_loss(pred.contiguous(), target.contiguous())
+        ctx.save_for_backward(grad)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None  # gout is the scalar 1.0 of loss.backward()
+
+
+def mse_loss(pred: Tensor, target: Tensor) -> Tensor:
+    return _MSELoss.apply(pred, target)
+
+
+def step_token_autograd(step_module, steps: Tensor) -> Tensor:
+    steps = steps.contiguous()
+    if steps.dtype not in (torch.int64, torch.float32):
+        steps = steps.to(torch.float32 if steps.is_floating_point() else torch.int64)
+    return _StepTokenFn.apply(steps, step_module._freq, step_module.token)
+
+
+def _layer(lp, h, heads, memory=None, ffn_norm=None):
+    qkv = _LNLinear.apply(h, lp.norm1.weight, lp.norm1.bias, lp.self_attn.in_proj_weight, lp.self_attn.in_proj_bias, False)
+    a = _SelfAttention.apply(qkv, heads)
+    h = _LinearRes.apply(a, lp.self_attn.out_proj.weight, lp.self_attn.out_proj.bias, h)
+    if memory is not None:
+        d = h.shape[-1]
+        w, b = lp.multihead_attn.in_proj_weight, lp.multihead_attn.in_proj_bias
+        q = _LNLinear.apply(h, lp.norm2.weight, lp.norm2.bias, w[:d], b[:d], False)
+        kv = _Linear.apply(memory, w[d:], b[d:])  # memory is NOT layer-normed
+        a = _CrossAttention.apply(q, kv, heads)
+        h = _LinearRes.apply(a, lp.multihead_attn.out_proj.weight, lp.multihead_attn.out_proj.bias, h)
+    u = _LNLinear.apply(h, ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias, True)
+    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h)
+
+
+def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
+    """Differentiable DiffusionActionGenerator.forward (reference ml/model/decoder.py:38-54)."""
+    T = x.shape[1]
+    pe = gen.positional_encoding.pe[0, :T].contiguous()
+    h = _PatchEmbed.apply(x, gen.embedding.weight, gen.embedding.bias, pe)
+    memory = memory.contiguous()
+    for lp in gen.transformer_decoder.layers:
+        h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3)
+    return _FcOut.apply(h, gen.fc_out.weight, gen.fc_out.bias)
+
+
+def encoder_forward_autograd(enc, x: Tensor) -> Tensor:
+    """Differentiable BaseEncoder.forward (reference ml/model/encoder/base.py:41-53)."""
+    n = x.shape[1] // enc.patch_size
+    pe = enc.positional_encoding.pe[0, :n].contiguous()
+    h = _PatchEmbed.apply(x, enc.embedding.weight, enc.embedding.bias, pe)
+    for lp in enc.transformer_encoder.layers:
+        h = _layer(lp, h, enc.num_heads, memory=None, ffn_norm=lp.norm2)
+    return h
+
+
+# --------------------------------------------------------------------------------------
+# optimizer: torch.optim.AdamW semantics on ONE flat fp32 buffer per quantity
+# --------------------------------------------------------------------------------------
+class FusedAdamW(torch.optim.Optimizer):
+    """AdamW(lr) with torch's defaults (betas 0.9/0.999, eps 1e-8, weight_decay 1e-2) as the
+    reference constructs it (train.py:162).  Parameters, gradients and both moments live in
+    four flat buffers (parameters are re-pointed to views), so a step is one kernel launch
+    and the data-parallel gradient exchange is one all-reduce.  ``state_dict()`` has torch
+    AdamW's layout (``state[i] = {step, exp_avg, exp_avg_sq}``), so checkpoints interchange.
+    Being a torch Optimizer, ``OneCycleLR`` drives ``lr`` and ``betas[0]`` as in the reference."""
+
+    def __init__(self, params: Iterable[Tensor], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._step = 0
+        at = 0
+        for p in params:
+            k = p.numel()
+            self.flat_param[at : at + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat_param[at : at + k].view(p.shape)
+            p.grad = self.flat_grad[at : at + k].view(p.shape)
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.flat_m[at : at + k].view(p.shape),
+                             "exp_avg_sq": self.flat_v[at : at + k].view(p.shape)}
+            at += k
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        at = 0
+        for p in self.param_groups[0]["params"]:  # keep .grad aliased to the flat buffer
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * at:
+                p.grad = self.flat_grad[at : at + k].view(p.shape)
+            at += k
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._step += 1
+        ops.adamw_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], self._step)
+        for p in g["params"]:
+            self.state[p]["step"] = torch.tensor(float(self._step))
+
+    def load_state_dict(self, state_dict):
+        views = {id(p): (self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in self.param_groups[0]["params"]}
+        super().load_state_dict(state_dict)
+        steps = []
+        for p in self.param_groups[0]["params"]:
+            st = self.state[p]
+            m, v = views[id(p)]
+            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+            steps.append(int(float(st["step"])))
+        self._step = max(steps) if steps else 0
+
+
+def allreduce_gradients(optimizer: FusedAdamW, world_size: int, group=None) -> None:
+    """Data-parallel gradient exchange: ONE sum all-reduce of the flat fp32 gradient buffer
+    over RCCL/xGMI (gloo on CPU tests), then the mean.  The reference is single-device."""
+    import torch.distributed as dist
+
+    if world_size <= 1:
+        return
+    dist.all_reduce(optimizer.flat_grad, op=dist.ReduceOp.SUM, group=group)
+    optimizer.flat_grad.mul_(1.0 / world_size)
+
+
+def train_step(model, optimizer: FusedAdamW, lr_scheduler, scheduler, joint_targets: Tensor, context=None,
+               input_data=None, noise: Optional[Tensor] = None, timesteps: Optional[Tensor] = None,
+               world_size: int = 1, generator: Optional[torch.Generator] = None) -> Tensor:
+    """One iteration of the reference loop body (train.py:204-240) on already-normalised
+    targets.  ``context`` given = the --decoder-pretraining path (train.py:221-224)."""
+    B = joint_targets.shape[0]
+    dev = joint_targets.device
+    optimizer.zero_grad()
+    if timesteps is None:
+        timesteps = torch.randint(0, scheduler.config["num_train_timesteps"], (B,), device=dev, generator=generator).long()
+    if noise is None:
+        noise = torch.randn(joint_targets.shape, device=dev, generator=generator)
+    noisy = scheduler.add_noise(joint_targets, noise, timesteps)
+    if context is not None:
+        pred = model.forward_with_context(context, noisy, timesteps)
+    else:
+        pred = model(input_data, noisy, timesteps)
+    loss = mse_loss(pred, noise)
+    loss.backward()
+    allreduce_gradients(optimizer, world_size)
+    optimizer.step()
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    return loss.detach()

@@ -1,0 +1,151 @@
+"""GPU parity of the training-side single ops against torch CPU autograd of the same math."""
+
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import denoiser_ref as ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from soccerdiffusion_amd import ops as o
+
+    return o
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("R,N,K", [(1000, 256, 256), (77, 768, 256), (300, 64, 64), (513, 256, 20), (200, 20, 256), (64, 128, 200), (5, 512, 512)])
+def test_gemm_tn(ops, R, N, K):
+    dY, X = _rand(R, N, seed=1), _rand(R, K, seed=2)
+    dW = torch.zeros(N, K, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ops.gemm_tn(dY.cuda(), X.cuda(), dW, db)
+    assert rel_err(dW, dY.double().T @ X.double()) < TOL
+    assert rel_err(db, dY.double().sum(0)) < TOL
+    ops.gemm_tn(dY.cuda(), X.cuda(), dW, db)  # accumulates
+    assert rel_err(dW, 2 * (dY.double().T @ X.double())) < TOL
+
+
+def test_gemm_tn_column_slices(ops):
+    R, d = 300, 64
+    big = _rand(R, 3 * d, seed=1).cuda()
+    X = _rand(R, d, seed=2).cuda()
+    dW = torch.zeros(d, d, device="cuda")
+    ops.gemm_tn(big[:, d : 2 * d], X, dW)
+    assert rel_err(dW, big[:, d : 2 * d].double().cpu().T @ X.double().cpu()) < TOL
+
+
+@pytest.mark.parametrize("d", [64, 128, 256, 512])
+def test_layernorm_fwd_bwd(ops, d):
+    R = 333
+    x = _rand(R, d, seed=1).requires_grad_(True)
+    g = (1 + _rand(d, seed=2, scale=0.1)).requires_grad_(True)
+    b = _rand(d, seed=3, scale=0.1).requires_grad_(True)
+    dy = _rand(R, d, seed=4)
+    dres = _rand(R, d, seed=5)
+    y = ref.layer_norm(x, g, b)
+    y.backward(dy)
+    yg, mean, rstd = ops.layernorm_fwd(x.detach().cuda(), g.detach().cuda(), b.detach().cuda())
+    assert rel_err(yg, y) < 1e-6
+    dx, dg, db = ops.layernorm_bwd(dy.cuda(), x.detach().cuda(), mean, rstd, g.detach().cuda(), dres=dres.cuda())
+    assert rel_err(dx, x.grad + dres) < TOL
+    assert rel_err(dg, g.grad) < TOL and rel_err(db, b.grad) < TOL
+
+
+def test_gelu_fwd_bwd(ops):
+    u = _rand(10000, seed=1, scale=2.0).requires_grad_(True)
+    dy = _rand(10000, seed=2)
+    y = ref.gelu_erf(u)
+    y.backward(dy)
+    assert rel_err(ops.gelu_fwd(u.detach().cuda()), y) < 1e-6
+    assert rel_err(ops.gelu_bwd(dy.cuda(), u.detach().cuda()), u.grad) < 1e-5
+
+
+@pytest.mark.parametrize("d,heads", [(64, 4), (128, 4), (256, 4), (512, 4)])
+@pytest.mark.parametrize("Tq,S", [(16, 16), (100, 100), (10, 31), (100, 11), (130, 70), (7, 312)])
+def test_attention_bwd(ops, d, heads, Tq, S):
+    B = 2
+    q = _rand(B, Tq, d, seed=1).requires_grad_(True)
+    k = _rand(B, S, d, seed=2).requires_grad_(True)
+    v = _rand(B, S, d, seed=3).requires_grad_(True)
+    dO = _rand(B, Tq, d, seed=4)
+    out = ref.attention(q, k, v, heads)
+    out.backward(dO)
+    qg, kg, vg = q.detach().cuda(), k.detach().cuda(), v.detach().cuda()
+    og, lse = ops.attention_lse(qg, kg, vg, heads)
+    assert rel_err(og, out) < TOL
+    dq, dk, dv = torch.empty_like(qg), torch.full_like(kg, float("nan")), torch.full_like(vg, float("nan"))
+    ops.attention_bwd(qg, kg, vg, og, dO.cuda(), lse, dq, dk, dv, heads)
+    assert rel_err(dq, q.grad) < TOL
+    assert rel_err(dk, k.grad) < TOL
+    assert rel_err(dv, v.grad) < TOL
+
+
+def test_attention_bwd_packed_qkv(ops):
+    """q, k, v (and their gradients) as column slices of one packed (B, T, 3d) buffer."""
+    B, T, d, heads = 3, 100, 256, 4
+    qkv = _rand(B, T, 3 * d, seed=1)
+    q, k, v = [t.clone().requires_grad_(True) for t in qkv.split(d, dim=-1)]
+    dO = _rand(B, T, d, seed=2)
+    ref.attention(q, k, v, heads).backward(dO)
+    g = qkv.cuda()
+    og, lse = ops.attention_lse(g[..., :d], g[..., d : 2 * d], g[..., 2 * d :], heads)
+    dqkv = torch.empty_like(g)
+    ops.attention_bwd(g[..., :d], g[..., d : 2 * d], g[..., 2 * d :], og, dO.cuda(), lse, dqkv[..., :d], dqkv[..., d : 2 * d],
+                      dqkv[..., 2 * d :], heads)
+    assert rel_err(dqkv, torch.cat([q.grad, k.grad, v.grad], -1)) < TOL
+
+
+def test_linear_strided_accumulates_slices(ops):
+    R, d = 200, 128
+    dY = _rand(R, 3 * d, seed=1)
+    W = _rand(3 * d, d, seed=2, scale=1 / math.sqrt(d))
+    want = dY @ W  # dX = dY W
+    g = dY.cuda()
+    out = None
+    for p in range(3):
+        Wt = W[p * d : (p + 1) * d].t().contiguous().cuda()
+        out = ops.linear_strided(g[:, p * d : (p + 1) * d], Wt, res=out, out=out)
+    assert rel_err(out, want) < TOL
+
+
+def test_small_k_matmul_and_colsum(ops):
+    A, Bm = _rand(1000, 20, seed=1), _rand(20, 256, seed=2)
+    assert rel_err(ops.small_k_matmul(A.cuda(), Bm.cuda()), A @ Bm) < 1e-5
+    src = _rand(50, 11, 256, seed=3).cuda()
+    out = torch.zeros(128, device="cuda")
+    ops.colsum(src[:, -1, 128:], out)
+    assert rel_err(out, src[:, -1, 128:].double().cpu().sum(0)) < 1e-5
+
+
+def test_mse_loss(ops):
+    a, b = _rand(256, 100, 20, seed=1), _rand(256, 100, 20, seed=2)
+    loss, grad = ops.mse_loss(a.cuda(), b.cuda())
+    want = torch.nn.functional.mse_loss(a.double(), b.double())
+    assert abs(float(loss) - float(want)) / float(want) < 1e-6
+    assert rel_err(grad, 2 * (a - b) / a.numel()) < 1e-6
+
+
+def test_adamw_matches_torch(ops):
+    n = 10007
+    p0, g = _rand(n, seed=1), _rand(n, seed=2, scale=0.01)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    pg, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        p.grad = g * step
+        opt.step()
+        ops.adamw_step(pg, (g * step).cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+    assert rel_err(pg, p.detach()) < 1e-6
+    st = opt.state[p]
+    assert rel_err(m, st["exp_avg"]) < 1e-6 and rel_err(v, st["exp_avg_sq"]) < 1e-6

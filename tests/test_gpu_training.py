@@ -1,0 +1,174 @@
+"""GPU parity of the training step: loss and EVERY parameter gradient against the values the
+reference itself produced (tests/golden, dropout p=0), the fused AdamW + OneCycleLR
+trajectory against torch's own optimizers, and checkpoint interchange."""
+
+import io
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ddim_ref
+from oracle import denoiser_ref as ref
+from test_gpu_model import _build
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check_grads(model, golden_grads):
+    named = dict(model.named_parameters())
+    assert set(golden_grads) == {k for k, p in named.items() if p.grad is not None}
+    scale = max(float(g.norm()) for g in golden_grads.values())
+    worst = 0.0
+    for k, g in golden_grads.items():
+        got = named[k].grad.detach().cpu()
+        err = float((got.double() - g.double()).norm())
+        # relative to the gradient's own norm, with a floor for gradients that are ~0 by
+        # construction (key bias of softmax attention)
+        rel = err / max(float(g.norm()), 1e-3 * scale)
+        worst = max(worst, rel)
+        assert rel < TOL, (k, rel)
+    return worst
+
+
+def test_decoder_pretraining_step_gradients_golden(g1):
+    from soccerdiffusion_amd import training
+
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    m.train()
+    tr = g1["train"]
+    pred = m.forward_with_context([g1["ctx"].cuda()], g1["x"].cuda(), g1["steps_int"].cuda())
+    loss = training.mse_loss(pred, tr["noise"].cuda())
+    assert rel_err(pred, tr["pred"]) < TOL
+    assert abs(float(loss) - float(tr["loss"])) / float(tr["loss"]) < 1e-5
+    loss.backward()
+    _check_grads(m, tr["grads"])
+
+
+def test_full_model_step_gradients_golden(g2):
+    from soccerdiffusion_amd import training
+
+    m = _build(g2["config"], full=True).cuda()
+    m.load_state_dict(g2["state_dict"])
+    m.train()
+    tr = g2["train"]
+    inp = {k: v.cuda() for k, v in g2["input_data"].items()}
+    pred = m(inp, g2["x"].cuda(), g2["steps"].cuda())
+    loss = training.mse_loss(pred, tr["noise"].cuda())
+    assert rel_err(pred, tr["pred"]) < TOL
+    loss.backward()
+    _check_grads(m, tr["grads"])
+
+
+def test_c2_shape_gradients_vs_oracle():
+    """BASELINE config 2 shape (d=256, L=4, T=100, M=11), small batch, vs CPU autograd of the oracle."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.synthetic import synthetic_state_dict
+
+    c = dict(d=256, J=20, L=4, T=100)
+    sd = synthetic_state_dict(256, 20, 4, seed=5)
+    m = _build(c, full=False).cuda()
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    B = 3
+    x0, eps = torch.randn(B, 100, 20, generator=g), torch.randn(B, 100, 20, generator=g)
+    ctx = torch.randn(B, 10, 256, generator=g)
+    t = torch.tensor([980, 500, 3])
+    acp = ddim_ref.alphas_cumprod()
+    x_t = ddim_ref.add_noise(x0, eps, t, acp)
+    _, want_loss, want = ref.train_loss_and_grads(sd, x_t, t, eps, context=[ctx])
+    pred = m.forward_with_context([ctx.cuda()], x_t.cuda(), t.cuda())
+    loss = training.mse_loss(pred, eps.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(want_loss)) / float(want_loss) < 1e-5
+    _check_grads(m, want)
+
+
+def test_fused_adamw_onecycle_matches_torch(g1):
+    """5 optimisation steps: GPU (HIP fwd/bwd + fused AdamW) vs CPU (oracle autograd + torch AdamW), same OneCycleLR."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    m.train()
+    opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=20)
+    noise_sched = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+
+    cpu = {k: v.clone() for k, v in g1["state_dict"].items()}
+    cpu_params = {k: torch.nn.Parameter(v.clone()) for k, v in cpu.items() if v.is_floating_point() and k not in ("mean", "std")}
+    copt = torch.optim.AdamW(list(cpu_params.values()), lr=1e-3)
+    csched = torch.optim.lr_scheduler.OneCycleLR(copt, max_lr=1e-3, total_steps=20)
+    acp = ddim_ref.alphas_cumprod()
+    g = torch.Generator().manual_seed(0)
+    for it in range(5):
+        x0, eps = torch.randn(2, 16, 20, generator=g), torch.randn(2, 16, 20, generator=g)
+        t = torch.randint(0, 1000, (2,), generator=g)
+        loss = training.train_step(m, opt, sched, noise_sched, x0.cuda(), context=[g1["ctx"].cuda()], noise=eps.cuda(),
+                                   timesteps=t.cuda())
+        sd_now = {**cpu, **{k: p.detach() for k, p in cpu_params.items()}}
+        _, closs, grads = ref.train_loss_and_grads(sd_now, ddim_ref.add_noise(x0, eps, t, acp), t, eps, context=[g1["ctx"]])
+        copt.zero_grad()
+        for k, p in cpu_params.items():
+            p.grad = grads.get(k, torch.zeros_like(p))
+        copt.step()
+        csched.step()
+        assert abs(float(loss) - float(closs)) / float(closs) < 1e-4, it
+        assert abs(opt.param_groups[0]["lr"] - copt.param_groups[0]["lr"]) < 1e-12
+        assert opt.param_groups[0]["betas"][0] == copt.param_groups[0]["betas"][0]  # cycle_momentum
+    have = dict(m.named_parameters())
+    d = g1["config"]["d"]
+    for k, p in cpu_params.items():
+        a, b = have[k].detach().cpu(), p.detach()
+        if k.endswith("in_proj_bias"):
+            # the key bias has an exactly-zero true gradient (softmax is shift invariant per query), so
+            # Adam's m/sqrt(v) turns pure rounding noise into O(lr) steps there, on any implementation
+            a, b = torch.cat([a[:d], a[2 * d :]]), torch.cat([b[:d], b[2 * d :]])
+        assert rel_err(a, b) < 1e-4, k
+
+
+def test_checkpoint_dict_interchange(g1, tmp_path):
+    """The checkpoint dictionary of train.py:243-250 round-trips, and torch's own AdamW /
+    OneCycleLR accept the optimizer and lr-scheduler entries."""
+    from soccerdiffusion_amd import training
+
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    m.train()
+    opt = training.FusedAdamW(m.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=10)
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    for _ in range(2):
+        training.train_step(m, opt, sched, ns, g1["x"].cuda(), context=[g1["ctx"].cuda()])
+    ckpt = {"model_state_dict": m.state_dict(), "optimizer_state_dict": opt.state_dict(),
+            "lr_scheduler_state_dict": sched.state_dict(), "hyperparams": {"hidden_dim": 64, "num_joints": 20},
+            "current_epoch": 0}
+    path = tmp_path / "ckpt.pth"
+    torch.save(ckpt, path)
+    back = torch.load(path, weights_only=True)  # the reference always loads with weights_only=True
+    assert set(back) == {"model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "hyperparams", "current_epoch"}
+    # torch's AdamW on a same-shaped model accepts the optimizer state
+    m2 = _build(g1["config"], full=False)
+    m2.load_state_dict(back["model_state_dict"])
+    topt = torch.optim.AdamW(m2.parameters(), lr=1e-4)
+    topt.load_state_dict(back["optimizer_state_dict"])
+    first = next(iter(topt.state.values()))
+    assert set(first) >= {"step", "exp_avg", "exp_avg_sq"} and float(first["step"]) == 2.0
+    # and our optimizer resumes from it
+    m3 = _build(g1["config"], full=False).cuda()
+    m3.load_state_dict(back["model_state_dict"])
+    opt3 = training.FusedAdamW(m3.parameters(), lr=1e-4)
+    opt3.load_state_dict(back["optimizer_state_dict"])
+    assert opt3._step == 2
+    assert rel_err(opt3.flat_m, opt.flat_m) < 1e-7 and rel_err(opt3.flat_v, opt.flat_v) < 1e-7
+    l1 = training.train_step(m, opt, None, ns, g1["x"].cuda(), context=[g1["ctx"].cuda()], noise=g1["train"]["noise"].cuda(),
+                             timesteps=g1["steps_int"].cuda())
+    l3 = training.train_step(m3, opt3, None, ns, g1["x"].cuda(), context=[g1["ctx"].cuda()], noise=g1["train"]["noise"].cuda(),
+                             timesteps=g1["steps_int"].cuda())
+    assert abs(float(l1) - float(l3)) < 1e-6
+    assert rel_err(opt3.flat_param, opt.flat_param) < 1e-6
