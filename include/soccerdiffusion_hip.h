@@ -131,6 +131,11 @@ int sd_ddim_add_noise(const float *x0, const float *noise, const int64_t *t, con
 int sd_ddim_step(const float *eps, const float *x, float *x_prev, float sqrt_a_t, float sqrt_1m_a_t,
                  float sqrt_a_prev, float sqrt_1m_a_prev, long n, void *stream);
 
+/* Normalizer.normalize (inverse = 0: (x - mean) / std) and .denormalize (inverse = 1:
+ * x * std + mean), per joint — soccer_diffusion/dataset/pytorch.py:410-414.  n = rows * J. */
+int sd_normalize(const float *x, const float *mean, const float *stdv, float *out, long n, int J, int inverse,
+                 void *stream);
+
 /* The iterated sampler — reference loops soccer_diffusion/ml/inference/plot.py:122-131,
  * ml/training/distill.py:179-189, ml/inference/ros.py:301-310: for every t in timesteps:
  * eps = forward_with_context(ctx, x, t); x = scheduler.step(eps, t, x).prev_sample.

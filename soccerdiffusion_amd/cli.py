@@ -1,0 +1,265 @@
+"""`train` and `sample` entry points with the flags, YAML schema and checkpoint dictionary of
+the reference's scripts (soccer_diffusion/ml/training/train.py:26-253,
+soccer_diffusion/ml/inference/plot.py:21-135).
+
+    python -m soccerdiffusion_amd.cli train -c cfg.yaml [-p ckpt] [-o out] [--decoder-pretraining] [--pretrained-decoder p]
+    python -m soccerdiffusion_amd.cli sample ckpt [--steps 30] [--num_samples 10]
+
+Differences, all additive: data comes from a tensor file (`--data file.pt`: dict with
+`joint_command` (N,T,J) and the optional context keys of the reference's `Result`
+dataclass) or from a synthetic sine-wave generator (`--synthetic N`; the SQLite dataset is
+SURVEY §8 f3, not this round); wandb and matplotlib are not used; under torchrun
+(WORLD_SIZE > 1) training is data parallel with one RCCL all-reduce of the flat gradient
+per step and `sample` shards the rollouts over the ranks.
+"""
+
+from __future__ import annotations
+
+import argparse
+import logging
+import math
+import os
+import sys
+from typing import Optional
+
+import torch
+import yaml
+
+logger = logging.getLogger("soccerdiffusion_amd")
+
+CONTEXT_KEYS = ("joint_command_history", "rotation", "joint_state", "game_state")
+
+
+def build_model(params: dict):
+    """End2EndDiffusionTransformer(**hyperparams) exactly as train.py:113-139 / plot.py:38-64 do."""
+    from .ml.model import End2EndDiffusionTransformer
+    from .ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from .ml.model.encoder.imu import IMUEncoder
+
+    return End2EndDiffusionTransformer(
+        num_joints=params["num_joints"],
+        hidden_dim=params["hidden_dim"],
+        use_action_history=params["use_action_history"],
+        num_action_history_encoder_layers=params["num_action_history_encoder_layers"],
+        max_action_context_length=params["action_context_length"],
+        use_imu=params["use_imu"],
+        imu_orientation_embedding_method=IMUEncoder.OrientationEmbeddingMethod(params["imu_orientation_embedding_method"]),
+        num_imu_encoder_layers=params["num_imu_encoder_layers"],
+        imu_context_length=params["imu_context_length"],
+        use_joint_states=params["use_joint_states"],
+        joint_state_encoder_layers=params["joint_state_encoder_layers"],
+        joint_state_context_length=params["joint_state_context_length"],
+        use_images=params["use_images"],
+        image_sequence_encoder_type=SequenceEncoderType(params["image_sequence_encoder_type"]),
+        image_encoder_type=ImageEncoderType(params["image_encoder_type"]),
+        num_image_sequence_encoder_layers=params["num_image_sequence_encoder_layers"],
+        image_context_length=params["image_context_length"],
+        image_use_final_avgpool=params.get("image_use_final_avgpool", True),
+        image_resolution=params.get("image_resolution", 480),
+        num_decoder_layers=params["num_decoder_layers"],
+        trajectory_prediction_length=params["trajectory_prediction_length"],
+        use_gamestate=params["use_gamestate"],
+        encoder_patch_size=params["encoder_patch_size"],
+    )
+
+
+def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
+    """Sine-wave joints around pi (the reference stores angles in [0, 2pi)), random unit
+    quaternions, random game states — shaped like the reference's `Result` fields."""
+    g = torch.Generator().manual_seed(seed)
+    J, T = params["num_joints"], params["trajectory_prediction_length"]
+    Ha, Hi, Hj = params["action_context_length"], params["imu_context_length"], params["joint_state_context_length"]
+    total = Ha + T
+    phase = torch.rand(n, 1, J, generator=g) * 2 * math.pi
+    freq = 0.5 + torch.rand(n, 1, J, generator=g)
+    t = torch.arange(total).view(1, total, 1) / 50.0
+    wave = math.pi + torch.sin(2 * math.pi * freq * t + phase)
+    quat = torch.randn(n, Hi, 4, generator=g)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    feat = 5 if params["imu_orientation_embedding_method"] == "five_dim" else 4
+    rot = quat if feat == 4 else torch.cat([quat[..., :3], torch.sin(quat[..., 3:]), torch.cos(quat[..., 3:])], -1)
+    return {
+        "joint_command": wave[:, Ha:].contiguous(),
+        "joint_command_history": wave[:, :Ha].contiguous(),
+        "joint_state": (wave[:, Ha - Hj : Ha] + 0.01 * torch.randn(n, Hj, J, generator=g)).contiguous(),
+        "rotation": rot.contiguous(),
+        "game_state": torch.randint(0, 4, (n,), generator=g),
+    }
+
+
+def load_data(args, params: dict) -> dict:
+    if args.data:
+        data = torch.load(args.data, map_location="cpu", weights_only=True)
+        if "joint_command" not in data:
+            raise SystemExit("--data file must hold a dict with a 'joint_command' (N, T, J) tensor")
+        return data
+    return synthetic_dataset(args.synthetic, params, seed=args.seed)
+
+
+def fit_normalizer(joint_command: torch.Tensor, n_samples: int, generator) -> tuple[torch.Tensor, torch.Tensor]:
+    """Normalizer.fit over `num_normalization_samples` random samples: per-joint mean and
+    UNBIASED std over all (sample, time) rows (train.py:108-110, dataset/pytorch.py:406-408)."""
+    idx = torch.randint(0, joint_command.shape[0], (n_samples,), generator=generator)
+    rows = joint_command[idx].reshape(-1, joint_command.shape[-1])
+    return rows.mean(dim=0), rows.std(dim=0)
+
+
+def _dist_env():
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    return rank, world, local
+
+
+def cmd_train(args) -> int:
+    assert args.config is not None or args.checkpoint is not None, "Either a config file or a checkpoint must be provided"
+    from . import ops, training
+    from .scheduler import DDIMScheduler
+
+    rank, world, local = _dist_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    checkpoint = None
+    params: dict = {}
+    if args.checkpoint is not None:
+        checkpoint = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
+        params = dict(checkpoint["hyperparams"])
+    if args.config is not None:
+        with open(args.config) as f:
+            config_params = yaml.safe_load(f)
+        for key, value in config_params.items():  # the YAML wins; differences are warned (train.py:57-70)
+            if key in params and params[key] != value:
+                logger.warning("parameter %s differs: checkpoint %r, config %r (using the config)", key, params[key], value)
+            params[key] = value
+    if params["train_denoising_timesteps"] != 1000:
+        raise SystemExit("train_denoising_timesteps must be 1000 (the scheduler table length; see scheduler.py)")
+
+    gen = torch.Generator().manual_seed(args.seed + rank)
+    data = load_data(args, params)
+    n_total = data["joint_command"].shape[0]
+    mean, std = fit_normalizer(data["joint_command"], params["num_normalization_samples"], torch.Generator().manual_seed(args.seed))
+
+    model = build_model(params).to(device)
+    model.mean.copy_(mean)
+    model.std.copy_(std)
+    if checkpoint is not None:
+        model.load_state_dict(checkpoint["model_state_dict"])
+    if args.pretrained_decoder is not None:
+        pre = torch.load(args.pretrained_decoder, map_location="cpu", weights_only=True)
+        model.load_state_dict(pre["model_state_dict"], strict=False)
+    model.train()
+
+    optimizer = training.FusedAdamW(model.parameters(), lr=params["lr"])
+    if checkpoint is not None and "optimizer_state_dict" in checkpoint:
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    bs = params["batch_size"]
+    shard = torch.arange(rank, n_total, world)  # each rank owns every world-th sample
+    steps_per_epoch = max(1, math.ceil(len(shard) / bs))
+    lr_scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=params["lr"], total_steps=params["epochs"] * steps_per_epoch)
+    scheduler = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    scheduler.config["num_train_timesteps"] = params["train_denoising_timesteps"]
+
+    on_device = {k: v.to(device) for k, v in data.items()}
+    dev_gen = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
+    for epoch in range(params["epochs"]):
+        order = shard[torch.randperm(len(shard), generator=gen)]
+        for i in range(steps_per_epoch):
+            idx = order[i * bs : (i + 1) * bs].to(device)
+            if world > 1 and len(idx) < bs and i > 0:
+                continue  # keep ranks in lock step: a short last batch would desynchronise the all-reduce
+            batch = {k: v[idx] for k, v in on_device.items()}
+            targets = ops.normalize(batch["joint_command"].contiguous(), model.mean, model.std)
+            if args.decoder_pretraining:
+                ctx = [torch.randn((len(idx), 10, params["hidden_dim"]), device=device, generator=dev_gen)]
+                loss = training.train_step(model, optimizer, lr_scheduler, scheduler, targets, context=ctx,
+                                           world_size=world, generator=dev_gen)
+            else:
+                inp = {k: batch[k].contiguous() for k in CONTEXT_KEYS if k in batch}
+                loss = training.train_step(model, optimizer, lr_scheduler, scheduler, targets, input_data=inp,
+                                           world_size=world, generator=dev_gen)
+            if i % 20 == 0 and rank == 0:
+                print(f"Epoch {epoch}, it {i}, Loss: {float(loss):.05f}, LR: {lr_scheduler.get_last_lr()[0]:0.7f}", flush=True)
+        if rank == 0:
+            torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "hyperparams": params,
+                        "current_epoch": epoch}, args.output)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def cmd_sample(args) -> int:
+    from . import ops
+
+    rank, world, local = _dist_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    checkpoint = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
+    params = checkpoint["hyperparams"]
+    model = build_model(params).to(device)
+    model.load_state_dict(checkpoint["model_state_dict"])
+    model.eval()
+    n = args.num_samples
+    mine = torch.arange(rank, n, world)  # embarrassingly parallel over ranks, no collective
+    data = load_data(args, params) if (args.data or params_need_context(params)) else {}
+    gen = torch.Generator(device=device).manual_seed(args.seed + rank)
+    B = len(mine)
+    if B == 0:
+        return 0
+    x_T = torch.randn(B, params["trajectory_prediction_length"], params["num_joints"], device=device, generator=gen)
+    with torch.no_grad():
+        if params_need_context(params):
+            idx = (mine % data["joint_command"].shape[0]).to(device)
+            inp = {k: data[k].to(device)[idx].contiguous() for k in CONTEXT_KEYS if k in data}
+            context = model.encode_input_data(inp)
+        else:
+            context = [torch.randn(B, 10, params["hidden_dim"], device=device, generator=gen)]
+        if params.get("distilled_decoder", False):  # single forward at t = 0 (plot.py:118-121)
+            traj = model.forward_with_context(context, x_T, torch.zeros(B, device=device))
+        else:
+            traj = model.sample(context, x_T, args.steps)
+        traj = ops.normalize(traj.contiguous(), model.mean, model.std, inverse=True)
+    out = args.output if world == 1 else f"{args.output}.rank{rank}"
+    torch.save({"trajectories": traj.cpu(), "noise": x_T.cpu(), "steps": args.steps, "indices": mine}, out)
+    if rank == 0:
+        print(f"sampled {n} trajectories of shape {tuple(traj.shape[1:])} with {args.steps} DDIM steps -> {args.output}")
+    return 0
+
+
+def params_need_context(params: dict) -> bool:
+    return any(params.get(k, False) for k in ("use_action_history", "use_imu", "use_joint_states", "use_gamestate"))
+
+
+def main(argv: Optional[list] = None) -> int:
+    logging.basicConfig(level=os.environ.get("LOGLEVEL", "INFO"))
+    ap = argparse.ArgumentParser(prog="cli", description="SoccerDiffusion denoiser on MI355X: train / sample")
+    sub = ap.add_subparsers(dest="command", required=True)
+    tr = sub.add_parser("train", help="train the model (flags of the reference's train.py)")
+    tr.add_argument("--config", "-c", type=str, default=None, help="Path to the configuration file")
+    tr.add_argument("--checkpoint", "-p", type=str, default=None, help="Path to the checkpoint to load")
+    tr.add_argument("--output", "-o", type=str, default="trajectory_transformer_model.pth", help="Path to save the model")
+    tr.add_argument("--decoder-pretraining", action="store_true", help="Train the decoder only, on random context")
+    tr.add_argument("--pretrained-decoder", type=str, default=None, help="Checkpoint whose decoder weights are loaded (strict=False)")
+    sa = sub.add_parser("sample", help="sample trajectories from a checkpoint (flags of the reference's plot.py)")
+    sa.add_argument("checkpoint", type=str, help="Path to the checkpoint to load")
+    sa.add_argument("--steps", type=int, default=30, help="Number of denoising steps")
+    sa.add_argument("--num_samples", type=int, default=10, help="Number of samples to generate")
+    sa.add_argument("--output", "-o", type=str, default="samples.pt", help="Where to save the sampled trajectories")
+    for p in (tr, sa):
+        p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
+        p.add_argument("--synthetic", type=int, default=2048, help="number of synthetic sine-wave samples when --data is absent")
+        p.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("soccerdiffusion_amd needs an MI355X (no CPU fallback)")
+    return cmd_train(args) if args.command == "train" else cmd_sample(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

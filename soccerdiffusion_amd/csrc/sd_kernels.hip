@@ -1038,6 +1038,15 @@ __global__ void ddim_step_kernel(const float *__restrict__ eps, const float *x, 
     }
 }
 
+// Normalizer.normalize / denormalize (reference dataset/pytorch.py:410-414): per-joint affine
+__global__ void normalize_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                 const float *__restrict__ stdv, float *__restrict__ out, long n, int J, int inverse) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % J);
+        out[i] = inverse ? x[i] * stdv[j] + mean[j] : (x[i] - mean[j]) / stdv[j];
+    }
+}
+
 __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride, float *dst, long dst_stride,
                                  long rows, int width) {
     const long n = rows * width;
@@ -1297,6 +1306,14 @@ extern "C" int sd_ddim_step(const float *eps, const float *x, float *x_prev, flo
     SD_LAUNCH(ddim_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps, x, x_prev, sqrt_a_t,
                        sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, n);
     SD_CHECK_LAUNCH("ddim_step_kernel");
+    return 0;
+}
+
+extern "C" int sd_normalize(const float *x, const float *mean, const float *stdv, float *out, long n, int J, int inverse,
+                            void *stream) {
+    if (!x || !mean || !stdv || !out || n <= 0 || J <= 0) return fail(SD_E_BADARG, "sd_normalize: bad argument");
+    SD_LAUNCH(normalize_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, out, n, J, inverse);
+    SD_CHECK_LAUNCH("normalize_kernel");
     return 0;
 }
 

@@ -264,6 +264,16 @@ def game_state_embed(idx: Tensor, table: Tensor) -> Tensor:
     return out
 
 
+def normalize(x: Tensor, mean: Tensor, std: Tensor, inverse: bool = False) -> Tensor:
+    """Normalizer.normalize / denormalize (reference dataset/pytorch.py:410-414), last dim = joints."""
+    lib = _lib.load()
+    _req(x, "x"); _req(mean, "mean"); _req(std, "std")
+    out = torch.empty_like(x)
+    check(lib.sd_normalize(x.data_ptr(), mean.data_ptr(), std.data_ptr(), out.data_ptr(), x.numel(), x.shape[-1],
+                           int(inverse), _stream()), "sd_normalize")
+    return out
+
+
 def ddim_add_noise(x0: Tensor, noise: Tensor, t: Tensor, acp: Tensor) -> Tensor:
     """scheduler.add_noise (reference call site ml/training/train.py:218)."""
     lib = _lib.load()

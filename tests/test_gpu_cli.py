@@ -1,0 +1,71 @@
+"""End-to-end through the `cli train` / `cli sample` entry points on the GPU (BASELINE config 1 shape)."""
+
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import yaml
+
+from conftest import REPO, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(hidden_dim=64, action_context_length=20, trajectory_prediction_length=16, epochs=2, batch_size=32, lr=1e-3,
+           train_denoising_timesteps=1000, image_context_length=0, imu_context_length=20, num_imu_encoder_layers=1,
+           joint_state_context_length=20, num_normalization_samples=100, num_joints=20, use_action_history=True,
+           num_action_history_encoder_layers=1, use_imu=True, imu_orientation_embedding_method="quaternion",
+           use_joint_states=True, joint_state_encoder_layers=1, use_images=False, image_sequence_encoder_type="transformer",
+           image_encoder_type="resnet18", num_image_sequence_encoder_layers=1, num_decoder_layers=2,
+           distill_teacher_inference_steps=30, use_gamestate=True, encoder_patch_size=5)
+
+
+def _run(*argv):
+    env = dict(os.environ, PYTHONPATH=REPO)
+    return subprocess.run([sys.executable, "-m", "soccerdiffusion_amd.cli", *argv], cwd=REPO, env=env, capture_output=True, text=True)
+
+
+def test_train_then_sample_full_model(tmp_path):
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump(CFG))
+    ckpt = tmp_path / "model.pth"
+    r = _run("train", "-c", str(cfg), "-o", str(ckpt), "--synthetic", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert len(losses) >= 2 and all(math.isfinite(x) for x in losses)
+    back = torch.load(ckpt, weights_only=True)
+    assert set(back) == {"model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "hyperparams", "current_epoch"}
+    assert back["hyperparams"] == CFG and back["current_epoch"] == 1
+    assert "mean" in back["model_state_dict"] and not any(k.endswith(".pe") for k in back["model_state_dict"])
+    # resume from the checkpoint (-p), hyper-parameters come from it
+    r = _run("train", "-p", str(ckpt), "-o", str(tmp_path / "resumed.pth"), "--synthetic", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = tmp_path / "samples.pt"
+    r = _run("sample", str(ckpt), "--steps", "10", "--num_samples", "6", "-o", str(out), "--synthetic", "64")
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = torch.load(out, weights_only=True)
+    assert s["trajectories"].shape == (6, 16, 20) and torch.isfinite(s["trajectories"]).all()
+
+
+def test_decoder_pretraining_loss_goes_down(tmp_path):
+    cfg = dict(CFG, use_action_history=False, use_imu=False, use_joint_states=False, use_gamestate=False, epochs=12, lr=3e-3)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    r = _run("train", "-c", str(path), "-o", str(tmp_path / "dec.pth"), "--decoder-pretraining", "--synthetic", "640")
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert losses[-1] < 0.7 * losses[0], losses
+    r = _run("sample", str(tmp_path / "dec.pth"), "--steps", "10", "--num_samples", "4", "-o", str(tmp_path / "s.pt"))
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_normalize_roundtrip():
+    from soccerdiffusion_amd import ops
+
+    x = torch.randn(5, 16, 20)
+    mean, std = torch.randn(20), 0.5 + torch.rand(20)
+    n = ops.normalize(x.cuda(), mean.cuda(), std.cuda())
+    assert rel_err(n, (x - mean) / std) < 1e-6
+    assert rel_err(ops.normalize(n, mean.cuda(), std.cuda(), inverse=True), x) < 1e-6
