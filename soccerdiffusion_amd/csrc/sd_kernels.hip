@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <algorithm>
 
 #include "../../include/soccerdiffusion_hip.h"
 
@@ -558,6 +559,191 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_b_kernel(ChainB
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Whole decoder layer tail in ONE kernel: chain A, the cross-attention core and chain B.
+//
+// The cross-attention of a row only needs that row's query and the (few) projected memory
+// rows of its own trajectory, so it is row-local too.  With 4 heads and D/4 = head dim the
+// head split coincides with the wave split of the panel GEMMs: wave w owns head w.  Q goes
+// through the LDS panel (the accumulator has features on lanes; S^T = K Q^T needs queries on
+// lanes), K/V fragments of the <= 64 keys of the panel's trajectories come straight from
+// L2, keys of other trajectories are masked to -inf, and the head's output overwrites its
+// own Q columns in the panel, which is then the A operand of the out-projection.
+// Used when (trajectories per panel) x (memory rows) <= 64; otherwise the host falls back
+// to chain A + attention_kernel + chain B.
+// --------------------------------------------------------------------------------------
+struct DecoderLayerArgs {
+    ChainAArgs a;      // a.q unused
+    ChainBArgs b;      // b.a / b.h unused (same panel)
+    const float *kv;   // [B*Mk, 2D] projected memory keys | values of this layer, Mk rows per trajectory
+    int T, Mk, B;
+    float scale_log2e;
+};
+
+template <int D, int NKT>
+__device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLayerArgs &g, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    constexpr int HD = D / 4, KS = HD / 8, FT = (HD + 31) / 32;
+    const int h = __builtin_amdgcn_readfirstlane(p.wave);  // one head per wave (made provably wave-uniform)
+    const int Mk = g.Mk;
+    const long b0 = p.r0 / g.T;
+    const int n_traj = (int)((p.r0 + p.R_left - 1) / g.T - b0) + 1;
+    const int n_keys = n_traj * Mk;  // <= 32 * NKT
+    // Memory rows of consecutive trajectories are consecutive in kv, so panel key number
+    // `key` (= local trajectory * Mk + m) is simply row b0*Mk + key: one base + 32-bit offsets.
+    // kvh is wave-uniform (scalar base); every access below is kvh[32-bit lane offset]
+    const float *kvh = g.kv + b0 * Mk * 2 * D + h * HD;
+#pragma unroll 1
+    for (int tq = 0; tq < 2; ++tq) {
+        const int qrow = tq * 32 + p.l31;
+        const bool q_ok = qrow < p.R_left;
+        const int key_lo = (int)((p.r0 + qrow) / g.T - b0) * Mk;  // this query's own trajectory: keys [key_lo, key_lo + Mk)
+        float *qbase = sA + qrow * C::LDA + h * HD;
+        f32x4 qf[KS];
+#pragma unroll
+        for (int st = 0; st < KS; ++st) qf[st] = *reinterpret_cast<const f32x4 *>(qbase + st * 8 + 4 * p.half);
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+            const int key = kt * 32 + p.l31;  // A-fragment row of this lane
+            const int koff = (key < n_keys ? key : 0) * 2 * D + 4 * p.half;
+            const float km = key < n_keys ? 1.f : 0.f;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const f32x4 kf = *reinterpret_cast<const f32x4 *>(kvh + koff + st * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j] * km, qf[st][j], sc[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads from being hoisted (registers)
+        }
+        // keys of other trajectories (and padding) -> -inf; softmax per query (lane column)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * p.half;
+                const bool ok = q_ok && key >= key_lo && key < key_lo + Mk;
+                const float v = ok ? sc[kt][r] : -INFINITY;
+                sc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;  // padded query row: every p becomes 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f((sc[kt][r] - mx) * g.scale_log2e);
+                sc[kt][r] = pv;
+                psum += pv;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        const float inv = psum > 0.f ? 1.0f / psum : 0.f;
+        // O^T = V^T P^T : A = V[key][h*HD + ft*32 + l31] from L2, B = P^T from the accumulator
+        f32x16 o[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
+        const int vlane = D + p.l31;  // V half of the row, this lane's feature
+        const float fm = 1.f;          // HD >= 32 here (D >= 128): every feature lane is live
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                if (kt * 32 + 8 * gq >= n_keys) continue;  // wave-uniform: 8 dead keys
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int r = 4 * gq + ri;
+                    const int key = kt * 32 + ri + 8 * gq + 4 * p.half;
+                    const int voff = (key < n_keys ? key : 0) * 2 * D + vlane;
+                    const float vm = key < n_keys ? fm : 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) {
+                        const float a = kvh[voff + ft * 32] * vm;
+                        o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // this head's output replaces its own Q columns of the panel (only this wave reads them)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int f = ft * 32 + 8 * gq + 4 * p.half;
+                if (f < HD) {
+                    f32x4 t = {o[ft][4 * gq] * inv, o[ft][4 * gq + 1] * inv, o[ft][4 * gq + 2] * inv, o[ft][4 * gq + 3] * inv};
+                    *reinterpret_cast<f32x4 *>(qbase + f) = t;
+                }
+            }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(DecoderLayerArgs g) {
+    using C = PanelCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.a.R);
+    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    const long wOff = (long)(p.wn * C::WN + p.l31) * D + 4 * p.half;
+    f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
+    chain_load_acc<D>(H, g.a.h, p);
+    chain_load_panel<D>(sA, g.a.a, p);
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.a.wo + wOff);        // h += a Wo^T + bo          (self-attention out)
+    chain_bias_act<D, 0>(H, g.a.bo, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
+    __syncthreads();
+    chain_zero<D>(U);
+    chain_gemm<D>(U, aBase, g.a.wq + wOff);        // q = LN2(h) Wq^T + bq
+    chain_bias_act<D, 0>(U, g.a.bq, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, U, p);
+    __syncthreads();
+    {   // a_c over the memory of each row's trajectory (wave-uniform choice of 1 or 2 key tiles)
+        const int n_traj = (int)((p.r0 + p.R_left - 1) / g.T - p.r0 / g.T) + 1;
+        if (n_traj * g.Mk <= 32) panel_cross_attention<D, 1>(sA, g, p);
+        else panel_cross_attention<D, 2>(sA, g, p);
+    }
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.b.wo + wOff);        // h += a_c Woc^T + boc
+    chain_bias_act<D, 0>(H, g.b.bo, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
+    __syncthreads();
+    chain_zero<D>(U);
+    chain_gemm<D>(U, aBase, g.b.w1 + wOff);        // u = gelu(LN3(h) W1^T + b1)
+    __syncthreads();
+    chain_gelu_to_lds<D>(sA, U, g.b.b1, p);
+    __syncthreads();
+    chain_gemm<D>(H, aBase, g.b.w2 + wOff);        // h += u W2^T + b2
+    chain_bias_act<D, 0>(H, g.b.b2, p);
+    chain_store_acc<D>(g.a.h, D, 0, H, p);
+    if (g.b.nln_w == nullptr) return;
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.b.nln_w, g.b.nln_b, p.lane, p.wave);
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {          // next layer's q | k | v
+        chain_zero<D>(U);
+        chain_gemm<D>(U, aBase, g.b.wqkv + (long)pass * D * D + wOff);
+        chain_bias_act<D, 0>(U, g.b.bqkv + pass * D, p);
+        chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+    }
+}
+
 template <typename Args, typename KA, typename KB, typename KC, typename KD>
 static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512, const char *name, hipStream_t s) {
     if (g.R <= 0) return fail(SD_E_BADARG, "chain: empty shape");
@@ -594,6 +780,40 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
                         "chain_b_kernel", s);
 }
 
+// true when the fused decoder-layer kernel applies: 4 heads == 4 waves each owning one head's
+// columns (D >= 128), and at most 64 memory keys among the trajectories touching a 64-row panel
+static bool fused_layer_ok(int d, int heads, int T, int Mk) {
+    if (heads != 4 || d < 128) return false;
+    const int n_traj = (63 + T - 1) / T + 1;
+    return (long)n_traj * Mk <= 64;
+}
+
+static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
+    if (g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer: empty shape");
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    dim3 grid((unsigned)((g.a.R + 63) / 64)), block(256);
+#define SD_DL(D_)                                                                                                \
+    do {                                                                                                         \
+        auto kfn = decoder_layer_kernel<D_>;                                                                     \
+        const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                              \
+        static bool attr_set = false;                                                                            \
+        if (lds > 64 * 1024 && !attr_set) {                                                                      \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        SD_LAUNCH(kfn, grid, block, lds, s, g);                                                                  \
+    } while (0)
+    switch (d) {
+        case 128: SD_DL(128); break;
+        case 256: SD_DL(256); break;
+        case 512: SD_DL(512); break;
+        default: return fail(SD_E_BADDIM, "decoder_layer: hidden_dim must be 128, 256 or 512");
+    }
+#undef SD_DL
+    SD_CHECK_LAUNCH("decoder_layer_kernel");
+    return 0;
+}
+
 // ======================================================================================
 // Attention core (self- and cross-attention), unmasked, one workgroup per (sample, head).
 //
@@ -623,12 +843,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                                                          float *__restrict__ lse2) {
     using C = AttnCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S_all = S + (k_extra ? 1 : 0);
+    // LDS is sized by the launcher for min(KC, S rounded up to a key tile) rows: short
+    // memories (cross-attention, M = 11) take 17 KB instead of 68 KB and 8 workgroups fit a CU
+    const int rows_cap = min(C::KC, ((S_all + 31) / 32) * 32);
     float *sK = smem;
-    float *sV = smem + C::KC * C::LDK;
+    float *sV = smem + rows_cap * C::LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int S_all = S + (k_extra ? 1 : 0);
     const float *qb = q + (long)b * Tq * ldq + h * HD;
     const float *kb = k + (long)b * S * ldkv + h * HD;
     const float *vb = v + (long)b * S * ldkv + h * HD;
@@ -792,10 +1015,13 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
 #define SD_ATTN(HD_)                                                                                             \
     do {                                                                                                         \
         auto kfn = attention_kernel<HD_>;                                                                        \
-        const size_t lds = AttnCfg<HD_>::LDS_BYTES;                                                              \
+        const int s_all = S + (k_extra ? 1 : 0);                                                                 \
+        const int rows_cap = std::min((int)AttnCfg<HD_>::KC, ((s_all + 31) / 32) * 32);                           \
+        const size_t lds = (size_t)rows_cap * (AttnCfg<HD_>::LDK + AttnCfg<HD_>::LDV) * sizeof(float);           \
         static bool attr_set = false;                                                                            \
-        if (lds > 64 * 1024 && !attr_set) {                                                                      \
-            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        if (!attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                      (int)AttnCfg<HD_>::LDS_BYTES);                                             \
             attr_set = true;                                                                                     \
         }                                                                                                        \
         SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e, lse2); \
@@ -1038,6 +1264,28 @@ __global__ void ddim_step_kernel(const float *__restrict__ eps, const float *x, 
     }
 }
 
+// Memory keys/values are kept per layer as [B][Mk][2D] (Mk = context rows + the step row) so
+// that a trajectory's rows are contiguous.  mode 0: copy the projected context rows
+// [B*Mc][2D] into rows 0..Mc-1 of each trajectory; mode 1: write the current step token's
+// projected row into row Mc of every trajectory.  grid = (blocks, layers).
+__global__ void kv_place_kernel(const float *__restrict__ src, long src_layer_stride, float *dst, long dst_layer_stride,
+                                int B, int Mc, int Mk, int w2, int mode) {
+    const float *sl = src + (long)blockIdx.y * src_layer_stride;
+    float *dl = dst + (long)blockIdx.y * dst_layer_stride;
+    const long n = (mode == 0) ? (long)B * Mc * w2 : (long)B * w2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % w2);
+        const long row = i / w2;
+        if (mode == 0) {
+            const long b = row / Mc;
+            const int m = (int)(row - b * Mc);
+            dl[((b * Mk) + m) * w2 + c] = sl[i];
+        } else {
+            dl[((row * Mk) + Mc) * w2 + c] = sl[c];
+        }
+    }
+}
+
 // Normalizer.normalize / denormalize (reference dataset/pytorch.py:410-414): per-joint affine
 __global__ void normalize_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                  const float *__restrict__ stdv, float *__restrict__ out, long n, int J, int inverse) {
@@ -1062,7 +1310,7 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride,
 // Layer drivers
 // ======================================================================================
 struct Scratch {  // carve-up of the caller's workspace (floats)
-    float *h, *qkv, *a, *u, *kv, *kvstep;
+    float *h, *qkv, *a, *u, *kv, *kvstep, *kvtmp;
 };
 
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -1076,12 +1324,14 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps) {
     s.u = ws + off; off += align64((size_t)R * d);
     s.kv = ws + off; off += align64((size_t)L * RM * 2 * d);
     s.kvstep = ws + off; off += align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d);
+    s.kvtmp = ws + off; off += align64((size_t)L * RM * 2 * d);
     return s;
 }
 
 extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps) {
-    const size_t R = (size_t)B * T, RM = (size_t)B * (M > 0 ? M : 1);
-    return align64(R * d) * 3 + align64(R * 3 * d) + align64((size_t)L * RM * 2 * d) +
+    // M memory rows per trajectory (+1: the sampler adds the step row to the context rows)
+    const size_t R = (size_t)B * T, RM = (size_t)B * ((M > 0 ? M : 0) + 1);
+    return align64(R * d) * 3 + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
            align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
 }
 
@@ -1090,30 +1340,34 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
 //   per layer: a = self-attention(qkv);  chain A: h += a Wo^T + bo, q = LN2(h) Wq^T + bq;
 //              a = cross-attention(q, memory K/V);  chain B: h += a Woc^T + boc,
 //              h += FFN(LN3(h)), qkv = LN1_{l+1}(h) Wqkv_{l+1}^T + b (if any)
-// kv(l): projected memory keys/values of layer l (B*Mk rows of 2d), kvx(l): optional extra
-// key/value row shared by the batch (the sampler's step token), or nullptr.
-template <typename KV, typename KVX>
-static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, KVX kvx,
-                         hipStream_t st) {
+// kv(l): projected memory keys | values of layer l, [B][Mk][2d] (a trajectory's rows contiguous).
+template <typename KV>
+static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, hipStream_t st) {
     const int d = w->d, heads = w->heads;
     const long R = (long)B * T;
     const sd_layer_weights &l0 = w->layers[0];
     int rc = linear(s.h, l0.sa_in_w, l0.sa_in_b, l0.n1_w, l0.n1_b, nullptr, s.qkv, (int)R, 3 * d, d, 0, st);
     if (rc) return rc;
+    const bool fused = fused_layer_ok(d, heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
     for (int l = 0; l < w->L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
         if (rc) return rc;
         ChainAArgs ga{s.a, s.h, lw.sa_out_w, lw.sa_out_b, lw.n2_w, lw.n2_b, lw.ca_in_w, lw.ca_in_b, s.u, R};
-        if ((rc = chain_a(ga, d, st))) return rc;
-        const float *kvl = kv(l), *kvxl = kvx(l);
-        rc = attention(s.u, d, kvl, kvl + d, 2 * d, kvxl, kvxl ? kvxl + d : nullptr, s.a, d, B, T, Mk, d, heads, st);
-        if (rc) return rc;
+        const float *kvl = kv(l);
         const bool last = l + 1 == w->L;
         const sd_layer_weights *nx = last ? nullptr : &w->layers[l + 1];
         ChainBArgs gb{s.a, s.h, lw.ca_out_w, lw.ca_out_b, lw.n3_w, lw.n3_b, lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b,
                       nx ? nx->n1_w : nullptr, nx ? nx->n1_b : nullptr, nx ? nx->sa_in_w : nullptr,
                       nx ? nx->sa_in_b : nullptr, s.qkv, R};
+        if (fused) {
+            DecoderLayerArgs gl{ga, gb, kvl, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f};
+            if ((rc = decoder_layer(gl, d, st))) return rc;
+            continue;
+        }
+        if ((rc = chain_a(ga, d, st))) return rc;
+        rc = attention(s.u, d, kvl, kvl + d, 2 * d, nullptr, nullptr, s.a, d, B, T, Mk, d, heads, st);
+        if (rc) return rc;
         if ((rc = chain_b(gb, d, st))) return rc;
     }
     return 0;
@@ -1170,8 +1424,7 @@ extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x,
     }
     const float *kvbase = s.kv;
     const size_t kvstride = (size_t)B * M * 2 * d;
-    rc = decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; },
-                       [](int) { return (const float *)nullptr; }, st);
+    rc = decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; }, st);
     if (rc) return rc;
     return fc_out(s.h, w->out_w, w->out_b, eps_out, nullptr, nullptr, R, d, w->J, st);
 }
@@ -1206,27 +1459,36 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T, L = w->L;
-    Scratch s = carve(workspace, R, (long)B * Mc, d, L, n_steps);
-    // once per rollout: K/V of the context rows and of all n_steps step tokens, per layer
+    Scratch s = carve(workspace, R, (long)B * (Mc + 1), d, L, n_steps);
+    // once per rollout: K/V of the context rows (placed as rows 0..Mc-1 of each trajectory's
+    // [Mk][2d] block, Mk = Mc + 1) and of all n_steps step tokens, per layer
+    const int Mk = Mc + 1;
+    const size_t kvstride = (size_t)B * Mk * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
         if (Mc > 0) {
-            rc = linear(ctx, wkv, bkv, nullptr, nullptr, nullptr, s.kv + (size_t)l * B * Mc * 2 * d, B * Mc, 2 * d, d, 0, st);
+            rc = linear(ctx, wkv, bkv, nullptr, nullptr, nullptr, s.kvtmp + (size_t)l * B * Mc * 2 * d, B * Mc, 2 * d, d, 0, st);
             if (rc) return rc;
         }
-        rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * n_steps * 2 * d, n_steps,
-                    2 * d, d, 0, st);
+        rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_steps, 2 * d, d, 0, st);
         if (rc) return rc;
     }
+    if (Mc > 0) {
+        SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * Mc * 2 * d), L), dim3(256), 0, st, s.kvtmp, (long)B * Mc * 2 * d, s.kv,
+                  (long)kvstride, B, Mc, Mk, 2 * d, 0);
+        SD_CHECK_LAUNCH("kv_place_kernel");
+    }
     for (int i = 0; i < n_steps; ++i) {
+        // this step's token row -> row Mc of every trajectory, all layers in one launch
+        SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * 2 * d), L), dim3(256), 0, st, s.kvstep + (size_t)i * 2 * d, (long)kvsstride,
+                  s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
+        SD_CHECK_LAUNCH("kv_place_kernel");
         rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
         if (rc) return rc;
         {
-            const float *kvbase = s.kv, *kvsbase = s.kvstep;
-            const size_t kvstride = (size_t)B * Mc * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
-            rc = decoder_stack(w, s, B, T, Mc, [=](int l) { return kvbase + l * kvstride; },
-                               [=](int l) { return kvsbase + l * kvsstride + (size_t)i * 2 * d; }, st);
+            const float *kvbase = s.kv;
+            rc = decoder_stack(w, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, st);
             if (rc) return rc;
         }
         rc = fc_out(s.h, w->out_w, w->out_b, nullptr, x, coef + 4 * i, R, d, w->J, st);

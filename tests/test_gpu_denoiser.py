@@ -50,7 +50,11 @@ def test_golden_encoders(ops, g2):
         assert rel_err(got, g2["encoded"][i]) < TOL
 
 
-@pytest.mark.parametrize("d,J,L,T,M,B", [(64, 20, 2, 16, 11, 2), (128, 22, 4, 10, 312, 3), (256, 20, 4, 100, 11, 5), (512, 20, 2, 10, 31, 2)])
+# the last five rows hit the fused decoder-layer kernel: 2 key tiles (62 keys), 3 trajectories per panel,
+# d=128 / d=512 heads, ten short trajectories per panel, a single memory row
+@pytest.mark.parametrize("d,J,L,T,M,B", [(64, 20, 2, 16, 11, 2), (128, 22, 4, 10, 312, 3), (256, 20, 4, 100, 11, 5), (512, 20, 2, 10, 31, 2),
+                                         (256, 20, 2, 100, 31, 3), (128, 20, 2, 40, 11, 4), (512, 22, 2, 100, 5, 2),
+                                         (256, 20, 2, 7, 3, 30), (256, 20, 1, 100, 1, 2)])
 def test_denoiser_vs_oracle(ops, d, J, L, T, M, B):
     sd = ref.synthetic_state_dict(d, J, L, seed=3)
     g = torch.Generator().manual_seed(5)
@@ -64,7 +68,8 @@ def test_denoiser_vs_oracle(ops, d, J, L, T, M, B):
     assert rel_err(ref.denoiser_forward(sd, x, mem), want) < TOL
 
 
-@pytest.mark.parametrize("d,L,T,Mc,B,n_steps", [(64, 2, 16, 10, 2, 10), (256, 4, 100, 10, 4, 50), (256, 4, 100, 0, 2, 50), (128, 2, 10, 30, 3, 30)])
+@pytest.mark.parametrize("d,L,T,Mc,B,n_steps", [(64, 2, 16, 10, 2, 10), (256, 4, 100, 10, 4, 50), (256, 4, 100, 0, 2, 50), (128, 2, 10, 30, 3, 30),
+                                                 (256, 2, 40, 20, 3, 10), (128, 2, 100, 3, 3, 10)])
 def test_ddim_sampler_every_step(ops, d, L, T, Mc, B, n_steps):
     """x after EVERY step vs the fp32 CPU oracle loop on identical weights, x_T, context."""
     J = 20
