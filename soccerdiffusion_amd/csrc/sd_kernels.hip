@@ -826,7 +826,7 @@ static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
 // ======================================================================================
 template <int HD>
 struct AttnCfg {
-    static constexpr int KC = (HD >= 128) ? 64 : 128;      // keys per LDS chunk
+    static constexpr int KC = 64;                          // keys per LDS chunk (2 tiles: 32 score registers, 4 workgroups/CU)
     static constexpr int FT = (HD + 31) / 32;              // 32-feature tiles of O^T
     static constexpr int LDK = HD + 4;                     // ds_read_b128 conflict-free
     static constexpr int LDV = FT * 32;                    // zero-padded feature columns
