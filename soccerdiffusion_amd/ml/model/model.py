@@ -131,13 +131,24 @@ class End2EndDiffusionTransformer(nn.Module):
 
     @torch.no_grad()
     def sample(self, context: Sequence[torch.Tensor], x_T: torch.Tensor, num_inference_steps: int,
-               return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None):
+               return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None, use_graph: bool = False):
         """The reference's denoising loop (plot.py:122-131 / distill.py:179-189 / ros.py:301-310)
-        as one native call: 50x (denoiser forward + DDIM update) with the context K/V cached."""
+        as one native call: n x (denoiser forward + DDIM update) with the context K/V cached.
+        ``use_graph`` replays the rollout from a hipGraph captured for this (B, T, M, n) shape."""
         ts = ops.ddim_timesteps(num_inference_steps)
         acp = ops.alphas_cumprod() if alphas_cumprod is None else alphas_cumprod
         coef = ops.ddim_coefficients(ts, acp, num_inference_steps)
-        tokens = self.step_encoding.table(ts, x_T.device)
         ctx = torch.cat(list(context), dim=1).contiguous() if len(context) else None
-        return ops.ddim_sample(self.diffusion_action_generator.packed(), ctx, tokens, coef, x_T.contiguous(),
-                               trace=return_trace)
+        packed = self.diffusion_action_generator.packed()
+        if use_graph and not return_trace:
+            B, T, _ = x_T.shape
+            Mc = 0 if ctx is None else ctx.shape[1]
+            key = (B, T, Mc, num_inference_steps, x_T.device, self.diffusion_action_generator._signature(),
+                   self.step_encoding.token._version)
+            cache = self.__dict__.setdefault("_graphs", {})
+            if key not in cache:
+                cache.clear()  # one shape at a time: a graph pins its workspace
+                cache[key] = ops.GraphedSampler(packed, B, T, Mc, self.step_encoding.table(ts, x_T.device), coef)
+            return cache[key](ctx, x_T)
+        tokens = self.step_encoding.table(ts, x_T.device)
+        return ops.ddim_sample(packed, ctx, tokens, coef, x_T.contiguous(), trace=return_trace)

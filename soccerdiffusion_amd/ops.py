@@ -296,6 +296,46 @@ def ddim_step(eps: Tensor, x: Tensor, coef4) -> Tensor:
     return out
 
 
+class GraphedSampler:
+    """The whole rollout (n_steps x (L x 2 + 3) kernel launches of ``sd_ddim_sample``) captured
+    once into a hipGraph and replayed: removes the per-launch host cost, which dominates at
+    small batch (the robot's B = 1, 30-step rollout).  Static shapes; the inputs are copied
+    into the captured buffers before every replay."""
+
+    def __init__(self, packed: _Packed, B: int, T: int, Mc: int, step_tokens: Tensor, coef: np.ndarray):
+        dev = step_tokens.device
+        self.packed, self.coef = packed, np.ascontiguousarray(coef, dtype=np.float32)
+        self.tokens = step_tokens.contiguous()
+        self.x = torch.zeros(B, T, packed.J, dtype=torch.float32, device=dev)
+        self.ctx = torch.zeros(B, Mc, packed.d, dtype=torch.float32, device=dev) if Mc > 0 else None
+        lib = _lib.load()
+        self.ws = torch.empty(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, len(self.coef)),
+                              dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._run()  # warm-up outside capture: lazy module load and LDS attributes happen here
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._run()
+
+    def _run(self):
+        B, T, _ = self.x.shape
+        check(_lib.load().sd_ddim_sample(C.byref(self.packed.struct), _ptr(self.ctx), self.tokens.data_ptr(),
+                                         self.coef.ctypes.data_as(_lib.c_float_p), self.x.data_ptr(), None,
+                                         self.ws.data_ptr(), B, T, 0 if self.ctx is None else self.ctx.shape[1],
+                                         len(self.coef), _stream()), "sd_ddim_sample")
+
+    def __call__(self, ctx: Optional[Tensor], x_T: Tensor) -> Tensor:
+        self.x.copy_(x_T)
+        if self.ctx is not None:
+            self.ctx.copy_(ctx)
+        self.graph.replay()
+        return self.x.clone()
+
+
 def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
                 trace: bool = False, inplace: bool = False):
     """The reference's sampling loop (ml/inference/plot.py:122-131, ml/training/distill.py:179-189)
