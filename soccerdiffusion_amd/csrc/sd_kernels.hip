@@ -78,6 +78,10 @@ struct PanelCfg {
     static constexpr size_t LDS_BYTES = (size_t)BM * LDA * sizeof(float);
 };
 
+template <int D>
+__device__ __forceinline__ void panel_layer_norm(float *sA, int lda, const float *ln_w, const float *ln_b, int lane, int wave,
+                                                 int rows);
+
 template <int D, bool HAS_LN, int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                           const float *__restrict__ bias,
@@ -103,30 +107,7 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
     __syncthreads();
 
     if constexpr (HAS_LN) {
-        // each wave normalises 16 rows; two-pass mean / biased variance in fp32
-        constexpr int PER_LANE = D / 64;
-        for (int row = wave; row < C::BM; row += 4) {
-            float v[PER_LANE];
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < PER_LANE; ++j) {
-                v[j] = sA[row * C::LDA + lane + 64 * j];
-                s += v[j];
-            }
-            const float mean = wave_sum(s) * (1.0f / D);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < PER_LANE; ++j) {
-                v[j] -= mean;
-                q += v[j] * v[j];
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + SD_LN_EPS);
-#pragma unroll
-            for (int j = 0; j < PER_LANE; ++j) {
-                const int c = lane + 64 * j;
-                sA[row * C::LDA + c] = v[j] * rstd * ln_w[c] + ln_b[c];
-            }
-        }
+        panel_layer_norm<D>(sA, C::LDA, ln_w, ln_b, lane, wave, C::BM);
         __syncthreads();
     }
 
@@ -444,33 +425,49 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
             }
 }
 
-// LayerNorm of the LDS panel in place (each wave 16 rows; two-pass, fp32)
+// LayerNorm of the LDS panel in place (two-pass, fp32).  A wave normalises 4 rows at a time:
+// 16 lanes per row (one DPP row), each lane D/16 values in 16-byte pieces, so the row sums
+// are in-lane adds + 4 DPP rotations, and 4 independent rows are in flight per wave.
 template <int D>
-__device__ __forceinline__ void chain_layer_norm(float *sA, const float *ln_w, const float *ln_b, int lane, int wave) {
-    using C = PanelCfg<D>;
-    constexpr int PER_LANE = D / 64;
-    for (int row = wave; row < C::BM; row += 4) {
-        float v[PER_LANE];
+__device__ __forceinline__ void panel_layer_norm(float *sA, int lda, const float *ln_w, const float *ln_b, int lane, int wave,
+                                                 int rows) {
+    constexpr int V4 = D / 64;  // 16-byte pieces per lane: lane i of a row owns columns 4*(i + 16*j) .. +3
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int row = wave * 4 + grp; row < rows; row += 16) {
+        f32x4 v[V4];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < PER_LANE; ++j) {
-            v[j] = sA[row * C::LDA + lane + 64 * j];
-            s += v[j];
+        for (int j = 0; j < V4; ++j) {
+            v[j] = *reinterpret_cast<const f32x4 *>(sA + row * lda + 4 * (sub + 16 * j));
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         }
-        const float mean = wave_sum(s) * (1.0f / D);
+        const float mean = row16_sum(s) * (1.0f / D);
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < PER_LANE; ++j) {
-            v[j] -= mean;
-            q += v[j] * v[j];
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + SD_LN_EPS);
+        for (int j = 0; j < V4; ++j) {
 #pragma unroll
-        for (int j = 0; j < PER_LANE; ++j) {
-            const int c = lane + 64 * j;
-            sA[row * C::LDA + c] = v[j] * rstd * ln_w[c] + ln_b[c];
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] -= mean;
+                q += v[j][e] * v[j][e];
+            }
+        }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / D) + SD_LN_EPS);
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + c);
+            const f32x4 gb = *reinterpret_cast<const f32x4 *>(ln_b + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = v[j][e] * rstd * gw[e] + gb[e];
+            *reinterpret_cast<f32x4 *>(sA + row * lda + c) = y;
         }
     }
+}
+
+template <int D>
+__device__ __forceinline__ void chain_layer_norm(float *sA, const float *ln_w, const float *ln_b, int lane, int wave) {
+    panel_layer_norm<D>(sA, PanelCfg<D>::LDA, ln_w, ln_b, lane, wave, PanelCfg<D>::BM);
 }
 
 struct ChainAArgs {
