@@ -49,7 +49,7 @@ def cpu_baseline(sd, seconds_budget=25.0):
     from oracle import ddim_ref
     from oracle import denoiser_ref as ref
 
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     Bc = 32
@@ -159,30 +159,34 @@ def main():
         cnt = (C.c_long * n)()
         _lib.check(lib.sd_profile_collect(ms, cnt, n), "sd_profile_collect")
         f = flops_per_traj_step()
-        # algorithmic FLOPs executed by panel_gemm launches in the timed region: the row
-        # GEMMs every step, plus (once per rollout) the K/V projection of the context rows
-        # and of the 50 step tokens.
-        gemm_flops = args.steps * (B * N_DDIM * f["gemm"] + L * 4 * (B * MC + N_DDIM) * D * D)
-        gemm_s = ms[0] / 1e3
-        achieved = gemm_flops / gemm_s / 1e12
+        names = _lib.KERNEL_CLASSES
+        dl = names.index("decoder_layer_kernel")
+        # Dominant kernel: decoder_layer_kernel, one launch per (DDIM step, layer): per trajectory it does the
+        # row GEMMs of SURVEY 8(d) except the first layer's LN1+QKV, which the head panel_gemm does (10Td^2 per
+        # layer + the next layer's 6Td^2 QKV for all but the last) plus the cross-attention core 4TMd.
+        # Summed over the L launches of a step:
+        per_traj_step_dl = (L * 16 - 6) * T * D * D + L * 4 * T * M * D
+        dl_flops = args.steps * B * N_DDIM * per_traj_step_dl
+        dl_s = ms[dl] / 1e3
+        achieved = dl_flops / dl_s / 1e12
         total_flops = args.steps * B * N_DDIM * f["total"]
         pmc = None
         pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
-                pmc = json.load(fh).get("panel_gemm_kernel_bytes_per_launch")
+                pmc = json.load(fh).get("decoder_layer_kernel_bytes_per_launch")
         roofline = {
             "bound": "mfma",
-            "kernel": "panel_gemm_kernel",
+            "kernel": "decoder_layer_kernel<256>",
             "achieved": round(achieved, 2),
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": pmc,
-            "launches": int(cnt[0]),
-            "avg_launch_ms": round(ms[0] / max(int(cnt[0]), 1), 5),
-            "flops_per_launch_avg": gemm_flops / max(int(cnt[0]), 1),
-            "kernel_time_share": {k: round(ms[i] / 1e3 / elapsed, 4) for i, k in enumerate(_lib.KERNEL_CLASSES)},
+            "launches": int(cnt[dl]),
+            "avg_launch_ms": round(ms[dl] / max(int(cnt[dl]), 1), 5),
+            "flops_per_launch_avg": dl_flops / max(int(cnt[dl]), 1),
+            "kernel_time_share": {k: round(ms[i] / 1e3 / elapsed, 4) for i, k in enumerate(names)},
             "whole_path": {
                 "achieved": round(total_flops / elapsed / 1e12, 2),
                 "frac": round(total_flops / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
 template <typename Args, typename KA, typename KB, typename KC, typename KD>
 static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512, const char *name, hipStream_t s) {
     if (g.R <= 0) return fail(SD_E_BADARG, "chain: empty shape");
-    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((g.R + 63) / 64)), block(256);
 #define SD_CHAIN(D_, K_)                                                                                        \
     do {                                                                                                        \
@@ -787,7 +787,7 @@ static bool fused_layer_ok(int d, int heads, int T, int Mk) {
 
 static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
     if (g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer: empty shape");
-    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((g.a.R + 63) / 64)), block(256);
 #define SD_DL(D_)                                                                                                \
     do {                                                                                                         \
