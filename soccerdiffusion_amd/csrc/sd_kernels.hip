@@ -303,6 +303,59 @@ __device__ __forceinline__ void chain_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelC
     }
 }
 
+// Weight-fragment ring that runs AHEAD of the GEMM it feeds: chain_prime() issues the loads of
+// k-steps 0 and 1 of the NEXT GEMM right after the current K loop, i.e. before the current
+// epilogue / stores / LayerNorm.  Their L2 latency hides behind that work, and — vmcnt being
+// in-order — they are older than the epilogue's stores, so the next K loop does not wait for
+// stores to drain before its first MFMA.  chain_gemm_primed() then keeps the ring 2 k-steps deep.
+template <int D>
+struct WeightRing {
+    f32x4 b[3][PanelCfg<D>::TN];
+};
+
+template <int D>
+__device__ __forceinline__ void chain_prime(WeightRing<D> &ring, const float *wBase) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+            ring.b[s][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + s * 8);
+}
+
+template <int D>
+__device__ __forceinline__ void chain_gemm_primed(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *aBase,
+                                                  const float *wBase, WeightRing<D> &ring) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 8;
+    f32x4 af[2][C::TM];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) af[0][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks % 3, fill = (ks + 2) % 3;
+        if (ks + 2 < NK) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                ring.b[fill][tn] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 2) * 8);
+        }
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                af[(ks + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + (ks + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][tm][j], ring.b[cur][tn][j], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // per-thread geometry of the accumulator tile map
 template <int D>
 struct ChainPos {
@@ -690,10 +743,13 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
     const long wOff = (long)(p.wn * C::WN + p.l31) * D + 4 * p.half;
     f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
+    WeightRing<D> ring;
+    chain_prime<D>(ring, g.a.wo + wOff);           // first weights in flight while the panel lands
     chain_load_acc<D>(H, g.a.h, p);
     chain_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
-    chain_gemm<D>(H, aBase, g.a.wo + wOff);        // h += a Wo^T + bo          (self-attention out)
+    chain_gemm_primed<D>(H, aBase, g.a.wo + wOff, ring);   // h += a Wo^T + bo   (self-attention out)
+    chain_prime<D>(ring, g.a.wq + wOff);
     chain_bias_act<D, 0>(H, g.a.bo, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
@@ -701,7 +757,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
     __syncthreads();
     chain_zero<D>(U);
-    chain_gemm<D>(U, aBase, g.a.wq + wOff);        // q = LN2(h) Wq^T + bq
+    chain_gemm_primed<D>(U, aBase, g.a.wq + wOff, ring);   // q = LN2(h) Wq^T + bq
+    chain_prime<D>(ring, g.b.wo + wOff);
     chain_bias_act<D, 0>(U, g.a.bq, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, U, p);
@@ -712,7 +769,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
         else panel_cross_attention<D, 2>(sA, g, p);
     }
     __syncthreads();
-    chain_gemm<D>(H, aBase, g.b.wo + wOff);        // h += a_c Woc^T + boc
+    chain_gemm_primed<D>(H, aBase, g.b.wo + wOff, ring);   // h += a_c Woc^T + boc
+    chain_prime<D>(ring, g.b.w1 + wOff);
     chain_bias_act<D, 0>(H, g.b.bo, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
@@ -720,22 +778,27 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     chain_layer_norm<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
     __syncthreads();
     chain_zero<D>(U);
-    chain_gemm<D>(U, aBase, g.b.w1 + wOff);        // u = gelu(LN3(h) W1^T + b1)
+    chain_gemm_primed<D>(U, aBase, g.b.w1 + wOff, ring);   // u = gelu(LN3(h) W1^T + b1)
+    chain_prime<D>(ring, g.b.w2 + wOff);
     __syncthreads();
     chain_gelu_to_lds<D>(sA, U, g.b.b1, p);
     __syncthreads();
-    chain_gemm<D>(H, aBase, g.b.w2 + wOff);        // h += u W2^T + b2
+    chain_gemm_primed<D>(H, aBase, g.b.w2 + wOff, ring);   // h += u W2^T + b2
+    const bool has_next = g.b.nln_w != nullptr;            // workgroup-uniform
+    if (has_next) chain_prime<D>(ring, g.b.wqkv + wOff);
     chain_bias_act<D, 0>(H, g.b.b2, p);
     chain_store_acc<D>(g.a.h, D, 0, H, p);
-    if (g.b.nln_w == nullptr) return;
+    if (!has_next) return;
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
     __syncthreads();
     chain_layer_norm<D>(sA, g.b.nln_w, g.b.nln_b, p.lane, p.wave);
     __syncthreads();
+#pragma unroll
     for (int pass = 0; pass < 3; ++pass) {          // next layer's q | k | v
         chain_zero<D>(U);
-        chain_gemm<D>(U, aBase, g.b.wqkv + (long)pass * D * D + wOff);
+        chain_gemm_primed<D>(U, aBase, g.b.wqkv + (long)pass * D * D + wOff, ring);
+        if (pass < 2) chain_prime<D>(ring, g.b.wqkv + (long)(pass + 1) * D * D + wOff);  // older than this pass's stores
         chain_bias_act<D, 0>(U, g.b.bqkv + pass * D, p);
         chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
     }
