@@ -1060,6 +1060,187 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Pipelined variant for Tq <= 128 (one query pass): ONE workgroup per sample walks all heads
+// and key chunks as a single stream of (head, chunk) units.  The K/V rows of unit u+1 are
+// loaded global -> registers while unit u computes and are written to LDS after it, and the
+// next head's Q fragments are fetched during the current head's last chunk, so after the
+// first unit no HBM/L2 latency is exposed (attention_kernel exposes it once per chunk).
+// --------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, (HD <= 64 ? 2 : 1)) void attention_pipe_kernel(const float *__restrict__ q, int ldq,
+                                                              const float *__restrict__ k, const float *__restrict__ v,
+                                                              int ldkv, float *__restrict__ out, int ldo, int Tq, int S,
+                                                              int heads, float scale_log2e, float *__restrict__ lse2) {
+    using C = AttnCfg<HD>;
+    constexpr int KV4 = HD / 4;
+    constexpr int NV = (C::KC * KV4 + 255) / 256;  // 16-byte pieces of K (and of V) per thread per chunk
+    constexpr int KT = C::KC / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sK = smem;
+    float *sV = smem + C::KC * C::LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x;
+    const int nchunks = (S + C::KC - 1) / C::KC;
+    const int nunits = heads * nchunks;
+    const int q0 = wave * 32;
+    const bool wave_active = q0 < Tq;  // wave-uniform
+    const int qi = q0 + l31;
+    const bool q_ok = qi < Tq;
+    const float *qrow = q + ((long)b * Tq + (q_ok ? qi : 0)) * ldq + 4 * half;
+    const float *kb = k + (long)b * S * ldkv;
+    const float *vb = v + (long)b * S * ldkv;
+
+    if constexpr (C::LDV > HD) {  // zero the feature padding of V once; staging never touches it
+        constexpr int PADW = C::LDV - HD;
+        for (int i = tid; i < C::KC * PADW; i += 256) sV[(i / PADW) * C::LDV + HD + (i % PADW)] = 0.f;
+    }
+    f32x4 kreg[NV], vreg[NV];
+    auto fetch = [&](int u) {  // unit u = (head, chunk): this thread's pieces of its 64 K/V rows
+        const int h = u / nchunks, kc0 = (u - h * nchunks) * C::KC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / KV4, c4 = idx - row * KV4;
+            const int key = kc0 + row;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+            if (idx < C::KC * KV4 && key < S) {
+                a = *reinterpret_cast<const f32x4 *>(kb + (long)key * ldkv + h * HD + c4 * 4);
+                d = *reinterpret_cast<const f32x4 *>(vb + (long)key * ldkv + h * HD + c4 * 4);
+            }
+            kreg[i] = a;
+            vreg[i] = d;
+        }
+    };
+    f32x4 qf[C::KSTEPS], qn[C::KSTEPS];
+    auto fetch_q = [&](int h, f32x4 (&dst)[C::KSTEPS]) {
+#pragma unroll
+        for (int st = 0; st < C::KSTEPS; ++st) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (q_ok) t = *reinterpret_cast<const f32x4 *>(qrow + h * HD + st * 8);
+            dst[st] = t;
+        }
+    };
+    fetch(0);
+    fetch_q(0, qn);
+    f32x16 o[C::FT];
+    float m_run = -INFINITY, l_part = 0.f;
+
+    for (int u = 0; u < nunits; ++u) {
+        const int h = u / nchunks, c = u - h * nchunks, kc0 = c * C::KC;
+        __syncthreads();  // every wave is done reading the previous unit's K/V
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / KV4, c4 = idx - row * KV4;
+            if (idx < C::KC * KV4) {
+                *reinterpret_cast<f32x4 *>(sK + row * C::LDK + c4 * 4) = kreg[i];
+                *reinterpret_cast<f32x4 *>(sV + row * C::LDV + c4 * 4) = vreg[i];
+            }
+        }
+        if (u + 1 < nunits) fetch(u + 1);  // in flight during this unit's MFMAs
+        if (c == 0) {
+#pragma unroll
+            for (int st = 0; st < C::KSTEPS; ++st) qf[st] = qn[st];
+#pragma unroll
+            for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
+            m_run = -INFINITY;
+            l_part = 0.f;
+        }
+        if (c == nchunks - 1 && h + 1 < heads) fetch_q(h + 1, qn);
+        __syncthreads();
+        if (wave_active) {
+            f32x16 sc[KT];
+            const int kt_valid = (min(S - kc0, C::KC) + 31) / 32;  // wave-uniform
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+                if (kt < kt_valid) {
+                    const float *kp = sK + (kt * 32 + l31) * C::LDK + 4 * half;
+#pragma unroll
+                    for (int st = 0; st < C::KSTEPS; ++st) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + st * 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[st][j], sc[kt], 0, 0, 0);
+                    }
+                }
+            }
+            float m_c = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kc0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float sv = (key < S) ? sc[kt][r] : -INFINITY;
+                    sc[kt][r] = sv;
+                    m_c = fmaxf(m_c, sv);
+                }
+            m_c = fmaxf(m_c, __shfl_xor(m_c, 32, 64));
+            const float m_new = fmaxf(m_run, m_c);
+            const float alpha = exp2f((m_run - m_new) * scale_log2e);
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f((sc[kt][r] - m_new) * scale_log2e);
+                    sc[kt][r] = pv;
+                    psum += pv;
+                }
+            l_part = l_part * alpha + psum;
+#pragma unroll
+            for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < kt_valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (kc0 + kt * 32 + 8 * g < S) {  // wave-uniform: skip 8 dead keys
+#pragma unroll
+                            for (int ri = 0; ri < 4; ++ri) {
+                                const int r = 4 * g + ri;
+                                const int krow = kt * 32 + ri + 8 * g + 4 * half;
+#pragma unroll
+                                for (int ft = 0; ft < C::FT; ++ft) {
+                                    const float a = sV[krow * C::LDV + ft * 32 + l31];
+                                    o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (c == nchunks - 1) {
+                const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+                const float inv = 1.0f / l_tot;
+                if (lse2 && q_ok && half == 0) lse2[((long)b * heads + h) * Tq + qi] = m_run * scale_log2e + log2f(l_tot);
+                if (q_ok) {
+                    float *op = out + ((long)b * Tq + qi) * ldo + h * HD;
+#pragma unroll
+                    for (int ft = 0; ft < C::FT; ++ft)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int f = ft * 32 + 8 * g + 4 * half;
+                            if (f < HD) {
+                                f32x4 t = {o[ft][4 * g] * inv, o[ft][4 * g + 1] * inv, o[ft][4 * g + 2] * inv,
+                                           o[ft][4 * g + 3] * inv};
+                                *reinterpret_cast<f32x4 *>(op + f) = t;
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
 static int attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
                      const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
                      hipStream_t s, float *lse2 = nullptr) {
@@ -1072,6 +1253,30 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     dim3 grid(B * heads), block(256);
+    if (Tq <= 128 && !k_extra && S > 0) {
+        dim3 gridp(B);
+#define SD_ATTNP(HD_)                                                                                            \
+    do {                                                                                                         \
+        auto kfn = attention_pipe_kernel<HD_>;                                                                   \
+        const size_t lds = AttnCfg<HD_>::LDS_BYTES;                                                              \
+        static bool attr_set = false;                                                                            \
+        if (lds > 64 * 1024 && !attr_set) {                                                                      \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        SD_LAUNCH(kfn, gridp, block, lds, s, q, ldq, k, v, ldkv, out, ldo, Tq, S, heads, sl2e, lse2);            \
+    } while (0)
+        switch (hd) {
+            case 16: SD_ATTNP(16); break;
+            case 32: SD_ATTNP(32); break;
+            case 64: SD_ATTNP(64); break;
+            case 128: SD_ATTNP(128); break;
+            default: return fail(SD_E_BADDIM, "attention: head dim must be 16, 32, 64 or 128");
+        }
+#undef SD_ATTNP
+        SD_CHECK_LAUNCH("attention_pipe_kernel");
+        return 0;
+    }
 #define SD_ATTN(HD_)                                                                                             \
     do {                                                                                                         \
         auto kfn = attention_kernel<HD_>;                                                                        \
