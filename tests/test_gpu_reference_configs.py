@@ -1,0 +1,84 @@
+"""The shapes of the reference's five shipped YAML configs (ml/training/config/*.yaml, images off:
+the image backbone is out of this round's scope), full model, forward + 30-step sampling on the
+GPU against the CPU oracle on identical weights and inputs."""
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ddim_ref
+from oracle import denoiser_ref as ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+BASE = dict(action_context_length=100, trajectory_prediction_length=10, epochs=1, batch_size=4, lr=1e-4,
+            train_denoising_timesteps=1000, image_context_length=10, imu_context_length=100, joint_state_context_length=100,
+            num_normalization_samples=10, num_joints=20, use_images=False, image_sequence_encoder_type="transformer",
+            image_encoder_type="resnet18", num_image_sequence_encoder_layers=1, distill_teacher_inference_steps=30)
+CONFIGS = {
+    # name: overrides (values of the reference YAML of the same name)
+    "default": dict(hidden_dim=128, use_action_history=True, num_action_history_encoder_layers=2, use_imu=True,
+                    imu_orientation_embedding_method="quaternion", num_imu_encoder_layers=2, use_joint_states=True,
+                    joint_state_encoder_layers=2, num_decoder_layers=4, use_gamestate=True, encoder_patch_size=1),
+    "decoder_only": dict(hidden_dim=256, use_action_history=False, num_action_history_encoder_layers=2, use_imu=False,
+                         imu_orientation_embedding_method="quaternion", num_imu_encoder_layers=2, use_joint_states=False,
+                         joint_state_encoder_layers=2, num_decoder_layers=4, use_gamestate=False, encoder_patch_size=10),
+    "larger_model": dict(hidden_dim=512, use_action_history=True, num_action_history_encoder_layers=4, use_imu=True,
+                         imu_orientation_embedding_method="quaternion", num_imu_encoder_layers=4, use_joint_states=True,
+                         joint_state_encoder_layers=4, num_decoder_layers=8, use_gamestate=True, encoder_patch_size=1),
+    "sim_scratch": dict(hidden_dim=256, use_action_history=True, num_action_history_encoder_layers=4, use_imu=True,
+                        imu_orientation_embedding_method="five_dim", num_imu_encoder_layers=2, use_joint_states=False,
+                        joint_state_encoder_layers=4, num_decoder_layers=6, use_gamestate=False, encoder_patch_size=5),
+    "num_joints_22": dict(hidden_dim=128, num_joints=22, use_action_history=True, num_action_history_encoder_layers=1, use_imu=False,
+                          imu_orientation_embedding_method="quaternion", num_imu_encoder_layers=1, use_joint_states=True,
+                          joint_state_encoder_layers=1, num_decoder_layers=2, use_gamestate=True, encoder_patch_size=10),
+}
+
+
+def _state_dict_for(params):
+    from soccerdiffusion_amd.synthetic import synthetic_state_dict
+
+    enc = {}
+    p = params["encoder_patch_size"]
+    if params["use_action_history"]:
+        enc["action_history_encoder"] = (params["num_joints"], p, params["num_action_history_encoder_layers"])
+    if params["use_imu"]:
+        enc["imu_encoder"] = (5 if params["imu_orientation_embedding_method"] == "five_dim" else 4, p, params["num_imu_encoder_layers"])
+    if params["use_joint_states"]:
+        enc["joint_states_encoder"] = (params["num_joints"], p, params["joint_state_encoder_layers"])
+    return synthetic_state_dict(params["hidden_dim"], params["num_joints"], params["num_decoder_layers"], seed=21, encoders=enc,
+                                game_state=params["use_gamestate"])
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_shipped_config_shapes(name):
+    from soccerdiffusion_amd import cli
+
+    params = {**BASE, **CONFIGS[name]}
+    sd = _state_dict_for(params)
+    model = cli.build_model(params).cuda().eval()
+    model.load_state_dict(sd)
+    B, T, J = 3, params["trajectory_prediction_length"], params["num_joints"]
+    data = cli.synthetic_dataset(B, params, seed=3)
+    inp = {k: data[k] for k in cli.CONTEXT_KEYS}
+    x = torch.randn(B, T, J, generator=torch.Generator().manual_seed(9))
+    steps = torch.tensor([980, 500, 0])
+    with torch.no_grad():
+        ctx_gpu = model.encode_input_data({k: v.cuda() for k, v in inp.items()})
+        eps = model.forward_with_context(ctx_gpu, x.cuda(), steps.cuda())
+    ctx_cpu = ref.encode_input_data(sd, inp)
+    assert len(ctx_gpu) == len(ctx_cpu)
+    for a, b in zip(ctx_gpu, ctx_cpu):
+        assert rel_err(a, b) < TOL
+    if not ctx_cpu:  # decoder_only: the reference trains it on random context (train.py:221-224)
+        ctx_cpu = [torch.randn(B, 10, params["hidden_dim"], generator=torch.Generator().manual_seed(4))]
+        ctx_gpu = [c.cuda() for c in ctx_cpu]
+        with torch.no_grad():
+            eps = model.forward_with_context(ctx_gpu, x.cuda(), steps.cuda())
+    assert rel_err(eps, ref.forward_with_context(sd, ctx_cpu, x, steps)) < TOL
+    # the deployed rollout: 30 DDIM steps (ros.py:301-310), every step checked
+    acp = ddim_ref.alphas_cumprod()
+    want = ddim_ref.sample(lambda xx, t: ref.forward_with_context(sd, ctx_cpu, xx, torch.full((B,), t, dtype=torch.int64)), x, 30, acp)
+    _, trace = model.sample(ctx_gpu, x.cuda(), 30, return_trace=True)
+    assert max(rel_err(trace[i], want[i]) for i in range(30)) < TOL
