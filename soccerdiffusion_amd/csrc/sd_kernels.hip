@@ -628,6 +628,11 @@ struct DecoderLayerArgs {
     const float *kv;   // [B*Mk, 2D] projected memory keys | values of this layer, Mk rows per trajectory
     int T, Mk, B;
     float scale_log2e;
+    // last layer only (b.nln_w == NULL): fc_out (+ DDIM update) fused behind the chain; fo_w NULL = store h instead
+    const float *fo_w, *fo_b;
+    float *eps, *x_io;
+    float c0, c1, c2, c3;
+    int J;
 };
 
 template <int D, int NKT>
@@ -735,7 +740,67 @@ __device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLa
     }
 }
 
+// fc_out (d -> J <= 64) + DDIM update on the panel that holds the final h (see fc_out_kernel)
 template <int D>
+__device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &g, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    constexpr int KH = D / 2;
+    const int tm = p.wave & 1, kh = p.wave >> 1;
+    const float *aB = sA + (tm * 32 + p.l31) * C::LDA + kh * KH + 4 * p.half;
+    const int J = g.J, n_tiles = (J + 31) / 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+    for (int tn = 0; tn < n_tiles; ++tn) {
+        const int j = tn * 32 + p.l31;
+        const float *wp = g.fo_w + (long)(j < J ? j : 0) * D + kh * KH + 4 * p.half;
+        const float wmask = j < J ? 1.f : 0.f;
+#pragma unroll 4
+        for (int k0 = 0; k0 < KH; k0 += 8) {
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(wp + k0);
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(aB + k0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (tn == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[0], 0, 0, 0);
+                else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // panel consumed: reuse it for the K-half exchange
+    if (kh == 1) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[((tm * 2 + tn) * 16 + r) * 64 + p.lane] = acc[tn][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        for (int tn = 0; tn < n_tiles; ++tn) {
+            const int j = tn * 32 + p.l31;
+            if (j >= J) continue;
+            const float bv = g.fo_b[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * p.half;
+                if (row >= p.R_left) continue;
+                const long gi = (p.r0 + row) * J + j;
+                const float e = (tn == 0 ? acc[0][r] : acc[1][r]) + sA[((tm * 2 + tn) * 16 + r) * 64 + p.lane] + bv;
+                if (g.eps) g.eps[gi] = e;
+                if (g.x_io) {
+                    const float xv = g.x_io[gi];
+                    const float x0 = (xv - g.c1 * e) / g.c0;
+                    g.x_io[gi] = g.c2 * x0 + g.c3 * e;
+                }
+            }
+        }
+    }
+}
+
+// TAIL = true is the last layer's instantiation (no next-layer QKV; fc_out + DDIM fused behind
+// the chain).  Separate instantiations keep the tail's registers out of the common kernel.
+template <int D, bool TAIL>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(DecoderLayerArgs g) {
     using C = PanelCfg<D>;
     extern __shared__ __attribute__((aligned(16))) float sA[];
@@ -784,6 +849,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     chain_gelu_to_lds<D>(sA, U, g.b.b1, p);
     __syncthreads();
     chain_gemm_primed<D>(H, aBase, g.b.w2 + wOff, ring);   // h += u W2^T + b2
+    if constexpr (TAIL) {
+        chain_bias_act<D, 0>(H, g.b.b2, p);
+        __syncthreads();                 // last layer: eps = h Wout^T + b (+ DDIM update of x) right here
+        chain_acc_to_lds<D>(sA, H, p);
+        __syncthreads();
+        panel_fc_out<D>(sA, g, p);
+        return;
+    }
     const bool has_next = g.b.nln_w != nullptr;            // workgroup-uniform
     if (has_next) chain_prime<D>(ring, g.b.wqkv + wOff);
     chain_bias_act<D, 0>(H, g.b.b2, p);
@@ -854,11 +927,14 @@ static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
     dim3 grid((unsigned)((g.a.R + 63) / 64)), block(256);
 #define SD_DL(D_)                                                                                                \
     do {                                                                                                         \
-        auto kfn = decoder_layer_kernel<D_>;                                                                     \
+        auto kfn = g.fo_w ? decoder_layer_kernel<D_, true> : decoder_layer_kernel<D_, false>;                    \
         const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                              \
         static bool attr_set = false;                                                                            \
         if (lds > 64 * 1024 && !attr_set) {                                                                      \
-            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, true>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, false>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
             attr_set = true;                                                                                     \
         }                                                                                                        \
         SD_LAUNCH(kfn, grid, block, lds, s, g);                                                                  \
@@ -1606,8 +1682,14 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
 //              a = cross-attention(q, memory K/V);  chain B: h += a Woc^T + boc,
 //              h += FFN(LN3(h)), qkv = LN1_{l+1}(h) Wqkv_{l+1}^T + b (if any)
 // kv(l): projected memory keys | values of layer l, [B][Mk][2d] (a trajectory's rows contiguous).
+struct TailArgs {  // fc_out (+ DDIM) after the last layer
+    float *eps, *x_io;
+    const float *coef;  // host, 4 floats, or NULL
+};
+
 template <typename KV>
-static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, hipStream_t st) {
+static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, const TailArgs &tail,
+                         hipStream_t st) {
     const int d = w->d, heads = w->heads;
     const long R = (long)B * T;
     const sd_layer_weights &l0 = w->layers[0];
@@ -1626,7 +1708,15 @@ static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, 
                       nx ? nx->n1_w : nullptr, nx ? nx->n1_b : nullptr, nx ? nx->sa_in_w : nullptr,
                       nx ? nx->sa_in_b : nullptr, s.qkv, R};
         if (fused) {
-            DecoderLayerArgs gl{ga, gb, kvl, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f};
+            DecoderLayerArgs gl{ga, gb, kvl, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f,
+                                nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, 1.f, 0.f, w->J};
+            if (last) {
+                gl.fo_w = w->out_w;
+                gl.fo_b = w->out_b;
+                gl.eps = tail.eps;
+                gl.x_io = tail.x_io;
+                if (tail.coef) { gl.c0 = tail.coef[0]; gl.c1 = tail.coef[1]; gl.c2 = tail.coef[2]; gl.c3 = tail.coef[3]; }
+            }
             if ((rc = decoder_layer(gl, d, st))) return rc;
             continue;
         }
@@ -1635,7 +1725,8 @@ static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, 
         if (rc) return rc;
         if ((rc = chain_b(gb, d, st))) return rc;
     }
-    return 0;
+    if (fused) return 0;  // the last fused layer already produced eps / updated x
+    return fc_out(s.h, w->out_w, w->out_b, tail.eps, tail.x_io, tail.coef, R, d, w->J, st);
 }
 
 // Encoder stack (self-attention + FFN layers): chain B with norm2 as the FFN norm.
@@ -1689,9 +1780,7 @@ extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x,
     }
     const float *kvbase = s.kv;
     const size_t kvstride = (size_t)B * M * 2 * d;
-    rc = decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; }, st);
-    if (rc) return rc;
-    return fc_out(s.h, w->out_w, w->out_b, eps_out, nullptr, nullptr, R, d, w->J, st);
+    return decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; }, TailArgs{eps_out, nullptr, nullptr}, st);
 }
 
 extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, float *out, float *workspace, int B,
@@ -1753,11 +1842,9 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         if (rc) return rc;
         {
             const float *kvbase = s.kv;
-            rc = decoder_stack(w, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, st);
+            rc = decoder_stack(w, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st);
             if (rc) return rc;
         }
-        rc = fc_out(s.h, w->out_w, w->out_b, nullptr, x, coef + 4 * i, R, d, w->J, st);
-        if (rc) return rc;
         if (trace) {
             const long n = (long)R * w->J;
             SD_LAUNCH(copy_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, trace + (size_t)i * n, n,
