@@ -161,11 +161,11 @@ def main():
         f = flops_per_traj_step()
         names = _lib.KERNEL_CLASSES
         dl = names.index("decoder_layer_kernel")
-        # Dominant kernel: decoder_layer_kernel, one launch per (DDIM step, layer): per trajectory it does the
-        # row GEMMs of SURVEY 8(d) except the first layer's LN1+QKV, which the head panel_gemm does (10Td^2 per
-        # layer + the next layer's 6Td^2 QKV for all but the last) plus the cross-attention core 4TMd.
-        # Summed over the L launches of a step:
-        per_traj_step_dl = (L * 16 - 6) * T * D * D + L * 4 * T * M * D
+        # Dominant kernel: decoder_layer_kernel, one launch per (DDIM step, layer).  Per trajectory it does the row
+        # GEMMs of SURVEY 8(d) except layer 0's LN1+QKV, which decoder_head_kernel does (10Td^2 per layer + the next
+        # layer's 6Td^2 QKV for all but the last), the cross-attention cores 4TMd and, in the last layer, fc_out
+        # 2TdJ.  Summed over the L launches of a step:
+        per_traj_step_dl = (L * 16 - 6) * T * D * D + L * 4 * T * M * D + 2 * T * D * J
         dl_flops = args.steps * B * N_DDIM * per_traj_step_dl
         dl_s = ms[dl] / 1e3
         achieved = dl_flops / dl_s / 1e12

@@ -234,7 +234,8 @@ int sd_adamw_step(float *p, const float *g, float *m, float *v, long n, double l
 #define SD_KCLASS_PATCH_EMBED 2  /* patch_embed_kernel                                  */
 #define SD_KCLASS_FC_OUT 3       /* fc_out_kernel (+ fused DDIM update)                 */
 #define SD_KCLASS_LAYER_CHAIN 4  /* decoder_layer_kernel / chain_a_kernel / chain_b_kernel */
-#define SD_KCLASS_COUNT 5
+#define SD_KCLASS_HEAD 5         /* decoder_head_kernel (embed + LN1 + QKV of layer 0)   */
+#define SD_KCLASS_COUNT 6
 int sd_profile_enable(int on);
 int sd_profile_collect(double *ms_by_class, long *launches_by_class, int n_classes);
 

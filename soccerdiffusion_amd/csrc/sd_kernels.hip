@@ -877,10 +877,93 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Head of a denoiser step in one launch: h = x Wemb^T + b + pe (nn.Linear(J -> d) on the MFMA,
+// K = J zero-padded to a multiple of 8), h stored, then qkv = LN1(h) Wqkv^T + b of layer 0.
+// Needs J % 4 == 0 (16-byte weight fragments); otherwise patch_embed + panel_gemm are used.
+// --------------------------------------------------------------------------------------
+struct DecoderHeadArgs {
+    const float *x;               // [R, J]
+    const float *emb_w, *emb_b;   // (D, J), (D)
+    const float *pe;              // [T_max, D]
+    const float *ln_w, *ln_b;     // layer 0 norm1
+    const float *wqkv, *bqkv;     // layer 0 in_proj (3D, D)
+    float *h, *qkv;               // [R, D], [R, 3D]
+    long R;
+    int T, J;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_kernel(DecoderHeadArgs g) {
+    using C = PanelCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.R);
+    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    const long wOff = (long)(p.wn * C::WN + p.l31) * D + 4 * p.half;
+    WeightRing<D> ring;
+    chain_prime<D>(ring, g.wqkv + wOff);
+    const int J = g.J, Jp = (J + 7) & ~7;  // <= 64 < LDA
+    for (int i = threadIdx.x; i < C::BM * Jp; i += 256) {
+        const int row = i / Jp, j = i - row * Jp;
+        sA[row * C::LDA + j] = (row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
+    }
+    __syncthreads();
+    f32x16 H[C::TM][C::TN];
+    chain_zero<D>(H);
+    for (int k0 = 0; k0 < Jp; k0 += 8) {
+        const int kk = k0 + 4 * p.half;
+        f32x4 bf[C::TN], af[C::TM];
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (kk < J) t = *reinterpret_cast<const f32x4 *>(g.emb_w + (long)(p.wn * C::WN + tn * 32 + p.l31) * J + kk);
+            bf[tn] = t;
+        }
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], H[tm][tn], 0, 0, 0);
+    }
+    // + bias + positional row (position = row index inside its trajectory)
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const int col = p.col(tn);
+        const float bv = g.emb_b[col];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p.row(tm, r);
+                const int pos = (int)((p.r0 + (row < p.R_left ? row : 0)) % g.T);
+                H[tm][tn][r] += bv + g.pe[(long)pos * D + col];
+            }
+    }
+    chain_store_acc<D>(g.h, D, 0, H, p);
+    __syncthreads();  // the x staging area is part of the panel
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    chain_layer_norm<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        chain_zero<D>(H);
+        chain_gemm_primed<D>(H, aBase, g.wqkv + (long)pass * D * D + wOff, ring);
+        if (pass < 2) chain_prime<D>(ring, g.wqkv + (long)(pass + 1) * D * D + wOff);
+        chain_bias_act<D, 0>(H, g.bqkv + pass * D, p);
+        chain_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+    }
+}
+
 template <typename Args, typename KA, typename KB, typename KC, typename KD>
-static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512, const char *name, hipStream_t s) {
+static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512, const char *name, hipStream_t s,
+                        int kclass = SD_KCLASS_LAYER_CHAIN) {
     if (g.R <= 0) return fail(SD_E_BADARG, "chain: empty shape");
-    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
+    ProfScope prof(kclass, s);
     dim3 grid((unsigned)((g.R + 63) / 64)), block(256);
 #define SD_CHAIN(D_, K_)                                                                                        \
     do {                                                                                                        \
@@ -911,6 +994,11 @@ static int chain_a(const ChainAArgs &g, int d, hipStream_t s) {
 static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
     return launch_chain(g, d, chain_b_kernel<64>, chain_b_kernel<128>, chain_b_kernel<256>, chain_b_kernel<512>,
                         "chain_b_kernel", s);
+}
+
+static int decoder_head(const DecoderHeadArgs &g, int d, hipStream_t s) {
+    return launch_chain(g, d, decoder_head_kernel<64>, decoder_head_kernel<128>, decoder_head_kernel<256>,
+                        decoder_head_kernel<512>, "decoder_head_kernel", s, SD_KCLASS_HEAD);
 }
 
 // true when the fused decoder-layer kernel applies: 4 heads == 4 waves each owning one head's
@@ -1688,12 +1776,20 @@ struct TailArgs {  // fc_out (+ DDIM) after the last layer
 };
 
 template <typename KV>
-static int decoder_stack(const sd_denoiser_weights *w, const Scratch &s, int B, int T, int Mk, KV kv, const TailArgs &tail,
-                         hipStream_t st) {
+static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scratch &s, int B, int T, int Mk, KV kv,
+                         const TailArgs &tail, hipStream_t st) {
     const int d = w->d, heads = w->heads;
     const long R = (long)B * T;
     const sd_layer_weights &l0 = w->layers[0];
-    int rc = linear(s.h, l0.sa_in_w, l0.sa_in_b, l0.n1_w, l0.n1_b, nullptr, s.qkv, (int)R, 3 * d, d, 0, st);
+    int rc;
+    if (w->J % 4 == 0) {  // embed + LN1 + QKV of layer 0 in one launch
+        DecoderHeadArgs gh{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J};
+        rc = decoder_head(gh, d, st);
+    } else {
+        rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
+        if (rc) return rc;
+        rc = linear(s.h, l0.sa_in_w, l0.sa_in_b, l0.n1_w, l0.n1_b, nullptr, s.qkv, (int)R, 3 * d, d, 0, st);
+    }
     if (rc) return rc;
     const bool fused = fused_layer_ok(d, heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
     for (int l = 0; l < w->L; ++l) {
@@ -1769,8 +1865,6 @@ extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x,
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T;
     Scratch s = carve(workspace, R, (long)B * M, d, w->L, 0);
-    rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
-    if (rc) return rc;
     for (int l = 0; l < w->L; ++l) {
         // memory is NOT layer-normed: K = mem Wk^T + bk, V = mem Wv^T + bv (rows [d:3d) of in_proj)
         const sd_layer_weights &lw = w->layers[l];
@@ -1780,7 +1874,7 @@ extern "C" int sd_denoiser_forward(const sd_denoiser_weights *w, const float *x,
     }
     const float *kvbase = s.kv;
     const size_t kvstride = (size_t)B * M * 2 * d;
-    return decoder_stack(w, s, B, T, M, [=](int l) { return kvbase + l * kvstride; }, TailArgs{eps_out, nullptr, nullptr}, st);
+    return decoder_stack(w, x, s, B, T, M, [=](int l) { return kvbase + l * kvstride; }, TailArgs{eps_out, nullptr, nullptr}, st);
 }
 
 extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, float *out, float *workspace, int B,
@@ -1838,11 +1932,9 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * 2 * d), L), dim3(256), 0, st, s.kvstep + (size_t)i * 2 * d, (long)kvsstride,
                   s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
         SD_CHECK_LAUNCH("kv_place_kernel");
-        rc = patch_embed(x, w->emb_w, w->emb_b, w->pe, s.h, B, T, w->J, 1, d, st);
-        if (rc) return rc;
         {
             const float *kvbase = s.kv;
-            rc = decoder_stack(w, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st);
+            rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st);
             if (rc) return rc;
         }
         if (trace) {
