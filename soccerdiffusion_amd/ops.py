@@ -518,6 +518,18 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, 
     return dx, dg, db
 
 
+def layernorm_bwd_into(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, dg: Tensor, db: Tensor) -> Tensor:
+    """LayerNorm backward that ACCUMULATES the affine gradients into existing dg / db buffers."""
+    lib = _lib.load()
+    _req(dy, "dy"); _req(x, "x")
+    d = x.shape[-1]
+    R = x.numel() // d
+    dx = torch.empty_like(x)
+    check(lib.sd_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), None,
+                                  dx.data_ptr(), dg.data_ptr(), db.data_ptr(), R, d, _stream()), "sd_op_layernorm_bwd")
+    return dx
+
+
 def gelu_fwd(pre: Tensor) -> Tensor:
     lib = _lib.load()
     _req(pre, "pre")

@@ -28,6 +28,34 @@ def _zeros_like_param(p: Tensor) -> Tensor:
     return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
 
 
+class _GradSink:
+    """Where a block's parameter gradients go.  When the parameters' ``.grad`` buffers are
+    preallocated (FusedAdamW aliases them to one flat buffer and zeroes it per step), the
+    backward kernels ACCUMULATE straight into them (dW += dY^T X with fp32 atomics) and the
+    autograd node returns None for those inputs: no zero-fill, no extra add kernel, no copy.
+    Otherwise fresh tensors are returned to autograd as usual."""
+
+    __slots__ = ("views",)
+
+    def __init__(self, *params_and_slices):
+        views = [] if params_and_slices else None
+        for item in params_and_slices:
+            p, sl = item if isinstance(item, tuple) else (item, None)
+            g = p.grad
+            if g is None or not g.is_cuda:
+                views = None
+                break
+            views.append(g if sl is None else g[sl])
+        self.views = views
+
+    def target(self, i: int, like: Tensor):
+        """(tensor to accumulate into, value to hand back to autograd)."""
+        if self.views is not None:
+            return self.views[i], None
+        z = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
+        return z, z
+
+
 def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
     """dX[R,d] = dY[R,N] @ W[N,d]: the forward panel kernel on W^T, one pass per d-wide
     column slice of dY (N = d, 2d or 3d), accumulated through the residual input."""
@@ -43,13 +71,14 @@ class _LNLinear(Function):
     """y = act(LayerNorm(x) W^T + b) — LN1+QKV, LN2+Q, LN3+FFN1(+GELU)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool):
+    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None):
         x2 = x.reshape(-1, x.shape[-1])
         pre = ops.linear(x2, W, b, ln=(ln_w, ln_b))
         y = ops.gelu_fwd(pre) if gelu else pre
         ctx.save_for_backward(x2, ln_w, ln_b, W, pre if gelu else None)
         ctx.gelu = gelu
         ctx.shape = x.shape
+        ctx.sink = sink if sink is not None else _GradSink()
         return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -58,21 +87,23 @@ class _LNLinear(Function):
         dy2 = dy.contiguous().view(-1, W.shape[0])
         dpre = ops.gelu_bwd(dy2, pre) if ctx.gelu else dy2
         n, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b)  # recomputed, not stored
-        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        (dg, rg), (dbeta, rbeta) = ctx.sink.target(0, ln_w), ctx.sink.target(1, ln_w)
+        (dW, rW), (db, rb) = ctx.sink.target(2, W), ctx.sink.target(3, W[:, 0])
         ops.gemm_tn(dpre, n, dW, db)
         dn = _dx_through_weight(dpre, W)
-        dx, dg, dbeta = ops.layernorm_bwd(dn, x2, mean, rstd, ln_w)
-        return dx.view(ctx.shape), dg, dbeta, dW, db, None
+        dx = ops.layernorm_bwd_into(dn, x2, mean, rstd, ln_w, dg, dbeta)
+        return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None
 
 
 class _LinearRes(Function):
     """y = res + a W^T + b — attention out-projection and FFN2 with the residual add."""
 
     @staticmethod
-    def forward(ctx, a, W, b, res):
+    def forward(ctx, a, W, b, res, sink=None):
         a2 = a.reshape(-1, a.shape[-1])
         ctx.save_for_backward(a2, W)
         ctx.shape = a.shape
+        ctx.sink = sink if sink is not None else _GradSink()
         y = ops.linear(a2, W, b, res=res.reshape(-1, W.shape[0]).contiguous())
         return y.view(*a.shape[:-1], W.shape[0])
 
@@ -80,30 +111,31 @@ class _LinearRes(Function):
     def backward(ctx, dy):
         a2, W = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
-        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
         ops.gemm_tn(dy2, a2, dW, db)
         da = _dx_through_weight(dy2, W)
-        return da.view(ctx.shape), dW, db, dy
+        return da.view(ctx.shape), rW, rb, dy, None
 
 
 class _Linear(Function):
     """y = a W^T + b (no norm) — K/V projection of the un-normalised memory rows."""
 
     @staticmethod
-    def forward(ctx, a, W, b):
+    def forward(ctx, a, W, b, sink=None):
         a2 = a.reshape(-1, a.shape[-1]).contiguous()
         ctx.save_for_backward(a2, W)
         ctx.shape = a.shape
+        ctx.sink = sink if sink is not None else _GradSink()
         return ops.linear(a2, W, b).view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         a2, W = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
-        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
         ops.gemm_tn(dy2, a2, dW, db)
         da = _dx_through_weight(dy2, W) if ctx.needs_input_grad[0] else None
-        return (da.view(ctx.shape) if da is not None else None), dW, db
+        return (da.view(ctx.shape) if da is not None else None), rW, rb, None
 
 
 class _SelfAttention(Function):
@@ -233,18 +265,23 @@ def step_token_autograd(step_module, steps: Tensor) -> Tensor:
 
 
 def _layer(lp, h, heads, memory=None, ffn_norm=None):
-    qkv = _LNLinear.apply(h, lp.norm1.weight, lp.norm1.bias, lp.self_attn.in_proj_weight, lp.self_attn.in_proj_bias, False)
+    sa, n1 = lp.self_attn, lp.norm1
+    qkv = _LNLinear.apply(h, n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias, False,
+                          _GradSink(n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias))
     a = _SelfAttention.apply(qkv, heads)
-    h = _LinearRes.apply(a, lp.self_attn.out_proj.weight, lp.self_attn.out_proj.bias, h)
+    h = _LinearRes.apply(a, sa.out_proj.weight, sa.out_proj.bias, h, _GradSink(sa.out_proj.weight, sa.out_proj.bias))
     if memory is not None:
         d = h.shape[-1]
-        w, b = lp.multihead_attn.in_proj_weight, lp.multihead_attn.in_proj_bias
-        q = _LNLinear.apply(h, lp.norm2.weight, lp.norm2.bias, w[:d], b[:d], False)
-        kv = _Linear.apply(memory, w[d:], b[d:])  # memory is NOT layer-normed
+        ca, n2 = lp.multihead_attn, lp.norm2
+        w, b = ca.in_proj_weight, ca.in_proj_bias
+        q = _LNLinear.apply(h, n2.weight, n2.bias, w[:d], b[:d], False,
+                            _GradSink(n2.weight, n2.bias, (w, slice(0, d)), (b, slice(0, d))))
+        kv = _Linear.apply(memory, w[d:], b[d:], _GradSink((w, slice(d, 3 * d)), (b, slice(d, 3 * d))))  # memory is NOT layer-normed
         a = _CrossAttention.apply(q, kv, heads)
-        h = _LinearRes.apply(a, lp.multihead_attn.out_proj.weight, lp.multihead_attn.out_proj.bias, h)
-    u = _LNLinear.apply(h, ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias, True)
-    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h)
+        h = _LinearRes.apply(a, ca.out_proj.weight, ca.out_proj.bias, h, _GradSink(ca.out_proj.weight, ca.out_proj.bias))
+    u = _LNLinear.apply(h, ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias, True,
+                        _GradSink(ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias))
+    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias))
 
 
 def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
