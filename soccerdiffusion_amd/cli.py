@@ -4,6 +4,7 @@ soccer_diffusion/ml/inference/plot.py:21-135).
 
     python -m soccerdiffusion_amd.cli train -c cfg.yaml [-p ckpt] [-o out] [--decoder-pretraining] [--pretrained-decoder p]
     python -m soccerdiffusion_amd.cli sample ckpt [--steps 30] [--num_samples 10]
+    python -m soccerdiffusion_amd.cli distill cfg.yaml teacher_ckpt [-o out]     (ml/training/distill.py:25-224)
 
 Differences, all additive: data comes from a tensor file (`--data file.pt`: dict with
 `joint_command` (N,T,J) and the optional context keys of the reference's `Result`
@@ -194,6 +195,89 @@ def cmd_train(args) -> int:
     return 0
 
 
+def cmd_distill(args) -> int:
+    """Single-step distillation (reference ml/training/distill.py:155-221): per batch the teacher
+    runs its `distill_teacher_inference_steps`-step DDIM rollout from pure noise under no_grad
+    (one native call), the student predicts the sample in ONE forward at t = 0 re-using the
+    teacher's context tokens, and is trained with MSE to the teacher's sample."""
+    from . import training
+
+    rank, world, local = _dist_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+    checkpoint = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
+    teacher_params = checkpoint["hyperparams"]
+    with open(args.config) as f:
+        params = yaml.safe_load(f)
+    for key, value in params.items():
+        if key not in teacher_params:
+            logger.warning("parameter %s in the config is not in the checkpoint's hyperparameters", key)
+        elif value != teacher_params[key]:
+            logger.warning("parameter %s differs from the teacher checkpoint: %r != %r", key, teacher_params[key], value)
+    params["distilled_decoder"] = True  # flags the student (distill.py:62)
+
+    teacher = build_model(params).to(device)
+    teacher.load_state_dict(checkpoint["model_state_dict"])
+    teacher.eval()
+    student = build_model(params).to(device)
+    student.load_state_dict(checkpoint["model_state_dict"])
+    student.train()
+    # the student's context encoders never see a gradient (the context comes from the teacher under
+    # no_grad), so torch's AdamW leaves them untouched; the flat optimizer therefore only owns the rest
+    trainable = [p for n, p in student.named_parameters() if n.startswith(("diffusion_action_generator.", "step_encoding."))]
+    optimizer = training.FusedAdamW(trainable, lr=params["lr"])
+
+    gen = torch.Generator().manual_seed(args.seed + rank)
+    data = load_data(args, params)
+    n_total = data["joint_command"].shape[0]
+    bs = params["batch_size"]
+    shard = torch.arange(rank, n_total, world)
+    steps_per_epoch = max(1, math.ceil(len(shard) / bs))
+    lr_scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=params["lr"], total_steps=params["epochs"] * steps_per_epoch)
+    on_device = {k: v.to(device) for k, v in data.items()}
+    dev_gen = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
+    n_teacher = params["distill_teacher_inference_steps"]
+    for epoch in range(params["epochs"]):
+        order = shard[torch.randperm(len(shard), generator=gen)]
+        mean_loss = 0.0
+        for i in range(steps_per_epoch):
+            idx = order[i * bs : (i + 1) * bs].to(device)
+            if world > 1 and len(idx) < bs and i > 0:
+                continue
+            batch = {k: v[idx] for k, v in on_device.items()}
+            noisy = torch.randn(batch["joint_command"].shape, device=device, generator=dev_gen)
+            optimizer.zero_grad()
+            with torch.no_grad():
+                if params_need_context(params):
+                    embedded = teacher.encode_input_data({k: batch[k].contiguous() for k in CONTEXT_KEYS if k in batch})
+                else:
+                    embedded = [torch.randn(len(idx), 10, params["hidden_dim"], device=device, generator=dev_gen)]
+                target = teacher.sample(embedded, noisy, n_teacher)
+            pred = student.forward_with_context(embedded, noisy, torch.zeros(len(idx), device=device))
+            loss = training.mse_loss(pred, target)
+            loss.backward()
+            training.allreduce_gradients(optimizer, world)
+            optimizer.step()
+            lr_scheduler.step()
+            mean_loss += float(loss)
+            if i % 20 == 0 and rank == 0:
+                print(f"Epoch {epoch}, it {i}, Loss: {mean_loss / (i + 1):.05f}, LR: {lr_scheduler.get_last_lr()[0]:0.7f}", flush=True)
+        if rank == 0:
+            torch.save({"model_state_dict": student.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                        "lr_scheduler_state_dict": lr_scheduler.state_dict(), "hyperparams": params,
+                        "current_epoch": epoch}, args.output)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def cmd_sample(args) -> int:
     from . import ops
 
@@ -251,14 +335,18 @@ def main(argv: Optional[list] = None) -> int:
     sa.add_argument("--steps", type=int, default=30, help="Number of denoising steps")
     sa.add_argument("--num_samples", type=int, default=10, help="Number of samples to generate")
     sa.add_argument("--output", "-o", type=str, default="samples.pt", help="Where to save the sampled trajectories")
-    for p in (tr, sa):
+    di = sub.add_parser("distill", help="distil the multi-step model into a single-step model (flags of the reference's distill.py)")
+    di.add_argument("config", type=str, help="Path to the training configuration file")
+    di.add_argument("checkpoint", type=str, help="Path to the checkpoint to load for the teacher model")
+    di.add_argument("--output", "-o", type=str, default="distilled_trajectory_transformer_model.pth", help="Path to save the distilled model")
+    for p in (tr, sa, di):
         p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
         p.add_argument("--synthetic", type=int, default=2048, help="number of synthetic sine-wave samples when --data is absent")
         p.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("soccerdiffusion_amd needs an MI355X (no CPU fallback)")
-    return cmd_train(args) if args.command == "train" else cmd_sample(args)
+    return {"train": cmd_train, "sample": cmd_sample, "distill": cmd_distill}[args.command](args)
 
 
 if __name__ == "__main__":

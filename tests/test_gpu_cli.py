@@ -69,3 +69,28 @@ def test_normalize_roundtrip():
     n = ops.normalize(x.cuda(), mean.cuda(), std.cuda())
     assert rel_err(n, (x - mean) / std) < 1e-6
     assert rel_err(ops.normalize(n, mean.cuda(), std.cuda(), inverse=True), x) < 1e-6
+
+
+def test_distill_then_single_step_sample(tmp_path):
+    """distill.py's flow: teacher checkpoint -> student flagged `distilled_decoder`, trained to hit the teacher's
+    30-step sample in one forward; `cli sample` then takes the single-step branch (plot.py:118-121)."""
+    cfg = dict(CFG, epochs=3, lr=2e-3, distill_teacher_inference_steps=10)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    teacher = tmp_path / "teacher.pth"
+    r = _run("train", "-c", str(path), "-o", str(teacher), "--synthetic", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    student = tmp_path / "student.pth"
+    r = _run("distill", str(path), str(teacher), "-o", str(student), "--synthetic", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses
+    t, s = torch.load(teacher, weights_only=True), torch.load(student, weights_only=True)
+    assert s["hyperparams"]["distilled_decoder"] is True and "distilled_decoder" not in t["hyperparams"]
+    # encoders are untouched by distillation, the decoder is not
+    k_enc, k_dec = "imu_encoder.embedding.weight", "diffusion_action_generator.fc_out.weight"
+    assert torch.equal(t["model_state_dict"][k_enc], s["model_state_dict"][k_enc])
+    assert not torch.equal(t["model_state_dict"][k_dec], s["model_state_dict"][k_dec])
+    r = _run("sample", str(student), "--num_samples", "4", "-o", str(tmp_path / "s.pt"), "--synthetic", "32")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert torch.isfinite(torch.load(tmp_path / "s.pt", weights_only=True)["trajectories"]).all()
