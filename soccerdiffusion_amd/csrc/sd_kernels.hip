@@ -474,7 +474,7 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = p.row(tm, r);
-                if (row < p.R_left) dst[(p.r0 + row) * ld + col0 + p.col(tn)] = acc[tm][tn][r];
+                if (row < p.R_left) __builtin_nontemporal_store(acc[tm][tn][r], dst + (p.r0 + row) * ld + col0 + p.col(tn));
             }
 }
 

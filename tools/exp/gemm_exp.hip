@@ -198,6 +198,68 @@ float run_cont(const float* A, const float* W, float* out, int R, int N, int ite
     return ms / iters;
 }
 
+// VARIANT 20: 32-row panels, 2 waves per workgroup (each wave 32 rows x 128 columns), 4 workgroups per CU
+__global__ __launch_bounds__(128) void gemm_bm32_kernel(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ out, int R, int N) {
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    constexpr int BM2 = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r0 = (long)blockIdx.x * BM2;
+    for (int i = tid; i < BM2 * (D / 4); i += 128) {
+        const int row = i / (D / 4), c4 = i % (D / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < R) v = *reinterpret_cast<const f32x4*>(A + (r0 + row) * D + c4 * 4);
+        *reinterpret_cast<f32x4*>(sA + row * LDA + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int l31 = lane & 31, half = lane >> 5;
+    const float* aBase = sA + l31 * LDA + 4 * half;
+    constexpr int NK = D / 8;
+    for (int n0 = 0; n0 < N; n0 += D) {
+        f32x16 acc[4];
+        for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const float* wBase = W + (long)(n0 + wave * 128 + l31) * D + 4 * half;
+        f32x4 b[2][4], a[2];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) b[0][tn] = *reinterpret_cast<const f32x4*>(wBase + (long)tn * 32 * D);
+        a[0] = *reinterpret_cast<const f32x4*>(aBase);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < NK) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) b[nxt][tn] = *reinterpret_cast<const f32x4*>(wBase + (long)tn * 32 * D + (ks + 1) * 8);
+                a[nxt] = *reinterpret_cast<const f32x4*>(aBase + (ks + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][j], b[cur][tn][j], acc[tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int tn = 0; tn < 4; ++tn) {
+            const int col = n0 + wave * 128 + tn * 32 + l31;
+            for (int r = 0; r < 16; ++r) {
+                const long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < R) out[row * N + col] = acc[tn][r];
+            }
+        }
+    }
+}
+
+float run_bm32(const float* A, const float* W, float* out, int R, int N, int iters) {
+    size_t lds = (size_t)32 * LDA * 4;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(gemm_bm32_kernel, dim3((R + 31) / 32), dim3(128), lds, 0, A, W, out, R, N);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm_bm32_kernel, dim3((R + 31) / 32), dim3(128), lds, 0, A, W, out, R, N);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
 // raw MFMA rate: 4 accumulators per wave, operands in registers, NW waves per SIMD
 __global__ __launch_bounds__(256) void mfma_only(float* out, int iters) {
     f32x16 acc[4];
@@ -265,6 +327,7 @@ int main(int argc, char** argv) {
         double md2 = 0; for (size_t i = 0; i < h2.size(); ++i) md2 = fmax(md2, fabs(h2[i] - h0b[i]));
         printf("   max diff v0 vs %s: %g\n", name, md2);
     };
+    t = run_bm32(A, W, o2, R, N, 10); printf("variant 20 (32-row panels, 2 waves/WG, 4 WG/CU): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v20");
     t = run_cont<2>(A, W, o2, R, N, 10); printf("variant 10 (continuous prefetch PF=2): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v10");
     t = run_cont<4>(A, W, o2, R, N, 10); printf("variant 11 (continuous prefetch PF=4): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v11");
     t = run_cont<8>(A, W, o2, R, N, 10); printf("variant 12 (continuous prefetch PF=8): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v12");
