@@ -394,6 +394,10 @@ template <int D>
 __device__ __forceinline__ void chain_load_acc(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *src,
                                                const ChainPos<D> &p) {
     using C = PanelCfg<D>;
+    // one wave-uniform base + 32-bit lane offsets: the compiler then keeps a single scalar
+    // pointer instead of 64 per-element 64-bit addresses (which it spilled)
+    const float *base = src + p.r0 * D;
+    const unsigned lane_off = (unsigned)((p.wm * C::WM + 4 * p.half) * D + p.wn * C::WN + p.l31);
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
@@ -401,7 +405,8 @@ __device__ __forceinline__ void chain_load_acc(f32x16 (&acc)[PanelCfg<D>::TM][Pa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = p.row(tm, r);
-                acc[tm][tn][r] = (row < p.R_left) ? src[(p.r0 + row) * D + p.col(tn)] : 0.f;
+                const unsigned off = lane_off + (unsigned)((tm * 32 + (r & 3) + 8 * (r >> 2)) * D + tn * 32);
+                acc[tm][tn][r] = (row < p.R_left) ? base[off] : 0.f;
             }
 }
 
@@ -467,6 +472,8 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
                                                 const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
                                                 const ChainPos<D> &p) {
     using C = PanelCfg<D>;
+    float *base = dst + p.r0 * ld + col0;  // wave-uniform; 32-bit lane offsets below (panel spans < 64 * 3D floats)
+    const unsigned lane_off = (unsigned)((p.wm * C::WM + 4 * p.half) * ld + p.wn * C::WN + p.l31);
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
@@ -474,7 +481,8 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = p.row(tm, r);
-                if (row < p.R_left) __builtin_nontemporal_store(acc[tm][tn][r], dst + (p.r0 + row) * ld + col0 + p.col(tn));
+                const unsigned off = lane_off + (unsigned)((tm * 32 + (r & 3) + 8 * (r >> 2)) * ld + tn * 32);
+                if (row < p.R_left) __builtin_nontemporal_store(acc[tm][tn][r], base + off);
             }
 }
 
@@ -823,7 +831,6 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     __syncthreads();
     chain_zero<D>(U);
     chain_gemm_primed<D>(U, aBase, g.a.wq + wOff, ring);   // q = LN2(h) Wq^T + bq
-    chain_prime<D>(ring, g.b.wo + wOff);
     chain_bias_act<D, 0>(U, g.a.bq, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, U, p);
@@ -833,6 +840,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
         if (n_traj * g.Mk <= 32) panel_cross_attention<D, 1>(sA, g, p);
         else panel_cross_attention<D, 2>(sA, g, p);
     }
+    chain_prime<D>(ring, g.b.wo + wOff);   // primed after the attention: its 24 registers are needed there
     __syncthreads();
     chain_gemm_primed<D>(H, aBase, g.b.wo + wOff, ring);   // h += a_c Woc^T + boc
     chain_prime<D>(ring, g.b.w1 + wOff);
