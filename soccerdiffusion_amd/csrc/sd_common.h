@@ -58,6 +58,22 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// 4x4 transpose inside every quad of lanes (lane i = lane & 3 holds column i of rows x0..x3 on
+// entry, row i of columns 0..3 on exit; an involution).  Turns the MFMA accumulator's "4
+// consecutive rows per lane" into "4 consecutive columns per lane", so tiles move to and
+// from memory 16 bytes per lane (4x fewer store/load instructions: +6..11 % on the panel GEMM).
+__device__ __forceinline__ void quad_transpose(float &x0, float &x1, float &x2, float &x3, int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    float ta = o1 ? x0 : x1, tb = o1 ? x2 : x3;
+    ta = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ta), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    tb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tb), 0xB1, 0xF, 0xF, false));
+    if (o1) { x0 = ta; x2 = tb; } else { x1 = ta; x3 = tb; }
+    float tc = o2 ? x0 : x2, td = o2 ? x1 : x3;
+    tc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tc), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    td = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, td), 0x4E, 0xF, 0xF, false));
+    if (o2) { x0 = tc; x1 = td; } else { x2 = tc; x3 = td; }
+}
+
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
 static inline unsigned grid_for(long n, int block = 256) {

@@ -472,17 +472,23 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
                                                 const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
                                                 const ChainPos<D> &p) {
     using C = PanelCfg<D>;
-    float *base = dst + p.r0 * ld + col0;  // wave-uniform; 32-bit lane offsets below (panel spans < 64 * 3D floats)
-    const unsigned lane_off = (unsigned)((p.wm * C::WM + 4 * p.half) * ld + p.wn * C::WN + p.l31);
+    // quad transpose -> each lane owns 4 consecutive columns of one row -> 16-byte non-temporal stores
+    float *base = dst + p.r0 * ld + col0;  // wave-uniform; 32-bit lane offsets below
+    const int i4 = p.lane & 3;
+    const unsigned lane_off = (unsigned)((p.wm * C::WM + 4 * p.half + i4) * ld + p.wn * C::WN + (p.l31 & ~3));
 #pragma unroll
     for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = p.row(tm, r);
-                const unsigned off = lane_off + (unsigned)((tm * 32 + (r & 3) + 8 * (r >> 2)) * ld + tn * 32);
-                if (row < p.R_left) __builtin_nontemporal_store(acc[tm][tn][r], base + off);
+            for (int g = 0; g < 4; ++g) {
+                float x0 = acc[tm][tn][4 * g], x1 = acc[tm][tn][4 * g + 1], x2 = acc[tm][tn][4 * g + 2], x3 = acc[tm][tn][4 * g + 3];
+                quad_transpose(x0, x1, x2, x3, p.lane);
+                const int row = p.wm * C::WM + tm * 32 + 8 * g + 4 * p.half + i4;
+                if (row < p.R_left) {
+                    const f32x4 v = {x0, x1, x2, x3};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + lane_off + (unsigned)((tm * 32 + 8 * g) * ld + tn * 32)));
+                }
             }
 }
 

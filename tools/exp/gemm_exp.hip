@@ -104,6 +104,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (VARIANT == 13) {
+            const int i4 = lane & 3;
+            for (int tn = 0; tn < 2; ++tn)
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float x0 = acc[tm][tn][4 * g], x1 = acc[tm][tn][4 * g + 1], x2 = acc[tm][tn][4 * g + 2], x3 = acc[tm][tn][4 * g + 3];
+                        auto dpp = [](float v, int ctrl_is_b1) {
+                            int iv = __builtin_bit_cast(int, v);
+                            int r = ctrl_is_b1 ? __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, false);
+                            return __builtin_bit_cast(float, r);
+                        };
+                        const bool o1 = i4 & 1, o2 = i4 & 2;
+                        float ta = o1 ? x0 : x1, tb = o1 ? x2 : x3;
+                        ta = dpp(ta, 1); tb = dpp(tb, 1);
+                        if (o1) { x0 = ta; x2 = tb; } else { x1 = ta; x3 = tb; }
+                        float tc = o2 ? x0 : x2, td = o2 ? x1 : x3;
+                        tc = dpp(tc, 0); td = dpp(td, 0);
+                        if (o2) { x0 = tc; x1 = td; } else { x2 = tc; x3 = td; }
+                        const long row = r0 + tm * 32 + 8 * g + 4 * half + i4;
+                        const int col = n0 + wave * 64 + tn * 32 + (l31 & ~3);
+                        if (row < R) { f32x4 v = {x0, x1, x2, x3}; *reinterpret_cast<f32x4*>(out + row * N + col) = v; }
+                    }
+        } else {
         const bool do_store = (VARIANT != 7) || (n0 + D >= N) || (R == 12345);
         if (do_store)
         for (int tn = 0; tn < 2; ++tn) {
@@ -115,6 +139,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                 }
         }
         else { for (int tn = 0; tn < 2; ++tn) for (int tm = 0; tm < 2; ++tm) asm volatile("" :: "v"(acc[tm][tn])); }
+        }
     }
 }
 
@@ -327,6 +352,7 @@ int main(int argc, char** argv) {
         double md2 = 0; for (size_t i = 0; i < h2.size(); ++i) md2 = fmax(md2, fabs(h2[i] - h0b[i]));
         printf("   max diff v0 vs %s: %g\n", name, md2);
     };
+    t = run<13>(A, W, o2, R, N, 10); printf("variant 13 (v1 + quad-transposed dwordx4 stores): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v13");
     t = run_bm32(A, W, o2, R, N, 10); printf("variant 20 (32-row panels, 2 waves/WG, 4 WG/CU): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v20");
     t = run_cont<2>(A, W, o2, R, N, 10); printf("variant 10 (continuous prefetch PF=2): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v10");
     t = run_cont<4>(A, W, o2, R, N, 10); printf("variant 11 (continuous prefetch PF=4): %.3f ms  %.1f TF\n", t, flops / t / 1e9); cmp("v11");
