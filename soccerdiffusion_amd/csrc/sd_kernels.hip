@@ -175,30 +175,29 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const float *__restrict
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- epilogue: bias, activation; each store instruction covers 2 rows x 128 B -----
+        // ---- epilogue: bias, activation, then a quad transpose so that every lane stores 16
+        // bytes (4 consecutive columns of one row): 4x fewer store instructions -----------------
+        const int i4 = lane & 3;
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
             const int col = n0 + wn * C::WN + tn * 32 + l31;
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm) {
-                float *op = out + (r0 + wm * C::WM + tm * 32 + 4 * half) * N + col;
-                if (full_panel) {
+                float *op = out + (r0 + wm * C::WM + tm * 32 + 4 * half + i4) * N + n0 + wn * C::WN + tn * 32 + (l31 & ~3);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[tm][tn][r] + bv;
+                for (int g = 0; g < 4; ++g) {
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[tm][tn][4 * g + e] + bv;
                         if constexpr (ACT == 1) v = gelu_erf(v);
-                        op[(long)((r & 3) + 8 * (r >> 2)) * N] = v;
+                        x[e] = v;
                     }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = (r & 3) + 8 * (r >> 2);
-                        if (r0 + wm * C::WM + tm * 32 + 4 * half + rr < R) {
-                            float v = acc[tm][tn][r] + bv;
-                            if constexpr (ACT == 1) v = gelu_erf(v);
-                            op[(long)rr * N] = v;
-                        }
+                    quad_transpose(x[0], x[1], x[2], x[3], lane);
+                    if (full_panel || r0 + wm * C::WM + tm * 32 + 4 * half + i4 + 8 * g < R) {
+                        const f32x4 v4 = {x[0], x[1], x[2], x[3]};
+                        *reinterpret_cast<f32x4 *>(op + (long)(8 * g) * N) = v4;
                     }
                 }
             }
