@@ -1332,18 +1332,24 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 2 : 1)) void attention_pipe_kernel
         if (wave_active) {
             f32x16 sc[KT];
             const int kt_valid = (min(S - kc0, C::KC) + 31) / 32;  // wave-uniform
+            // K fragments double-buffered and the order "read next, then 4 MFMAs" pinned: hipcc otherwise
+            // issues every ds_read right before the MFMAs that need it and exposes the LDS latency each time
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
                 if (kt < kt_valid) {
                     const float *kp = sK + (kt * 32 + l31) * C::LDK + 4 * half;
+                    f32x4 kf[2];
+                    kf[0] = *reinterpret_cast<const f32x4 *>(kp);
 #pragma unroll
                     for (int st = 0; st < C::KSTEPS; ++st) {
-                        const f32x4 kf = *reinterpret_cast<const f32x4 *>(kp + st * 8);
+                        if (st + 1 < C::KSTEPS) kf[(st + 1) & 1] = *reinterpret_cast<const f32x4 *>(kp + (st + 1) * 8);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[st][j], sc[kt], 0, 0, 0);
+                            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[st & 1][j], qf[st][j], sc[kt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -1375,24 +1381,35 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 2 : 1)) void attention_pipe_kernel
             for (int ft = 0; ft < C::FT; ++ft)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+            // P V: groups of 4 accumulator registers (8 keys); the V operands of the next group are read
+            // while the current group's MFMAs run (pinned); dead groups (keys past S) are skipped
+            {
+                const float *vp = sV + (4 * half) * C::LDV + l31;
+                float av[2][4][C::FT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt < kt_valid) {
+                for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (kc0 + kt * 32 + 8 * g < S) {  // wave-uniform: skip 8 dead keys
+                    for (int ft = 0; ft < C::FT; ++ft) av[0][ri][ft] = vp[ri * C::LDV + ft * 32];
 #pragma unroll
-                            for (int ri = 0; ri < 4; ++ri) {
-                                const int r = 4 * g + ri;
-                                const int krow = kt * 32 + ri + 8 * g + 4 * half;
+                for (int gg = 0; gg < KT * 4; ++gg) {
+                    const int kt = gg >> 2, g = gg & 3;
+                    if (gg + 1 < KT * 4) {
+                        const int kt1 = (gg + 1) >> 2, g1 = (gg + 1) & 3;
 #pragma unroll
-                                for (int ft = 0; ft < C::FT; ++ft) {
-                                    const float a = sV[krow * C::LDV + ft * 32 + l31];
-                                    o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
-                                }
-                            }
-                        }
+                        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                            for (int ft = 0; ft < C::FT; ++ft)
+                                av[(gg + 1) & 1][ri][ft] = vp[(kt1 * 32 + 8 * g1 + ri) * C::LDV + ft * 32];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kc0 + kt * 32 + 8 * g < S) {  // wave-uniform
+#pragma unroll
+                        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                            for (int ft = 0; ft < C::FT; ++ft)
+                                o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gg & 1][ri][ft], sc[kt][4 * g + ri], o[ft], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (c == nchunks - 1) {
