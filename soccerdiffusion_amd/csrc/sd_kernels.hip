@@ -667,9 +667,8 @@ __device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLa
         const bool q_ok = qrow < p.R_left;
         const int key_lo = (int)((p.r0 + qrow) / g.T - b0) * Mk;  // this query's own trajectory: keys [key_lo, key_lo + Mk)
         float *qbase = sA + qrow * C::LDA + h * HD;
-        f32x4 qf[KS];
-#pragma unroll
-        for (int st = 0; st < KS; ++st) qf[st] = *reinterpret_cast<const f32x4 *>(qbase + st * 8 + 4 * p.half);
+        const float *qfrag = qbase + 4 * p.half;  // Q fragments are re-read from the panel per k-step (LDS is cheap,
+                                                  // 32 registers are not: the K fragments of a tile are held instead)
         f32x16 sc[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -678,11 +677,19 @@ __device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLa
             const int key = kt * 32 + p.l31;  // A-fragment row of this lane
             const int koff = (key < n_keys ? key : 0) * 2 * D + 4 * p.half;
             const float km = key < n_keys ? 1.f : 0.f;
+            // all K fragments of the tile are requested before the first MFMA (one L2 round trip per
+            // tile instead of one per k-step: hipcc otherwise waits vmcnt(0) after every load)
+            f32x4 kf[KS];
+#pragma unroll
+            for (int st = 0; st < KS; ++st) kf[st] = *reinterpret_cast<const f32x4 *>(kvh + koff + st * 8);
+            f32x4 qv[2];
+            qv[0] = *reinterpret_cast<const f32x4 *>(qfrag);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
-                const f32x4 kf = *reinterpret_cast<const f32x4 *>(kvh + koff + st * 8);
+                if (st + 1 < KS) qv[(st + 1) & 1] = *reinterpret_cast<const f32x4 *>(qfrag + (st + 1) * 8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j] * km, qf[st][j], sc[kt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[st][j] * km, qv[st & 1][j], sc[kt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads from being hoisted (registers)
         }
@@ -719,25 +726,36 @@ __device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLa
             for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
         const int vlane = D + p.l31;  // V half of the row, this lane's feature
         const float fm = 1.f;          // HD >= 32 here (D >= 128): every feature lane is live
+        // V operands: the 4 x FT values of the NEXT 8-key group are requested before the current
+        // group's MFMAs (pinned), so one L2 latency is exposed per tile pass instead of one per MFMA
+        auto load_v = [&](int gg, float (&dst)[4][FT]) {
+            const int kt = gg >> 2, gq = gg & 3;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+            for (int ri = 0; ri < 4; ++ri) {
+                const int key = kt * 32 + ri + 8 * gq + 4 * p.half;
+                const int voff = (key < n_keys ? key : 0) * 2 * D + vlane;
+                const float vm = key < n_keys ? fm : 0.f;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                if (kt * 32 + 8 * gq >= n_keys) continue;  // wave-uniform: 8 dead keys
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    const int r = 4 * gq + ri;
-                    const int key = kt * 32 + ri + 8 * gq + 4 * p.half;
-                    const int voff = (key < n_keys ? key : 0) * 2 * D + vlane;
-                    const float vm = key < n_keys ? fm : 0.f;
-#pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) {
-                        const float a = kvh[voff + ft * 32] * vm;
-                        o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sc[kt][r], o[ft], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ft = 0; ft < FT; ++ft) dst[ri][ft] = kvh[voff + ft * 32] * vm;
             }
+        };
+        float av[2][4][FT];
+        load_v(0, av[0]);
+#pragma unroll
+        for (int gg = 0; gg < NKT * 4; ++gg) {
+            const int kt = gg >> 2, gq = gg & 3;
+            const bool live = kt * 32 + 8 * gq < n_keys;           // wave-uniform
+            const bool next_live = gg + 1 < NKT * 4 && ((gg + 1) >> 2) * 32 + 8 * ((gg + 1) & 3) < n_keys;
+            if (next_live) load_v(gg + 1, av[(gg + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (live) {
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft)
+                        o[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gg & 1][ri][ft], sc[kt][4 * gq + ri], o[ft], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // this head's output replaces its own Q columns of the panel (only this wave reads them)
 #pragma unroll
