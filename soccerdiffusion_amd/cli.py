@@ -6,10 +6,10 @@ soccer_diffusion/ml/inference/plot.py:21-135).
     python -m soccerdiffusion_amd.cli sample ckpt [--steps 30] [--num_samples 10]
     python -m soccerdiffusion_amd.cli distill cfg.yaml teacher_ckpt [-o out]     (ml/training/distill.py:25-224)
 
-Differences, all additive: data comes from a tensor file (`--data file.pt`: dict with
-`joint_command` (N,T,J) and the optional context keys of the reference's `Result`
-dataclass) or from a synthetic sine-wave generator (`--synthetic N`; the SQLite dataset is
-SURVEY §8 f3, not this round); wandb and matplotlib are not used; under torchrun
+Differences, all additive: data comes from the reference's SQLite database (`--db file`,
+read once into HBM by soccerdiffusion_amd/dataset.py; images are not served), from a tensor
+file (`--data file.pt`: dict with `joint_command` (N,T,J) and the optional context keys of
+the reference's `Result` dataclass) or from a synthetic sine-wave generator (`--synthetic N`); wandb and matplotlib are not used; under torchrun
 (WORLD_SIZE > 1) training is data parallel with one RCCL all-reduce of the flat gradient
 per step and `sample` shards the rollouts over the ranks.
 """
@@ -88,6 +88,42 @@ def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
     }
 
 
+class DataSource:
+    """Uniform access for the loops: number of samples, device batches by index, and the
+    joint commands of a few samples for the normaliser fit."""
+
+    def __init__(self, tensors: Optional[dict] = None, dataset=None, device=None):
+        self.dataset = dataset.to(device) if dataset is not None else None
+        self.tensors = {k: v.to(device) for k, v in tensors.items()} if tensors is not None else None
+        self.n = len(dataset) if dataset is not None else tensors["joint_command"].shape[0]
+
+    def batch(self, idx: torch.Tensor) -> dict:
+        if self.dataset is not None:
+            return self.dataset.batch(idx)
+        dev = self.tensors["joint_command"].device
+        return {k: v[idx.to(dev)] for k, v in self.tensors.items()}
+
+
+def open_database(path: str, params: dict):
+    """The reference's SQLite database (dataset/models.py schema) through the pre-extracting feed."""
+    from .dataset import SoccerDiffusionDataset
+
+    return SoccerDiffusionDataset(
+        db_path=path, num_joints=params["num_joints"], num_frames_video=params["image_context_length"],
+        num_samples_joint_trajectory_future=params["trajectory_prediction_length"],
+        num_samples_joint_trajectory=params["action_context_length"], num_samples_imu=params["imu_context_length"],
+        num_samples_joint_states=params["joint_state_context_length"],
+        imu_representation=params["imu_orientation_embedding_method"], use_action_history=params["use_action_history"],
+        use_imu=params["use_imu"], use_joint_states=params["use_joint_states"], use_images=params["use_images"],
+        use_game_state=params["use_gamestate"], image_resolution=params.get("image_resolution", 480))
+
+
+def data_source(args, params: dict, device) -> DataSource:
+    if getattr(args, "db", None):
+        return DataSource(dataset=open_database(args.db, params), device=device)
+    return DataSource(tensors=load_data(args, params), device=device)
+
+
 def load_data(args, params: dict) -> dict:
     if args.data:
         data = torch.load(args.data, map_location="cpu", weights_only=True)
@@ -95,14 +131,6 @@ def load_data(args, params: dict) -> dict:
             raise SystemExit("--data file must hold a dict with a 'joint_command' (N, T, J) tensor")
         return data
     return synthetic_dataset(args.synthetic, params, seed=args.seed)
-
-
-def fit_normalizer(joint_command: torch.Tensor, n_samples: int, generator) -> tuple[torch.Tensor, torch.Tensor]:
-    """Normalizer.fit over `num_normalization_samples` random samples: per-joint mean and
-    UNBIASED std over all (sample, time) rows (train.py:108-110, dataset/pytorch.py:406-408)."""
-    idx = torch.randint(0, joint_command.shape[0], (n_samples,), generator=generator)
-    rows = joint_command[idx].reshape(-1, joint_command.shape[-1])
-    return rows.mean(dim=0), rows.std(dim=0)
 
 
 def _dist_env():
@@ -139,9 +167,12 @@ def cmd_train(args) -> int:
         raise SystemExit("train_denoising_timesteps must be 1000 (the scheduler table length; see scheduler.py)")
 
     gen = torch.Generator().manual_seed(args.seed + rank)
-    data = load_data(args, params)
-    n_total = data["joint_command"].shape[0]
-    mean, std = fit_normalizer(data["joint_command"], params["num_normalization_samples"], torch.Generator().manual_seed(args.seed))
+    source = data_source(args, params, device)
+    n_total = source.n
+    norm_idx = torch.randint(0, n_total, (params["num_normalization_samples"],), generator=torch.Generator().manual_seed(args.seed))
+    from .dataset import fit_normalizer as fit_rows
+
+    mean, std = fit_rows(source.batch(norm_idx)["joint_command"].cpu())  # train.py:108-110
 
     model = build_model(params).to(device)
     model.mean.copy_(mean)
@@ -163,15 +194,14 @@ def cmd_train(args) -> int:
     scheduler = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
     scheduler.config["num_train_timesteps"] = params["train_denoising_timesteps"]
 
-    on_device = {k: v.to(device) for k, v in data.items()}
     dev_gen = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
     for epoch in range(params["epochs"]):
         order = shard[torch.randperm(len(shard), generator=gen)]
         for i in range(steps_per_epoch):
-            idx = order[i * bs : (i + 1) * bs].to(device)
+            idx = order[i * bs : (i + 1) * bs]
             if world > 1 and len(idx) < bs and i > 0:
                 continue  # keep ranks in lock step: a short last batch would desynchronise the all-reduce
-            batch = {k: v[idx] for k, v in on_device.items()}
+            batch = source.batch(idx)
             targets = ops.normalize(batch["joint_command"].contiguous(), model.mean, model.std)
             if args.decoder_pretraining:
                 ctx = [torch.randn((len(idx), 10, params["hidden_dim"]), device=device, generator=dev_gen)]
@@ -232,23 +262,22 @@ def cmd_distill(args) -> int:
     optimizer = training.FusedAdamW(trainable, lr=params["lr"])
 
     gen = torch.Generator().manual_seed(args.seed + rank)
-    data = load_data(args, params)
-    n_total = data["joint_command"].shape[0]
+    source = data_source(args, params, device)
+    n_total = source.n
     bs = params["batch_size"]
     shard = torch.arange(rank, n_total, world)
     steps_per_epoch = max(1, math.ceil(len(shard) / bs))
     lr_scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=params["lr"], total_steps=params["epochs"] * steps_per_epoch)
-    on_device = {k: v.to(device) for k, v in data.items()}
     dev_gen = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
     n_teacher = params["distill_teacher_inference_steps"]
     for epoch in range(params["epochs"]):
         order = shard[torch.randperm(len(shard), generator=gen)]
         mean_loss = 0.0
         for i in range(steps_per_epoch):
-            idx = order[i * bs : (i + 1) * bs].to(device)
+            idx = order[i * bs : (i + 1) * bs]
             if world > 1 and len(idx) < bs and i > 0:
                 continue
-            batch = {k: v[idx] for k, v in on_device.items()}
+            batch = source.batch(idx)
             noisy = torch.randn(batch["joint_command"].shape, device=device, generator=dev_gen)
             optimizer.zero_grad()
             with torch.no_grad():
@@ -291,7 +320,7 @@ def cmd_sample(args) -> int:
     model.eval()
     n = args.num_samples
     mine = torch.arange(rank, n, world)  # embarrassingly parallel over ranks, no collective
-    data = load_data(args, params) if (args.data or params_need_context(params)) else {}
+    source = data_source(args, params, device) if (args.data or getattr(args, "db", None) or params_need_context(params)) else None
     gen = torch.Generator(device=device).manual_seed(args.seed + rank)
     B = len(mine)
     if B == 0:
@@ -299,8 +328,8 @@ def cmd_sample(args) -> int:
     x_T = torch.randn(B, params["trajectory_prediction_length"], params["num_joints"], device=device, generator=gen)
     with torch.no_grad():
         if params_need_context(params):
-            idx = (mine % data["joint_command"].shape[0]).to(device)
-            inp = {k: data[k].to(device)[idx].contiguous() for k in CONTEXT_KEYS if k in data}
+            batch = source.batch(mine % source.n)
+            inp = {k: batch[k].contiguous() for k in CONTEXT_KEYS if k in batch}
             context = model.encode_input_data(inp)
         else:
             context = [torch.randn(B, 10, params["hidden_dim"], device=device, generator=gen)]
@@ -341,6 +370,7 @@ def main(argv: Optional[list] = None) -> int:
     di.add_argument("--output", "-o", type=str, default="distilled_trajectory_transformer_model.pth", help="Path to save the distilled model")
     for p in (tr, sa, di):
         p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
+        p.add_argument("--db", type=str, default=None, help="SQLite database in the reference's schema (SOCCER_DIFFUSION_DB_PATH of the reference)")
         p.add_argument("--synthetic", type=int, default=2048, help="number of synthetic sine-wave samples when --data is absent")
         p.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)

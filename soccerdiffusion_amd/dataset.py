@@ -1,0 +1,263 @@
+"""Data feed for training: the reference's ``SoccerDiffusionDataset`` semantics
+(soccer_diffusion/dataset/pytorch.py:54-398) on top of the same SQLite schema
+(soccer_diffusion/dataset/models.py), re-designed for feeding GPUs.
+
+The reference issues 4-6 SQL queries (through pandas) per *sample* from 32 DataLoader worker
+processes.  Here every recording is read ONCE at construction (one ordered query per table)
+into dense tensors, and a whole batch is assembled with a few vectorised gathers — on the
+host or, after ``.to(device)``, directly in HBM (a 50 Hz recording is ~10 KB/s: days of data
+fit).  Sample indexing, windows, front padding (zeros / identity quaternion), the game-state
+lookup and the field names of ``Result`` are the reference's.  Images are not served
+(SURVEY §8 f2).
+"""
+
+from __future__ import annotations
+
+import math
+import sqlite3
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+
+# JointStates.get_ordered_joint_names() — soccer_diffusion/dataset/models.py:222-247 (alphabetical)
+JOINT_NAMES_22 = [
+    "HeadPan", "HeadTilt", "LAnklePitch", "LAnkleRoll", "LElbow", "LElbowYaw", "LHipPitch", "LHipRoll", "LHipYaw", "LKnee",
+    "LShoulderPitch", "LShoulderRoll", "RAnklePitch", "RAnkleRoll", "RElbow", "RElbowYaw", "RHipPitch", "RHipRoll",
+    "RHipYaw", "RKnee", "RShoulderPitch", "RShoulderRoll",
+]
+# int(RobotState) = index in the sorted names — models.py:13-25
+ROBOT_STATES = ["PLAYING", "POSITIONING", "STOPPED", "UNKNOWN"]
+
+
+@dataclass
+class Result:
+    """Field names of SoccerDiffusionDataset.Result (dataset/pytorch.py:41-52)."""
+
+    joint_command: torch.Tensor
+    joint_command_history: Optional[torch.Tensor]
+    joint_state: Optional[torch.Tensor]
+    image_data: Optional[torch.Tensor]
+    image_stamps: Optional[torch.Tensor]
+    rotation: Optional[torch.Tensor]
+    game_state: Optional[torch.Tensor]
+
+
+def quats_to_5d(quats: np.ndarray) -> np.ndarray:
+    """xyzw quaternions -> (axis xyz, sin angle, cos angle) — soccer_diffusion/utils/utils.py:9-24.
+    The axis-angle conversion is transforms3d's ``quat2axangle`` (third-party, absent offline:
+    restated from its published algorithm; identity maps to axis (1,0,0), angle 0)."""
+    q = np.asarray(quats, dtype=np.float64)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    nq = w * w + x * x + y * y + z * z
+    eps = np.finfo(np.float64).eps
+    tiny = nq < eps ** 2
+    s = np.sqrt(np.where(tiny, 1.0, nq))
+    w, x, y, z = w / s, x / s, y / s, z / s
+    len2 = x * x + y * y + z * z
+    ident = tiny | (len2 < (3 * eps) ** 2)
+    theta = 2 * np.arccos(np.clip(w, -1.0, 1.0))
+    inv = 1.0 / np.sqrt(np.where(ident, 1.0, len2))
+    axis = np.stack([x * inv, y * inv, z * inv], axis=-1)
+    axis[ident] = (1.0, 0.0, 0.0)
+    theta = np.where(ident, 0.0, theta)
+    return np.concatenate([axis, np.sin(theta)[:, None], np.cos(theta)[:, None]], axis=-1)
+
+
+class SoccerDiffusionDataset(torch.utils.data.Dataset):
+    """Same constructor keywords as the reference class (image-related ones accepted and ignored
+    unless ``use_images`` is set, which raises)."""
+
+    Result = Result
+
+    def __init__(
+        self,
+        db_connection: Optional[sqlite3.Connection] = None,
+        num_samples_imu: int = 100,
+        imu_representation="quaternion",
+        num_samples_joint_states: int = 100,
+        num_samples_joint_trajectory: int = 100,
+        num_samples_joint_trajectory_future: int = 10,
+        sampling_rate: int = 100,
+        max_fps_video: int = 10,
+        num_frames_video: int = 50,
+        image_resolution: int = 480,
+        trajectory_stride: int = 1,
+        num_joints: int = 20,
+        use_images: bool = True,
+        use_imu: bool = True,
+        use_joint_states: bool = True,
+        use_action_history: bool = True,
+        use_game_state: bool = True,
+        db_path: Optional[str] = None,
+        joint_names: Optional[Sequence[str]] = None,
+    ):
+        if use_images:
+            raise NotImplementedError("image context is not served (SURVEY §8 f2); construct with use_images=False")
+        if db_connection is None:
+            if db_path is None:
+                raise ValueError("pass db_connection or db_path")
+            db_connection = sqlite3.connect(f"file:{db_path}?mode=ro", uri=True)
+        self.imu_representation = getattr(imu_representation, "value", imu_representation)
+        self.num_samples_imu = num_samples_imu
+        self.num_samples_joint_states = num_samples_joint_states
+        self.num_samples_joint_trajectory = num_samples_joint_trajectory
+        self.num_samples_joint_trajectory_future = num_samples_joint_trajectory_future
+        self.sampling_rate = sampling_rate
+        self.trajectory_stride = trajectory_stride
+        self.num_joints = num_joints
+        self.use_imu, self.use_joint_states = use_imu, use_joint_states
+        self.use_action_history, self.use_game_state = use_action_history, use_game_state
+        if joint_names is None:
+            # the reference selects all 22 columns and asserts num_joints == 22; the shipped
+            # YAMLs still say 20: serve the 20 pre-migration joints then (no elbow yaw) instead of failing
+            joint_names = JOINT_NAMES_22 if num_joints == 22 else [n for n in JOINT_NAMES_22 if not n.endswith("ElbowYaw")]
+        assert len(joint_names) == num_joints, "The number of joints is not correct"
+        self.joint_names = list(joint_names)
+
+        cur = db_connection.cursor()
+        cols = ", ".join(f'"{n}"' for n in self.joint_names)
+        counts = cur.execute("SELECT recording_id, COUNT(*) FROM JointCommands GROUP BY recording_id").fetchall()
+        self.num_samples = 0
+        self.sample_boundaries: list[tuple[int, int, int]] = []
+        self._rec: dict[int, dict] = {}
+        for recording_id, n in counts:
+            assert n > 0, "Recording length is negative or zero"
+            before = self.num_samples
+            self.num_samples += int((n - num_samples_joint_trajectory_future) / trajectory_stride)
+            self.sample_boundaries.append((before, self.num_samples, recording_id))
+
+            def table(name, columns):
+                rows = cur.execute(f"SELECT {columns} FROM {name} WHERE recording_id = ? ORDER BY stamp ASC", (recording_id,)).fetchall()
+                return torch.tensor(np.asarray(rows, dtype=np.float32).reshape(len(rows), len(columns.split(","))))
+
+            rec = {"cmd": table("JointCommands", cols)}
+            if use_joint_states:
+                rec["state"] = table("JointStates", cols)
+            if use_imu:
+                quat = table("Rotation", "x, y, z, w")
+                rec["imu"] = quat if self.imu_representation == "quaternion" else torch.tensor(quats_to_5d(quat.numpy())).float()
+            if use_game_state:
+                rows = cur.execute("SELECT stamp, state FROM GameState WHERE recording_id = ? ORDER BY stamp ASC", (recording_id,)).fetchall()
+                rec["gs_stamp"] = torch.tensor([r[0] for r in rows], dtype=torch.float64)
+                rec["gs_state"] = torch.tensor([ROBOT_STATES.index(r[1]) for r in rows], dtype=torch.int64)
+            self._rec[recording_id] = rec
+        self._starts = torch.tensor([b[0] for b in self.sample_boundaries], dtype=torch.int64)
+        feat = 4 if self.imu_representation == "quaternion" else 5
+        pad = torch.tensor([0.0, 0.0, 0.0, 1.0])  # identity quaternion, converted like the data
+        self._imu_pad = pad if feat == 4 else torch.tensor(quats_to_5d(pad[None].numpy())[0]).float()
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def to(self, device) -> "SoccerDiffusionDataset":
+        """Moves the pre-extracted recordings (e.g. into HBM); batches are then assembled there."""
+        for rec in self._rec.values():
+            for k, v in rec.items():
+                rec[k] = v.to(device)
+        self._imu_pad = self._imu_pad.to(device)
+        return self
+
+    # ---- one sample, exactly the reference's __getitem__ (pytorch.py:295-384) -----------------
+    def _locate(self, idx: int) -> tuple[int, int]:
+        for start, end, recording_id in self.sample_boundaries:
+            if start <= idx < end:
+                return recording_id, int(idx - start) * self.trajectory_stride
+        raise IndexError("Could not find the recording that contains the sample")
+
+    @staticmethod
+    def _history(data: torch.Tensor, end: int, n: int, pad_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+        start = max(0, end - n)
+        rows = data[start:end]
+        if rows.shape[0] < n:
+            fill = torch.zeros(n - rows.shape[0], data.shape[1], dtype=data.dtype, device=data.device)
+            if pad_row is not None:
+                fill = fill + pad_row
+            rows = torch.cat((fill, rows), dim=0)
+        return rows
+
+    def __getitem__(self, idx: int) -> Result:
+        recording_id, i = self._locate(int(idx))
+        rec = self._rec[recording_id]
+        stamp = i / self.sampling_rate
+        T = self.num_samples_joint_trajectory_future
+        cmd = rec["cmd"][i : i + T]
+        assert len(cmd) == T, "The joint command has the wrong length"
+        game_state = None
+        if self.use_game_state:
+            k = int(torch.searchsorted(rec["gs_stamp"], torch.tensor(stamp, dtype=torch.float64, device=rec["gs_stamp"].device), right=True)) - 1
+            game_state = rec["gs_state"][k] if k >= 0 else torch.tensor(ROBOT_STATES.index("UNKNOWN"), device=cmd.device)
+        return Result(
+            joint_command=cmd,
+            joint_command_history=self._history(rec["cmd"], i, self.num_samples_joint_trajectory) if self.use_action_history else None,
+            joint_state=self._history(rec["state"], i, self.num_samples_joint_states) if self.use_joint_states else None,
+            image_data=None,
+            image_stamps=None,
+            rotation=self._history(rec["imu"], i, self.num_samples_imu, self._imu_pad) if self.use_imu else None,
+            game_state=game_state,
+        )
+
+    @staticmethod
+    def collate_fn(batch: Iterable[Result]) -> Result:
+        batch = list(batch)
+
+        def stack(name):
+            return torch.stack([getattr(x, name) for x in batch]) if getattr(batch[0], name) is not None else None
+
+        return Result(stack("joint_command"), stack("joint_command_history"), stack("joint_state"), None, None,
+                      stack("rotation"), stack("game_state"))
+
+    # ---- a whole batch at once (what the training loop uses) ---------------------------------
+    def batch(self, indices: torch.Tensor) -> dict[str, torch.Tensor]:
+        """``collate_fn([self[i] for i in indices])`` as a dict of the non-None fields, assembled
+        with vectorised gathers on whatever device the recordings live on."""
+        indices = indices.to(torch.int64).cpu()
+        which = torch.searchsorted(self._starts, indices, right=True) - 1
+        out: dict[str, list] = {}
+        for r in which.unique().tolist():
+            start, _, recording_id = self.sample_boundaries[r]
+            rec = self._rec[recording_id]
+            dev = rec["cmd"].device
+            sel = (which == r).nonzero().flatten()
+            i = ((indices[sel] - start) * self.trajectory_stride).to(dev)
+
+            def window(data, n, offset, pad_row=None):
+                pos = i[:, None] + torch.arange(n, device=dev)[None, :] + offset       # rows [i+offset, i+offset+n)
+                ok = pos >= 0
+                rows = data[pos.clamp(min=0, max=data.shape[0] - 1)]
+                fill = torch.zeros(data.shape[1], device=dev) if pad_row is None else pad_row
+                return torch.where(ok[..., None], rows, fill)
+
+            parts = {"joint_command": window(rec["cmd"], self.num_samples_joint_trajectory_future, 0)}
+            if self.use_action_history:
+                parts["joint_command_history"] = window(rec["cmd"], self.num_samples_joint_trajectory, -self.num_samples_joint_trajectory)
+            if self.use_joint_states:
+                parts["joint_state"] = window(rec["state"], self.num_samples_joint_states, -self.num_samples_joint_states)
+            if self.use_imu:
+                parts["rotation"] = window(rec["imu"], self.num_samples_imu, -self.num_samples_imu, self._imu_pad)
+            if self.use_game_state:
+                stamps = i.to(torch.float64) / self.sampling_rate
+                k = torch.searchsorted(rec["gs_stamp"], stamps, right=True) - 1
+                unknown = torch.full_like(k, ROBOT_STATES.index("UNKNOWN"))
+                parts["game_state"] = torch.where(k >= 0, rec["gs_state"][k.clamp(min=0)], unknown) if len(rec["gs_state"]) else unknown
+            for name, t in parts.items():
+                out.setdefault(name, []).append((sel, t))
+        result = {}
+        for name, chunks in out.items():
+            first = chunks[0][1]
+            full = torch.empty((len(indices),) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            for sel, t in chunks:
+                full[sel.to(first.device)] = t
+            result[name] = full
+        return result
+
+    def tensors(self) -> dict[str, torch.Tensor]:
+        """Every sample materialised (for small databases / the cli's in-memory path)."""
+        return self.batch(torch.arange(len(self)))
+
+
+def fit_normalizer(joint_command: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Normalizer.fit (dataset/pytorch.py:406-408): per-joint mean and UNBIASED std over all rows."""
+    rows = joint_command.reshape(-1, joint_command.shape[-1])
+    return rows.mean(dim=0), rows.std(dim=0)

@@ -94,3 +94,25 @@ def test_distill_then_single_step_sample(tmp_path):
     r = _run("sample", str(student), "--num_samples", "4", "-o", str(tmp_path / "s.pt"), "--synthetic", "32")
     assert r.returncode == 0, r.stderr[-2000:]
     assert torch.isfinite(torch.load(tmp_path / "s.pt", weights_only=True)["trajectories"]).all()
+
+
+def test_train_and_sample_from_sqlite_database(tmp_path):
+    """`--db`: the reference's SQLite schema through the pre-extracting feed, batches gathered in HBM."""
+    from test_cpu_dataset import _make_db
+
+    db = tmp_path / "db.sqlite3"
+    _make_db(str(db), lengths=(400, 150)).close()
+    cfg = dict(CFG, num_joints=22, epochs=2, batch_size=64)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    ckpt = tmp_path / "m.pth"
+    r = _run("train", "-c", str(path), "-o", str(ckpt), "--db", str(db))
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert losses and all(math.isfinite(x) for x in losses)
+    sd = torch.load(ckpt, weights_only=True)["model_state_dict"]
+    assert sd["mean"].shape == (22,) and float(sd["mean"].mean()) > 2.0  # joint angles live around pi
+    r = _run("sample", str(ckpt), "--steps", "10", "--num_samples", "5", "-o", str(tmp_path / "s.pt"), "--db", str(db))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = torch.load(tmp_path / "s.pt", weights_only=True)["trajectories"]
+    assert out.shape == (5, 16, 22) and torch.isfinite(out).all()
