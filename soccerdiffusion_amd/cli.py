@@ -79,7 +79,12 @@ def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
     quat = quat / quat.norm(dim=-1, keepdim=True)
     feat = 5 if params["imu_orientation_embedding_method"] == "five_dim" else 4
     rot = quat if feat == 4 else torch.cat([quat[..., :3], torch.sin(quat[..., 3:]), torch.cos(quat[..., 3:])], -1)
+    extra = {}
+    if params.get("use_images"):  # (n, F, 3, R, R) noise frames; the SQLite image blobs are not served
+        R = params.get("image_resolution", 480)
+        extra["image_data"] = torch.rand(n, params["image_context_length"], 3, R, R, generator=g)
     return {
+        **extra,
         "joint_command": wave[:, Ha:].contiguous(),
         "joint_command_history": wave[:, :Ha].contiguous(),
         "joint_state": (wave[:, Ha - Hj : Ha] + 0.01 * torch.randn(n, Hj, J, generator=g)).contiguous(),

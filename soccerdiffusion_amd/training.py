@@ -201,8 +201,16 @@ class _PatchEmbed(Function):
             patches = x[:, : n * p].reshape(B, n, p, C).permute(0, 1, 3, 2).reshape(B * n, C * p).contiguous()
         dW = torch.zeros(d, patches.shape[1], dtype=torch.float32, device=W.device)
         db = torch.zeros(d, dtype=torch.float32, device=W.device)
-        ops.gemm_tn(dy.contiguous().view(-1, d), patches, dW, db)
-        return None, dW.view(W.shape), db, None
+        dy2 = dy.contiguous().view(-1, d)
+        ops.gemm_tn(dy2, patches, dW, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # only the image tokens are a differentiable input (they come from the ResNet): kernel size 1, C = d
+            if W.dim() == 3 and W.shape[2] == 1 and W.shape[1] == d:
+                dx = _dx_through_weight(dy2, W.view(d, d)).view(x.shape)
+            else:
+                raise NotImplementedError("input gradient of a patch embedding is only implemented for kernel size 1 with C = hidden_dim")
+        return dx, dW.view(W.shape), db, None
 
 
 class _FcOut(Function):

@@ -147,3 +147,25 @@ def test_scheduler_rejects_unsupported_configs():
     s.config["num_train_timesteps"] = 500  # the reference's post-construction override (train.py:186)
     with pytest.raises(ValueError):
         s.set_timesteps(10)
+
+
+def test_image_encoder_state_dict_keys_follow_torchvision():
+    """Reference checkpoints hold the backbone under torchvision's names (image.py:61-73)."""
+    from soccerdiffusion_amd.ml.model.encoder.image import (ImageEncoderType, ResNetImageEncoder, SequenceEncoderType,
+                                                            image_sequence_encoder_factory)
+
+    enc = image_sequence_encoder_factory(SequenceEncoderType.TRANSFORMER, ImageEncoderType.RESNET18, 64, 1, 10, False, 480)
+    keys = set(enc.state_dict())
+    for k in ("image_encoder.encoder.conv1.weight", "image_encoder.encoder.bn1.running_var",
+              "image_encoder.encoder.layer1.1.conv2.weight", "image_encoder.encoder.layer3.0.downsample.0.weight",
+              "image_encoder.encoder.layer4.1.bn2.num_batches_tracked", "image_encoder.encoder.avgpool.weight",
+              "image_encoder.encoder.fc.bias", "transformer_encoder.embedding.weight",
+              "transformer_encoder.transformer_encoder.layers.0.self_attn.in_proj_weight"):
+        assert k in keys, k
+    assert not any("layer1.0.downsample" in k for k in keys)
+    assert ResNetImageEncoder.calculate_output_size(480) == 15 and ResNetImageEncoder.calculate_output_size(224) == 7
+    assert enc.image_encoder.encoder.fc.in_features == 15 * 15 * 32
+    backbone = sum(p.numel() for n, p in enc.image_encoder.encoder.named_parameters() if not n.startswith(("fc", "avgpool")))
+    assert backbone == 11_176_512  # torchvision resnet18 without its classifier
+    r50 = ResNetImageEncoder(ImageEncoderType.RESNET50, 64, True, 224)
+    assert sum(p.numel() for p in r50.parameters()) == 23_508_032 + 2048 * 64 + 64

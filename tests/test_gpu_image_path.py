@@ -1,0 +1,102 @@
+"""image context (ResNet per frame -> token -> 8-head sequence encoder).
+The backbone is torch.nn (MIOpen); what is checked here is the wiring the reference defines
+(image.py:34-41, 107-128), the HIP sequence encoder against the oracle with 8 heads, and that
+gradients reach the backbone through the HIP encoder's input."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, use_final_avgpool=True, seq="transformer", d=128, R=64, F=3):
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from soccerdiffusion_amd.ml.model.model import End2EndDiffusionTransformer
+
+    torch.manual_seed(0)
+    return End2EndDiffusionTransformer(
+        num_joints=20, hidden_dim=d, use_action_history=True, num_action_history_encoder_layers=1,
+        max_action_context_length=20, use_imu=False, imu_orientation_embedding_method="quaternion",
+        num_imu_encoder_layers=1, imu_context_length=20, use_joint_states=False, joint_state_encoder_layers=1,
+        joint_state_context_length=20, use_images=True, image_encoder_type=ImageEncoderType.RESNET18,
+        image_sequence_encoder_type=SequenceEncoderType(seq), num_image_sequence_encoder_layers=1,
+        image_context_length=F, image_use_final_avgpool=use_final_avgpool, image_resolution=R, use_gamestate=True,
+        num_decoder_layers=2, trajectory_prediction_length=12, encoder_patch_size=4).to(dev)
+
+
+@pytest.mark.parametrize("avgpool", [True, False])
+@pytest.mark.parametrize("seq", ["transformer", "none"])
+def test_image_tokens_join_the_memory(avgpool, seq):
+    dev = torch.device("cuda:0")
+    m = _model(dev, avgpool, seq).eval()
+    B, F, R = 3, 3, 64
+    g = torch.Generator().manual_seed(1)
+    data = {"joint_command_history": torch.randn(B, 20, 20, generator=g).to(dev),
+            "image_data": torch.rand(B, F, 3, R, R, generator=g).to(dev),
+            "game_state": torch.randint(0, 4, (B,), generator=g).to(dev)}
+    with torch.no_grad():
+        ctx = m.encode_input_data(data)
+        assert [tuple(c.shape) for c in ctx] == [(B, 5, 128), (B, F, 128), (B, 1, 128)]  # history, images, game state
+        eps = m(data, torch.randn(B, 12, 20, device=dev), torch.tensor([5, 500, 999], device=dev))
+    assert eps.shape == (B, 12, 20) and torch.isfinite(eps).all()
+
+
+def test_sequence_encoder_matches_oracle_with_8_heads():
+    from oracle import denoiser_ref as ref
+
+    dev = torch.device("cuda:0")
+    m = _model(dev).eval()
+    enc = m.image_sequence_encoder
+    B, F, R = 2, 3, 64
+    imgs = torch.rand(B, F, 3, R, R, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        tokens = enc.image_encoder(imgs)
+        got = enc(imgs)
+    sd = {k: v.detach().cpu() for k, v in enc.transformer_encoder.state_dict().items()}
+    want = ref.encoder_forward(sd, tokens.cpu(), "", heads=8)
+    err = (got.cpu() - want).abs().max() / want.abs().max()
+    assert err < 1e-4, err  # fp32 tolerance of north_star
+
+
+def test_gradients_reach_the_backbone():
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+    from soccerdiffusion_amd.training import FusedAdamW, train_step
+
+    dev = torch.device("cuda:0")
+    m = _model(dev).train()
+    opt = FusedAdamW(m.parameters(), lr=1e-3)
+    sch = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    B, F, R = 4, 3, 64
+    g = torch.Generator().manual_seed(3)
+    data = {"joint_command_history": torch.randn(B, 20, 20, generator=g).to(dev),
+            "image_data": torch.rand(B, F, 3, R, R, generator=g).to(dev),
+            "game_state": torch.randint(0, 4, (B,), generator=g).to(dev)}
+    target = torch.randn(B, 12, 20, generator=g).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    conv1 = m.image_sequence_encoder.image_encoder.encoder.conv1.weight
+    before = conv1.detach().clone()
+    losses = []
+    for _ in range(3):
+        losses.append(float(train_step(m, opt, None, sch, target, input_data=data, generator=gen)))
+        assert conv1.grad is not None and torch.isfinite(conv1.grad).all() and conv1.grad.abs().max() > 0
+    assert all(l == l for l in losses)
+    assert (conv1.detach() - before).abs().max() > 0  # the optimizer moved the backbone
+
+
+def test_patch_embed_input_gradient_matches_torch():
+    """dX of the kernel-size-1 token embedding (the only differentiable encoder input)."""
+    from soccerdiffusion_amd.training import _PatchEmbed
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    d, B, S = 64, 3, 7
+    x = torch.randn(B, S, d, generator=g).to(dev).requires_grad_()
+    W = (0.1 * torch.randn(d, d, 1, generator=g)).to(dev).requires_grad_()
+    b = torch.randn(d, generator=g).to(dev).requires_grad_()
+    pe = torch.randn(S, d, generator=g).to(dev)
+    dy = torch.randn(B, S, d, generator=g).to(dev)
+    _PatchEmbed.apply(x, W, b, pe).backward(dy)
+    x2, W2, b2 = (t.detach().clone().requires_grad_() for t in (x, W, b))
+    (torch.nn.functional.conv1d(x2.transpose(1, 2), W2, b2).transpose(1, 2) + pe).backward(dy)
+    for a, c in ((x.grad, x2.grad), (W.grad, W2.grad), (b.grad, b2.grad)):
+        assert (a - c).abs().max() / c.abs().max() < 1e-4
