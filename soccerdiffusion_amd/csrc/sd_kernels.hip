@@ -646,6 +646,9 @@ struct DecoderLayerArgs {
     float *eps, *x_io;
     float c0, c1, c2, c3;
     int J;
+    // folded cross-attention (see panel_folded_scores): per trajectory 64 rows [head][16 key slots] of
+    // (K_h Wq_h | V_h Wo_h^T), 2D floats each, and the score bias bq_h . K_h[key]; NULL = unfolded path
+    const float *gv, *cb;
 };
 
 template <int D, int NKT>
@@ -771,6 +774,165 @@ __device__ __forceinline__ void panel_cross_attention(float *sA, const DecoderLa
     }
 }
 
+// --------------------------------------------------------------------------------------
+// Folded cross-attention (sampling: the memory is fixed over the rollout, so everything that
+// depends only on memory and weights is computed once, by xattn_fold_kernel):
+//     scores_h = (LN2(h) Wq_h^T + bq_h) K_h^T  = LN2(h) (K_h Wq_h)^T + bq_h . K_h      =: LN2(h) G_h^T + c_h
+//     out      = sum_h P_h V_h Woc_h^T + boc    = [P_0 .. P_3] [V_0 Woc_0^T ; .. ]      =: P V'
+// so the Q projection (2 T d^2) and the out projection (2 T d^2) of the layer disappear; what is
+// left is a (64 x D) x (D x 128) and a (64 x 128) x (128 x D) product per panel, 128 = 2 trajectories
+// x 4 heads x 16 key slots.  Row k = tl*64 + head*16 + key of the per-trajectory gv block is both
+// the G row (first D floats) and the V' row (last D floats) of that key, so the 128 rows seen by
+// a panel are consecutive in memory from its first trajectory on.
+// --------------------------------------------------------------------------------------
+constexpr int FOLD_RING = 8;   // k-steps of G in flight (first touch comes from HBM, not L2)
+constexpr int FOLD_VRING = 4;
+
+template <int D>
+struct FoldState {
+    f32x4 g[FOLD_RING];
+    f32x4 c[4];
+    const float *gbase;   // wave-uniform: first gv row of the panel's first trajectory
+    unsigned goff;        // this lane's G row (A operand row = key slot l31 of head `wave`)
+    int n_traj;
+};
+
+template <int D>
+__device__ __forceinline__ void fold_prime(FoldState<D> &f, const DecoderLayerArgs &g, const ChainPos<D> &p) {
+    const int h = __builtin_amdgcn_readfirstlane(p.wave);
+    const long b0 = p.r0 / g.T;
+    f.n_traj = (int)((p.r0 + p.R_left - 1) / g.T - b0) + 1;
+    f.gbase = g.gv + b0 * 64 * 2 * D;
+    const int tl = (f.n_traj > 1) ? (p.l31 >> 4) : 0;   // a lone trajectory: the other half tile re-reads it (masked)
+    f.goff = (unsigned)((tl * 64 + h * 16 + (p.l31 & 15)) * 2 * D + 4 * p.half);
+#pragma unroll
+    for (int s = 0; s < FOLD_RING - 1; ++s) f.g[s] = *reinterpret_cast<const f32x4 *>(f.gbase + f.goff + s * 8);
+    const float *cbase = g.cb + b0 * 64 + h * 16 + 4 * p.half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // score-bias of accumulator rows 4q..4q+3: key slot 8q + 4*half + i
+        f.c[q] = *reinterpret_cast<const f32x4 *>(cbase + ((f.n_traj > 1) ? (q >> 1) * 64 : 0) + (q & 1) * 8);
+}
+
+// S^T (32 key slots x 64 queries) of head `wave`; then softmax per query and P -> panel columns
+template <int D>
+__device__ __forceinline__ void panel_folded_scores(float *sA, FoldState<D> &f, const DecoderLayerArgs &g,
+                                                    const ChainPos<D> &p, float (&vr)[FOLD_VRING][4][PanelCfg<D>::TN],
+                                                    unsigned voff) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 8;
+    const int h = __builtin_amdgcn_readfirstlane(p.wave);
+    const float *hB = sA + p.l31 * C::LDA + 4 * p.half;
+    f32x16 sc[2];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[tq][r] = 0.f;
+    f32x4 hf[2][2];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) hf[0][tq] = *reinterpret_cast<const f32x4 *>(hB + tq * 32 * C::LDA);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks % FOLD_RING, fill = (ks + FOLD_RING - 1) % FOLD_RING;
+        if (ks + FOLD_RING - 1 < NK)
+            f.g[fill] = *reinterpret_cast<const f32x4 *>(f.gbase + f.goff + (ks + FOLD_RING - 1) * 8);
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq)
+                hf[(ks + 1) & 1][tq] = *reinterpret_cast<const f32x4 *>(hB + tq * 32 * C::LDA + (ks + 1) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq)
+                sc[tq] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.g[cur][j], hf[ks & 1][tq][j], sc[tq], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // first V' rows in flight while the softmax runs (they come from HBM on first touch)
+#pragma unroll
+    for (int s = 0; s < FOLD_VRING - 1; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) vr[s][j][tn] = f.gbase[voff + (unsigned)((s * 8 + j) * 2 * D + tn * 32)];
+    __syncthreads();   // every wave has read LN2(h): the panel now receives P
+    const long b0 = p.r0 / g.T;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+        const int qrow = tq * 32 + p.l31;
+        const bool q_ok = qrow < p.R_left;
+        const int key_lo = (int)((p.r0 + qrow) / g.T - b0) * 16;   // own trajectory: slots [key_lo, key_lo + Mk)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * p.half;
+            const bool ok = q_ok && kk >= key_lo && kk < key_lo + g.Mk;
+            const float v = ok ? sc[tq][r] + f.c[r >> 2][r & 3] : -INFINITY;
+            sc[tq][r] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = exp2f((sc[tq][r] - mx) * g.scale_log2e);
+            sc[tq][r] = pv;
+            psum += pv;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        const float inv = psum > 0.f ? 1.0f / psum : 0.f;
+        // P[query][k], k = tl*64 + head*16 + key: accumulator rows 4q..4q+3 are slots 8q + 4*half + 0..3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = {sc[tq][4 * q] * inv, sc[tq][4 * q + 1] * inv, sc[tq][4 * q + 2] * inv, sc[tq][4 * q + 3] * inv};
+            *reinterpret_cast<f32x4 *>(sA + qrow * C::LDA + (q >> 1) * 64 + h * 16 + (q & 1) * 8 + 4 * p.half) = t;
+        }
+    }
+}
+
+// H += P V'   (K = 64 per trajectory touched by the panel)
+template <int D>
+__device__ __forceinline__ void panel_folded_pv(f32x16 (&H)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *aBase,
+                                                const float *gbase, unsigned voff, int n_traj,
+                                                float (&vr)[FOLD_VRING][4][PanelCfg<D>::TN]) {
+    using C = PanelCfg<D>;
+    f32x4 af[2][C::TM];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) af[0][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        if (part == 1 && n_traj < 2) break;   // workgroup-uniform
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int ks = part * 8 + k8;
+            const int cur = ks % FOLD_VRING, fill = (ks + FOLD_VRING - 1) % FOLD_VRING;
+            const bool more = (ks + FOLD_VRING - 1 < 8) || (n_traj > 1 && ks + FOLD_VRING - 1 < 16);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn)
+                        vr[fill][j][tn] = gbase[voff + (unsigned)(((ks + FOLD_VRING - 1) * 8 + j) * 2 * D + tn * 32)];
+            }
+            if (ks + 1 < 16) {
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+                    af[(ks + 1) & 1][tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + (ks + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn)
+                        H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][tm][j], vr[cur][j][tn], H[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // fc_out (d -> J <= 64) + DDIM update on the panel that holds the final h (see fc_out_kernel)
 template <int D>
 __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &g, const ChainPos<D> &p) {
@@ -831,7 +993,7 @@ __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &
 
 // TAIL = true is the last layer's instantiation (no next-layer QKV; fc_out + DDIM fused behind
 // the chain).  Separate instantiations keep the tail's registers out of the common kernel.
-template <int D, bool TAIL>
+template <int D, bool TAIL, bool FOLD>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(DecoderLayerArgs g) {
     using C = PanelCfg<D>;
     extern __shared__ __attribute__((aligned(16))) float sA[];
@@ -845,27 +1007,43 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     chain_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
     chain_gemm_primed<D>(H, aBase, g.a.wo + wOff, ring);   // h += a Wo^T + bo   (self-attention out)
-    chain_prime<D>(ring, g.a.wq + wOff);
-    chain_bias_act<D, 0>(H, g.a.bo, p);
-    __syncthreads();
-    chain_acc_to_lds<D>(sA, H, p);
-    __syncthreads();
-    chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
-    __syncthreads();
-    chain_zero<D>(U);
-    chain_gemm_primed<D>(U, aBase, g.a.wq + wOff, ring);   // q = LN2(h) Wq^T + bq
-    chain_bias_act<D, 0>(U, g.a.bq, p);
-    __syncthreads();
-    chain_acc_to_lds<D>(sA, U, p);
-    __syncthreads();
-    {   // a_c over the memory of each row's trajectory (wave-uniform choice of 1 or 2 key tiles)
-        const int n_traj = (int)((p.r0 + p.R_left - 1) / g.T - p.r0 / g.T) + 1;
-        if (n_traj * g.Mk <= 32) panel_cross_attention<D, 1>(sA, g, p);
-        else panel_cross_attention<D, 2>(sA, g, p);
+    if constexpr (FOLD) {
+        FoldState<D> fs;
+        fold_prime<D>(fs, g, p);          // G rows + score bias in flight behind the epilogue and LN2
+        chain_bias_act<D, 0>(H, g.a.bo, p);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, H, p);
+        __syncthreads();
+        chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
+        __syncthreads();
+        float vr[FOLD_VRING][4][C::TN];
+        const unsigned voff = (unsigned)(4 * p.half * 2 * D + D + p.wn * C::WN + p.l31);
+        panel_folded_scores<D>(sA, fs, g, p, vr, voff);
+        __syncthreads();
+        panel_folded_pv<D>(H, aBase, fs.gbase, voff, fs.n_traj, vr);   // h += P V' + boc
+    } else {
+        chain_prime<D>(ring, g.a.wq + wOff);
+        chain_bias_act<D, 0>(H, g.a.bo, p);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, H, p);
+        __syncthreads();
+        chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
+        __syncthreads();
+        chain_zero<D>(U);
+        chain_gemm_primed<D>(U, aBase, g.a.wq + wOff, ring);   // q = LN2(h) Wq^T + bq
+        chain_bias_act<D, 0>(U, g.a.bq, p);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, U, p);
+        __syncthreads();
+        {   // a_c over the memory of each row's trajectory (wave-uniform choice of 1 or 2 key tiles)
+            const int n_traj = (int)((p.r0 + p.R_left - 1) / g.T - p.r0 / g.T) + 1;
+            if (n_traj * g.Mk <= 32) panel_cross_attention<D, 1>(sA, g, p);
+            else panel_cross_attention<D, 2>(sA, g, p);
+        }
+        chain_prime<D>(ring, g.b.wo + wOff);   // primed after the attention: its 24 registers are needed there
+        __syncthreads();
+        chain_gemm_primed<D>(H, aBase, g.b.wo + wOff, ring);   // h += a_c Woc^T + boc
     }
-    chain_prime<D>(ring, g.b.wo + wOff);   // primed after the attention: its 24 registers are needed there
-    __syncthreads();
-    chain_gemm_primed<D>(H, aBase, g.b.wo + wOff, ring);   // h += a_c Woc^T + boc
     chain_prime<D>(ring, g.b.w1 + wOff);
     chain_bias_act<D, 0>(H, g.b.bo, p);
     __syncthreads();
@@ -1046,13 +1224,18 @@ static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
     dim3 grid((unsigned)((g.a.R + 63) / 64)), block(256);
 #define SD_DL(D_)                                                                                                \
     do {                                                                                                         \
-        auto kfn = g.fo_w ? decoder_layer_kernel<D_, true> : decoder_layer_kernel<D_, false>;                    \
+        auto kfn = g.gv ? (g.fo_w ? decoder_layer_kernel<D_, true, true> : decoder_layer_kernel<D_, false, true>)  \
+                        : (g.fo_w ? decoder_layer_kernel<D_, true, false> : decoder_layer_kernel<D_, false, false>); \
         const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                              \
         static bool attr_set = false;                                                                            \
         if (lds > 64 * 1024 && !attr_set) {                                                                      \
-            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, true>,                              \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, true, true>,                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, false>,                             \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, false, true>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, true, false>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, false, false>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
             attr_set = true;                                                                                     \
         }                                                                                                        \
@@ -1763,6 +1946,96 @@ __global__ void kv_place_kernel(const float *__restrict__ src, long src_layer_st
     }
 }
 
+// Folding of the cross-attention projections into the projected memory (once per rollout, see
+// panel_folded_scores).  For memory row r = item*keys_per_item + m and head h (= blockIdx.y):
+//     G  = K_h[r] Wq_h          (D floats)   K_h = kv[r][h*HD .. +HD),  Wq_h = rows h*HD.. of Wq (D x D)
+//     V' = V_h[r] Wo[:, h]^T    (D floats)   V_h = kv[r][D + h*HD ..),  Wo[:, h] = columns h*HD.. of Wo
+//     c  = bq_h . K_h[r]
+// written to row item*item_rows + h*head_rows + key0 + m of gv ([rows][2D]) / cb ([rows]).
+// VALU kernel (0.5 % of a rollout's flops): a block owns FOLD_RB memory rows in LDS, thread = column.
+constexpr int FOLD_RB = 16;
+
+__global__ __launch_bounds__(256) void xattn_fold_kernel(const float *__restrict__ kv, long n_rows, int keys_per_item,
+                                                         const float *__restrict__ wq, const float *__restrict__ bq,
+                                                         const float *__restrict__ wo, float *__restrict__ gv,
+                                                         float *__restrict__ cb, long item_rows, int head_rows, int key0,
+                                                         int D, int HD) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Ks = sm, *Vs = sm + FOLD_RB * HD;
+    const int h = blockIdx.y;
+    const long r0 = (long)blockIdx.x * FOLD_RB;
+    for (int i = threadIdx.x; i < FOLD_RB * HD; i += 256) {
+        const int r = i / HD, j = i - r * HD;
+        const bool ok = r0 + r < n_rows;
+        Ks[i] = ok ? kv[(r0 + r) * 2 * D + h * HD + j] : 0.f;
+        Vs[i] = ok ? kv[(r0 + r) * 2 * D + D + h * HD + j] : 0.f;
+    }
+    __syncthreads();
+    long dst[FOLD_RB];
+#pragma unroll
+    for (int r = 0; r < FOLD_RB; ++r) {
+        const long row = r0 + r, item = row / keys_per_item;
+        dst[r] = item * item_rows + (long)h * head_rows + key0 + (row - item * keys_per_item);
+    }
+    if (threadIdx.x < FOLD_RB && r0 + threadIdx.x < n_rows) {
+        float c = 0.f;
+        for (int j = 0; j < HD; ++j) c += bq[h * HD + j] * Ks[threadIdx.x * HD + j];
+        const long row = r0 + threadIdx.x, item = row / keys_per_item;
+        cb[item * item_rows + (long)h * head_rows + key0 + (row - item * keys_per_item)] = c;
+    }
+    for (int n = threadIdx.x; n < D; n += 256) {
+        float acc[FOLD_RB];
+#pragma unroll
+        for (int r = 0; r < FOLD_RB; ++r) acc[r] = 0.f;
+        for (int j = 0; j < HD; j += 4) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = wq[(long)(h * HD + j + e) * D + n];
+#pragma unroll
+            for (int r = 0; r < FOLD_RB; ++r) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(Ks + r * HD + j);
+                acc[r] += k4[0] * w[0] + k4[1] * w[1] + k4[2] * w[2] + k4[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FOLD_RB; ++r)
+            if (r0 + r < n_rows) gv[dst[r] * 2 * D + n] = acc[r];
+#pragma unroll
+        for (int r = 0; r < FOLD_RB; ++r) acc[r] = 0.f;
+        for (int j = 0; j < HD; j += 4) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wo + (long)n * D + h * HD + j);
+#pragma unroll
+            for (int r = 0; r < FOLD_RB; ++r) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(Vs + r * HD + j);
+                acc[r] += v4[0] * w[0] + v4[1] * w[1] + v4[2] * w[2] + v4[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FOLD_RB; ++r)
+            if (r0 + r < n_rows) gv[dst[r] * 2 * D + D + n] = acc[r];
+    }
+}
+
+// The current step token's folded rows ([4 heads][2D] + 4 score biases per layer) -> key slot Mc of
+// every trajectory.  grid = (blocks, layers).
+__global__ void fold_place_kernel(const float *__restrict__ src, const float *__restrict__ csrc, long src_layer_stride,
+                                  long csrc_layer_stride, float *gv, float *cb, long gv_layer_stride,
+                                  long cb_layer_stride, int B, int Mc, int w2) {
+    const float *sl = src + (long)blockIdx.y * src_layer_stride;
+    const float *cl = csrc + (long)blockIdx.y * csrc_layer_stride;
+    float *gl = gv + (long)blockIdx.y * gv_layer_stride;
+    float *bl = cb + (long)blockIdx.y * cb_layer_stride;
+    const long n = (long)B * 4 * w2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % w2);
+        const long bh = i / w2;           // trajectory * 4 + head
+        const int h = (int)(bh & 3);
+        const long row = (bh >> 2) * 64 + h * 16 + Mc;
+        gl[row * w2 + c] = sl[h * w2 + c];
+        if (c == 0) bl[row] = cl[h];
+    }
+}
+
 // Normalizer.normalize / denormalize (reference dataset/pytorch.py:410-414): per-joint affine
 __global__ void normalize_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                  const float *__restrict__ stdv, float *__restrict__ out, long n, int J, int inverse) {
@@ -1788,11 +2061,15 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride,
 // ======================================================================================
 struct Scratch {  // carve-up of the caller's workspace (floats)
     float *h, *qkv, *a, *u, *kv, *kvstep, *kvtmp;
+    float *gv, *cb, *gvstep, *cstep;   // folded cross-attention (sampler only)
 };
+
+// folded cross-attention applies: fused layer kernel, <= 16 key slots per head, <= 2 trajectories per panel
+static bool fold_ok(int d, int heads, int T, int Mk) { return heads == 4 && d >= 128 && Mk <= 16 && T >= 64; }
 
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps) {
+static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long B = 0) {
     Scratch s;
     size_t off = 0;
     s.h = ws + off; off += align64((size_t)R * d);
@@ -1802,14 +2079,25 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps) {
     s.kv = ws + off; off += align64((size_t)L * RM * 2 * d);
     s.kvstep = ws + off; off += align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d);
     s.kvtmp = ws + off; off += align64((size_t)L * RM * 2 * d);
+    s.gv = s.cb = s.gvstep = s.cstep = nullptr;
+    if (n_steps > 0) {
+        s.gv = ws + off; off += align64((size_t)L * B * 64 * 2 * d);
+        s.cb = ws + off; off += align64((size_t)L * B * 64);
+        s.gvstep = ws + off; off += align64((size_t)L * n_steps * 4 * 2 * d);
+        s.cstep = ws + off; off += align64((size_t)L * n_steps * 4);
+    }
     return s;
 }
 
 extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps) {
     // M memory rows per trajectory (+1: the sampler adds the step row to the context rows)
     const size_t R = (size_t)B * T, RM = (size_t)B * ((M > 0 ? M : 0) + 1);
-    return align64(R * d) * 3 + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
-           align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
+    size_t n = align64(R * d) * 3 + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
+               align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
+    if (n_steps > 0)   // folded cross-attention blocks of the sampler: 64 rows of 2d (+ 1 bias) per trajectory and layer
+        n += align64((size_t)L * B * 64 * 2 * d) + align64((size_t)L * B * 64) + align64((size_t)L * n_steps * 4 * 2 * d) +
+             align64((size_t)L * n_steps * 4);
+    return n;
 }
 
 // Decoder stack on the fused row chains.  On entry s.h holds the embedded trajectory rows.
@@ -1823,9 +2111,14 @@ struct TailArgs {  // fc_out (+ DDIM) after the last layer
     const float *coef;  // host, 4 floats, or NULL
 };
 
+struct FoldArgs {  // folded cross-attention blocks per layer (gv NULL: unfolded)
+    const float *gv, *cb;
+    size_t gv_stride, cb_stride;
+};
+
 template <typename KV>
 static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scratch &s, int B, int T, int Mk, KV kv,
-                         const TailArgs &tail, hipStream_t st) {
+                         const TailArgs &tail, hipStream_t st, const FoldArgs &fold = FoldArgs{nullptr, nullptr, 0, 0}) {
     const int d = w->d, heads = w->heads;
     const long R = (long)B * T;
     const sd_layer_weights &l0 = w->layers[0];
@@ -1853,7 +2146,8 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
                       nx ? nx->sa_in_b : nullptr, s.qkv, R};
         if (fused) {
             DecoderLayerArgs gl{ga, gb, kvl, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f,
-                                nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, 1.f, 0.f, w->J};
+                                nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, 1.f, 0.f, w->J,
+                                fold.gv ? fold.gv + l * fold.gv_stride : nullptr, fold.gv ? fold.cb + l * fold.cb_stride : nullptr};
             if (last) {
                 gl.fo_w = w->out_w;
                 gl.fo_b = w->out_b;
@@ -1955,11 +2249,14 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T, L = w->L;
-    Scratch s = carve(workspace, R, (long)B * (Mc + 1), d, L, n_steps);
+    Scratch s = carve(workspace, R, (long)B * (Mc + 1), d, L, n_steps, B);
     // once per rollout: K/V of the context rows (placed as rows 0..Mc-1 of each trajectory's
     // [Mk][2d] block, Mk = Mc + 1) and of all n_steps step tokens, per layer
     const int Mk = Mc + 1;
     const size_t kvstride = (size_t)B * Mk * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
+    const bool fold = fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
+    const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
+    const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
@@ -1970,17 +2267,46 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_steps, 2 * d, d, 0, st);
         if (rc) return rc;
     }
-    if (Mc > 0) {
+    if (fold) {
+        // the memory is fixed over the rollout: fold Wq into its keys and Woc into its values once
+        const int hd = d / 4;
+        const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
+        hipError_t e = hipMemsetAsync(s.gv, 0, L * gvstride * sizeof(float), st);   // unused key slots must be finite
+        if (e == hipSuccess) e = hipMemsetAsync(s.cb, 0, L * cbstride * sizeof(float), st);
+        if (e != hipSuccess) return fail((int)e, "sd_ddim_sample: hipMemsetAsync failed");
+        for (int l = 0; l < L; ++l) {
+            const sd_layer_weights &lw = w->layers[l];
+            if (Mc > 0) {
+                const long rows = (long)B * Mc;
+                SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((rows + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st,
+                          s.kvtmp + (size_t)l * B * Mc * 2 * d, rows, Mc, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w,
+                          s.gv + l * gvstride, s.cb + l * cbstride, 64L, 16, 0, d, hd);
+                SD_CHECK_LAUNCH("xattn_fold_kernel");
+            }
+            SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((n_steps + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st,
+                      s.kvstep + (size_t)l * kvsstride, (long)n_steps, 1, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w,
+                      s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd);
+            SD_CHECK_LAUNCH("xattn_fold_kernel");
+        }
+    } else if (Mc > 0) {
         SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * Mc * 2 * d), L), dim3(256), 0, st, s.kvtmp, (long)B * Mc * 2 * d, s.kv,
                   (long)kvstride, B, Mc, Mk, 2 * d, 0);
         SD_CHECK_LAUNCH("kv_place_kernel");
     }
     for (int i = 0; i < n_steps; ++i) {
         // this step's token row -> row Mc of every trajectory, all layers in one launch
-        SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * 2 * d), L), dim3(256), 0, st, s.kvstep + (size_t)i * 2 * d, (long)kvsstride,
-                  s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
-        SD_CHECK_LAUNCH("kv_place_kernel");
-        {
+        if (fold) {
+            SD_LAUNCH(fold_place_kernel, dim3(grid_for((long)B * 4 * 2 * d), L), dim3(256), 0, st, s.gvstep + (size_t)i * 4 * 2 * d,
+                      s.cstep + (size_t)i * 4, (long)gvsstride, (long)cssstride, s.gv, s.cb, (long)gvstride, (long)cbstride, B, Mc,
+                      2 * d);
+            SD_CHECK_LAUNCH("fold_place_kernel");
+            rc = decoder_stack(w, x, s, B, T, Mk, [=](int) { return (const float *)nullptr; }, TailArgs{nullptr, x, coef + 4 * i}, st,
+                               FoldArgs{s.gv, s.cb, gvstride, cbstride});
+            if (rc) return rc;
+        } else {
+            SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * 2 * d), L), dim3(256), 0, st, s.kvstep + (size_t)i * 2 * d, (long)kvsstride,
+                      s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
+            SD_CHECK_LAUNCH("kv_place_kernel");
             const float *kvbase = s.kv;
             rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st);
             if (rc) return rc;

@@ -69,7 +69,11 @@ def test_denoiser_vs_oracle(ops, d, J, L, T, M, B):
 
 
 @pytest.mark.parametrize("d,L,T,Mc,B,n_steps", [(64, 2, 16, 10, 2, 10), (256, 4, 100, 10, 4, 50), (256, 4, 100, 0, 2, 50), (128, 2, 10, 30, 3, 30),
-                                                 (256, 2, 40, 20, 3, 10), (128, 2, 100, 3, 3, 10)])
+                                                 (256, 2, 40, 20, 3, 10), (128, 2, 100, 3, 3, 10),
+                                                 # folded cross-attention (T >= 64, <= 16 memory rows): panel/trajectory
+                                                 # alignments, full key slots, d = 512; and 17 rows -> unfolded kernel
+                                                 (512, 2, 64, 15, 3, 6), (256, 2, 70, 15, 7, 8), (256, 2, 100, 16, 3, 6),
+                                                 (128, 3, 97, 12, 9, 5)])
 def test_ddim_sampler_every_step(ops, d, L, T, Mc, B, n_steps):
     """x after EVERY step vs the fp32 CPU oracle loop on identical weights, x_T, context."""
     J = 20
