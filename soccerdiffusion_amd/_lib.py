@@ -17,7 +17,8 @@ import os
 import torch  # noqa: F401
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsoccerdiffusion_hip.so")
+# SD_HIP_LIB: developer hook to load another build of the same library (kernel A/B runs, tools/ab_build.sh)
+LIB_PATH = os.environ.get("SD_HIP_LIB") or os.path.join(_PKG, "lib", "libsoccerdiffusion_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 

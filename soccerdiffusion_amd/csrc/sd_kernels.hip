@@ -381,11 +381,26 @@ template <int D>
 __device__ __forceinline__ void chain_load_panel(float *sA, const float *src, const ChainPos<D> &p) {
     using C = PanelCfg<D>;
     constexpr int VEC_PER_ROW = D / 4;
-    for (int i = threadIdx.x; i < C::BM * VEC_PER_ROW; i += 256) {
-        const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < p.R_left) v = *reinterpret_cast<const f32x4 *>(src + (p.r0 + row) * D + c4 * 4);
-        *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v;
+    constexpr int ITERS = C::BM * VEC_PER_ROW / 256, BATCH = ITERS < 16 ? ITERS : 16;
+    // every load of a batch is in flight before the first LDS write (a plain copy loop is compiled into one
+    // HBM round trip per iteration: 16 x ~2 us per panel)
+    const float *base = src + p.r0 * D;   // wave-uniform; 32-bit lane offsets
+#pragma unroll
+    for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = threadIdx.x + (b0 + b) * 256;
+            const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+            v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < p.R_left) v[b] = *reinterpret_cast<const f32x4 *>(base + (unsigned)(row * D + c4 * 4));
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = threadIdx.x + (b0 + b) * 256;
+            const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+            *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v[b];
+        }
     }
 }
 
@@ -635,6 +650,26 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_b_kernel(ChainB
 // Used when (trajectories per panel) x (memory rows) <= 64; otherwise the host falls back
 // to chain A + attention_kernel + chain B.
 // --------------------------------------------------------------------------------------
+// Diagnostic build only (-DSD_STAMPS, tools/stamps.py): every wave records the shader clock at phase
+// boundaries of decoder_layer_kernel into a host-provided buffer [layer][workgroup][wave][32].
+#ifdef SD_STAMPS
+__device__ unsigned long long *g_stamp_buf = nullptr;
+__device__ long g_stamp_wgs = 0;
+#define SD_STAMP(slot, i)                                                                                              \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63) == 0 && g_stamp_buf)                                                                    \
+            g_stamp_buf[(((long)(slot) * g_stamp_wgs + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + (i)] =             \
+                __builtin_amdgcn_s_memtime();                                                                          \
+    } while (0)
+extern "C" int sd_debug_set_stamps(void *buf, long wgs) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wgs), &wgs, sizeof(wgs));
+    return (int)e;
+}
+#else
+#define SD_STAMP(slot, i)
+#endif
+
 struct DecoderLayerArgs {
     ChainAArgs a;      // a.q unused
     ChainBArgs b;      // b.a / b.h unused (same panel)
@@ -649,6 +684,7 @@ struct DecoderLayerArgs {
     // folded cross-attention (see panel_folded_scores): per trajectory 64 rows [head][16 key slots] of
     // (K_h Wq_h | V_h Wo_h^T), 2D floats each, and the score bias bq_h . K_h[key]; NULL = unfolded path
     const float *gv, *cb;
+    int slot;   // layer index (stamp builds)
 };
 
 template <int D, int NKT>
@@ -848,6 +884,7 @@ __device__ __forceinline__ void panel_folded_scores(float *sA, FoldState<D> &f, 
                 sc[tq] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.g[cur][j], hf[ks & 1][tq][j], sc[tq], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    SD_STAMP(g.slot, 4);
     // first V' rows in flight while the softmax runs (they come from HBM on first touch)
 #pragma unroll
     for (int s = 0; s < FOLD_VRING - 1; ++s)
@@ -950,14 +987,24 @@ __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &
         const int j = tn * 32 + p.l31;
         const float *wp = g.fo_w + (long)(j < J ? j : 0) * D + kh * KH + 4 * p.half;
         const float wmask = j < J ? 1.f : 0.f;
-#pragma unroll 4
-        for (int k0 = 0; k0 < KH; k0 += 8) {
-            const f32x4 bf = *reinterpret_cast<const f32x4 *>(wp + k0);
-            const f32x4 af = *reinterpret_cast<const f32x4 *>(aB + k0);
+        // the weight fragments are requested 16 k-steps at a time (one L2 round trip per batch, not per k-step)
+        constexpr int KB = 16;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (tn == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[0], 0, 0, 0);
-                else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[jj] * wmask, acc[1], 0, 0, 0);
+        for (int kb = 0; kb < KH / 8; kb += KB) {
+            f32x4 bf[KB];
+#pragma unroll
+            for (int s = 0; s < KB; ++s)
+                if (kb + s < KH / 8) bf[s] = *reinterpret_cast<const f32x4 *>(wp + (kb + s) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) {
+                if (kb + s >= KH / 8) break;
+                const f32x4 af = *reinterpret_cast<const f32x4 *>(aB + (kb + s) * 8);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (tn == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[s][jj] * wmask, acc[0], 0, 0, 0);
+                    else acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj], bf[s][jj] * wmask, acc[1], 0, 0, 0);
+                }
             }
         }
     }
@@ -974,17 +1021,26 @@ __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &
             const int j = tn * 32 + p.l31;
             if (j >= J) continue;
             const float bv = g.fo_b[j];
+            // all 16 x values are requested before the first is used (a load-update-store loop costs an HBM
+            // round trip per element)
+            float xv[16];
+            float *xb = g.x_io ? g.x_io + p.r0 * J : nullptr;
+            if (xb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * p.half;
+                    xv[r] = row < p.R_left ? xb[(unsigned)(row * J + j)] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * p.half;
                 if (row >= p.R_left) continue;
-                const long gi = (p.r0 + row) * J + j;
                 const float e = (tn == 0 ? acc[0][r] : acc[1][r]) + sA[((tm * 2 + tn) * 16 + r) * 64 + p.lane] + bv;
-                if (g.eps) g.eps[gi] = e;
-                if (g.x_io) {
-                    const float xv = g.x_io[gi];
-                    const float x0 = (xv - g.c1 * e) / g.c0;
-                    g.x_io[gi] = g.c2 * x0 + g.c3 * e;
+                if (g.eps) g.eps[(p.r0 + row) * J + j] = e;
+                if (xb) {
+                    const float x0 = (xv[r] - g.c1 * e) / g.c0;
+                    xb[(unsigned)(row * J + j)] = g.c2 * x0 + g.c3 * e;
                 }
             }
         }
@@ -1002,11 +1058,21 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     const long wOff = (long)(p.wn * C::WN + p.l31) * D + 4 * p.half;
     f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
     WeightRing<D> ring;
+    SD_STAMP(g.slot, 0);
+#ifdef SD_STAMPS
+    if ((threadIdx.x & 63) == 0 && g_stamp_buf) {   // where this workgroup runs: HW_ID (cu/sh/se) and XCC_ID
+        unsigned long long *sb = g_stamp_buf + (((long)g.slot * g_stamp_wgs + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32;
+        sb[30] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        sb[31] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     chain_prime<D>(ring, g.a.wo + wOff);           // first weights in flight while the panel lands
     chain_load_acc<D>(H, g.a.h, p);
     chain_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
+    SD_STAMP(g.slot, 1);
     chain_gemm_primed<D>(H, aBase, g.a.wo + wOff, ring);   // h += a Wo^T + bo   (self-attention out)
+    SD_STAMP(g.slot, 2);
     if constexpr (FOLD) {
         FoldState<D> fs;
         fold_prime<D>(fs, g, p);          // G rows + score bias in flight behind the epilogue and LN2
@@ -1016,11 +1082,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
         __syncthreads();
         chain_layer_norm<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
         __syncthreads();
+        SD_STAMP(g.slot, 3);
         float vr[FOLD_VRING][4][C::TN];
         const unsigned voff = (unsigned)(4 * p.half * 2 * D + D + p.wn * C::WN + p.l31);
         panel_folded_scores<D>(sA, fs, g, p, vr, voff);
         __syncthreads();
+        SD_STAMP(g.slot, 5);
         panel_folded_pv<D>(H, aBase, fs.gbase, voff, fs.n_traj, vr);   // h += P V' + boc
+        SD_STAMP(g.slot, 6);
     } else {
         chain_prime<D>(ring, g.a.wq + wOff);
         chain_bias_act<D, 0>(H, g.a.bo, p);
@@ -1051,19 +1120,25 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     __syncthreads();
     chain_layer_norm<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
     __syncthreads();
+    SD_STAMP(g.slot, 7);
     chain_zero<D>(U);
     chain_gemm_primed<D>(U, aBase, g.b.w1 + wOff, ring);   // u = gelu(LN3(h) W1^T + b1)
+    SD_STAMP(g.slot, 8);
     chain_prime<D>(ring, g.b.w2 + wOff);
     __syncthreads();
     chain_gelu_to_lds<D>(sA, U, g.b.b1, p);
     __syncthreads();
+    SD_STAMP(g.slot, 9);
     chain_gemm_primed<D>(H, aBase, g.b.w2 + wOff, ring);   // h += u W2^T + b2
+    SD_STAMP(g.slot, 10);
     if constexpr (TAIL) {
         chain_bias_act<D, 0>(H, g.b.b2, p);
         __syncthreads();                 // last layer: eps = h Wout^T + b (+ DDIM update of x) right here
         chain_acc_to_lds<D>(sA, H, p);
         __syncthreads();
+        SD_STAMP(g.slot, 11);
         panel_fc_out<D>(sA, g, p);
+        SD_STAMP(g.slot, 12);
         return;
     }
     const bool has_next = g.b.nln_w != nullptr;            // workgroup-uniform
@@ -1071,18 +1146,22 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_kernel(
     chain_bias_act<D, 0>(H, g.b.b2, p);
     chain_store_acc<D>(g.a.h, D, 0, H, p);
     if (!has_next) return;
+    SD_STAMP(g.slot, 11);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
     __syncthreads();
     chain_layer_norm<D>(sA, g.b.nln_w, g.b.nln_b, p.lane, p.wave);
     __syncthreads();
+    SD_STAMP(g.slot, 12);
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {          // next layer's q | k | v
         chain_zero<D>(U);
         chain_gemm_primed<D>(U, aBase, g.b.wqkv + (long)pass * D * D + wOff, ring);
+        SD_STAMP(g.slot, 13 + 2 * pass);
         if (pass < 2) chain_prime<D>(ring, g.b.wqkv + (long)(pass + 1) * D * D + wOff);  // older than this pass's stores
         chain_bias_act<D, 0>(U, g.b.bqkv + pass * D, p);
         chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+        SD_STAMP(g.slot, 14 + 2 * pass);
     }
 }
 
@@ -2147,7 +2226,7 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
         if (fused) {
             DecoderLayerArgs gl{ga, gb, kvl, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f,
                                 nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, 1.f, 0.f, w->J,
-                                fold.gv ? fold.gv + l * fold.gv_stride : nullptr, fold.gv ? fold.cb + l * fold.cb_stride : nullptr};
+                                fold.gv ? fold.gv + l * fold.gv_stride : nullptr, fold.gv ? fold.cb + l * fold.cb_stride : nullptr, l};
             if (last) {
                 gl.fo_w = w->out_w;
                 gl.fo_b = w->out_b;
