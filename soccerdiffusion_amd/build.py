@@ -15,7 +15,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "sd_kernels.hip"), os.path.join(PKG, "csrc", "sd_train.hip")]
-HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG, "csrc", "sd_common.h")]
+HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG, "csrc", "sd_common.h"),
+       os.path.join(PKG, "csrc", "sd_f16x3.h")]
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsoccerdiffusion_hip.so")
 ARCH = "gfx950"

@@ -1,0 +1,708 @@
+// fp32-grade row GEMMs of the sampler on the fp16 matrix pipe (included by sd_kernels.hip after the fused fp32 kernels).
+//
+// Every GEMM operand x is pre-scaled by a power of two s and stored as TWO fp16 numbers, hi = fp16(s x) and
+// lo = fp16(s x - hi): 22 mantissa bits.  a.b is then three v_mfma_f32_32x32x16_f16 (lo.hi, hi.lo, hi.hi; lo.lo is below
+// fp32's own rounding) accumulated in fp32 and un-scaled in the epilogue.  Measured (tools/exp/gemm_f16x3.hip): relative
+// L2 error against fp64 1.8e-7 for K = 256 - lower than the fp32 FMA chain's 2.8e-7 - at 2.4x the rate of
+// v_mfma_f32_32x32x2_f32, which is 16x slower per flop than the fp16 instruction and, sharing the VALU's fp32 lanes,
+// also stalls the co-resident wave's LayerNorm/GELU work (tools/stamps.py).
+//
+// Weights (static over a rollout) are split once per sd_ddim_sample call into "fragment-major" planes: the 16 bytes
+// lane l needs for (k-step, column tile, plane) sit at [..][lane][8], so one wave-load reads 1 KiB contiguous (8 cache
+// lines instead of 64 - with 3 MFMAs per product the row-major layout is bound by the L1 tag rate).  Activations
+// are split by whoever writes the LDS panel: an LDS row holds either D floats or {hi[D], lo[D]} halfs, same bytes.
+// The folded cross-attention operands (G = K_h Wq_h, V' = V_h Wo_h^T) get the same treatment once per rollout; the step
+// token's row, identical for every trajectory, is read from one shared block per (layer, step) instead of being
+// copied into every trajectory.
+//
+// Used by sd_ddim_sample for hidden_dim 256 when the folded path applies; everything else stays on the fp32 kernels.
+#pragma once
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float F16_ACT_SCALE = 8.0f;     // LayerNorm outputs, attention outputs, GELU outputs (|x| < 8190)
+constexpr float F16_P_SCALE = 1024.0f;    // softmax probabilities (<= 1)
+constexpr int F16_GRING = 4;              // k-steps of G in flight
+
+__device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = x[e] * scale;
+        h[e] = (f16)v;
+        l[e] = (f16)(v - (float)h[e]);
+    }
+}
+
+// power of two s with max * s in [8192, 16384)
+__device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
+    const float m = __builtin_bit_cast(float, maxbits);
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+    int e;
+    (void)frexpf(m, &e);   // m = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// once-per-rollout preparation
+// ---------------------------------------------------------------------------------------------------
+__global__ void f16_absmax_kernel(const float *__restrict__ x, long n, unsigned *out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+// rows of [G (D) | V' (D)]: separate maxima
+__global__ void f16_absmax_gv_kernel(const float *__restrict__ gv, long rows, int D, unsigned *outG, unsigned *outV) {
+    float mg = 0.f, mv = 0.f;
+    const long n = rows * 2 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = fabsf(gv[i]);
+        if ((i % (2 * D)) < D) mg = fmaxf(mg, a);
+        else mv = fmaxf(mv, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+        mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(outG, __builtin_bit_cast(unsigned, mg));
+        atomicMax(outV, __builtin_bit_cast(unsigned, mv));
+    }
+}
+
+// W (N x D, row-major fp32, N a multiple of D) -> fragment-major split planes
+//   dst[pass = n / D][wn][ks][tn][plane][lane][8],  n = pass*D + wn*WN + tn*32 + (lane & 31),  k = ks*16 + 8*(lane >> 5) + e
+template <int D>
+__global__ void f16_pack_weight_kernel(const float *__restrict__ W, int N, const unsigned *maxbits, f16 *__restrict__ dst,
+                                       float *scale_out) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16;
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const long total = (long)N * (D / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (D / 8)), k8 = (int)(i % (D / 8));
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(W + (long)n * D + k8 * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(W + (long)n * D + k8 * 8 + 4);
+        f16x4 h0, l0, h1, l1;
+        f16_split4(a, scale, h0, l0);
+        f16_split4(b, scale, h1, l1);
+        const int pass = n / D, nn = n % D, wn = nn / C::WN, tn = (nn % C::WN) / 32, l31 = nn & 31;
+        const int ks = k8 >> 1, lane = (k8 & 1) * 32 + l31;
+        f16 *o = dst + ((((long)(pass * C::WAVES_N + wn) * NK + ks) * C::TN + tn) * 2) * 512 + lane * 8;
+        *reinterpret_cast<f16x4 *>(o) = h0;
+        *reinterpret_cast<f16x4 *>(o + 4) = h1;
+        *reinterpret_cast<f16x4 *>(o + 512) = l0;
+        *reinterpret_cast<f16x4 *>(o + 516) = l1;
+    }
+}
+
+// G rows -> per (item, head) blocks [ks][plane][half][16 slots][8]: the A operand of S^T = G LN2(h)^T.
+// src row (item*4 + h)*src_slots + s holds slot slot0 + s; slots without a source row are written as zeros.
+template <int D>
+__global__ void f16_pack_g_kernel(const float *__restrict__ src, long items, int src_slots, int slot0, const unsigned *maxbits,
+                                  f16 *__restrict__ dst, float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) *scale_out = scale;
+    const long total = items * 4 * 16 * (D / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(i % (D / 8));
+        const int slot = (int)((i / (D / 8)) % 16);
+        const long ih = i / (D / 8) / 16;   // item*4 + head
+        f16x4 h0 = {0, 0, 0, 0}, l0 = h0, h1 = h0, l1 = h0;
+        const int s = slot - slot0;
+        if (s >= 0 && s < src_slots) {
+            const float *row = src + (ih * src_slots + s) * 2 * D + k8 * 8;
+            f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
+            f16_split4(*reinterpret_cast<const f32x4 *>(row + 4), scale, h1, l1);
+        }
+        f16 *o = dst + ih * (32 * D) + (((k8 >> 1) * 2) * 2 + (k8 & 1)) * 128 + slot * 8;
+        *reinterpret_cast<f16x4 *>(o) = h0;
+        *reinterpret_cast<f16x4 *>(o + 4) = h1;
+        *reinterpret_cast<f16x4 *>(o + 256) = l0;       // plane stride: 2 halves x 128
+        *reinterpret_cast<f16x4 *>(o + 260) = l1;
+    }
+}
+
+// V' rows -> per (trajectory, head) blocks [wn][tn][plane][lane][8]: the B operand of H += P V' for the k-step
+// (trajectory, head); lane = 32*half + (col & 31) holds slots 8*half .. 8*half + 7 of column col.
+template <int D>
+__global__ void f16_pack_v_kernel(const float *__restrict__ gv, long items, const unsigned *maxbits, f16 *__restrict__ dst,
+                                  float *scale_out) {
+    using C = PanelCfg<D>;
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) *scale_out = scale;
+    const long total = items * 4 * 2 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % D), half = (int)((i / D) & 1);
+        const long ih = i / D / 2;
+        f16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = gv[(ih * 16 + 8 * half + e) * 2 * D + D + col] * scale;
+            hh[e] = (f16)v;
+            ll[e] = (f16)(v - (float)hh[e]);
+        }
+        const int wn = col / C::WN, tn = (col % C::WN) / 32, lane = half * 32 + (col & 31);
+        f16 *o = dst + ih * (32 * D) + ((wn * C::TN + tn) * 2) * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = hh[e];
+            o[512 + e] = ll[e];
+        }
+    }
+}
+
+// step token: one block per (layer, step) with k = head (k >= 4 zero): the extra k-step of H += P V'
+template <int D>
+__global__ void f16_pack_vstep_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits,
+                                      f16 *__restrict__ dst) {
+    using C = PanelCfg<D>;
+    const float scale = f16_scale_from_bits(*maxbits);
+    const long total = items * 2 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % D), half = (int)((i / D) & 1);
+        const long item = i / D / 2;
+        const int wn = col / C::WN, tn = (col % C::WN) / 32, lane = half * 32 + (col & 31);
+        f16 *o = dst + item * (32 * D) + ((wn * C::TN + tn) * 2) * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = 0.f;
+            if (half == 0 && e < 4) v = gvstep[(item * 4 + e) * 2 * D + D + col] * scale;
+            const f16 h = (f16)v;
+            o[e] = h;
+            o[512 + e] = (f16)(v - (float)h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device pieces of the fused kernels
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+struct F16Ring {
+    f16x8 b[3][PanelCfg<D>::TN][2];   // [slot][column tile][plane]
+};
+
+// wf: this wave's fragment stream of one pass, + lane*8 already applied
+template <int D>
+__device__ __forceinline__ void f16_prime(F16Ring<D> &ring, const f16 *wf) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) ring.b[s][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + ((s * C::TN + tn) * 2 + pl) * 512);
+}
+
+// acc += A(panel planes) W^T over K = D;  aH: (f16*)panel + row*(2*LDA) + 8*half of this lane's first row
+template <int D>
+__device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const f16 *aH, const f16 *wf,
+                                         F16Ring<D> &ring) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    f16x8 af[2][C::TM][2];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks % 3, fill = (ks + 2) % 3;
+        if (ks + 2 < NK) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    ring.b[fill][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + (((ks + 2) * C::TN + tn) * 2 + pl) * 512);
+        }
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    af[(ks + 1) & 1][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // small terms first: lo.hi, hi.lo, hi.hi
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][tm][TA[t]], ring.b[cur][tn][TB[t]], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// H += U*c + bias   /   U = U*c + bias
+template <int D, bool INTO_H>
+__device__ __forceinline__ void f16_unscale(f32x16 (&H)[PanelCfg<D>::TM][PanelCfg<D>::TN], f32x16 (&U)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                            float c, const float *bias, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const float bv = bias[p.col(tn)];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (INTO_H) H[tm][tn][r] += U[tm][tn][r] * c + bv;
+                else U[tm][tn][r] = U[tm][tn][r] * c + bv;
+            }
+    }
+}
+
+// gelu(U*c + b1) -> split planes of the panel
+template <int D>
+__device__ __forceinline__ void f16_gelu_to_planes(float *sA, const f32x16 (&U)[PanelCfg<D>::TM][PanelCfg<D>::TN], float c,
+                                                   const float *bias, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    constexpr int ROWP = 2 * C::LDA;
+    f16 *sH = reinterpret_cast<f16 *>(sA);
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const float bv = bias[p.col(tn)];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = gelu_erf(U[tm][tn][r] * c + bv) * F16_ACT_SCALE;
+                const f16 h = (f16)v;
+                f16 *o = sH + p.row(tm, r) * ROWP + p.col(tn);
+                o[0] = h;
+                o[D] = (f16)(v - (float)h);
+            }
+    }
+}
+
+// LayerNorm of the fp32 panel rows, written back IN PLACE as split planes {hi[D], lo[D]} (same bytes per row).
+// All 16 lanes of a row have their values in registers before the first of them stores (one wave, program order).
+template <int D>
+__device__ __forceinline__ void f16_layer_norm_to_planes(float *sA, const float *ln_w, const float *ln_b, int lane, int wave) {
+    using C = PanelCfg<D>;
+    constexpr int V4 = D / 64;
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int row = wave * 4 + grp; row < C::BM; row += 16) {
+        f32x4 v[V4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + 4 * (sub + 16 * j));
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = row16_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] -= mean;
+                q += v[j][e] * v[j][e];
+            }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / D) + SD_LN_EPS);
+        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + c);
+            const f32x4 gb = *reinterpret_cast<const f32x4 *>(ln_b + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = v[j][e] * rstd * gw[e] + gb[e];
+            f16x4 h, l;
+            f16_split4(y, F16_ACT_SCALE, h, l);
+            *reinterpret_cast<f16x4 *>(rowp + c) = h;
+            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
+        }
+    }
+}
+
+// attention output rows (fp32, HBM) -> split planes of the panel
+template <int D>
+__device__ __forceinline__ void f16_load_panel(float *sA, const float *src, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    constexpr int VEC_PER_ROW = D / 4;
+    constexpr int ITERS = C::BM * VEC_PER_ROW / 256, BATCH = ITERS < 16 ? ITERS : 16;
+    const float *base = src + p.r0 * D;
+#pragma unroll
+    for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = threadIdx.x + (b0 + b) * 256;
+            const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+            v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < p.R_left) v[b] = *reinterpret_cast<const f32x4 *>(base + (unsigned)(row * D + c4 * 4));
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int i = threadIdx.x + (b0 + b) * 256;
+            const int row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+            f16x4 h, l;
+            f16_split4(v[b], F16_ACT_SCALE, h, l);
+            f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
+            *reinterpret_cast<f16x4 *>(rowp + c4 * 4) = h;
+            *reinterpret_cast<f16x4 *>(rowp + D + c4 * 4) = l;
+        }
+    }
+}
+
+struct F16LayerArgs {
+    DecoderLayerArgs g;                       // fp32 pointers (h, a, qkv, biases, LN parameters, cb, tail); g.gv unused
+    const f16 *wf_o, *wf_1, *wf_2, *wf_qkv;   // split fragment-major weights (wf_qkv: next layer's in_proj, 3 passes)
+    const float *sc_own, *sc_next;            // scales: sc_own[0..2] = Wo, W1, W2, sc_own[4] = G, sc_own[5] = V'; sc_next[3] = in_proj
+    const f16 *g16, *v16;                     // this layer: per (trajectory, head) blocks of 32*D halfs
+    const f16 *gstep, *vstep;                 // this layer and step: 4 head blocks / one block
+    const float *cstep;                       // 4 score biases of the step token
+};
+
+struct F16Scores {
+    f16x8 g[F16_GRING][2];
+    f32x4 c[4];
+    const f16 *gp;     // this lane's G row: block base + half*128 + slot*8
+    long b0;
+    int n_traj;
+};
+
+template <int D>
+__device__ __forceinline__ void f16_scores_prime(F16Scores &f, const F16LayerArgs &fa, const ChainPos<D> &p) {
+    const DecoderLayerArgs &g = fa.g;
+    const int h = __builtin_amdgcn_readfirstlane(p.wave);
+    const int Mc = g.Mk - 1;
+    f.b0 = p.r0 / g.T;
+    f.n_traj = (int)((p.r0 + p.R_left - 1) / g.T - f.b0) + 1;
+    const int slot = p.l31 & 15, tl = (f.n_traj > 1) ? (p.l31 >> 4) : 0;
+    const f16 *blk = (slot == Mc) ? fa.gstep + h * (32 * D) : fa.g16 + ((f.b0 + tl) * 4 + h) * (32 * D);
+    f.gp = blk + p.half * 128 + slot * 8;
+#pragma unroll
+    for (int s = 0; s < F16_GRING - 1; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) f.g[s][pl] = *reinterpret_cast<const f16x8 *>(f.gp + (s * 2 + pl) * 256);
+    const float *cbase = g.cb + f.b0 * 64 + h * 16 + 4 * p.half;
+    const float cs = fa.cstep[h];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // accumulator rows 4q..4q+3 are key slots 8*(q&1) + 4*half + i of trajectory q>>1
+        f.c[q] = *reinterpret_cast<const f32x4 *>(cbase + ((f.n_traj > 1) ? (q >> 1) * 64 : 0) + (q & 1) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((q & 1) * 8 + 4 * p.half + i == Mc) f.c[q][i] = cs;
+    }
+}
+
+// S^T of head `wave` on the fp16 pipe, softmax, P -> split planes (columns k = tl*64 + head*16 + slot, and the step
+// token's probability of head h at column 128 + h; columns 132..143 zero)
+template <int D>
+__device__ __forceinline__ void f16_scores(float *sA, F16Scores &f, const F16LayerArgs &fa, const ChainPos<D> &p, float cg) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    const DecoderLayerArgs &g = fa.g;
+    const int h = __builtin_amdgcn_readfirstlane(p.wave);
+    const int Mc = g.Mk - 1;
+    f16 *sH = reinterpret_cast<f16 *>(sA);
+    const f16 *hB = sH + p.l31 * ROWP + 8 * p.half;
+    f32x16 sc[2];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[tq][r] = 0.f;
+    f16x8 hf[2][2][2];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hf[0][tq][pl] = *reinterpret_cast<const f16x8 *>(hB + tq * 32 * ROWP + pl * D);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int cur = ks % F16_GRING, fill = (ks + F16_GRING - 1) % F16_GRING;
+        if (ks + F16_GRING - 1 < NK) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f.g[fill][pl] = *reinterpret_cast<const f16x8 *>(f.gp + ((ks + F16_GRING - 1) * 2 + pl) * 256);
+        }
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    hf[(ks + 1) & 1][tq][pl] = *reinterpret_cast<const f16x8 *>(hB + tq * 32 * ROWP + pl * D + (ks + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+            sc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.g[cur][1], hf[ks & 1][tq][0], sc[tq], 0, 0, 0);
+            sc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.g[cur][0], hf[ks & 1][tq][1], sc[tq], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) sc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.g[cur][0], hf[ks & 1][tq][0], sc[tq], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every wave has read LN2(h): the panel now receives P
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+        const int qrow = tq * 32 + p.l31;
+        const bool q_ok = qrow < p.R_left;
+        const int key_lo = (int)((p.r0 + qrow) / g.T - f.b0) * 16;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * p.half;
+            const bool ok = q_ok && kk >= key_lo && kk < key_lo + g.Mk;
+            const float v = ok ? sc[tq][r] * cg + f.c[r >> 2][r & 3] : -INFINITY;
+            sc[tq][r] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx == -INFINITY) mx = 0.f;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = exp2f((sc[tq][r] - mx) * g.scale_log2e);
+            sc[tq][r] = pv;
+            psum += pv;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        const float inv = (psum > 0.f ? 1.0f / psum : 0.f) * F16_P_SCALE;
+        f16 *rowp = sH + qrow * ROWP;
+        float pstep = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = {sc[tq][4 * q] * inv, sc[tq][4 * q + 1] * inv, sc[tq][4 * q + 2] * inv, sc[tq][4 * q + 3] * inv};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((q & 1) * 8 + 4 * p.half + i == Mc && (q >> 1) * 16 == key_lo) pstep = t[i];
+            f16x4 ph, pl;
+            f16_split4(t, 1.0f, ph, pl);
+            const int kcol = (q >> 1) * 64 + h * 16 + (q & 1) * 8 + 4 * p.half;
+            *reinterpret_cast<f16x4 *>(rowp + kcol) = ph;
+            *reinterpret_cast<f16x4 *>(rowp + D + kcol) = pl;
+        }
+        // step-token column of this head (held by the half that owns slot Mc) and this wave's share of the zero padding
+        if (((Mc >> 2) & 1) == p.half) {
+            const f16 sh = (f16)pstep;
+            rowp[128 + h] = sh;
+            rowp[D + 128 + h] = (f16)(pstep - (float)sh);
+        } else {
+#pragma unroll
+            for (int z = 0; z < 3; ++z) {
+                rowp[132 + 3 * h + z] = (f16)0.f;
+                rowp[D + 132 + 3 * h + z] = (f16)0.f;
+            }
+        }
+    }
+}
+
+// U = P V' (K = 64 per trajectory of the panel + the step-token k-step)
+template <int D, int NT>
+__device__ __forceinline__ void f16_pv(f32x16 (&U)[PanelCfg<D>::TM][PanelCfg<D>::TN], const f16 *aH, const F16LayerArgs &fa,
+                                       const ChainPos<D> &p, long b0) {
+    using C = PanelCfg<D>;
+    constexpr int ROWP = 2 * C::LDA, NS = 4 * NT + 1;
+    const unsigned loff = (unsigned)(p.wn * C::TN * 2 * 512 + p.lane * 8);
+    const f16 *vb = fa.v16 + b0 * 4 * (32 * D);   // wave-uniform; blocks of the NT trajectories are consecutive
+    auto bsrc = [&](int s, int tn, int pl) -> const f16 * {
+        return (s < 4 * NT ? vb + s * (32 * D) : fa.vstep) + loff + (tn * 2 + pl) * 512;
+    };
+    f16x8 bq[3][C::TN][2], af[2][C::TM][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) bq[s][tn][pl] = *reinterpret_cast<const f16x8 *>(bsrc(s, tn, pl));
+    // P columns: k-step s < 4*NT covers k = s*16 .. (tl = s / 4, head = s % 4); the step-token step reads k = 128..143
+    auto kcol = [&](int s) { return s < 4 * NT ? s * 16 : 128; };
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + kcol(0));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int cur = s % 3, fill = (s + 2) % 3;
+        if (s + 2 < NS) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bq[fill][tn][pl] = *reinterpret_cast<const f16x8 *>(bsrc(s + 2, tn, pl));
+        }
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    af[(s + 1) & 1][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + kcol(s + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    U[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][tm][TA[t]], bq[cur][tn][TB[t]], U[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decoder layer (folded cross-attention) with every row GEMM on the fp16 pipe
+// ---------------------------------------------------------------------------------------------------
+template <int D, bool TAIL>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_kernel(F16LayerArgs fa) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;   // halfs per (pass, wave) fragment stream
+    const DecoderLayerArgs &g = fa.g;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.a.R);
+    const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
+    const long wOff = (long)p.wn * WSTREAM + p.lane * 8;
+    const float c_o = 1.0f / (F16_ACT_SCALE * fa.sc_own[0]), c_1 = 1.0f / (F16_ACT_SCALE * fa.sc_own[1]);
+    const float c_2 = 1.0f / (F16_ACT_SCALE * fa.sc_own[2]), c_g = 1.0f / (F16_ACT_SCALE * fa.sc_own[4]);
+    const float c_v = 1.0f / (F16_P_SCALE * fa.sc_own[5]);
+    f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
+    F16Ring<D> ring;
+    f16_prime<D>(ring, fa.wf_o + wOff);
+    chain_load_acc<D>(H, g.a.h, p);
+    f16_load_panel<D>(sA, g.a.a, p);
+    __syncthreads();
+    chain_zero<D>(U);
+    f16_gemm<D>(U, aH, fa.wf_o + wOff, ring);                 // h += a Wo^T + bo   (self-attention out)
+    F16Scores fs;
+    f16_scores_prime<D>(fs, fa, p);
+    f16_unscale<D, true>(H, U, c_o, g.a.bo, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    f16_layer_norm_to_planes<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
+    __syncthreads();
+    f16_scores<D>(sA, fs, fa, p, c_g);
+    __syncthreads();
+    chain_zero<D>(U);
+    if (fs.n_traj > 1) f16_pv<D, 2>(U, aH, fa, p, fs.b0);     // h += P V' + boc
+    else f16_pv<D, 1>(U, aH, fa, p, fs.b0);
+    f16_prime<D>(ring, fa.wf_1 + wOff);
+    f16_unscale<D, true>(H, U, c_v, g.b.bo, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    f16_layer_norm_to_planes<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
+    __syncthreads();
+    chain_zero<D>(U);
+    f16_gemm<D>(U, aH, fa.wf_1 + wOff, ring);                 // u = gelu(LN3(h) W1^T + b1)
+    f16_prime<D>(ring, fa.wf_2 + wOff);
+    __syncthreads();
+    f16_gelu_to_planes<D>(sA, U, c_1, g.b.b1, p);
+    __syncthreads();
+    chain_zero<D>(U);
+    f16_gemm<D>(U, aH, fa.wf_2 + wOff, ring);                 // h += u W2^T + b2
+    if constexpr (TAIL) {
+        f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, H, p);                        // fp32 rows: fc_out (+ DDIM) stays on the fp32 path
+        __syncthreads();
+        panel_fc_out<D>(sA, g, p);
+        return;
+    } else {
+        const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
+        f16_prime<D>(ring, fa.wf_qkv + wOff);
+        f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
+        chain_store_acc<D>(g.a.h, D, 0, H, p);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, H, p);
+        __syncthreads();
+        f16_layer_norm_to_planes<D>(sA, g.b.nln_w, g.b.nln_b, p.lane, p.wave);
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {                // next layer's q | k | v
+            chain_zero<D>(U);
+            f16_gemm<D>(U, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, ring);
+            if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
+            f16_unscale<D, false>(H, U, c_q, g.b.bqkv + pass * D, p);
+            chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+        }
+    }
+}
+
+// head of a step: h = x Wemb^T + b + pe on the fp32 MFMA (K = J), then qkv = LN1(h) Wqkv^T + b of layer 0 on the fp16 pipe
+struct F16HeadArgs {
+    DecoderHeadArgs g;
+    const f16 *wf_qkv;
+    const float *sc;     // sc[3] = scale of layer 0's in_proj
+};
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kernel(F16HeadArgs fa) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;
+    const DecoderHeadArgs &g = fa.g;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.R);
+    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
+    const long wOff = (long)p.wn * WSTREAM + p.lane * 8;
+    const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc[3]);
+    F16Ring<D> ring;
+    f16_prime<D>(ring, fa.wf_qkv + wOff);
+    const int J = g.J, Jp = (J + 7) & ~7;
+    for (int i = threadIdx.x; i < C::BM * Jp; i += 256) {
+        const int row = i / Jp, j = i - row * Jp;
+        sA[row * C::LDA + j] = (row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
+    }
+    __syncthreads();
+    f32x16 H[C::TM][C::TN];
+    chain_zero<D>(H);
+    for (int k0 = 0; k0 < Jp; k0 += 8) {
+        const int kk = k0 + 4 * p.half;
+        f32x4 bf[C::TN], af[C::TM];
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (kk < J) t = *reinterpret_cast<const f32x4 *>(g.emb_w + (long)(p.wn * C::WN + tn * 32 + p.l31) * J + kk);
+            bf[tn] = t;
+        }
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], H[tm][tn], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const int col = p.col(tn);
+        const float bv = g.emb_b[col];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = p.row(tm, r);
+                const int pos = (int)((p.r0 + (row < p.R_left ? row : 0)) % g.T);
+                H[tm][tn][r] += bv + g.pe[(long)pos * D + col];
+            }
+    }
+    chain_store_acc<D>(g.h, D, 0, H, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    f16_layer_norm_to_planes<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        chain_zero<D>(H);
+        f16_gemm<D>(H, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, ring);
+        if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
+        f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
+        chain_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+    }
+}

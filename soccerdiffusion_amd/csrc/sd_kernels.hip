@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/soccerdiffusion_hip.h"
 
@@ -1284,6 +1286,40 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
                         "chain_b_kernel", s);
 }
 
+#include "sd_f16x3.h"
+
+static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
+    if (fa.g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer_f16: empty shape");
+    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
+    dim3 grid((unsigned)((fa.g.a.R + 63) / 64)), block(256);
+    const size_t lds = PanelCfg<256>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (fa.g.fo_w) SD_LAUNCH((decoder_layer_f16_kernel<256, true>), grid, block, lds, s, fa);
+    else SD_LAUNCH((decoder_layer_f16_kernel<256, false>), grid, block, lds, s, fa);
+    SD_CHECK_LAUNCH("decoder_layer_f16_kernel");
+    return 0;
+}
+
+static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s) {
+    if (fa.g.R <= 0) return fail(SD_E_BADARG, "decoder_head_f16: empty shape");
+    ProfScope prof(SD_KCLASS_HEAD, s);
+    dim3 grid((unsigned)((fa.g.R + 63) / 64)), block(256);
+    const size_t lds = PanelCfg<256>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    SD_LAUNCH((decoder_head_f16_kernel<256>), grid, block, lds, s, fa);
+    SD_CHECK_LAUNCH("decoder_head_f16_kernel");
+    return 0;
+}
+
 static int decoder_head(const DecoderHeadArgs &g, int d, hipStream_t s) {
     return launch_chain(g, d, decoder_head_kernel<64>, decoder_head_kernel<128>, decoder_head_kernel<256>,
                         decoder_head_kernel<512>, "decoder_head_kernel", s, SD_KCLASS_HEAD);
@@ -2141,7 +2177,19 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride,
 struct Scratch {  // carve-up of the caller's workspace (floats)
     float *h, *qkv, *a, *u, *kv, *kvstep, *kvtmp;
     float *gv, *cb, *gvstep, *cstep;   // folded cross-attention (sampler only)
+    // fp16x3 operands of the sampler (sd_f16x3.h): split weights, folded blocks, scales
+    f16 *wf, *g16, *v16, *gstep16, *vstep16;
+    float *scales;
+    unsigned *maxbits;
 };
+
+// the fp16x3 kernels are instantiated for hidden_dim 256 (the folded fp32 kernels serve the other sizes);
+// SD_SAMPLER_GEMM=f32 keeps the fp32-MFMA kernels (A/B runs)
+static bool f16_ok(int d, int J) {
+    static const char *env = getenv("SD_SAMPLER_GEMM");
+    if (env && strcmp(env, "f32") == 0) return false;
+    return d == 256 && J % 4 == 0;
+}
 
 // folded cross-attention applies: fused layer kernel, <= 16 key slots per head, <= 2 trajectories per panel
 static bool fold_ok(int d, int heads, int T, int Mk) { return heads == 4 && d >= 128 && Mk <= 16 && T >= 64; }
@@ -2165,6 +2213,18 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.gvstep = ws + off; off += align64((size_t)L * n_steps * 4 * 2 * d);
         s.cstep = ws + off; off += align64((size_t)L * n_steps * 4);
     }
+    s.wf = s.g16 = s.v16 = s.gstep16 = s.vstep16 = nullptr;
+    s.scales = nullptr;
+    s.maxbits = nullptr;
+    if (n_steps > 0 && d == 256) {   // sizes in floats (2 halfs each)
+        s.wf = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * 6 * d * d);
+        s.g16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * 4 * 16 * d);
+        s.v16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * 4 * 16 * d);
+        s.gstep16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * n_steps * 4 * 16 * d);
+        s.vstep16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * n_steps * 16 * d);
+        s.scales = ws + off; off += align64((size_t)(L + 1) * 8);
+        s.maxbits = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)(L + 1) * 8);
+    }
     return s;
 }
 
@@ -2176,6 +2236,9 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
     if (n_steps > 0)   // folded cross-attention blocks of the sampler: 64 rows of 2d (+ 1 bias) per trajectory and layer
         n += align64((size_t)L * B * 64 * 2 * d) + align64((size_t)L * B * 64) + align64((size_t)L * n_steps * 4 * 2 * d) +
              align64((size_t)L * n_steps * 4);
+    if (n_steps > 0 && d == 256)   // fp16x3 operands (sd_f16x3.h)
+        n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
+             align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8);
     return n;
 }
 
@@ -2244,6 +2307,120 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
     }
     if (fused) return 0;  // the last fused layer already produced eps / updated x
     return fc_out(s.h, w->out_w, w->out_b, tail.eps, tail.x_io, tail.coef, R, d, w->J, st);
+}
+
+// ---- fp16x3 sampler path (sd_f16x3.h) --------------------------------------------------------------
+// split weights of layer l: [Wo | W1 | W2 | in_proj (3 passes)] in fragment-major planes, 12 d^2 halfs
+static f16 *f16_wf(const Scratch &s, int l, int d, int which) {   // which: 0 Wo, 1 W1, 2 W2, 3 in_proj
+    return s.wf + ((size_t)l * 6 + (which < 3 ? which : 3)) * 2 * d * d;
+}
+
+// once per rollout, after the fp32 fold (gv, gvstep): scales, split weights, split folded blocks
+static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
+    const int d = w->d, L = w->L;
+    const size_t gvstride = (size_t)B * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
+    hipError_t e = hipMemsetAsync(s.maxbits, 0, (size_t)(L + 1) * 8 * sizeof(unsigned), st);
+    if (e != hipSuccess) return fail((int)e, "f16_prepare: hipMemsetAsync failed");
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
+        const int rows[4] = {d, d, d, 3 * d};
+        unsigned *mb = s.maxbits + l * 8;
+        for (int m = 0; m < 4; ++m) {
+            SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)rows[m] * d)), dim3(256), 0, st, mats[m], (long)rows[m] * d, mb + m);
+            SD_CHECK_LAUNCH("f16_absmax_kernel");
+        }
+        if (Mc > 0) {
+            SD_LAUNCH(f16_absmax_gv_kernel, dim3(grid_for((long)B * 64 * 2 * d)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * 64, d,
+                      mb + 4, mb + 5);
+            SD_CHECK_LAUNCH("f16_absmax_gv_kernel");
+        }
+        SD_LAUNCH(f16_absmax_gv_kernel, dim3(grid_for((long)n_steps * 4 * 2 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride,
+                  (long)n_steps * 4, d, mb + 4, mb + 5);
+        SD_CHECK_LAUNCH("f16_absmax_gv_kernel");
+    }
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
+        const int rows[4] = {d, d, d, 3 * d};
+        unsigned *mb = s.maxbits + l * 8;
+        float *sc = s.scales + l * 8;
+        for (int m = 0; m < 4; ++m) {
+            SD_LAUNCH((f16_pack_weight_kernel<256>), dim3(grid_for((long)rows[m] * d / 8)), dim3(256), 0, st, mats[m], rows[m], mb + m,
+                      f16_wf(s, l, d, m), sc + m);
+            SD_CHECK_LAUNCH("f16_pack_weight_kernel");
+        }
+        const size_t blk = (size_t)32 * d;
+        if (Mc > 0) {
+            SD_LAUNCH((f16_pack_g_kernel<256>), dim3(grid_for((long)B * 4 * 16 * d / 8)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, 16, 0,
+                      mb + 4, s.g16 + (size_t)l * B * 4 * blk, sc + 4);
+            SD_CHECK_LAUNCH("f16_pack_g_kernel");
+            SD_LAUNCH((f16_pack_v_kernel<256>), dim3(grid_for((long)B * 4 * 2 * d)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, mb + 5,
+                      s.v16 + (size_t)l * B * 4 * blk, sc + 5);
+            SD_CHECK_LAUNCH("f16_pack_v_kernel");
+        } else {   // no context rows: the per-trajectory blocks are all zero
+            e = hipMemsetAsync(s.g16 + (size_t)l * B * 4 * blk, 0, (size_t)B * 4 * blk * sizeof(f16), st);
+            if (e == hipSuccess) e = hipMemsetAsync(s.v16 + (size_t)l * B * 4 * blk, 0, (size_t)B * 4 * blk * sizeof(f16), st);
+            if (e != hipSuccess) return fail((int)e, "f16_prepare: hipMemsetAsync failed");
+        }
+        SD_LAUNCH((f16_pack_g_kernel<256>), dim3(grid_for((long)n_steps * 4 * 16 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride,
+                  (long)n_steps, 1, Mc, mb + 4, s.gstep16 + (size_t)l * n_steps * 4 * blk, Mc > 0 ? (float *)nullptr : sc + 4);
+        SD_CHECK_LAUNCH("f16_pack_g_kernel");
+        if (Mc == 0) {   // scale of V' was not written by a per-trajectory pack
+            SD_LAUNCH((f16_pack_v_kernel<256>), dim3(1), dim3(64), 0, st, s.gvstep, 0L, mb + 5, s.v16, sc + 5);
+            SD_CHECK_LAUNCH("f16_pack_v_kernel");
+        }
+        SD_LAUNCH((f16_pack_vstep_kernel<256>), dim3(grid_for((long)n_steps * 2 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride,
+                  (long)n_steps, mb + 5, s.vstep16 + (size_t)l * n_steps * blk);
+        SD_CHECK_LAUNCH("f16_pack_vstep_kernel");
+    }
+    return 0;
+}
+
+// one denoiser step + DDIM update on the fp16x3 kernels (step index i selects the step-token blocks)
+static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
+                             const float *coef, hipStream_t st) {
+    const int d = w->d, heads = w->heads, L = w->L, Mk = Mc + 1;
+    const long R = (long)B * T;
+    const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
+    const sd_layer_weights &l0 = w->layers[0];
+    F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
+                   f16_wf(s, 0, d, 3), s.scales};
+    int rc = decoder_head_f16(fh, st);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
+        if (rc) return rc;
+        const bool last = l + 1 == L;
+        const sd_layer_weights *nx = last ? nullptr : &w->layers[l + 1];
+        ChainAArgs ga{s.a, s.h, lw.sa_out_w, lw.sa_out_b, lw.n2_w, lw.n2_b, lw.ca_in_w, lw.ca_in_b, s.u, R};
+        ChainBArgs gb{s.a, s.h, lw.ca_out_w, lw.ca_out_b, lw.n3_w, lw.n3_b, lw.lin1_w, lw.lin1_b, lw.lin2_w, lw.lin2_b,
+                      nx ? nx->n1_w : nullptr, nx ? nx->n1_b : nullptr, nx ? nx->sa_in_w : nullptr, nx ? nx->sa_in_b : nullptr,
+                      s.qkv, R};
+        F16LayerArgs fa{};
+        fa.g = DecoderLayerArgs{ga, gb, nullptr, T, Mk, B, (1.0f / sqrtf((float)(d / heads))) * 1.44269504088896340736f,
+                                nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, 1.f, 0.f, w->J, nullptr, s.cb + l * cbstride, l};
+        if (last) {
+            fa.g.fo_w = w->out_w;
+            fa.g.fo_b = w->out_b;
+            fa.g.x_io = x;
+            fa.g.c0 = coef[0]; fa.g.c1 = coef[1]; fa.g.c2 = coef[2]; fa.g.c3 = coef[3];
+        }
+        fa.wf_o = f16_wf(s, l, d, 0);
+        fa.wf_1 = f16_wf(s, l, d, 1);
+        fa.wf_2 = f16_wf(s, l, d, 2);
+        fa.wf_qkv = last ? nullptr : f16_wf(s, l + 1, d, 3);
+        fa.sc_own = s.scales + l * 8;
+        fa.sc_next = s.scales + (l + 1) * 8;
+        fa.g16 = s.g16 + (size_t)l * B * 4 * blk;
+        fa.v16 = s.v16 + (size_t)l * B * 4 * blk;
+        fa.gstep = s.gstep16 + ((size_t)l * n_steps + i) * 4 * blk;
+        fa.vstep = s.vstep16 + ((size_t)l * n_steps + i) * blk;
+        fa.cstep = s.cstep + ((size_t)l * n_steps + i) * 4;
+        if ((rc = decoder_layer_f16(fa, st))) return rc;
+    }
+    return 0;
 }
 
 // Encoder stack (self-attention + FFN layers): chain B with norm2 as the FFN norm.
@@ -2336,6 +2513,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     const bool fold = fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
     const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
+    const bool f16 = fold && f16_ok(d, w->J) && s.wf != nullptr;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
@@ -2367,6 +2545,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
                       s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd);
             SD_CHECK_LAUNCH("xattn_fold_kernel");
         }
+        if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
     } else if (Mc > 0) {
         SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * Mc * 2 * d), L), dim3(256), 0, st, s.kvtmp, (long)B * Mc * 2 * d, s.kv,
                   (long)kvstride, B, Mc, Mk, 2 * d, 0);
@@ -2374,7 +2553,9 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     }
     for (int i = 0; i < n_steps; ++i) {
         // this step's token row -> row Mc of every trajectory, all layers in one launch
-        if (fold) {
+        if (f16) {
+            if ((rc = decoder_stack_f16(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st))) return rc;
+        } else if (fold) {
             SD_LAUNCH(fold_place_kernel, dim3(grid_for((long)B * 4 * 2 * d), L), dim3(256), 0, st, s.gvstep + (size_t)i * 4 * 2 * d,
                       s.cstep + (size_t)i * 4, (long)gvsstride, (long)cssstride, s.gv, s.cb, (long)gvstride, (long)cbstride, B, Mc,
                       2 * d);
