@@ -442,6 +442,7 @@ __device__ __forceinline__ void f16_scores(float *sA, F16Scores &f, const F16Lay
         for (int tq = 0; tq < 2; ++tq) sc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.g[cur][0], hf[ks & 1][tq][0], sc[tq], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    SD_STAMP(g.slot, 4);
     __syncthreads();   // every wave has read LN2(h): the panel now receives P
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq) {
@@ -568,12 +569,15 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     const float c_v = 1.0f / (F16_P_SCALE * fa.sc_own[5]);
     f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
     F16Ring<D> ring;
+    SD_STAMP(g.slot, 0);
     f16_prime<D>(ring, fa.wf_o + wOff);
     chain_load_acc<D>(H, g.a.h, p);
     f16_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
+    SD_STAMP(g.slot, 1);
     chain_zero<D>(U);
     f16_gemm<D>(U, aH, fa.wf_o + wOff, ring);                 // h += a Wo^T + bo   (self-attention out)
+    SD_STAMP(g.slot, 2);
     F16Scores fs;
     f16_scores_prime<D>(fs, fa, p);
     f16_unscale<D, true>(H, U, c_o, g.a.bo, p);
@@ -582,11 +586,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     __syncthreads();
     f16_layer_norm_to_planes<D>(sA, g.a.ln_w, g.a.ln_b, p.lane, p.wave);
     __syncthreads();
+    SD_STAMP(g.slot, 3);
     f16_scores<D>(sA, fs, fa, p, c_g);
     __syncthreads();
+    SD_STAMP(g.slot, 5);
     chain_zero<D>(U);
     if (fs.n_traj > 1) f16_pv<D, 2>(U, aH, fa, p, fs.b0);     // h += P V' + boc
     else f16_pv<D, 1>(U, aH, fa, p, fs.b0);
+    SD_STAMP(g.slot, 6);
     f16_prime<D>(ring, fa.wf_1 + wOff);
     f16_unscale<D, true>(H, U, c_v, g.b.bo, p);
     __syncthreads();
@@ -594,38 +601,48 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     __syncthreads();
     f16_layer_norm_to_planes<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
     __syncthreads();
+    SD_STAMP(g.slot, 7);
     chain_zero<D>(U);
     f16_gemm<D>(U, aH, fa.wf_1 + wOff, ring);                 // u = gelu(LN3(h) W1^T + b1)
+    SD_STAMP(g.slot, 8);
     f16_prime<D>(ring, fa.wf_2 + wOff);
     __syncthreads();
     f16_gelu_to_planes<D>(sA, U, c_1, g.b.b1, p);
     __syncthreads();
+    SD_STAMP(g.slot, 9);
     chain_zero<D>(U);
     f16_gemm<D>(U, aH, fa.wf_2 + wOff, ring);                 // h += u W2^T + b2
+    SD_STAMP(g.slot, 10);
     if constexpr (TAIL) {
         f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
         __syncthreads();
         chain_acc_to_lds<D>(sA, H, p);                        // fp32 rows: fc_out (+ DDIM) stays on the fp32 path
         __syncthreads();
+        SD_STAMP(g.slot, 11);
         panel_fc_out<D>(sA, g, p);
+        SD_STAMP(g.slot, 12);
         return;
     } else {
         const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
         f16_prime<D>(ring, fa.wf_qkv + wOff);
         f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
         chain_store_acc<D>(g.a.h, D, 0, H, p);
+        SD_STAMP(g.slot, 11);
         __syncthreads();
         chain_acc_to_lds<D>(sA, H, p);
         __syncthreads();
         f16_layer_norm_to_planes<D>(sA, g.b.nln_w, g.b.nln_b, p.lane, p.wave);
         __syncthreads();
+        SD_STAMP(g.slot, 12);
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {                // next layer's q | k | v
             chain_zero<D>(U);
             f16_gemm<D>(U, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, ring);
+            SD_STAMP(g.slot, 13 + 2 * pass);
             if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
             f16_unscale<D, false>(H, U, c_q, g.b.bqkv + pass * D, p);
             chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+            SD_STAMP(g.slot, 14 + 2 * pass);
         }
     }
 }
@@ -704,5 +721,206 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
         chain_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Self-attention of the sampler on the fp16 pipe (head dim 64, T <= 128).  Same structure as attention_pipe_kernel:
+// one workgroup per sample streams (head, 64-key chunk) units, wave w owns queries 32w..32w+31, S^T = K Q^T so that a
+// query is a lane column and P^T is the B operand of O^T = V^T P^T straight from the accumulator.  K and V are split
+// into fp16 pairs when a chunk is staged (K rows as they are, V transposed: the A operand of O^T needs 8 keys of one
+// feature per lane), Q when a head's fragments are fetched, P after the exponentials.  With the k-slot order of a
+// 16-key group defined as {4*half + 0..3, 8 + 4*half + 0..3}, a lane's 8 consecutive accumulator registers ARE its
+// B fragment, and the matching V^T fragment is two 8-byte LDS reads.
+// ---------------------------------------------------------------------------------------------------
+constexpr float F16_QKV_SCALE = 8.0f;
+constexpr int ATT16_PITCH = 136;   // halfs per LDS row: {hi[64], lo[64]} + 8 (272 B: 16 rows hit 16 distinct 4-bank groups)
+
+__global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__restrict__ qkv, int ld, float *__restrict__ out, int ldo,
+                                                              int T, int heads, float scale_log2e) {
+    constexpr int HD = 64, KC = 64;
+    __shared__ __attribute__((aligned(16))) f16 sK[KC * ATT16_PITCH];
+    __shared__ __attribute__((aligned(16))) f16 sV[HD * ATT16_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x, D = heads * HD;
+    const int nchunks = (T + KC - 1) / KC, nunits = heads * nchunks;
+    const int qi = wave * 32 + l31;
+    const bool wave_active = wave * 32 < T, q_ok = qi < T;
+    const float *base = qkv + (long)b * T * ld;
+    const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);          // raw S^T accumulator -> log2-domain score
+    const float c_o = 1.0f / (F16_P_SCALE * F16_QKV_SCALE);
+
+    // staging: K pieces (key = idx / 16, 4 features) keep rows contiguous; V pieces put the 64 keys on the lanes so that
+    // the transposed 2-byte LDS writes of one instruction are contiguous
+    f32x4 kreg[4], vreg[4];
+    auto fetch = [&](int u) {
+        const int h = u / nchunks, kc0 = (u - h * nchunks) * KC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int krow = idx >> 4, kc4 = idx & 15;
+            const int vrow = idx & 63, vc4 = idx >> 6;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
+            if (kc0 + krow < T) a = *reinterpret_cast<const f32x4 *>(base + (long)(kc0 + krow) * ld + D + h * HD + kc4 * 4);
+            if (kc0 + vrow < T) d = *reinterpret_cast<const f32x4 *>(base + (long)(kc0 + vrow) * ld + 2 * D + h * HD + vc4 * 4);
+            kreg[i] = a;
+            vreg[i] = d;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int krow = idx >> 4, kc4 = idx & 15;
+            const int vrow = idx & 63, vc4 = idx >> 6;
+            f16x4 hh, ll;
+            f16_split4(kreg[i], F16_QKV_SCALE, hh, ll);
+            *reinterpret_cast<f16x4 *>(sK + krow * ATT16_PITCH + kc4 * 4) = hh;
+            *reinterpret_cast<f16x4 *>(sK + krow * ATT16_PITCH + HD + kc4 * 4) = ll;
+            f16_split4(vreg[i], F16_QKV_SCALE, hh, ll);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sV[(vc4 * 4 + e) * ATT16_PITCH + vrow] = hh[e];
+                sV[(vc4 * 4 + e) * ATT16_PITCH + KC + vrow] = ll[e];
+            }
+        }
+    };
+    f32x4 qraw[8];
+    f16x8 qf[4][2];
+    const float *qrow = base + (long)(q_ok ? qi : 0) * ld + 8 * half;
+    auto fetch_q = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (q_ok) t = *reinterpret_cast<const f32x4 *>(qrow + h * HD + (i >> 1) * 16 + (i & 1) * 4);
+            qraw[i] = t;
+        }
+    };
+    fetch(0);
+    fetch_q(0);
+    f32x16 o[2];
+    float m_run = -INFINITY, l_part = 0.f;
+
+    for (int u = 0; u < nunits; ++u) {
+        const int h = u / nchunks, c = u - h * nchunks, kc0 = c * KC;
+        __syncthreads();   // every wave is done reading the previous unit's K/V
+        stage();
+        if (u + 1 < nunits) fetch(u + 1);
+        if (c == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f16x4 h0, l0, h1, l1;
+                f16_split4(qraw[2 * ks], F16_QKV_SCALE, h0, l0);
+                f16_split4(qraw[2 * ks + 1], F16_QKV_SCALE, h1, l1);
+                qf[ks][0] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                qf[ks][1] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
+            m_run = -INFINITY;
+            l_part = 0.f;
+        }
+        if (c == nchunks - 1 && h + 1 < heads) fetch_q(h + 1);
+        __syncthreads();
+        if (!wave_active) continue;
+        const int n_valid = min(T - kc0, KC);             // keys of this chunk
+        const int kt_valid = (n_valid + 31) / 32;
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+            if (kt < kt_valid) {
+                const f16 *kp = sK + (kt * 32 + l31) * ATT16_PITCH + 8 * half;
+                f16x8 kf[2][2];
+                kf[0][0] = *reinterpret_cast<const f16x8 *>(kp);
+                kf[0][1] = *reinterpret_cast<const f16x8 *>(kp + HD);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks + 1 < 4) {
+                        kf[(ks + 1) & 1][0] = *reinterpret_cast<const f16x8 *>(kp + (ks + 1) * 16);
+                        kf[(ks + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(kp + HD + (ks + 1) * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][1], qf[ks][0], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][0], qf[ks][1], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][0], qf[ks][0], sc[kt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (n_valid < KC) {   // wave-uniform: only the last chunk of a head has keys to mask
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (key >= n_valid) sc[kt][r] = -INFINITY;
+                }
+        }
+        float m_c = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m_c = fmaxf(m_c, fmaxf(sc[0][r], sc[1][r]));
+        m_c = fmaxf(m_c, __shfl_xor(m_c, 32, 64));
+        const float m_new = fmaxf(m_run, m_c);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
+        m_run = m_new;
+        const float mb = m_new * c_s;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sc[kt][r] * c_s - mb);
+                sc[kt][r] = pv;
+                psum += pv;
+            }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+        // O^T += V^T P^T, 16 keys per step: registers 8*j2 .. 8*j2+7 of tile kt are this lane's B fragment
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int kt = gg >> 1, j2 = gg & 1;
+            if (kt * 32 + j2 * 16 >= n_valid) break;   // wave-uniform: no live key in this and the later groups
+            f16x8 ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = sc[kt][8 * j2 + e] * F16_P_SCALE;
+                ph[e] = (f16)t;
+                pl[e] = (f16)(t - (float)ph[e]);
+            }
+            const f16 *vp = sV + l31 * ATT16_PITCH + kt * 32 + j2 * 16 + 4 * half;
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const f16 *vr = vp + ft * 32 * ATT16_PITCH;
+                const f16x4 a0 = *reinterpret_cast<const f16x4 *>(vr), a1 = *reinterpret_cast<const f16x4 *>(vr + 8);
+                const f16x4 b0 = *reinterpret_cast<const f16x4 *>(vr + KC), b1 = *reinterpret_cast<const f16x4 *>(vr + KC + 8);
+                const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[ft], 0, 0, 0);
+                o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[ft], 0, 0, 0);
+                o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
+            }
+        }
+        if (c == nchunks - 1) {
+            const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+            const float inv = c_o / l_tot;
+            if (q_ok) {
+                float *op = out + ((long)b * T + qi) * ldo + h * HD;
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 t = {o[ft][4 * g4] * inv, o[ft][4 * g4 + 1] * inv, o[ft][4 * g4 + 2] * inv, o[ft][4 * g4 + 3] * inv};
+                        *reinterpret_cast<f32x4 *>(op + ft * 32 + 8 * g4 + 4 * half) = t;
+                    }
+            }
+        }
     }
 }

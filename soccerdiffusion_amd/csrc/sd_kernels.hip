@@ -1305,6 +1305,15 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     return 0;
 }
 
+// self-attention over qkv [B*T][3d] on the fp16 pipe (head dim 64, T <= 128)
+static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s) {
+    ProfScope prof(SD_KCLASS_ATTENTION, s);
+    const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
+    SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
+    SD_CHECK_LAUNCH("attention_f16_kernel");
+    return 0;
+}
+
 static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s) {
     if (fa.g.R <= 0) return fail(SD_E_BADARG, "decoder_head_f16: empty shape");
     ProfScope prof(SD_KCLASS_HEAD, s);
@@ -2390,7 +2399,8 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
     if (rc) return rc;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
-        rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
+        if (d / heads == 64 && T <= 128) rc = attention_f16(s.qkv, s.a, B, T, d, heads, st);
+        else rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
         if (rc) return rc;
         const bool last = l + 1 == L;
         const sd_layer_weights *nx = last ? nullptr : &w->layers[l + 1];
