@@ -97,6 +97,13 @@ const char *sd_last_error(void);
  * for batch B, horizon T (decoder tokens or encoder patches), memory tokens M. */
 size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
 
+/* Which kernels sd_ddim_sample runs for this shape (reporting only; results agree within fp32 rounding):
+ *   0 = fp32 MFMA, per-step cross-attention projections;
+ *   1 = fp32 MFMA with the cross-attention Q/out projections folded into the cached memory (heads 4, Mc + 1 <= 16, T >= 64);
+ *   2 = mode 1 with every row GEMM and the self-attention as 3 fp16 MFMAs on split (hi + lo) operands, fp32
+ *       accumulate (hidden_dim 256; SD_SAMPLER_GEMM=f32 in the environment selects mode 1 instead). */
+int sd_sampler_mode(int d, int heads, int T, int Mc, int J);
+
 /* StepToken.forward — soccer_diffusion/ml/model/misc.py:25-35.
  * steps: B values, int64 if steps_is_i64 else fp32.  freq: d/4 host-built frequencies
  * (built in fp32 exactly as misc.py:32 does).  token: learned (d/2).  Writes row b of the

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sd_abi_version": (C.c_int, []),
     "sd_last_error": (C.c_char_p, []),
     "sd_workspace_floats": (C.c_size_t, [C.c_int] * 6),
+    "sd_sampler_mode": (C.c_int, [C.c_int] * 5),
     "sd_step_token": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "sd_denoiser_forward": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_encoder_forward": (C.c_int, [C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

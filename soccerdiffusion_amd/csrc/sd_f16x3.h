@@ -189,21 +189,22 @@ struct F16Ring {
     f16x8 b[3][PanelCfg<D>::TN][2];   // [slot][column tile][plane]
 };
 
-// wf: this wave's fragment stream of one pass, + lane*8 already applied
+// wf: this wave's fragment stream of one pass (wave-uniform pointer: scalar base); loff = lane*8 halfs
 template <int D>
-__device__ __forceinline__ void f16_prime(F16Ring<D> &ring, const f16 *wf) {
+__device__ __forceinline__ void f16_prime(F16Ring<D> &ring, const f16 *wf, unsigned loff) {
     using C = PanelCfg<D>;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) ring.b[s][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + ((s * C::TN + tn) * 2 + pl) * 512);
+            for (int pl = 0; pl < 2; ++pl) ring.b[s][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + loff + (unsigned)(((s * C::TN + tn) * 2 + pl) * 512));
 }
 
-// acc += A(panel planes) W^T over K = D;  aH: (f16*)panel + row*(2*LDA) + 8*half of this lane's first row
-template <int D>
-__device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const f16 *aH, const f16 *wf,
+// acc (+)= A(panel planes) W^T over K = D;  aH: (f16*)panel + row*(2*LDA) + 8*half of this lane's first row.
+// ZERO: the accumulator starts at 0 (passed to the first MFMA as the inline constant, no register clearing)
+template <int D, bool ZERO>
+__device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const f16 *aH, const f16 *wf, unsigned loff,
                                          F16Ring<D> &ring) {
     using C = PanelCfg<D>;
     constexpr int NK = D / 16, ROWP = 2 * C::LDA;
@@ -215,13 +216,16 @@ __device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
         const int cur = ks % 3, fill = (ks + 2) % 3;
+#ifndef SD_ABL_NO_WLOAD   // ablation builds (tools/ab_build.sh): results are wrong, timings tell what bounds the kernel
         if (ks + 2 < NK) {
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    ring.b[fill][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + (((ks + 2) * C::TN + tn) * 2 + pl) * 512);
+                    ring.b[fill][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + loff + (unsigned)((((ks + 2) * C::TN + tn) * 2 + pl) * 512));
         }
+#endif
+#ifndef SD_ABL_NO_ALOAD
         if (ks + 1 < NK) {
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
@@ -229,6 +233,7 @@ __device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg
                 for (int pl = 0; pl < 2; ++pl)
                     af[(ks + 1) & 1][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // small terms first: lo.hi, hi.lo, hi.hi
 #pragma unroll
@@ -236,8 +241,17 @@ __device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][tm][TA[t]], ring.b[cur][tn][TB[t]], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    if (ZERO && ks == 0 && t == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][tm][TA[0]], ring.b[cur][tn][TB[0]], z, 0, 0, 0);
+                    } else {
+#ifdef SD_ABL_ONE_MFMA
+                        if (t == 2)
+#endif
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][tm][TA[t]], ring.b[cur][tn][TB[t]], acc[tm][tn], 0, 0, 0);
+                    }
+                }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -274,7 +288,7 @@ __device__ __forceinline__ void f16_gelu_to_planes(float *sA, const f32x16 (&U)[
         for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = gelu_erf(U[tm][tn][r] * c + bv) * F16_ACT_SCALE;
+                const float v = gelu_erf_fast(U[tm][tn][r] * c + bv) * F16_ACT_SCALE;
                 const f16 h = (f16)v;
                 f16 *o = sH + p.row(tm, r) * ROWP + p.col(tn);
                 o[0] = h;
@@ -353,6 +367,15 @@ __device__ __forceinline__ void f16_load_panel(float *sA, const float *src, cons
             *reinterpret_cast<f16x4 *>(rowp + D + c4 * 4) = l;
         }
     }
+}
+
+// accumulator tile -> global rows.  Measured (tools/stamps.py): 64 one-register stores per pass (no lane shuffles) take
+// 25-30 k cycles, the 16 quad-transposed 16-byte stores of chain_store_acc 6 k: the store path is bound by
+// wave-instructions, not by bytes or by the ~4 VALU instructions per value of the transpose.
+template <int D>
+__device__ __forceinline__ void f16_store_acc(float *dst, int ld, int col0, const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                              const ChainPos<D> &p) {
+    chain_store_acc<D>(dst, ld, col0, acc, p);
 }
 
 struct F16LayerArgs {
@@ -563,20 +586,20 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     extern __shared__ __attribute__((aligned(16))) float sA[];
     const ChainPos<D> p(g.a.R);
     const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
-    const long wOff = (long)p.wn * WSTREAM + p.lane * 8;
+    const long wOff = (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM;   // wave-uniform: scalar base + 32-bit lane offset
+    const unsigned loff = (unsigned)p.lane * 8;
     const float c_o = 1.0f / (F16_ACT_SCALE * fa.sc_own[0]), c_1 = 1.0f / (F16_ACT_SCALE * fa.sc_own[1]);
     const float c_2 = 1.0f / (F16_ACT_SCALE * fa.sc_own[2]), c_g = 1.0f / (F16_ACT_SCALE * fa.sc_own[4]);
     const float c_v = 1.0f / (F16_P_SCALE * fa.sc_own[5]);
     f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
     F16Ring<D> ring;
     SD_STAMP(g.slot, 0);
-    f16_prime<D>(ring, fa.wf_o + wOff);
+    f16_prime<D>(ring, fa.wf_o + wOff, loff);
     chain_load_acc<D>(H, g.a.h, p);
     f16_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
     SD_STAMP(g.slot, 1);
-    chain_zero<D>(U);
-    f16_gemm<D>(U, aH, fa.wf_o + wOff, ring);                 // h += a Wo^T + bo   (self-attention out)
+    f16_gemm<D, true>(U, aH, fa.wf_o + wOff, loff, ring);                 // h += a Wo^T + bo   (self-attention out)
     SD_STAMP(g.slot, 2);
     F16Scores fs;
     f16_scores_prime<D>(fs, fa, p);
@@ -594,7 +617,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     if (fs.n_traj > 1) f16_pv<D, 2>(U, aH, fa, p, fs.b0);     // h += P V' + boc
     else f16_pv<D, 1>(U, aH, fa, p, fs.b0);
     SD_STAMP(g.slot, 6);
-    f16_prime<D>(ring, fa.wf_1 + wOff);
+    f16_prime<D>(ring, fa.wf_1 + wOff, loff);
     f16_unscale<D, true>(H, U, c_v, g.b.bo, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
@@ -602,16 +625,14 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     f16_layer_norm_to_planes<D>(sA, g.b.ln_w, g.b.ln_b, p.lane, p.wave);
     __syncthreads();
     SD_STAMP(g.slot, 7);
-    chain_zero<D>(U);
-    f16_gemm<D>(U, aH, fa.wf_1 + wOff, ring);                 // u = gelu(LN3(h) W1^T + b1)
+    f16_gemm<D, true>(U, aH, fa.wf_1 + wOff, loff, ring);                 // u = gelu(LN3(h) W1^T + b1)
     SD_STAMP(g.slot, 8);
-    f16_prime<D>(ring, fa.wf_2 + wOff);
+    f16_prime<D>(ring, fa.wf_2 + wOff, loff);
     __syncthreads();
     f16_gelu_to_planes<D>(sA, U, c_1, g.b.b1, p);
     __syncthreads();
     SD_STAMP(g.slot, 9);
-    chain_zero<D>(U);
-    f16_gemm<D>(U, aH, fa.wf_2 + wOff, ring);                 // h += u W2^T + b2
+    f16_gemm<D, true>(U, aH, fa.wf_2 + wOff, loff, ring);                 // h += u W2^T + b2
     SD_STAMP(g.slot, 10);
     if constexpr (TAIL) {
         f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
@@ -624,9 +645,9 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
         return;
     } else {
         const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
-        f16_prime<D>(ring, fa.wf_qkv + wOff);
+        f16_prime<D>(ring, fa.wf_qkv + wOff, loff);
         f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
-        chain_store_acc<D>(g.a.h, D, 0, H, p);
+        f16_store_acc<D>(g.a.h, D, 0, H, p);
         SD_STAMP(g.slot, 11);
         __syncthreads();
         chain_acc_to_lds<D>(sA, H, p);
@@ -636,12 +657,11 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
         SD_STAMP(g.slot, 12);
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {                // next layer's q | k | v
-            chain_zero<D>(U);
-            f16_gemm<D>(U, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, ring);
+            f16_gemm<D, true>(U, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, loff, ring);
             SD_STAMP(g.slot, 13 + 2 * pass);
-            if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
+            if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
             f16_unscale<D, false>(H, U, c_q, g.b.bqkv + pass * D, p);
-            chain_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+            f16_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
             SD_STAMP(g.slot, 14 + 2 * pass);
         }
     }
@@ -664,10 +684,11 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
     const ChainPos<D> p(g.R);
     const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
     const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
-    const long wOff = (long)p.wn * WSTREAM + p.lane * 8;
+    const long wOff = (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM;   // wave-uniform: scalar base + 32-bit lane offset
+    const unsigned loff = (unsigned)p.lane * 8;
     const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc[3]);
     F16Ring<D> ring;
-    f16_prime<D>(ring, fa.wf_qkv + wOff);
+    f16_prime<D>(ring, fa.wf_qkv + wOff, loff);
     const int J = g.J, Jp = (J + 7) & ~7;
     for (int i = threadIdx.x; i < C::BM * Jp; i += 256) {
         const int row = i / Jp, j = i - row * Jp;
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
                 H[tm][tn][r] += bv + g.pe[(long)pos * D + col];
             }
     }
-    chain_store_acc<D>(g.h, D, 0, H, p);
+    f16_store_acc<D>(g.h, D, 0, H, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
     __syncthreads();
@@ -716,11 +737,10 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
-        chain_zero<D>(H);
-        f16_gemm<D>(H, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, ring);
-        if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff);
+        f16_gemm<D, true>(H, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, loff, ring);
+        if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
-        chain_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
     }
 }
 

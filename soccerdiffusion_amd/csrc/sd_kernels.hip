@@ -420,9 +420,11 @@ __device__ __forceinline__ void chain_load_acc(f32x16 (&acc)[PanelCfg<D>::TM][Pa
         for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                // rows past the end of the last panel re-read row 0 (their results are never stored): no per-element
+                // branch, which is what a predicated load compiles to
                 const int row = p.row(tm, r);
                 const unsigned off = lane_off + (unsigned)((tm * 32 + (r & 3) + 8 * (r >> 2)) * D + tn * 32);
-                acc[tm][tn][r] = (row < p.R_left) ? base[off] : 0.f;
+                acc[tm][tn][r] = base[row < p.R_left ? off : (unsigned)(p.wn * C::WN + p.l31 + tn * 32)];
             }
 }
 
@@ -2503,6 +2505,12 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
                        (long)R, d);
     SD_CHECK_LAUNCH("copy_rows_kernel");
     return 0;
+}
+
+extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
+    const int Mk = Mc + 1;
+    if (!(fold_ok(d, heads, T, Mk) && fused_layer_ok(d, heads, T, Mk))) return 0;
+    return f16_ok(d, J) ? 2 : 1;
 }
 
 extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,

@@ -99,3 +99,38 @@ def test_ddim_sampler_every_step(ops, d, L, T, Mc, B, n_steps):
     assert max(errs) < TOL, errs
     assert torch.equal(x0, trace[-1])
     assert torch.isfinite(x0).all()
+
+
+def test_fp16x3_sampler_is_fp32_grade(ops):
+    """The split-operand fp16 MFMA path (sd_sampler_mode 2) against the FP64 oracle loop: its error over a full
+    50-step rollout must stay at the level of the fp32 CPU path's own error (both ~4e-7), 100x inside the 1e-4
+    tolerance of north_star - i.e. the 3-MFMA products are not a reduced-precision shortcut."""
+    from soccerdiffusion_amd import _lib
+
+    d, L, T, Mc, B, n_steps, J = 256, 4, 100, 10, 3, 50, 20
+    assert _lib.load().sd_sampler_mode(d, 4, T, Mc, J) == 2
+    sd = ref.synthetic_state_dict(d, J, L, seed=21)
+    g = torch.Generator().manual_seed(77)
+    x_T = torch.randn(B, T, J, generator=g)
+    ctx = torch.randn(B, Mc, d, generator=g)
+    acp = ddim_ref.alphas_cumprod()
+    ts = ddim_ref.timesteps(n_steps).tolist()
+
+    def denoise(dtype):
+        return lambda x, t: ref.forward_with_context(sd, [ctx], x, torch.full((B,), t, dtype=torch.int64), dtype=dtype)
+
+    want64 = ddim_ref.sample(denoise(torch.float64), x_T.double(), n_steps, acp)
+    want32 = ddim_ref.sample(denoise(torch.float32), x_T, n_steps, acp)
+    packed = ops.pack_denoiser(sd, "cuda", max_len=T)
+    freq = ops.step_frequencies(d).cuda()
+    toks = ops.step_token(torch.tensor(ts).cuda(), freq, sd["step_encoding.token"].cuda()).reshape(n_steps, d)
+    coef = ops.ddim_coefficients(ts, acp, n_steps)
+    _, trace = ops.ddim_sample(packed, ctx.cuda(), toks, coef, x_T.cuda(), trace=True)
+
+    def rel64(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+
+    e_native = max(rel64(trace[i], want64[i]) for i in range(n_steps))
+    e_cpu32 = max(rel64(want32[i], want64[i]) for i in range(n_steps))
+    assert e_native < 2e-6, e_native
+    assert e_native < 4 * e_cpu32 + 1e-7, (e_native, e_cpu32)
