@@ -60,3 +60,24 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     report[counter] = rep
 
 json.dump(report, open(os.path.join(out, "summary.json"), "w"), indent=1)
+
+# HBM traffic per launch for bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is
+# doubled per the gfx950 note of MI355X_MICROARCH.md (HBM / rocprofv3 section); the passes are separate runs.
+if "FETCH_SIZE" in report and "WRITE_SIZE" in report:
+    per = {}
+    for k, fv in report["FETCH_SIZE"].items():
+        wv = report["WRITE_SIZE"].get(k)
+        if not wv or not fv["dispatches"]:
+            continue
+        per[k] = {"hbm_bytes_per_launch": (2 * fv["total"] / fv["dispatches"] + wv["total"] / wv["dispatches"]) * 1024,
+                  "dispatches": fv["dispatches"]}
+    layer = [k for k in per if k.startswith("decoder_layer")]
+    dom = max(layer, key=lambda k: per[k]["dispatches"]) if layer else None
+    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_gpu.sh); FETCH_SIZE doubled per the "
+                         "gfx950 note in MI355X_MICROARCH.md; KiB units",
+               "workload": "bench.py --steps 1 (B=4096)", "dominant_kernel": dom,
+               "decoder_layer_kernel_bytes_per_launch": per[dom]["hbm_bytes_per_launch"] if dom else None, "per_kernel": per}
+    json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print("\n== HBM bytes per launch (2 x FETCH + WRITE):")
+    for k, v in per.items():
+        print(f"{k:110s} {v['hbm_bytes_per_launch'] / 1e9:8.3f} GB")
