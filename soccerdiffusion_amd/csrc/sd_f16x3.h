@@ -689,58 +689,87 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
     const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc[3]);
     F16Ring<D> ring;
     f16_prime<D>(ring, fa.wf_qkv + wOff, loff);
-    const int J = g.J, Jp = (J + 7) & ~7;
-    for (int i = threadIdx.x; i < C::BM * Jp; i += 256) {
-        const int row = i / Jp, j = i - row * Jp;
-        sA[row * C::LDA + j] = (row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
-    }
-    __syncthreads();
-    f32x16 H[C::TM][C::TN];
-    chain_zero<D>(H);
-    for (int k0 = 0; k0 < Jp; k0 += 8) {
-        const int kk = k0 + 4 * p.half;
-        f32x4 bf[C::TN], af[C::TM];
+    const int J = g.J, Jp = (J + 7) & ~7;   // <= 64
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 0);
+    // x rows -> panel (fp32, K = J zero-padded), 4 loads in flight per thread and round trip
+    for (int i0 = threadIdx.x; i0 < C::BM * Jp; i0 += 4 * 256) {
+        float xv[4];
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (kk < J) t = *reinterpret_cast<const f32x4 *>(g.emb_w + (long)(p.wn * C::WN + tn * 32 + p.l31) * J + kk);
-            bf[tn] = t;
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + b * 256;
+            const int row = i / Jp, j = i - row * Jp;
+            xv[b] = (i < C::BM * Jp && row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
         }
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + k0);
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + b * 256;
+            const int row = i / Jp, j = i - row * Jp;
+            if (i < C::BM * Jp) sA[row * C::LDA + j] = xv[b];
+        }
+    }
+    // embedding weights of all k-steps (J <= 64: at most 8) requested up front
+    f32x4 ew[8][C::TN];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int kk = ks * 8 + 4 * p.half;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (ks * 8 < Jp && kk < J) t = *reinterpret_cast<const f32x4 *>(g.emb_w + (long)(p.wn * C::WN + tn * 32 + p.l31) * J + kk);
+            ew[ks][tn] = t;
+        }
+    __syncthreads();
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 1);
+    f32x16 H[C::TM][C::TN];
+    chain_zero<D>(H);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks * 8 >= Jp) break;
+        f32x4 af[C::TM];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + ks * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn)
-                    H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], H[tm][tn], 0, 0, 0);
+                    H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], ew[ks][tn][j], H[tm][tn], 0, 0, 0);
     }
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 2);
+    {   // + bias + positional row.  Position = row index inside its trajectory: ONE modulo per lane, then offsets (< 64 <= T)
+        const int pos0 = (int)((p.r0 + p.wm * C::WM + 4 * p.half) % g.T);
 #pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn) {
-        const int col = p.col(tn);
-        const float bv = g.emb_b[col];
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int col = p.col(tn);
+            const float bv = g.emb_b[col];
+            const float *pec = g.pe + col;
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm)
+            for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = p.row(tm, r);
-                const int pos = (int)((p.r0 + (row < p.R_left ? row : 0)) % g.T);
-                H[tm][tn][r] += bv + g.pe[(long)pos * D + col];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    int pos = pos0 + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    pos = pos >= g.T ? pos - g.T : pos;
+                    H[tm][tn][r] += bv + pec[(unsigned)(pos * D)];
+                }
+        }
     }
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 3);
     f16_store_acc<D>(g.h, D, 0, H, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
     __syncthreads();
     f16_layer_norm_to_planes<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
     __syncthreads();
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 4);
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         f16_gemm<D, true>(H, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, loff, ring);
+        SD_STAMP(SD_STAMP_HEAD_SLOT, 5 + 2 * pass);
         if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
         f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        SD_STAMP(SD_STAMP_HEAD_SLOT, 6 + 2 * pass);
     }
 }
 
@@ -767,23 +796,38 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
     const int nchunks = (T + KC - 1) / KC, nunits = heads * nchunks;
     const int qi = wave * 32 + l31;
     const bool wave_active = wave * 32 < T, q_ok = qi < T;
-    const float *base = qkv + (long)b * T * ld;
+    const float *base = qkv + (long)b * T * ld;   // workgroup-uniform: scalar base, 32-bit offsets below
     const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);          // raw S^T accumulator -> log2-domain score
-    const float c_o = 1.0f / (F16_P_SCALE * F16_QKV_SCALE);
+    const float c_o = 1.0f / F16_QKV_SCALE;                                   // P carries its 2^10 into the row sum as well
 
     // staging: K pieces (key = idx / 16, 4 features) keep rows contiguous; V pieces put the 64 keys on the lanes so that
-    // the transposed 2-byte LDS writes of one instruction are contiguous
+    // the transposed 2-byte LDS writes of one instruction are contiguous.  Inside a 16-key group V^T stores key k at
+    // position (k&3) + 4*((k>>3)&1) + 8*((k>>2)&1): the 8 k-slots of a lane half are then one 16-byte read.
+    unsigned koff[4], voff[4];   // global offsets (floats) of this thread's pieces relative to (chunk, head)
+    int klds[4], vlds[4], krow[4], vrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        krow[i] = idx >> 4;
+        const int kc4 = idx & 15;
+        vrow[i] = idx & 63;
+        const int vc4 = idx >> 6;
+        koff[i] = (unsigned)(krow[i] * ld + kc4 * 4);
+        voff[i] = (unsigned)(vrow[i] * ld + vc4 * 4);
+        klds[i] = krow[i] * ATT16_PITCH + kc4 * 4;
+        const int k16 = vrow[i] & 15;
+        vlds[i] = (vc4 * 4) * ATT16_PITCH + (vrow[i] & ~15) + (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
+    }
     f32x4 kreg[4], vreg[4];
     auto fetch = [&](int u) {
         const int h = u / nchunks, kc0 = (u - h * nchunks) * KC;
+        const float *kb = base + (long)kc0 * ld + D + h * HD;   // uniform
+        const int left = T - kc0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int krow = idx >> 4, kc4 = idx & 15;
-            const int vrow = idx & 63, vc4 = idx >> 6;
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
-            if (kc0 + krow < T) a = *reinterpret_cast<const f32x4 *>(base + (long)(kc0 + krow) * ld + D + h * HD + kc4 * 4);
-            if (kc0 + vrow < T) d = *reinterpret_cast<const f32x4 *>(base + (long)(kc0 + vrow) * ld + 2 * D + h * HD + vc4 * 4);
+            if (krow[i] < left) a = *reinterpret_cast<const f32x4 *>(kb + koff[i]);
+            if (vrow[i] < left) d = *reinterpret_cast<const f32x4 *>(kb + D + voff[i]);
             kreg[i] = a;
             vreg[i] = d;
         }
@@ -791,31 +835,25 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int krow = idx >> 4, kc4 = idx & 15;
-            const int vrow = idx & 63, vc4 = idx >> 6;
             f16x4 hh, ll;
             f16_split4(kreg[i], F16_QKV_SCALE, hh, ll);
-            *reinterpret_cast<f16x4 *>(sK + krow * ATT16_PITCH + kc4 * 4) = hh;
-            *reinterpret_cast<f16x4 *>(sK + krow * ATT16_PITCH + HD + kc4 * 4) = ll;
+            *reinterpret_cast<f16x4 *>(sK + klds[i]) = hh;
+            *reinterpret_cast<f16x4 *>(sK + klds[i] + HD) = ll;
             f16_split4(vreg[i], F16_QKV_SCALE, hh, ll);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sV[(vc4 * 4 + e) * ATT16_PITCH + vrow] = hh[e];
-                sV[(vc4 * 4 + e) * ATT16_PITCH + KC + vrow] = ll[e];
+                sV[vlds[i] + e * ATT16_PITCH] = hh[e];
+                sV[vlds[i] + e * ATT16_PITCH + KC] = ll[e];
             }
         }
     };
     f32x4 qraw[8];
     f16x8 qf[4][2];
-    const float *qrow = base + (long)(q_ok ? qi : 0) * ld + 8 * half;
+    const unsigned qoff = (unsigned)((q_ok ? qi : 0) * ld + 8 * half);
     auto fetch_q = [&](int h) {
+        const float *qb = base + h * HD;   // uniform
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (q_ok) t = *reinterpret_cast<const f32x4 *>(qrow + h * HD + (i >> 1) * 16 + (i & 1) * 4);
-            qraw[i] = t;
-        }
+        for (int i = 0; i < 8; ++i) qraw[i] = *reinterpret_cast<const f32x4 *>(qb + qoff + (unsigned)((i >> 1) * 16 + (i & 1) * 4));
     };
     fetch(0);
     fetch_q(0);
@@ -836,10 +874,6 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 qf[ks][0] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 qf[ks][1] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[ft][r] = 0.f;
             m_run = -INFINITY;
             l_part = 0.f;
         }
@@ -849,10 +883,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
         const int n_valid = min(T - kc0, KC);             // keys of this chunk
         const int kt_valid = (n_valid + 31) / 32;
         f32x16 sc[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
             if (kt < kt_valid) {
                 const f16 *kp = sK + (kt * 32 + l31) * ATT16_PITCH + 8 * half;
                 f16x8 kf[2][2];
@@ -865,11 +898,14 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                         kf[(ks + 1) & 1][1] = *reinterpret_cast<const f16x8 *>(kp + HD + (ks + 1) * 16);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][1], qf[ks][0], sc[kt], 0, 0, 0);
+                    if (ks == 0) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[0][0], zero16, 0, 0, 0);
+                    else sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][1], qf[ks][0], sc[kt], 0, 0, 0);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][0], qf[ks][1], sc[kt], 0, 0, 0);
                     sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks & 1][0], qf[ks][0], sc[kt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+                sc[kt] = zero16;
             }
         }
         if (n_valid < KC) {   // wave-uniform: only the last chunk of a head has keys to mask
@@ -881,14 +917,15 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                     if (key >= n_valid) sc[kt][r] = -INFINITY;
                 }
         }
-        float m_c = fmaxf(sc[0][0], sc[1][0]);
+        float m_c = sc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m_c = fmaxf(m_c, fmaxf(sc[0][r], sc[1][r]));
+        for (int r = 0; r < 16; ++r) {   // v_max3_f32: hipcc keeps two v_max_f32 for nested fmaxf
+            if (r == 0) asm("v_max_f32 %0, %1, %2" : "=v"(m_c) : "v"(sc[0][0]), "v"(sc[1][0]));
+            else asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m_c) : "v"(m_c), "v"(sc[0][r]), "v"(sc[1][r]));
+        }
         m_c = fmaxf(m_c, __shfl_xor(m_c, 32, 64));
         const float m_new = fmaxf(m_run, m_c);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
-        m_run = m_new;
-        const float mb = m_new * c_s;
+        const float mb = m_new * c_s - 10.0f;             // the 2^10 of F16_P_SCALE rides in the exponent
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -898,11 +935,17 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 sc[kt][r] = pv;
                 psum += pv;
             }
-        l_part = l_part * alpha + psum;
+        if (c == 0) {   // wave-uniform: first chunk of a head, nothing to rescale
+            l_part = psum;
+        } else {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
+            l_part = l_part * alpha + psum;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+            for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
+        }
+        m_run = m_new;
         // O^T += V^T P^T, 16 keys per step: registers 8*j2 .. 8*j2+7 of tile kt are this lane's B fragment
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
@@ -911,19 +954,17 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
             f16x8 ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float t = sc[kt][8 * j2 + e] * F16_P_SCALE;
+                const float t = sc[kt][8 * j2 + e];
                 ph[e] = (f16)t;
                 pl[e] = (f16)(t - (float)ph[e]);
             }
-            const f16 *vp = sV + l31 * ATT16_PITCH + kt * 32 + j2 * 16 + 4 * half;
+            const f16 *vp = sV + l31 * ATT16_PITCH + kt * 32 + j2 * 16 + 8 * half;
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
-                const f16 *vr = vp + ft * 32 * ATT16_PITCH;
-                const f16x4 a0 = *reinterpret_cast<const f16x4 *>(vr), a1 = *reinterpret_cast<const f16x4 *>(vr + 8);
-                const f16x4 b0 = *reinterpret_cast<const f16x4 *>(vr + KC), b1 = *reinterpret_cast<const f16x4 *>(vr + KC + 8);
-                const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[ft], 0, 0, 0);
+                const f16x8 vh = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16_PITCH);
+                const f16x8 vl = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16_PITCH + KC);
+                if (c == 0 && gg == 0) o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, zero16, 0, 0, 0);
+                else o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[ft], 0, 0, 0);
                 o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[ft], 0, 0, 0);
                 o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
             }

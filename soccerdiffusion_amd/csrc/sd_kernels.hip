@@ -673,6 +673,7 @@ extern "C" int sd_debug_set_stamps(void *buf, long wgs) {
 #else
 #define SD_STAMP(slot, i)
 #endif
+#define SD_STAMP_HEAD_SLOT 4   /* diagnostic builds, L = 4: the head kernel's stamps go behind the layers' */
 
 struct DecoderLayerArgs {
     ChainAArgs a;      // a.q unused

@@ -38,19 +38,23 @@ def main():
     x = torch.randn(B, T, J, device="cuda")
     ctx = torch.randn(B, MC, D, device="cuda")
     wgs = (B * T + 63) // 64
-    buf = torch.zeros(L, wgs, 4, 32, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(L + 1, wgs, 4, 32, dtype=torch.int64, device="cuda")   # slot L: the head kernel
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())   # warm
     assert fn(buf.data_ptr(), wgs) == 0
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())
     torch.cuda.synchronize()
     fn(None, 0)
     st = buf.cpu().double()
-    for l in (L - 2, L - 1):
+    for l in (L - 2, L - 1, L):
         s = st[l]                                  # [wgs][4][32]
         used = [i for i in range(30) if (s[:, :, i] > 0).all()]
+        if not used:
+            continue
         w0 = s[:, 0]
         life = s[:, :, used[-1]].max(1).values - s[:, :, used[0]].min(1).values
-        print(f"layer {l}: workgroup lifetime median {life.median():.0f} cycles")
+        if not used:
+            continue
+        print(f"{'head kernel' if l == L else 'layer %d' % l}: workgroup lifetime median {life.median():.0f} cycles")
         print(f"   {'phase (ends at stamp)':26s} {'min':>8s} {'p10':>8s} {'wave0 med':>10s} {'p90':>9s} {'share':>7s}   {'slowest-wave med':>16s}  {'skew at end med':>16s}")
         prev = used[0]
         for i in used[1:]:
