@@ -24,7 +24,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float F16_ACT_SCALE = 8.0f;     // LayerNorm outputs, attention outputs, GELU outputs (|x| < 8190)
 constexpr float F16_P_SCALE = 1024.0f;    // softmax probabilities (<= 1)
-constexpr int F16_GRING = 4;              // k-steps of G in flight
+#ifndef SD_F16_GRING
+#define SD_F16_GRING 4
+#endif
+constexpr int F16_GRING = SD_F16_GRING;   // k-steps of G in flight
 
 __device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
 #pragma unroll
@@ -783,9 +786,12 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
 // B fragment, and the matching V^T fragment is two 8-byte LDS reads.
 // ---------------------------------------------------------------------------------------------------
 constexpr float F16_QKV_SCALE = 8.0f;
+#ifndef SD_ATT16_WGS
+#define SD_ATT16_WGS 2
+#endif
 constexpr int ATT16_PITCH = 136;   // halfs per LDS row: {hi[64], lo[64]} + 8 (272 B: 16 rows hit 16 distinct 4-bank groups)
 
-__global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__restrict__ qkv, int ld, float *__restrict__ out, int ldo,
+__global__ __launch_bounds__(256, SD_ATT16_WGS) void attention_f16_kernel(const float *__restrict__ qkv, int ld, float *__restrict__ out, int ldo,
                                                               int T, int heads, float scale_log2e) {
     constexpr int HD = 64, KC = 64;
     __shared__ __attribute__((aligned(16))) f16 sK[KC * ATT16_PITCH];
@@ -862,8 +868,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
 
     for (int u = 0; u < nunits; ++u) {
         const int h = u / nchunks, c = u - h * nchunks, kc0 = c * KC;
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 0);
         __syncthreads();   // every wave is done reading the previous unit's K/V
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 1);
         stage();
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 2);
         if (u + 1 < nunits) fetch(u + 1);
         if (c == 0) {
 #pragma unroll
@@ -878,7 +887,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
             l_part = 0.f;
         }
         if (c == nchunks - 1 && h + 1 < heads) fetch_q(h + 1);
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 3);
         __syncthreads();
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 4);
         if (!wave_active) continue;
         const int n_valid = min(T - kc0, KC);             // keys of this chunk
         const int kt_valid = (n_valid + 31) / 32;
@@ -908,6 +919,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 sc[kt] = zero16;
             }
         }
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 5);
         if (n_valid < KC) {   // wave-uniform: only the last chunk of a head has keys to mask
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -946,6 +958,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 for (int r = 0; r < 16; ++r) o[ft][r] *= alpha;
         }
         m_run = m_new;
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 6);
         // O^T += V^T P^T, 16 keys per step: registers 8*j2 .. 8*j2+7 of tile kt are this lane's B fragment
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
@@ -969,6 +982,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
             }
         }
+        if (u == 2) SD_STAMP(SD_STAMP_ATT_SLOT, 7);
+        if (u == 3) SD_STAMP(SD_STAMP_ATT_SLOT, 8);
         if (c == nchunks - 1) {
             const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
             const float inv = c_o / l_tot;
@@ -983,5 +998,170 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                     }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Same computation, one workgroup per (sample, head): all T <= 128 keys of the head are staged at once, so a
+// workgroup pays one HBM round trip and two barriers in total (the streaming kernel above pays them per 64-key
+// chunk: its (head, chunk) unit took 14 k cycles against 1.5 k of MFMA and 3 k of VALU work - tools/stamps.py),
+// and the softmax is a single pass over 4 score tiles.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ATT16H_KP = 136;   // K rows: {hi[64], lo[64]} + 8 halfs
+constexpr int ATT16H_VP = 264;   // V^T rows: {hi[128 keys], lo[128 keys]} + 8 halfs (528 B = 132 dwords = 4 mod 64)
+constexpr size_t ATT16H_LDS = (size_t)(128 * ATT16H_KP + 64 * ATT16H_VP) * sizeof(f16);
+
+__global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float *__restrict__ qkv, int ld, float *__restrict__ out, int ldo,
+                                                                   int T, int heads, float scale_log2e) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) f16 smem16[];
+    f16 *sK = smem16, *sV = smem16 + 128 * ATT16H_KP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, D = heads * HD;
+    const int qi = wave * 32 + l31;
+    const bool q_ok = qi < T;
+    const float *base = qkv + (long)b * T * ld + h * HD;   // workgroup-uniform
+    const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);
+    const float c_o = 1.0f / F16_QKV_SCALE;
+
+    // every load of the workgroup is issued before anything is converted
+    f32x4 kreg[8], vreg[8], qraw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        const int krow = idx >> 4, kc4 = idx & 15;   // K: 16 pieces per key row
+        const int vrow = idx & 127, vc4 = idx >> 7;  // V: the keys on the lanes (transposed 2-byte LDS writes stay contiguous)
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
+        if (krow < T) a = *reinterpret_cast<const f32x4 *>(base + D + (unsigned)(krow * ld + kc4 * 4));
+        if (vrow < T) d = *reinterpret_cast<const f32x4 *>(base + 2 * D + (unsigned)(vrow * ld + vc4 * 4));
+        kreg[i] = a;
+        vreg[i] = d;
+    }
+    {
+        const unsigned qoff = (unsigned)((q_ok ? qi : 0) * ld + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qraw[i] = *reinterpret_cast<const f32x4 *>(base + qoff + (unsigned)((i >> 1) * 16 + (i & 1) * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        const int krow = idx >> 4, kc4 = idx & 15;
+        const int vrow = idx & 127, vc4 = idx >> 7;
+        f16x4 hh, ll;
+        f16_split4(kreg[i], F16_QKV_SCALE, hh, ll);
+        *reinterpret_cast<f16x4 *>(sK + krow * ATT16H_KP + kc4 * 4) = hh;
+        *reinterpret_cast<f16x4 *>(sK + krow * ATT16H_KP + HD + kc4 * 4) = ll;
+        f16_split4(vreg[i], F16_QKV_SCALE, hh, ll);
+        const int k16 = vrow & 15;   // key position inside its 16-key group: the 8 k-slots of a lane half contiguous
+        const int vpos = (vrow & ~15) + (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sV[(vc4 * 4 + e) * ATT16H_VP + vpos] = hh[e];
+            sV[(vc4 * 4 + e) * ATT16H_VP + 128 + vpos] = ll[e];
+        }
+    }
+    f16x8 qf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f16x4 h0, l0, h1, l1;
+        f16_split4(qraw[2 * ks], F16_QKV_SCALE, h0, l0);
+        f16_split4(qraw[2 * ks + 1], F16_QKV_SCALE, h1, l1);
+        qf[ks][0] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        qf[ks][1] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+    __syncthreads();
+    if (wave * 32 >= T) return;   // no barrier follows
+    const int kt_valid = (T + 31) / 32;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 sc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < kt_valid) {
+            const f16 *kp = sK + (kt * 32 + l31) * ATT16H_KP + 8 * half;
+            f16x8 kf[4][2];   // the tile's 8 fragments in one go: one LDS latency per tile
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks][0] = *reinterpret_cast<const f16x8 *>(kp + ks * 16);
+                kf[ks][1] = *reinterpret_cast<const f16x8 *>(kp + HD + ks * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks == 0) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[0][0], zero16, 0, 0, 0);
+                else sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qf[ks][0], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][1], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][0], sc[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = -INFINITY;
+        }
+    }
+    {   // keys past T in the last live tile
+        const int kt = kt_valid - 1;   // wave-uniform
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+            if (t4 == kt && (T & 31)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t4 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= T) sc[t4][r] = -INFINITY;
+            }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m01, m23;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m01) : "v"(m), "v"(sc[0][r]), "v"(sc[1][r]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m23) : "v"(m01), "v"(sc[2][r]), "v"(sc[3][r]));
+        m = m23;
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = m * c_s - 10.0f;   // the 2^10 of F16_P_SCALE rides in the exponent
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sc[kt][r] * c_s - mb);
+            sc[kt][r] = pv;
+            psum += pv;
+        }
+    f32x16 o[2];
+    const int n_groups = (T + 15) / 16;   // live 16-key groups
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+        if (gg >= n_groups) break;   // wave-uniform
+        const int kt = gg >> 1, j2 = gg & 1;
+        f16x8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = sc[kt][8 * j2 + e];
+            ph[e] = (f16)t;
+            pl[e] = (f16)(t - (float)ph[e]);
+        }
+        const f16 *vp = sV + l31 * ATT16H_VP + gg * 16 + 8 * half;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const f16x8 vh = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16H_VP);
+            const f16x8 vl = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16H_VP + 128);
+            if (gg == 0) o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, zero16, 0, 0, 0);
+            else o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[ft], 0, 0, 0);
+            o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[ft], 0, 0, 0);
+            o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
+        }
+    }
+    const float l_tot = psum + __shfl_xor(psum, 32, 64);
+    const float inv = c_o / l_tot;
+    if (q_ok) {
+        float *op = out + ((long)b * T + qi) * ldo + h * HD;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t = {o[ft][4 * g4] * inv, o[ft][4 * g4 + 1] * inv, o[ft][4 * g4 + 2] * inv, o[ft][4 * g4 + 3] * inv};
+                *reinterpret_cast<f32x4 *>(op + ft * 32 + 8 * g4 + 4 * half) = t;
+            }
     }
 }

@@ -371,7 +371,11 @@ struct ChainPos {
         half = lane >> 5;
         wm = wave / C::WAVES_N;
         wn = wave % C::WAVES_N;
-        r0 = (long)blockIdx.x * C::BM;
+        // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8): relabel them so that consecutive panels -
+        // which share a trajectory's folded cross-attention blocks - run on the same XCD and meet in its L2.
+        const unsigned nb = gridDim.x, q8 = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+        const unsigned panel = xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+        r0 = (long)panel * C::BM;
         const long left = R - r0;
         R_left = left < C::BM ? (int)left : C::BM;
     }
@@ -673,6 +677,7 @@ extern "C" int sd_debug_set_stamps(void *buf, long wgs) {
 #else
 #define SD_STAMP(slot, i)
 #endif
+#define SD_STAMP_ATT_SLOT 5    /* attention_f16_kernel, unit 2 of the last launch (stamp 8: same point one unit later) */
 #define SD_STAMP_HEAD_SLOT 4   /* diagnostic builds, L = 4: the head kernel's stamps go behind the layers' */
 
 struct DecoderLayerArgs {
@@ -1312,8 +1317,19 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
 static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s) {
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
-    SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
-    SD_CHECK_LAUNCH("attention_f16_kernel");
+    static const char *env = getenv("SD_ATT16");   // "stream": the per-sample streaming kernel (A/B runs)
+    if (env && strcmp(env, "stream") == 0) {
+        SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
+        SD_CHECK_LAUNCH("attention_f16_kernel");
+        return 0;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
+        attr_set = true;
+    }
+    SD_LAUNCH(attention_f16_head_kernel, dim3(B * heads), dim3(256), ATT16H_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+    SD_CHECK_LAUNCH("attention_f16_head_kernel");
     return 0;
 }
 

@@ -38,15 +38,15 @@ def main():
     x = torch.randn(B, T, J, device="cuda")
     ctx = torch.randn(B, MC, D, device="cuda")
     wgs = (B * T + 63) // 64
-    buf = torch.zeros(L + 1, wgs, 4, 32, dtype=torch.int64, device="cuda")   # slot L: the head kernel
+    buf = torch.zeros(L + 2, max(wgs, B), 4, 32, dtype=torch.int64, device="cuda")   # slot L: head kernel, L+1: attention
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())   # warm
-    assert fn(buf.data_ptr(), wgs) == 0
+    assert fn(buf.data_ptr(), max(wgs, B)) == 0
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())
     torch.cuda.synchronize()
     fn(None, 0)
     st = buf.cpu().double()
-    for l in (L - 2, L - 1, L):
-        s = st[l]                                  # [wgs][4][32]
+    for l in (L - 2, L - 1, L, L + 1):
+        s = st[l][: (B if l == L + 1 else wgs)]     # [workgroups][4][32]
         used = [i for i in range(30) if (s[:, :, i] > 0).all()]
         if not used:
             continue
@@ -54,7 +54,7 @@ def main():
         life = s[:, :, used[-1]].max(1).values - s[:, :, used[0]].min(1).values
         if not used:
             continue
-        print(f"{'head kernel' if l == L else 'layer %d' % l}: workgroup lifetime median {life.median():.0f} cycles")
+        print(f"{'head kernel' if l == L else 'attention (unit 2: 1 barrier, 2 stage, 3 fetch issue+Q, 4 barrier, 5 S, 6 softmax, 7 PV; 8 = 7 of the next unit)' if l == L + 1 else 'layer %d' % l}: workgroup lifetime median {life.median():.0f} cycles")
         print(f"   {'phase (ends at stamp)':26s} {'min':>8s} {'p10':>8s} {'wave0 med':>10s} {'p90':>9s} {'share':>7s}   {'slowest-wave med':>16s}  {'skew at end med':>16s}")
         prev = used[0]
         for i in used[1:]:
