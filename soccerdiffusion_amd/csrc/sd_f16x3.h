@@ -381,6 +381,38 @@ __device__ __forceinline__ void f16_store_acc(float *dst, int ld, int col0, cons
     chain_store_acc<D>(dst, ld, col0, acc, p);
 }
 
+// q | k | v tile of one pass -> the head-major buffer [sample][head][q|k|v][token][64]: wave wn's 64 columns are head wn
+// (D = 4 x 64), so its 64 x 64 tile is one contiguous 16-KB run per sample (the row-major [R][3D] layout scatters it in
+// 256-byte pieces at a 3-KB stride; the attention kernel then reads each head's Q, K and V as contiguous 25-KB blocks).
+template <int D>
+__device__ __forceinline__ void f16_store_qkv(float *qkv, int which, int T, const f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN],
+                                              const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    static_assert(C::WN == 64 && C::WAVES_M == 1, "head-major stores assume 4 heads of 64 features");
+    const long b0 = p.r0 / T;
+    const int t0 = (int)(p.r0 - b0 * T);
+    float *base = qkv + ((b0 * 4 + p.wn) * 3 + which) * (long)T * 64;     // this wave's head, first sample of the panel
+    const unsigned next_sample = (unsigned)(4 * 3 * T * 64);               // same head, next sample
+    const int i4 = p.lane & 3;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float x0 = acc[tm][tn][4 * g], x1 = acc[tm][tn][4 * g + 1], x2 = acc[tm][tn][4 * g + 2], x3 = acc[tm][tn][4 * g + 3];
+                quad_transpose(x0, x1, x2, x3, p.lane);
+                const int row = tm * 32 + 8 * g + 4 * p.half + i4;
+                if (row < p.R_left) {
+                    int t = t0 + row;
+                    unsigned off = 0;
+                    if (t >= T) { t -= T; off = next_sample; }      // T >= 64: at most one sample boundary inside a panel
+                    const f32x4 v = {x0, x1, x2, x3};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + off + (unsigned)(t * 64 + tn * 32 + (p.l31 & ~3))));
+                }
+            }
+}
+
 struct F16LayerArgs {
     DecoderLayerArgs g;                       // fp32 pointers (h, a, qkv, biases, LN parameters, cb, tail); g.gv unused
     const f16 *wf_o, *wf_1, *wf_2, *wf_qkv;   // split fragment-major weights (wf_qkv: next layer's in_proj, 3 passes)
@@ -388,6 +420,7 @@ struct F16LayerArgs {
     const f16 *g16, *v16;                     // this layer: per (trajectory, head) blocks of 32*D halfs
     const f16 *gstep, *vstep;                 // this layer and step: 4 head blocks / one block
     const float *cstep;                       // 4 score biases of the step token
+    int qkv_head_major;                       // layout of g.b.qkv (f16_store_qkv) - what attention_f16_head_kernel reads
 };
 
 struct F16Scores {
@@ -664,7 +697,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
             SD_STAMP(g.slot, 13 + 2 * pass);
             if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
             f16_unscale<D, false>(H, U, c_q, g.b.bqkv + pass * D, p);
-            f16_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
+            if (fa.qkv_head_major) f16_store_qkv<D>(g.b.qkv, pass, g.T, U, p);
+            else f16_store_acc<D>(g.b.qkv, 3 * D, pass * D, U, p);
             SD_STAMP(g.slot, 14 + 2 * pass);
         }
     }
@@ -675,6 +709,7 @@ struct F16HeadArgs {
     DecoderHeadArgs g;
     const f16 *wf_qkv;
     const float *sc;     // sc[3] = scale of layer 0's in_proj
+    int qkv_head_major;
 };
 
 template <int D>
@@ -771,7 +806,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         SD_STAMP(SD_STAMP_HEAD_SLOT, 5 + 2 * pass);
         if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
-        f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        if (fa.qkv_head_major) f16_store_qkv<D>(g.qkv, pass, g.T, H, p);
+        else f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
         SD_STAMP(SD_STAMP_HEAD_SLOT, 6 + 2 * pass);
     }
 }
@@ -1011,7 +1047,9 @@ constexpr int ATT16H_KP = 136;   // K rows: {hi[64], lo[64]} + 8 halfs
 constexpr int ATT16H_VP = 264;   // V^T rows: {hi[128 keys], lo[128 keys]} + 8 halfs (528 B = 132 dwords = 4 mod 64)
 constexpr size_t ATT16H_LDS = (size_t)(128 * ATT16H_KP + 64 * ATT16H_VP) * sizeof(f16);
 
-__global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float *__restrict__ qkv, int ld, float *__restrict__ out, int ldo,
+// HM: qkv is the head-major buffer written by f16_store_qkv ([sample][head][q|k|v][token][64]); else [token][3D] rows.
+template <bool HM>
+__global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float *__restrict__ qkv, int ld_rm, float *__restrict__ out, int ldo,
                                                                    int T, int heads, float scale_log2e) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) f16 smem16[];
@@ -1021,7 +1059,10 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, D = heads * HD;
     const int qi = wave * 32 + l31;
     const bool q_ok = qi < T;
-    const float *base = qkv + (long)b * T * ld + h * HD;   // workgroup-uniform
+    // workgroup-uniform bases of this head's Q, K, V rows and their row stride
+    const int ld = HM ? HD : ld_rm;
+    const float *base = HM ? qkv + (long)blockIdx.x * 3 * T * HD : qkv + (long)b * T * ld_rm + h * HD;
+    const long k_at = HM ? (long)T * HD : D, v_at = 2 * k_at;
     const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);
     const float c_o = 1.0f / F16_QKV_SCALE;
 
@@ -1033,8 +1074,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
         const int krow = idx >> 4, kc4 = idx & 15;   // K: 16 pieces per key row
         const int vrow = idx & 127, vc4 = idx >> 7;  // V: the keys on the lanes (transposed 2-byte LDS writes stay contiguous)
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
-        if (krow < T) a = *reinterpret_cast<const f32x4 *>(base + D + (unsigned)(krow * ld + kc4 * 4));
-        if (vrow < T) d = *reinterpret_cast<const f32x4 *>(base + 2 * D + (unsigned)(vrow * ld + vc4 * 4));
+        if (krow < T) a = *reinterpret_cast<const f32x4 *>(base + k_at + (unsigned)(krow * ld + kc4 * 4));
+        if (vrow < T) d = *reinterpret_cast<const f32x4 *>(base + v_at + (unsigned)(vrow * ld + vc4 * 4));
         kreg[i] = a;
         vreg[i] = d;
     }

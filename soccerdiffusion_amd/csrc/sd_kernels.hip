@@ -1314,21 +1314,23 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
 }
 
 // self-attention over qkv [B*T][3d] on the fp16 pipe (head dim 64, T <= 128)
-static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s) {
+static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s, bool head_major) {
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
     static const char *env = getenv("SD_ATT16");   // "stream": the per-sample streaming kernel (A/B runs)
-    if (env && strcmp(env, "stream") == 0) {
+    if (!head_major && env && strcmp(env, "stream") == 0) {
         SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
         SD_CHECK_LAUNCH("attention_f16_kernel");
         return 0;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
+        (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
+        (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
         attr_set = true;
     }
-    SD_LAUNCH(attention_f16_head_kernel, dim3(B * heads), dim3(256), ATT16H_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+    if (head_major) SD_LAUNCH((attention_f16_head_kernel<true>), dim3(B * heads), dim3(256), ATT16H_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+    else SD_LAUNCH((attention_f16_head_kernel<false>), dim3(B * heads), dim3(256), ATT16H_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
     SD_CHECK_LAUNCH("attention_f16_head_kernel");
     return 0;
 }
@@ -2412,13 +2414,16 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
     const long R = (long)B * T;
     const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
     const sd_layer_weights &l0 = w->layers[0];
+    // q | k | v go to the attention kernel head-major when it is the fp16 one (head dim 64, T <= 128; SD_QKV=rows: A/B runs)
+    static const char *qenv = getenv("SD_QKV");
+    const bool att16 = d / heads == 64 && T <= 128, hm = att16 && heads == 4 && !(qenv && strcmp(qenv, "rows") == 0);
     F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
-                   f16_wf(s, 0, d, 3), s.scales};
+                   f16_wf(s, 0, d, 3), s.scales, hm ? 1 : 0};
     int rc = decoder_head_f16(fh, st);
     if (rc) return rc;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
-        if (d / heads == 64 && T <= 128) rc = attention_f16(s.qkv, s.a, B, T, d, heads, st);
+        if (att16) rc = attention_f16(s.qkv, s.a, B, T, d, heads, st, hm);
         else rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
         if (rc) return rc;
         const bool last = l + 1 == L;
@@ -2447,6 +2452,7 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
         fa.gstep = s.gstep16 + ((size_t)l * n_steps + i) * 4 * blk;
         fa.vstep = s.vstep16 + ((size_t)l * n_steps + i) * blk;
         fa.cstep = s.cstep + ((size_t)l * n_steps + i) * 4;
+        fa.qkv_head_major = hm ? 1 : 0;
         if ((rc = decoder_layer_f16(fa, st))) return rc;
     }
     return 0;
