@@ -134,3 +134,35 @@ def test_fp16x3_sampler_is_fp32_grade(ops):
     e_cpu32 = max(rel64(want32[i], want64[i]) for i in range(n_steps))
     assert e_native < 2e-6, e_native
     assert e_native < 4 * e_cpu32 + 1e-7, (e_native, e_cpu32)
+
+
+@pytest.mark.parametrize("env", [{"SD_SAMPLER_GEMM": "f32"}, {"SD_QKV": "rows"}, {"SD_QKV": "rows", "SD_ATT16": "stream"}])
+def test_sampler_kernel_variants_agree_with_oracle(env):
+    """The alternative kernel selections of sd_ddim_sample (fp32-MFMA fold, row-major q|k|v with the per-head or the
+    streaming fp16 attention) are read from the environment once per process: run each in a child process against the
+    fp32 oracle (1e-4 of north_star; measured 4e-7)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import ddim_ref, denoiser_ref as ref
+from soccerdiffusion_amd import ops
+d, L, T, Mc, B, n, J = 256, 2, 100, 10, 3, 6, 20
+sd = ref.synthetic_state_dict(d, J, L, seed=5)
+g = torch.Generator().manual_seed(6)
+x_T = torch.randn(B, T, J, generator=g); ctx = torch.randn(B, Mc, d, generator=g)
+acp = ddim_ref.alphas_cumprod(); ts = ddim_ref.timesteps(n).tolist()
+want = ddim_ref.sample(lambda x, t: ref.forward_with_context(sd, [ctx], x, torch.full((B,), t, dtype=torch.int64)), x_T, n, acp)
+packed = ops.pack_denoiser(sd, "cuda", max_len=T)
+toks = ops.step_token(torch.tensor(ts).cuda(), ops.step_frequencies(d).cuda(), sd["step_encoding.token"].cuda()).reshape(n, d)
+_, trace = ops.ddim_sample(packed, ctx.cuda(), toks, ops.ddim_coefficients(ts, acp, n), x_T.cuda(), trace=True)
+err = max(float((trace[i].cpu() - want[i]).norm() / want[i].norm()) for i in range(n))
+print("ERR", err)
+assert err < 1e-4, err
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ERR" in out.stdout
