@@ -1206,3 +1206,218 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
             }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The generic row-panel linear layer (panel_gemm_kernel) on the fp16 pipe:
+//     out[R,N] = act(LN?(A)[R,D] W[N,D]^T + bias) (+ res)
+// for callers that hand over plain fp32 operands of unknown magnitude (training forward and dX, encoders, the memory
+// K/V projection).  The LDS panel is split in place with a power-of-two scale PER ROW (row abs-max -> [8192, 16384)), so
+// gradients of any size keep 22 bits; W is split in registers as its fragments arrive, with a fixed scale 2^8 (the
+// fp16 subnormal range bounds lo's absolute error by 2^-25/256 = 1.2e-10 per weight; |w| >= 256 would overflow, loudly).
+// Per 16-deep k-step and wave: 12 fp16 MFMAs (384 cycles) + ~80 VALU instructions for the two splits, against
+// 32 fp32 MFMAs (2048 cycles).
+// ---------------------------------------------------------------------------------------------------
+constexpr float F16_W_SCALE = 256.0f;
+
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)));
+    return v;
+}
+
+// fp32 panel rows (optionally LayerNorm-ed on the way) -> split planes in place + 1/scale per row
+template <int D, bool HAS_LN>
+__device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const float *ln_w, const float *ln_b, int lane, int wave) {
+    using C = PanelCfg<D>;
+    constexpr int V4 = D / 64;
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int row = wave * 4 + grp; row < C::BM; row += 16) {
+        f32x4 v[V4];
+#pragma unroll
+        for (int j = 0; j < V4; ++j) v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + 4 * (sub + 16 * j));
+        if constexpr (HAS_LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+            const float mean = row16_sum(s) * (1.0f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[j][e] -= mean;
+                    q += v[j][e] * v[j][e];
+                }
+            const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / D) + SD_LN_EPS);
+#pragma unroll
+            for (int j = 0; j < V4; ++j) {
+                const int c = 4 * (sub + 16 * j);
+                const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + c);
+                const f32x4 gb = *reinterpret_cast<const f32x4 *>(ln_b + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * rstd * gw[e] + gb[e];
+            }
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
+        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, row16_max(m)));
+        if (sub == 0) sInv[row] = 1.0f / scale;
+        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            f16x4 h, l;
+            f16_split4(v[j], scale, h, l);
+            *reinterpret_cast<f16x4 *>(rowp + c) = h;
+            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
+        }
+    }
+}
+
+template <int D, bool HAS_LN, int ACT, bool HAS_RES>
+__global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                            const float *__restrict__ bias, const float *__restrict__ ln_w,
+                                                            const float *__restrict__ ln_b, const float *res, float *out, int R,
+                                                            int N, int lda) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    float *sInv = sA + C::BM * C::LDA;   // 64 row un-scales behind the panel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r0 = (long)blockIdx.x * C::BM;
+    {   // panel load, every load of a batch in flight before the first LDS write
+        constexpr int VEC_PER_ROW = D / 4, ITERS = C::BM * VEC_PER_ROW / 256, BATCH = ITERS < 16 ? ITERS : 16;
+#pragma unroll
+        for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+            f32x4 v[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const int i = tid + (b0 + b) * 256, row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+                v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r0 + row < R) v[b] = *reinterpret_cast<const f32x4 *>(A + (r0 + row) * lda + c4 * 4);
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const int i = tid + (b0 + b) * 256, row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
+                *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v[b];
+            }
+        }
+    }
+    __syncthreads();
+    f16_rows_to_planes<D, HAS_LN>(sA, sInv, ln_w, ln_b, lane, wave);
+    __syncthreads();
+
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const int l31 = lane & 31, half = lane >> 5;
+    const f16 *aH = reinterpret_cast<const f16 *>(sA) + (wm * C::WM + l31) * ROWP + 8 * half;
+    const bool full_panel = r0 + C::BM <= R;  // workgroup-uniform
+    // un-scale of this lane's accumulator rows: rows tm*32 + 8g + 4*half + 0..3 are registers 4g .. 4g+3
+    f32x4 inv[C::TM][4];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            inv[tm][g] = *reinterpret_cast<const f32x4 *>(sInv + wm * C::WM + tm * 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) inv[tm][g][e] *= 1.0f / F16_W_SCALE;
+        }
+
+    for (int n0 = 0; n0 < N; n0 += D) {
+        f32x16 acc[C::TM][C::TN];
+        const float *wBase = W + (long)(n0 + wn * C::WN + l31) * D + 8 * half;
+        f32x4 braw[2][C::TN][2];
+        f16x8 af[2][C::TM][2];
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            braw[0][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
+            braw[0][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + 4);
+        }
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < NK) {
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    braw[nxt][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16);
+                    braw[nxt][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16 + 4);
+                }
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        af[nxt][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
+            }
+            f16x8 bh[C::TN], bl[C::TN];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) {
+                f16x4 h0, l0, h1, l1;
+                f16_split4(braw[cur][tn][0], F16_W_SCALE, h0, l0);
+                f16_split4(braw[cur][tn][1], F16_W_SCALE, h1, l1);
+                bh[tn] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                bl[tn] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    if (ks == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][tm][1], bh[tn], z, 0, 0, 0);
+                    } else {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][1], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bl[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bh[tn], acc[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // epilogue: un-scale (per row), bias, residual, activation; quad transpose -> 16-byte stores
+        const int i4 = lane & 3;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int col = n0 + wn * C::WN + tn * 32 + l31;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                const long orow = r0 + wm * C::WM + tm * 32 + 4 * half + i4;
+                float *op = out + orow * N + n0 + wn * C::WN + tn * 32 + (l31 & ~3);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[tm][tn][4 * g + e] * inv[tm][g][e] + bv;
+                        if constexpr (HAS_RES) {
+                            const long row = r0 + wm * C::WM + tm * 32 + 8 * g + 4 * half + e;
+                            v += (full_panel || row < R) ? res[row * N + col] : 0.f;
+                        }
+                        if constexpr (ACT == 1) v = gelu_erf(v);
+                        x[e] = v;
+                    }
+                    quad_transpose(x[0], x[1], x[2], x[3], lane);
+                    if (full_panel || orow + 8 * g < R) {
+                        const f32x4 v4 = {x[0], x[1], x[2], x[3]};
+                        *reinterpret_cast<f32x4 *>(op + (long)(8 * g) * N) = v4;
+                    }
+                }
+            }
+        }
+    }
+}

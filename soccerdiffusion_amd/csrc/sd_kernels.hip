@@ -238,12 +238,19 @@ static int launch_panel(const float *A, int lda, const float *W, const float *bi
     return 0;
 }
 
+int linear16(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+             float *out, int R, int N, int d, int act, hipStream_t s, int lda);
+
 int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
            float *out, int R, int N, int d, int act, hipStream_t s, int lda) {
     if (lda == 0) lda = d;
     if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "linear: row stride must be >= d and a multiple of 4");
     if (!A || !W || !out || R <= 0 || N <= 0) return fail(SD_E_BADARG, "linear: null pointer or empty shape");
     if (N % d != 0) return fail(SD_E_BADDIM, "linear: N must be a multiple of d");
+    {   // split-fp16 kernel (sd_f16x3.h) unless SD_LINEAR=f32 asks for the fp32 MFMA
+        static const char *env = getenv("SD_LINEAR");
+        if (!(env && strcmp(env, "f32") == 0)) return linear16(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);
+    }
     switch (d) {
         case 64: return launch_panel<64>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
         case 128: return launch_panel<128>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
@@ -1295,6 +1302,48 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
 }
 
 #include "sd_f16x3.h"
+
+template <int D>
+static int launch_panel16(const float *A, int lda, const float *W, const float *bias, const float *ln_w, const float *ln_b,
+                          const float *res, float *out, int R, int N, int act, hipStream_t s) {
+    using C = PanelCfg<D>;
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    dim3 grid((R + C::BM - 1) / C::BM), block(256);
+    const size_t lds = C::LDS_BYTES + C::BM * sizeof(float);
+#define SD_PANEL16(LN_, ACT_, RES_)                                                                            \
+    do {                                                                                                       \
+        auto kfn = panel_gemm16_kernel<D, LN_, ACT_, RES_>;                                                    \
+        static bool attr_set = false;                                                                          \
+        if (lds > 64 * 1024 && !attr_set) {                                                                    \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda);                      \
+    } while (0)
+    const bool ln = ln_w != nullptr;
+    const bool rs = res != nullptr;
+    if (ln && act == 0 && !rs) SD_PANEL16(true, 0, false);
+    else if (ln && act == 1 && !rs) SD_PANEL16(true, 1, false);
+    else if (!ln && act == 0 && !rs) SD_PANEL16(false, 0, false);
+    else if (!ln && act == 0 && rs) SD_PANEL16(false, 0, true);
+    else if (!ln && act == 1 && !rs) SD_PANEL16(false, 1, false);
+    else if (ln && act == 0 && rs) SD_PANEL16(true, 0, true);
+    else return fail(SD_E_BADARG, "sd_op_linear: unsupported LN/act/res combination");
+#undef SD_PANEL16
+    SD_CHECK_LAUNCH("panel_gemm16_kernel");
+    return 0;
+}
+
+int linear16(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+             float *out, int R, int N, int d, int act, hipStream_t s, int lda) {
+    switch (d) {
+        case 64: return launch_panel16<64>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 128: return launch_panel16<128>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 256: return launch_panel16<256>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+        case 512: return launch_panel16<512>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
+    }
+    return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+}
 
 static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     if (fa.g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer_f16: empty shape");
