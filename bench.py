@@ -209,6 +209,11 @@ def main():
             "sampler_mode": {0: "fp32 MFMA", 1: "fp32 MFMA, folded cross-attention",
                              2: "fp16x3 split-operand MFMA (fp32 accumulate), folded cross-attention"}[mode],
             "algorithmic_tflops": round(alg_tflops, 2),   # executed FLOPs counted once; the fp32 MFMA peak is 157.3
+            # the same kernel against the HBM roof: per launch it must read a and h, write h and the next q|k|v (the last
+            # layer writes x only) and read each trajectory's folded cross-attention blocks once
+            "hbm": (lambda by: {"algorithmic_bytes_per_launch_avg": by, "achieved": round(by / (dl_s / max(int(cnt[dl]), 1)) / 1e9, 1),
+                                "peak": 8000.0, "unit": "GB/s", "frac": round(by / (dl_s / max(int(cnt[dl]), 1)) / 8e12, 4)})(
+                B * T * D * 4 * ((L - 1) * 6 + 2) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)),
             "executed_mfma_flops_per_algorithmic_flop": mfma_factor,
             "traffic": pmc,
             "launches": int(cnt[dl]),
