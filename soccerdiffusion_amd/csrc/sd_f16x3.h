@@ -259,7 +259,8 @@ __device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg
     }
 }
 
-// H += U*c + bias   /   U = U*c + bias
+// H += U*c + bias   /   U = U*c + bias.  Written on whole accumulator vectors so that the backend emits packed
+// v_pk_fma_f32 (two fp32 FMAs per instruction)
 template <int D, bool INTO_H>
 __device__ __forceinline__ void f16_unscale(f32x16 (&H)[PanelCfg<D>::TM][PanelCfg<D>::TN], f32x16 (&U)[PanelCfg<D>::TM][PanelCfg<D>::TN],
                                             float c, const float *bias, const ChainPos<D> &p) {
@@ -268,12 +269,10 @@ __device__ __forceinline__ void f16_unscale(f32x16 (&H)[PanelCfg<D>::TM][PanelCf
     for (int tn = 0; tn < C::TN; ++tn) {
         const float bv = bias[p.col(tn)];
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (INTO_H) H[tm][tn][r] += U[tm][tn][r] * c + bv;
-                else U[tm][tn][r] = U[tm][tn][r] * c + bv;
-            }
+        for (int tm = 0; tm < C::TM; ++tm) {
+            if constexpr (INTO_H) H[tm][tn] = H[tm][tn] + (U[tm][tn] * c + bv);
+            else U[tm][tn] = U[tm][tn] * c + bv;
+        }
     }
 }
 
