@@ -17,9 +17,12 @@
  *     of the failing launch.  sd_last_error() returns a static description.
  *   - inputs are never modified unless the argument is documented as in/out.
  *
- * Numerics: all arithmetic is fp32.  GEMMs run on v_mfma_f32_32x32x2_f32 (exact fp32
- * fma chain), LayerNorm eps = 1e-5 biased variance, GELU = exact erf form, softmax in
- * fp32.  Parity bar: <= 1e-4 relative L2 vs the fp32 CPU path (BASELINE.json).
+ * Numerics: data, accumulation and every elementwise operation are fp32.  Contractions run either on
+ * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) or - the row GEMMs behind sd_op_linear*, and sd_ddim_sample
+ * in mode 2 (sd_sampler_mode) - as three v_mfma_f32_32x32x16_f16 per product on operands split into fp16
+ * hi + lo pairs (22 mantissa bits, fp32 accumulate): measured error against fp64 at or below the fp32 fma
+ * chain's own.  LayerNorm eps = 1e-5 biased variance, GELU = exact erf form, softmax in
+ * fp32.  Parity bar: <= 1e-4 relative L2 vs the fp32 CPU path (BASELINE.json); measured ~4e-7.
  */
 #ifndef SOCCERDIFFUSION_HIP_H
 #define SOCCERDIFFUSION_HIP_H

@@ -1,8 +1,10 @@
 // MI355X (gfx950 / CDNA4) kernels + C ABI for the SoccerDiffusion denoiser hot path.
 // Interface and reference citations: include/soccerdiffusion_hip.h.  Design: DESIGN.md.
 //
-// Everything is fp32.  Contractions run on v_mfma_f32_32x32x2_f32 (exact fp32 fma
-// chain, 64 FLOP/clk/SIMD).  Fragment maps used throughout (wave = 64 lanes):
+// Data and accumulation are fp32.  Contractions in this file run on v_mfma_f32_32x32x2_f32 (exact fp32 fma
+// chain, 64 FLOP/clk/SIMD); sd_f16x3.h (included below) holds the split-fp16 versions of the row GEMMs, the
+// folded decoder layer and the self-attention that linear() and sd_ddim_sample use where they apply.
+// Fragment maps of the fp32 MFMA used throughout (wave = 64 lanes):
 //   A operand: lane l holds A[i = l & 31][k = l >> 5]
 //   B operand: lane l holds B[k = l >> 5][j = l & 31]
 //   C/D:       lane l, reg r holds D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31]
