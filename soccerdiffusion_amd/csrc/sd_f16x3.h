@@ -711,7 +711,8 @@ struct F16HeadArgs {
     int qkv_head_major;
 };
 
-template <int D>
+// ONE_WRAP: T >= 64, so the positional index of a row wraps at most once inside a 64-row panel
+template <int D, bool ONE_WRAP>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kernel(F16HeadArgs fa) {
     using C = PanelCfg<D>;
     constexpr int NK = D / 16, ROWP = 2 * C::LDA;
@@ -786,7 +787,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int pos = pos0 + tm * 32 + (r & 3) + 8 * (r >> 2);
-                    pos = pos >= g.T ? pos - g.T : pos;
+                    if constexpr (ONE_WRAP) pos = pos >= g.T ? pos - g.T : pos;
+                    else pos %= g.T;
                     H[tm][tn][r] += bv + pec[(unsigned)(pos * D)];
                 }
         }
@@ -805,8 +807,12 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         SD_STAMP(SD_STAMP_HEAD_SLOT, 5 + 2 * pass);
         if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
-        if (fa.qkv_head_major) f16_store_qkv<D>(g.qkv, pass, g.T, H, p);
-        else f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        if constexpr (C::WN == 64) {
+            if (fa.qkv_head_major) f16_store_qkv<D>(g.qkv, pass, g.T, H, p);
+            else f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        } else {
+            f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
+        }
         SD_STAMP(SD_STAMP_HEAD_SLOT, 6 + 2 * pass);
     }
 }
@@ -1417,6 +1423,83 @@ __global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restri
                     }
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row chains of the unfused decoder layer (the reference's shipped shapes: horizon 10, hundreds of memory rows, where
+// the cross-attention cannot be folded) on the fp16 pipe, hidden_dim 128 / 256:
+//   KIND 0 (chain A): h += a Wo^T + bo ;  q = LN2(h) Wq^T + bq
+//   KIND 1 (chain B): h += a Woc^T + boc ;  h += W2 gelu(W1 LN3(h) + b1) + b2 ;  qkv' = LN1'(h) Wqkv'^T + b'  (if a next layer)
+// A single workgroup's GEMM unit is 192 fp16 MFMAs (6 k cycles) instead of 512 fp32 ones (33 k): at the robot's B = 1 the
+// rollout is one serial chain of such units.
+// ---------------------------------------------------------------------------------------------------
+struct F16ChainArgs {
+    ChainAArgs a;                       // KIND 0
+    ChainBArgs b;                       // KIND 1
+    const f16 *w0, *w1, *w2, *wqkv;     // fragment-major split weights: (Wo, Wq) or (Woc, W1, W2, next in_proj)
+    const float *sc;                    // scales of w0, w1, w2
+    const float *sc_next;               // scale of wqkv
+};
+
+template <int D, int KIND>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void chain_f16_kernel(F16ChainArgs fa) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
+    constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const long R = KIND == 0 ? fa.a.R : fa.b.R;
+    const ChainPos<D> p(R);
+    const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
+    const long wOff = (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM;
+    const unsigned loff = (unsigned)p.lane * 8;
+    const float c0 = 1.0f / (F16_ACT_SCALE * fa.sc[0]), c1 = 1.0f / (F16_ACT_SCALE * fa.sc[1]);
+    f32x16 H[C::TM][C::TN], U[C::TM][C::TN];
+    F16Ring<D> ring;
+    f16_prime<D>(ring, fa.w0 + wOff, loff);
+    float *h = KIND == 0 ? fa.a.h : fa.b.h;
+    chain_load_acc<D>(H, h, p);
+    f16_load_panel<D>(sA, KIND == 0 ? fa.a.a : fa.b.a, p);
+    __syncthreads();
+    f16_gemm<D, true>(U, aH, fa.w0 + wOff, loff, ring);
+    f16_prime<D>(ring, fa.w1 + wOff, loff);
+    f16_unscale<D, true>(H, U, c0, KIND == 0 ? fa.a.bo : fa.b.bo, p);
+    if constexpr (KIND == 0) f16_store_acc<D>(h, D, 0, H, p);
+    __syncthreads();
+    chain_acc_to_lds<D>(sA, H, p);
+    __syncthreads();
+    f16_layer_norm_to_planes<D>(sA, KIND == 0 ? fa.a.ln_w : fa.b.ln_w, KIND == 0 ? fa.a.ln_b : fa.b.ln_b, p.lane, p.wave);
+    __syncthreads();
+    f16_gemm<D, true>(U, aH, fa.w1 + wOff, loff, ring);
+    if constexpr (KIND == 0) {
+        f16_unscale<D, false>(H, U, c1, fa.a.bq, p);
+        f16_store_acc<D>(fa.a.q, D, 0, U, p);
+        return;
+    } else {
+        const float c2 = 1.0f / (F16_ACT_SCALE * fa.sc[2]);
+        f16_prime<D>(ring, fa.w2 + wOff, loff);
+        __syncthreads();
+        f16_gelu_to_planes<D>(sA, U, c1, fa.b.b1, p);
+        __syncthreads();
+        f16_gemm<D, true>(U, aH, fa.w2 + wOff, loff, ring);
+        const bool has_next = fa.b.nln_w != nullptr;   // workgroup-uniform
+        if (has_next) f16_prime<D>(ring, fa.wqkv + wOff, loff);
+        f16_unscale<D, true>(H, U, c2, fa.b.b2, p);
+        f16_store_acc<D>(h, D, 0, H, p);
+        if (!has_next) return;
+        const float cq = 1.0f / (F16_ACT_SCALE * fa.sc_next[0]);
+        __syncthreads();
+        chain_acc_to_lds<D>(sA, H, p);
+        __syncthreads();
+        f16_layer_norm_to_planes<D>(sA, fa.b.nln_w, fa.b.nln_b, p.lane, p.wave);
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            f16_gemm<D, true>(U, aH, fa.wqkv + (long)pass * C::WAVES_N * WSTREAM + wOff, loff, ring);
+            if (pass < 2) f16_prime<D>(ring, fa.wqkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
+            f16_unscale<D, false>(H, U, cq, fa.b.bqkv + pass * D, p);
+            f16_store_acc<D>(fa.b.qkv, 3 * D, pass * D, U, p);
         }
     }
 }

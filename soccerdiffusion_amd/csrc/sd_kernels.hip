@@ -1386,17 +1386,47 @@ static int attention_f16(const float *qkv, float *out, int B, int T, int d, int 
     return 0;
 }
 
-static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s) {
+template <int D>
+static int chain_f16_launch(const F16ChainArgs &fa, int kind, hipStream_t s) {
+    const long R = kind == 0 ? fa.a.R : fa.b.R;
+    if (R <= 0) return fail(SD_E_BADARG, "chain_f16: empty shape");
+    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
+    dim3 grid((unsigned)((R + 63) / 64)), block(256);
+    const size_t lds = PanelCfg<D>::LDS_BYTES;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)chain_f16_kernel<D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)chain_f16_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (kind == 0) SD_LAUNCH((chain_f16_kernel<D, 0>), grid, block, lds, s, fa);
+    else SD_LAUNCH((chain_f16_kernel<D, 1>), grid, block, lds, s, fa);
+    SD_CHECK_LAUNCH("chain_f16_kernel");
+    return 0;
+}
+static int chain_f16(const F16ChainArgs &fa, int d, int kind, hipStream_t s) {
+    return d == 128 ? chain_f16_launch<128>(fa, kind, s) : chain_f16_launch<256>(fa, kind, s);
+}
+
+static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s, int d = 256) {
     if (fa.g.R <= 0) return fail(SD_E_BADARG, "decoder_head_f16: empty shape");
     ProfScope prof(SD_KCLASS_HEAD, s);
     dim3 grid((unsigned)((fa.g.R + 63) / 64)), block(256);
-    const size_t lds = PanelCfg<256>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    const bool one_wrap = fa.g.T >= 64;
+    if (d == 128) {
+        if (one_wrap) SD_LAUNCH((decoder_head_f16_kernel<128, true>), grid, block, PanelCfg<128>::LDS_BYTES, s, fa);
+        else SD_LAUNCH((decoder_head_f16_kernel<128, false>), grid, block, PanelCfg<128>::LDS_BYTES, s, fa);
+    } else {
+        const size_t lds = PanelCfg<256>::LDS_BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (one_wrap) SD_LAUNCH((decoder_head_f16_kernel<256, true>), grid, block, lds, s, fa);
+        else SD_LAUNCH((decoder_head_f16_kernel<256, false>), grid, block, lds, s, fa);
     }
-    SD_LAUNCH((decoder_head_f16_kernel<256>), grid, block, lds, s, fa);
     SD_CHECK_LAUNCH("decoder_head_f16_kernel");
     return 0;
 }
@@ -2262,6 +2292,11 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
     f16 *wf, *g16, *v16, *gstep16, *vstep16;
     float *scales;
     unsigned *maxbits;
+    // split weights of the unfused row chains (chain_f16_kernel, hidden_dim 128 / 256): per layer
+    // [Wo | Wq | Woc | W1 | W2 | in_proj x 3], their scales and abs-max words
+    f16 *wfc;
+    float *scc;
+    unsigned *mbc;
 };
 
 // the fp16x3 kernels are instantiated for hidden_dim 256 (the folded fp32 kernels serve the other sizes);
@@ -2306,6 +2341,14 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.scales = ws + off; off += align64((size_t)(L + 1) * 8);
         s.maxbits = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)(L + 1) * 8);
     }
+    s.wfc = nullptr;
+    s.scc = nullptr;
+    s.mbc = nullptr;
+    if (n_steps > 0 && (d == 128 || d == 256)) {
+        s.wfc = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * 8 * d * d);
+        s.scc = ws + off; off += align64((size_t)L * 8);
+        s.mbc = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)L * 8);
+    }
     return s;
 }
 
@@ -2320,6 +2363,7 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
     if (n_steps > 0 && d == 256)   // fp16x3 operands (sd_f16x3.h)
         n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
              align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8);
+    if (n_steps > 0 && (d == 128 || d == 256)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
     return n;
 }
 
@@ -2339,14 +2383,59 @@ struct FoldArgs {  // folded cross-attention blocks per layer (gv NULL: unfolded
     size_t gv_stride, cb_stride;
 };
 
+// split weights of the unfused chains of layer l (which: 0 Wo, 1 Wq, 2 Woc, 3 W1, 4 W2, 5 in_proj)
+static f16 *f16_wfc(const Scratch &s, int l, int d, int which) { return s.wfc + ((size_t)l * 8 + which) * 2 * d * d; }
+
+template <int D>
+static int f16_prepare_chain_d(const sd_denoiser_weights *w, const Scratch &s, hipStream_t st) {
+    const int d = w->d, L = w->L;
+    hipError_t e = hipMemsetAsync(s.mbc, 0, (size_t)L * 8 * sizeof(unsigned), st);
+    if (e != hipSuccess) return fail((int)e, "f16_prepare_chain: hipMemsetAsync failed");
+    for (int pass = 0; pass < 2; ++pass)
+        for (int l = 0; l < L; ++l) {
+            const sd_layer_weights &lw = w->layers[l];
+            const float *mats[6] = {lw.sa_out_w, lw.ca_in_w, lw.ca_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
+            const int rows[6] = {d, d, d, d, d, 3 * d};
+            for (int m = 0; m < 6; ++m) {
+                if (pass == 0) {
+                    SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)rows[m] * d)), dim3(256), 0, st, mats[m], (long)rows[m] * d, s.mbc + l * 8 + m);
+                    SD_CHECK_LAUNCH("f16_absmax_kernel");
+                } else {
+                    SD_LAUNCH((f16_pack_weight_kernel<D>), dim3(grid_for((long)rows[m] * d / 8)), dim3(256), 0, st, mats[m], rows[m],
+                              s.mbc + l * 8 + m, f16_wfc(s, l, d, m), s.scc + l * 8 + m);
+                    SD_CHECK_LAUNCH("f16_pack_weight_kernel");
+                }
+            }
+        }
+    return 0;
+}
+static int f16_prepare_chain(const sd_denoiser_weights *w, const Scratch &s, hipStream_t st) {
+    return w->d == 128 ? f16_prepare_chain_d<128>(w, s, st) : f16_prepare_chain_d<256>(w, s, st);
+}
+
+// the unfused row chains run on the fp16 pipe when their split weights were prepared (sampler, hidden_dim 128 / 256;
+// SD_SAMPLER_GEMM=f32 keeps the fp32 kernels)
+static bool chain16_ok(int d, int J) {
+    static const char *env = getenv("SD_SAMPLER_GEMM");
+    if (env && strcmp(env, "f32") == 0) return false;
+    return (d == 128 || d == 256) && J % 4 == 0;
+}
+
 template <typename KV>
 static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scratch &s, int B, int T, int Mk, KV kv,
-                         const TailArgs &tail, hipStream_t st, const FoldArgs &fold = FoldArgs{nullptr, nullptr, 0, 0}) {
+                         const TailArgs &tail, hipStream_t st, const FoldArgs &fold = FoldArgs{nullptr, nullptr, 0, 0},
+                         bool chain16 = false) {
     const int d = w->d, heads = w->heads;
     const long R = (long)B * T;
     const sd_layer_weights &l0 = w->layers[0];
     int rc;
-    if (w->J % 4 == 0) {  // embed + LN1 + QKV of layer 0 in one launch
+    const bool fused = fused_layer_ok(d, heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
+    chain16 = chain16 && !fused && s.wfc != nullptr;
+    if (chain16) {
+        F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
+                       f16_wfc(s, 0, d, 5), s.scc + 2, 0};   // the head reads sc[3]: the scale of layer 0's in_proj = scc[5]
+        rc = decoder_head_f16(fh, st, d);
+    } else if (w->J % 4 == 0) {  // embed + LN1 + QKV of layer 0 in one launch
         DecoderHeadArgs gh{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J};
         rc = decoder_head(gh, d, st);
     } else {
@@ -2355,7 +2444,6 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
         rc = linear(s.h, l0.sa_in_w, l0.sa_in_b, l0.n1_w, l0.n1_b, nullptr, s.qkv, (int)R, 3 * d, d, 0, st);
     }
     if (rc) return rc;
-    const bool fused = fused_layer_ok(d, heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
     for (int l = 0; l < w->L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         rc = attention(s.qkv, 3 * d, s.qkv + d, s.qkv + 2 * d, 3 * d, nullptr, nullptr, s.a, d, B, T, T, d, heads, st);
@@ -2379,6 +2467,17 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
                 if (tail.coef) { gl.c0 = tail.coef[0]; gl.c1 = tail.coef[1]; gl.c2 = tail.coef[2]; gl.c3 = tail.coef[3]; }
             }
             if ((rc = decoder_layer(gl, d, st))) return rc;
+            continue;
+        }
+        if (chain16) {
+            F16ChainArgs fa{ga, gb, f16_wfc(s, l, d, 0), f16_wfc(s, l, d, 1), nullptr, nullptr, s.scc + l * 8, nullptr};
+            if ((rc = chain_f16(fa, d, 0, st))) return rc;
+            rc = attention(s.u, d, kvl, kvl + d, 2 * d, nullptr, nullptr, s.a, d, B, T, Mk, d, heads, st);
+            if (rc) return rc;
+            // chain B: (Woc, W1, W2) of this layer, in_proj of the next
+            F16ChainArgs fb{ga, gb, f16_wfc(s, l, d, 2), f16_wfc(s, l, d, 3), f16_wfc(s, l, d, 4),
+                            last ? nullptr : f16_wfc(s, l + 1, d, 5), s.scc + l * 8 + 2, s.scc + (last ? l : l + 1) * 8 + 5};
+            if ((rc = chain_f16(fb, d, 1, st))) return rc;
             continue;
         }
         if ((rc = chain_a(ga, d, st))) return rc;
@@ -2606,6 +2705,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
     const bool f16 = fold && f16_ok(d, w->J) && s.wf != nullptr;
+    const bool chain16 = !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
@@ -2616,6 +2716,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_steps, 2 * d, d, 0, st);
         if (rc) return rc;
     }
+    if (chain16 && (rc = f16_prepare_chain(w, s, st))) return rc;
     if (fold) {
         // the memory is fixed over the rollout: fold Wq into its keys and Woc into its values once
         const int hd = d / 4;
@@ -2660,7 +2761,8 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
                       s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
             SD_CHECK_LAUNCH("kv_place_kernel");
             const float *kvbase = s.kv;
-            rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st);
+            rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st,
+                               FoldArgs{nullptr, nullptr, 0, 0}, chain16);
             if (rc) return rc;
         }
         if (trace) {
