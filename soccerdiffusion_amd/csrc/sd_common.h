@@ -96,6 +96,29 @@ __device__ __forceinline__ float gelu_erf_fast(float u) {
     return 0.5f * u * (z >= 0.f ? 2.0f - e : e);
 }
 
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// x*scale as an fp16 pair: hi = fp16(x*scale), lo = fp16(x*scale - hi)  (22 mantissa bits)
+__device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = x[e] * scale;
+        h[e] = (f16)v;
+        l[e] = (f16)(v - (float)h[e]);
+    }
+}
+
+// power of two s with max * s in [8192, 16384) from the bits of an abs-max
+__device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
+    const float m = __builtin_bit_cast(float, maxbits);
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+    int e;
+    (void)frexpf(m, &e);   // m = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
 static inline unsigned grid_for(long n, int block = 256) {
     long g = (n + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;

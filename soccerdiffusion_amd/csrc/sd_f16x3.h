@@ -18,34 +18,12 @@
 // Used by sd_ddim_sample for hidden_dim 256 when the folded path applies; everything else stays on the fp32 kernels.
 #pragma once
 
-typedef _Float16 f16;
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 constexpr float F16_ACT_SCALE = 8.0f;     // LayerNorm outputs, attention outputs, GELU outputs (|x| < 8190)
 constexpr float F16_P_SCALE = 1024.0f;    // softmax probabilities (<= 1)
 #ifndef SD_F16_GRING
 #define SD_F16_GRING 4
 #endif
 constexpr int F16_GRING = SD_F16_GRING;   // k-steps of G in flight
-
-__device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float v = x[e] * scale;
-        h[e] = (f16)v;
-        l[e] = (f16)(v - (float)h[e]);
-    }
-}
-
-// power of two s with max * s in [8192, 16384)
-__device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
-    const float m = __builtin_bit_cast(float, maxbits);
-    if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
-    int e;
-    (void)frexpf(m, &e);   // m = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, 14 - e);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // once-per-rollout preparation
