@@ -22,7 +22,9 @@
 // fp32 atomics (each instruction = two 128-B row segments).  Columns past N / K and rows
 // past R read as zero.  The bias gradient falls out of the A fragments.
 // ======================================================================================
+#ifndef TN_RC
 #define TN_RC 256
+#endif
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ dY, int ldy,
                                                        const float *__restrict__ X, int ldx, float *dW, int ldw,
                                                        float *db, long R, int N, int K) {
