@@ -358,6 +358,43 @@ __device__ __forceinline__ void f16_store_acc(float *dst, int ld, int col0, cons
     chain_store_acc<D>(dst, ld, col0, acc, p);
 }
 
+// The residual stream h is private to the sampler's chain kernels, so it lives in HBM in ACCUMULATOR order:
+// [panel][wave][j = (tn, tm, g)][lane][4 floats] - every load / store is a contiguous 1-KiB wave access of registers
+// 4g .. 4g+3, no quad transposes (4 VALU instructions per value) and 16 instead of 64 load instructions per wave.
+template <int D>
+__device__ __forceinline__ float *f16_h_frag(float *h, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    return h + ((p.r0 / C::BM) * 4 + p.wave) * (long)(C::TM * C::TN * 16 * 64) + p.lane * 4;
+}
+template <int D>
+__device__ __forceinline__ void f16_load_h(f32x16 (&H)[PanelCfg<D>::TM][PanelCfg<D>::TN], const float *h, const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    const float *base = f16_h_frag<D>(const_cast<float *>(h), p);
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (unsigned)(((tn * C::TM + tm) * 4 + g) * 256));
+                H[tm][tn][4 * g] = v[0]; H[tm][tn][4 * g + 1] = v[1]; H[tm][tn][4 * g + 2] = v[2]; H[tm][tn][4 * g + 3] = v[3];
+            }
+}
+template <int D>
+__device__ __forceinline__ void f16_store_h(float *h, const f32x16 (&H)[PanelCfg<D>::TM][PanelCfg<D>::TN], const ChainPos<D> &p) {
+    using C = PanelCfg<D>;
+    float *base = f16_h_frag<D>(h, p);
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {H[tm][tn][4 * g], H[tm][tn][4 * g + 1], H[tm][tn][4 * g + 2], H[tm][tn][4 * g + 3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + (unsigned)(((tn * C::TM + tm) * 4 + g) * 256)));
+            }
+}
+
 // q | k | v tile of one pass -> the head-major buffer [sample][head][q|k|v][token][64]: wave wn's 64 columns are head wn
 // (D = 4 x 64), so its 64 x 64 tile is one contiguous 16-KB run per sample (the row-major [R][3D] layout scatters it in
 // 256-byte pieces at a 3-KB stride; the attention kernel then reads each head's Q, K and V as contiguous 25-KB blocks).
@@ -398,6 +435,7 @@ struct F16LayerArgs {
     const f16 *gstep, *vstep;                 // this layer and step: 4 head blocks / one block
     const float *cstep;                       // 4 score biases of the step token
     int qkv_head_major;                       // layout of g.b.qkv (f16_store_qkv) - what attention_f16_head_kernel reads
+    int h_frag;                               // g.a.h is in accumulator order (f16_load_h / f16_store_h)
 };
 
 struct F16Scores {
@@ -608,7 +646,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     F16Ring<D> ring;
     SD_STAMP(g.slot, 0);
     f16_prime<D>(ring, fa.wf_o + wOff, loff);
-    chain_load_acc<D>(H, g.a.h, p);
+    if (fa.h_frag) f16_load_h<D>(H, g.a.h, p);
+    else chain_load_acc<D>(H, g.a.h, p);
     f16_load_panel<D>(sA, g.a.a, p);
     __syncthreads();
     SD_STAMP(g.slot, 1);
@@ -660,7 +699,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
         const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
         f16_prime<D>(ring, fa.wf_qkv + wOff, loff);
         f16_unscale<D, true>(H, U, c_2, g.b.b2, p);
-        f16_store_acc<D>(g.a.h, D, 0, H, p);
+        if (fa.h_frag) f16_store_h<D>(g.a.h, H, p);
+        else f16_store_acc<D>(g.a.h, D, 0, H, p);
         SD_STAMP(g.slot, 11);
         __syncthreads();
         chain_acc_to_lds<D>(sA, H, p);
@@ -687,6 +727,7 @@ struct F16HeadArgs {
     const f16 *wf_qkv;
     const float *sc;     // sc[3] = scale of layer 0's in_proj
     int qkv_head_major;
+    int h_frag;
 };
 
 // ONE_WRAP: T >= 64, so the positional index of a row wraps at most once inside a 64-row panel
@@ -772,7 +813,8 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         }
     }
     SD_STAMP(SD_STAMP_HEAD_SLOT, 3);
-    f16_store_acc<D>(g.h, D, 0, H, p);
+    if (fa.h_frag) f16_store_h<D>(g.h, H, p);
+    else f16_store_acc<D>(g.h, D, 0, H, p);
     __syncthreads();
     chain_acc_to_lds<D>(sA, H, p);
     __syncthreads();

@@ -2315,7 +2315,7 @@ static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long B = 0) {
     Scratch s;
     size_t off = 0;
-    s.h = ws + off; off += align64((size_t)R * d);
+    s.h = ws + off; off += align64((size_t)((R + 63) / 64 * 64) * d);   // whole panels (accumulator-order layout)
     s.qkv = ws + off; off += align64((size_t)R * 3 * d);
     s.a = ws + off; off += align64((size_t)R * d);
     s.u = ws + off; off += align64((size_t)R * d);
@@ -2355,7 +2355,7 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
 extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps) {
     // M memory rows per trajectory (+1: the sampler adds the step row to the context rows)
     const size_t R = (size_t)B * T, RM = (size_t)B * ((M > 0 ? M : 0) + 1);
-    size_t n = align64(R * d) * 3 + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
+    size_t n = align64(R * d) * 2 + align64((R + 63) / 64 * 64 * d) + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
                align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
     if (n_steps > 0)   // folded cross-attention blocks of the sampler: 64 rows of 2d (+ 1 bias) per trajectory and layer
         n += align64((size_t)L * B * 64 * 2 * d) + align64((size_t)L * B * 64) + align64((size_t)L * n_steps * 4 * 2 * d) +
@@ -2433,7 +2433,7 @@ static int decoder_stack(const sd_denoiser_weights *w, const float *x, const Scr
     chain16 = chain16 && !fused && s.wfc != nullptr;
     if (chain16) {
         F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
-                       f16_wfc(s, 0, d, 5), s.scc + 2, 0};   // the head reads sc[3]: the scale of layer 0's in_proj = scc[5]
+                       f16_wfc(s, 0, d, 5), s.scc + 2, 0, 0};   // the head reads sc[3]: the scale of layer 0's in_proj = scc[5]
         rc = decoder_head_f16(fh, st, d);
     } else if (w->J % 4 == 0) {  // embed + LN1 + QKV of layer 0 in one launch
         DecoderHeadArgs gh{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J};
@@ -2567,8 +2567,10 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
     // q | k | v go to the attention kernel head-major when it is the fp16 one (head dim 64, T <= 128; SD_QKV=rows: A/B runs)
     static const char *qenv = getenv("SD_QKV");
     const bool att16 = d / heads == 64 && T <= 128, hm = att16 && heads == 4 && !(qenv && strcmp(qenv, "rows") == 0);
+    static const char *henv = getenv("SD_H");   // "rows": h stays row-major (A/B runs)
+    const int hfrag = !(henv && strcmp(henv, "rows") == 0);
     F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
-                   f16_wf(s, 0, d, 3), s.scales, hm ? 1 : 0};
+                   f16_wf(s, 0, d, 3), s.scales, hm ? 1 : 0, hfrag};
     int rc = decoder_head_f16(fh, st);
     if (rc) return rc;
     for (int l = 0; l < L; ++l) {
@@ -2603,6 +2605,7 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
         fa.vstep = s.vstep16 + ((size_t)l * n_steps + i) * blk;
         fa.cstep = s.cstep + ((size_t)l * n_steps + i) * 4;
         fa.qkv_head_major = hm ? 1 : 0;
+        fa.h_frag = hfrag;
         if ((rc = decoder_layer_f16(fa, st))) return rc;
     }
     return 0;
