@@ -7,7 +7,7 @@ soccer_diffusion/ml/inference/plot.py:21-135).
     python -m soccerdiffusion_amd.cli distill cfg.yaml teacher_ckpt [-o out]     (ml/training/distill.py:25-224)
 
 Differences, all additive: data comes from the reference's SQLite database (`--db file`,
-read once into HBM by soccerdiffusion_amd/dataset.py; images are not served), from a tensor
+read once into HBM by soccerdiffusion_amd/dataset.py, image frames included), from a tensor
 file (`--data file.pt`: dict with `joint_command` (N,T,J) and the optional context keys of
 the reference's `Result` dataclass) or from a synthetic sine-wave generator (`--synthetic N`); wandb and matplotlib are not used; under torchrun
 (WORLD_SIZE > 1) training is data parallel with one RCCL all-reduce of the flat gradient
@@ -80,7 +80,7 @@ def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
     feat = 5 if params["imu_orientation_embedding_method"] == "five_dim" else 4
     rot = quat if feat == 4 else torch.cat([quat[..., :3], torch.sin(quat[..., 3:]), torch.cos(quat[..., 3:])], -1)
     extra = {}
-    if params.get("use_images"):  # (n, F, 3, R, R) noise frames; the SQLite image blobs are not served
+    if params.get("use_images"):  # (n, F, 3, R, R) noise frames
         R = params.get("image_resolution", 480)
         extra["image_data"] = torch.rand(n, params["image_context_length"], 3, R, R, generator=g)
     return {

@@ -7,8 +7,8 @@ processes.  Here every recording is read ONCE at construction (one ordered query
 into dense tensors, and a whole batch is assembled with a few vectorised gathers — on the
 host or, after ``.to(device)``, directly in HBM (a 50 Hz recording is ~10 KB/s: days of data
 fit).  Sample indexing, windows, front padding (zeros / identity quaternion), the game-state
-lookup and the field names of ``Result`` are the reference's.  Images are not served
-(SURVEY §8 f2).
+lookup and the field names of ``Result`` are the reference's.  Image frames are kept as the
+stored uint8 blobs (691 KB per frame: an hour at 10 fps is 25 GB of the 288 GB) and preprocessed per batch.
 """
 
 from __future__ import annotations
@@ -65,9 +65,15 @@ def quats_to_5d(quats: np.ndarray) -> np.ndarray:
     return np.concatenate([axis, np.sin(theta)[:, None], np.cos(theta)[:, None]], axis=-1)
 
 
+IMAGE_SIZE = 480  # the recordings store 480 x 480 rgb8 frames (dataset/models.py:111-113, pytorch.py:209)
+
+
 class SoccerDiffusionDataset(torch.utils.data.Dataset):
-    """Same constructor keywords as the reference class (image-related ones accepted and ignored
-    unless ``use_images`` is set, which raises)."""
+    """Same constructor keywords as the reference class.  Images (``use_images``): the 480x480 rgb8 blobs of a
+    recording are read once and kept as uint8; a batch gathers each sample's last ``num_frames_video`` frames of
+    the preceding ``(num_frames_video + 1) / max_fps_video`` seconds, front-padded with zeros, and applies the
+    reference's preprocessing (dataset/pytorch.py:173-229): area down-scaling (integer factors of 480 only),
+    [0, 1] scaling, ImageNet mean/std, channels first."""
 
     Result = Result
 
@@ -93,8 +99,8 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
         db_path: Optional[str] = None,
         joint_names: Optional[Sequence[str]] = None,
     ):
-        if use_images:
-            raise NotImplementedError("image context is not served (SURVEY §8 f2); construct with use_images=False")
+        if use_images and (image_resolution <= 0 or IMAGE_SIZE % image_resolution != 0):
+            raise NotImplementedError(f"image_resolution must divide {IMAGE_SIZE} (cv2.INTER_AREA is restated for integer factors only)")
         if db_connection is None:
             if db_path is None:
                 raise ValueError("pass db_connection or db_path")
@@ -107,6 +113,8 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
         self.sampling_rate = sampling_rate
         self.trajectory_stride = trajectory_stride
         self.num_joints = num_joints
+        self.use_images, self.image_resolution = use_images, image_resolution
+        self.max_fps_video, self.num_frames_video = max_fps_video, num_frames_video
         self.use_imu, self.use_joint_states = use_imu, use_joint_states
         self.use_action_history, self.use_game_state = use_action_history, use_game_state
         if joint_names is None:
@@ -142,6 +150,12 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
                 rows = cur.execute("SELECT stamp, state FROM GameState WHERE recording_id = ? ORDER BY stamp ASC", (recording_id,)).fetchall()
                 rec["gs_stamp"] = torch.tensor([r[0] for r in rows], dtype=torch.float64)
                 rec["gs_state"] = torch.tensor([ROBOT_STATES.index(r[1]) for r in rows], dtype=torch.int64)
+            if use_images:
+                rows = cur.execute("SELECT stamp, data FROM Image WHERE recording_id = ? ORDER BY stamp ASC", (recording_id,)).fetchall()
+                rec["img_stamp"] = torch.tensor([r[0] for r in rows], dtype=torch.float64)
+                frames = np.stack([np.frombuffer(r[1], dtype=np.uint8).reshape(IMAGE_SIZE, IMAGE_SIZE, 3) for r in rows]) if rows else \
+                    np.zeros((0, IMAGE_SIZE, IMAGE_SIZE, 3), np.uint8)
+                rec["img"] = torch.from_numpy(frames.copy())
             self._rec[recording_id] = rec
         self._starts = torch.tensor([b[0] for b in self.sample_boundaries], dtype=torch.int64)
         feat = 4 if self.imu_representation == "quaternion" else 5
@@ -177,10 +191,57 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
             rows = torch.cat((fill, rows), dim=0)
         return rows
 
+    # ---- images (dataset/pytorch.py:173-229) ----------------------------------------------------
+    def _image_frames(self, rec, stamps: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """For sample time stamps (n,) -> frame indices (n, F) into rec["img"] (-1 = zero padding) and their stamps."""
+        F = self.num_frames_video
+        dev = rec["img_stamp"].device
+        stamps = stamps.to(dev, torch.float64)
+        ctx = (F + 1) / self.max_fps_video
+        hi = torch.searchsorted(rec["img_stamp"], stamps, right=True)           # frames with stamp <= t
+        lo = torch.searchsorted(rec["img_stamp"], stamps - ctx, right=False)    # first frame with stamp >= t - ctx
+        n = (hi - lo).clamp(max=F)
+        slot = torch.arange(F, device=dev)[None, :]
+        idx = hi[:, None] - F + slot                                            # the last F frames before hi ...
+        ok = slot >= (F - n)[:, None]                                           # ... of which only the last n exist
+        idx = torch.where(ok, idx, torch.full_like(idx, -1))
+        st = torch.where(ok, rec["img_stamp"][idx.clamp(min=0)] if len(rec["img_stamp"]) else torch.zeros_like(idx, dtype=torch.float64),
+                         (stamps - ctx)[:, None].expand(-1, F))
+        return idx, st
+
+    def _preprocess(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 (..., 480, 480, 3) -> float32 (..., 3, R, R): INTER_AREA (exact block mean, rounded like cv2's
+        saturate_cast), ToDtype(scale=True), Normalize(ImageNet)."""
+        R = self.image_resolution
+        x = frames_u8.to(torch.float32)
+        k = IMAGE_SIZE // R
+        if k > 1:
+            shp = x.shape[:-3]
+            x = x.reshape(*shp, R, k, R, k, 3).mean(dim=(-4, -2))
+            x = torch.round(x)                      # half to even, as cvRound
+        x = x / 255.0
+        mean = torch.tensor((0.485, 0.456, 0.406), device=x.device)
+        std = torch.tensor((0.229, 0.224, 0.225), device=x.device)
+        x = (x - mean) / std
+        return x.movedim(-1, -3).contiguous()
+
+    def _images(self, rec, stamps: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        idx, st = self._image_frames(rec, stamps)
+        R = self.image_resolution
+        out = torch.zeros(idx.shape + (3, R, R), dtype=torch.float32, device=rec["img"].device)
+        live = idx >= 0
+        if live.any():
+            out[live] = self._preprocess(rec["img"][idx[live]])
+        return st.to(torch.float32), out
+
     def __getitem__(self, idx: int) -> Result:
         recording_id, i = self._locate(int(idx))
         rec = self._rec[recording_id]
         stamp = i / self.sampling_rate
+        image_stamps = image_data = None
+        if self.use_images:
+            st, im = self._images(rec, torch.tensor([stamp], dtype=torch.float64))
+            image_stamps, image_data = st[0], im[0]
         T = self.num_samples_joint_trajectory_future
         cmd = rec["cmd"][i : i + T]
         assert len(cmd) == T, "The joint command has the wrong length"
@@ -192,8 +253,8 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
             joint_command=cmd,
             joint_command_history=self._history(rec["cmd"], i, self.num_samples_joint_trajectory) if self.use_action_history else None,
             joint_state=self._history(rec["state"], i, self.num_samples_joint_states) if self.use_joint_states else None,
-            image_data=None,
-            image_stamps=None,
+            image_data=image_data,
+            image_stamps=image_stamps,
             rotation=self._history(rec["imu"], i, self.num_samples_imu, self._imu_pad) if self.use_imu else None,
             game_state=game_state,
         )
@@ -205,8 +266,8 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
         def stack(name):
             return torch.stack([getattr(x, name) for x in batch]) if getattr(batch[0], name) is not None else None
 
-        return Result(stack("joint_command"), stack("joint_command_history"), stack("joint_state"), None, None,
-                      stack("rotation"), stack("game_state"))
+        return Result(stack("joint_command"), stack("joint_command_history"), stack("joint_state"), stack("image_data"),
+                      stack("image_stamps"), stack("rotation"), stack("game_state"))
 
     # ---- a whole batch at once (what the training loop uses) ---------------------------------
     def batch(self, indices: torch.Tensor) -> dict[str, torch.Tensor]:
@@ -241,6 +302,8 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
                 k = torch.searchsorted(rec["gs_stamp"], stamps, right=True) - 1
                 unknown = torch.full_like(k, ROBOT_STATES.index("UNKNOWN"))
                 parts["game_state"] = torch.where(k >= 0, rec["gs_state"][k.clamp(min=0)], unknown) if len(rec["gs_state"]) else unknown
+            if self.use_images:
+                parts["image_stamps"], parts["image_data"] = self._images(rec, i.to(torch.float64) / self.sampling_rate)
             for name, t in parts.items():
                 out.setdefault(name, []).append((sel, t))
         result = {}

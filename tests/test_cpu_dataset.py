@@ -22,7 +22,12 @@ def _make_db(path, lengths=(180, 75)):
         cur.execute(f"CREATE TABLE {t} (_id INTEGER PRIMARY KEY AUTOINCREMENT, stamp FLOAT, recording_id INTEGER, {jcols})")
     cur.execute("CREATE TABLE Rotation (_id INTEGER PRIMARY KEY AUTOINCREMENT, stamp FLOAT, recording_id INTEGER, x FLOAT, y FLOAT, z FLOAT, w FLOAT)")
     cur.execute("CREATE TABLE GameState (_id INTEGER PRIMARY KEY AUTOINCREMENT, stamp FLOAT, recording_id INTEGER, state TEXT)")
+    cur.execute("CREATE TABLE Image (_id INTEGER PRIMARY KEY AUTOINCREMENT, stamp FLOAT, recording_id INTEGER, data BLOB)")
     rng = np.random.default_rng(0)
+    for rid, n_img in ((1, 9), (2, 2)):   # ~4 fps, inserted out of order; recording 2 has fewer frames than the context asks for
+        for j in rng.permutation(n_img):
+            frame = rng.integers(0, 256, size=(480, 480, 3), dtype=np.uint8)
+            cur.execute("INSERT INTO Image (stamp, recording_id, data) VALUES (?, ?, ?)", (0.3 + 0.27 * j, rid, frame.tobytes()))
     for rid, n in enumerate(lengths, start=1):
         cur.execute("INSERT INTO Recording VALUES (?, 'team', '2024', 'lab', 'f.mcap')", (rid,))
         order = rng.permutation(n)  # rows are inserted out of order: only ORDER BY stamp gives the sequence
@@ -127,6 +132,51 @@ def test_fit_normalizer_is_unbiased_std():
     assert torch.allclose(mean, rows.mean(0)) and torch.allclose(std, rows.std(0, unbiased=True))
 
 
-def test_images_are_rejected(db):
+def _reference_images(con, rid, stamp, F, fps, R):
+    """query_image_data (dataset/pytorch.py:173-229) restated: the SQL as it is, the frames' preprocessing in numpy
+    (cv2 and torchvision are absent: INTER_AREA for an integer factor is the rounded block mean)."""
+    ctx = (F + 1) / fps
+    rows = con.execute("SELECT stamp, data FROM Image WHERE recording_id = ? AND stamp BETWEEN ? - ? AND ? ORDER BY stamp ASC",
+                       (rid, stamp, ctx, stamp)).fetchall()
+    rows = rows[-F:] if len(rows) > F else rows
+    frames, stamps = [], []
+    for st, data in rows:
+        img = np.frombuffer(data, dtype=np.uint8).reshape(480, 480, 3).astype(np.float64)
+        k = 480 // R
+        if k > 1:
+            img = np.rint(img.reshape(R, k, R, k, 3).mean(axis=(1, 3)))
+        img = (img / 255.0 - np.array((0.485, 0.456, 0.406))) / np.array((0.229, 0.224, 0.225))
+        frames.append(img.transpose(2, 0, 1))
+        stamps.append(st)
+    pad = F - len(frames)
+    frames = [np.zeros((3, R, R))] * pad + frames
+    stamps = [stamp - ctx] * pad + stamps
+    return np.asarray(stamps, np.float32), np.stack(frames).astype(np.float32)
+
+
+@pytest.mark.parametrize("R", [480, 120])
+def test_images_match_reference_query(db, R):
+    F, fps = 3, 2
+    ds = SoccerDiffusionDataset(db, num_samples_imu=5, num_samples_joint_states=5, num_samples_joint_trajectory=5,
+                                num_samples_joint_trajectory_future=4, sampling_rate=50, num_joints=22, use_images=True,
+                                num_frames_video=F, max_fps_video=fps, image_resolution=R)
+    picks = [0, 20, 60, 100, 175, 176 + 3, 176 + 60]
+    batch = ds.batch(torch.tensor(picks))
+    assert batch["image_data"].shape == (len(picks), F, 3, R, R) and batch["image_data"].dtype == torch.float32
+    for n, idx in enumerate(picks):
+        for start, end, rid in ds.sample_boundaries:
+            if start <= idx < end:
+                break
+        stamp = (idx - start) / 50
+        want_st, want = _reference_images(db, rid, stamp, F, fps, R)
+        item = ds[idx]
+        for got_st, got in ((item.image_stamps, item.image_data), (batch["image_stamps"][n], batch["image_data"][n])):
+            assert np.allclose(got_st.numpy(), want_st, atol=1e-6)
+            assert np.abs(got.numpy() - want).max() < 1e-5
+    # frames before any image / beyond the context are zero padding
+    assert float(batch["image_data"][0].abs().max()) == 0.0
+
+
+def test_image_resolution_must_divide_480(db):
     with pytest.raises(NotImplementedError):
-        SoccerDiffusionDataset(db, use_images=True)
+        SoccerDiffusionDataset(db, use_images=True, image_resolution=224)
