@@ -28,7 +28,7 @@ import yaml
 
 logger = logging.getLogger("soccerdiffusion_amd")
 
-CONTEXT_KEYS = ("joint_command_history", "rotation", "joint_state", "game_state")
+CONTEXT_KEYS = ("joint_command_history", "rotation", "joint_state", "image_data", "game_state")
 
 
 def build_model(params: dict):

@@ -116,3 +116,23 @@ def test_train_and_sample_from_sqlite_database(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = torch.load(tmp_path / "s.pt", weights_only=True)["trajectories"]
     assert out.shape == (5, 16, 22) and torch.isfinite(out).all()
+
+
+def test_train_with_image_context_from_sqlite_database(tmp_path):
+    """BASELINE config 5 in miniature: frames from the Image table -> ResNet-18 token per frame -> 8-head HIP
+    sequence encoder -> memory of the denoiser; one epoch of `cli train --db` (image_resolution 120, hidden 128)."""
+    from test_cpu_dataset import _make_db
+
+    db = tmp_path / "db.sqlite3"
+    _make_db(str(db), lengths=(120, 60)).close()
+    cfg = dict(CFG, hidden_dim=128, num_joints=22, epochs=1, batch_size=16, use_images=True, image_context_length=2,
+               image_resolution=120, image_use_final_avgpool=True, use_imu=False, use_joint_states=False, num_decoder_layers=1)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    ckpt = tmp_path / "m.pth"
+    r = _run("train", "-c", str(path), "-o", str(ckpt), "--db", str(db))
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert losses and all(math.isfinite(x) for x in losses)
+    sd = torch.load(ckpt, weights_only=True)["model_state_dict"]
+    assert "image_sequence_encoder.image_encoder.encoder.conv1.weight" in sd
