@@ -1405,7 +1405,7 @@ static int chain_f16_launch(const F16ChainArgs &fa, int kind, hipStream_t s) {
     return 0;
 }
 static int chain_f16(const F16ChainArgs &fa, int d, int kind, hipStream_t s) {
-    return d == 128 ? chain_f16_launch<128>(fa, kind, s) : chain_f16_launch<256>(fa, kind, s);
+    return d == 128 ? chain_f16_launch<128>(fa, kind, s) : d == 256 ? chain_f16_launch<256>(fa, kind, s) : chain_f16_launch<512>(fa, kind, s);
 }
 
 static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s, int d = 256) {
@@ -1416,6 +1416,16 @@ static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s, int d = 256) {
     if (d == 128) {
         if (one_wrap) SD_LAUNCH((decoder_head_f16_kernel<128, true>), grid, block, PanelCfg<128>::LDS_BYTES, s, fa);
         else SD_LAUNCH((decoder_head_f16_kernel<128, false>), grid, block, PanelCfg<128>::LDS_BYTES, s, fa);
+    } else if (d == 512) {
+        const size_t lds = PanelCfg<512>::LDS_BYTES;
+        static bool attr_set512 = false;
+        if (!attr_set512) {
+            (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set512 = true;
+        }
+        if (one_wrap) SD_LAUNCH((decoder_head_f16_kernel<512, true>), grid, block, lds, s, fa);
+        else SD_LAUNCH((decoder_head_f16_kernel<512, false>), grid, block, lds, s, fa);
     } else {
         const size_t lds = PanelCfg<256>::LDS_BYTES;
         static bool attr_set = false;
@@ -2292,7 +2302,7 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
     f16 *wf, *g16, *v16, *gstep16, *vstep16;
     float *scales;
     unsigned *maxbits;
-    // split weights of the unfused row chains (chain_f16_kernel, hidden_dim 128 / 256): per layer
+    // split weights of the unfused row chains (chain_f16_kernel, hidden_dim 128 / 256 / 512): per layer
     // [Wo | Wq | Woc | W1 | W2 | in_proj x 3], their scales and abs-max words
     f16 *wfc;
     float *scc;
@@ -2344,7 +2354,7 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
     s.wfc = nullptr;
     s.scc = nullptr;
     s.mbc = nullptr;
-    if (n_steps > 0 && (d == 128 || d == 256)) {
+    if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) {
         s.wfc = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * 8 * d * d);
         s.scc = ws + off; off += align64((size_t)L * 8);
         s.mbc = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)L * 8);
@@ -2363,7 +2373,7 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
     if (n_steps > 0 && d == 256)   // fp16x3 operands (sd_f16x3.h)
         n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
              align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8);
-    if (n_steps > 0 && (d == 128 || d == 256)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
+    if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
     return n;
 }
 
@@ -2410,15 +2420,15 @@ static int f16_prepare_chain_d(const sd_denoiser_weights *w, const Scratch &s, h
     return 0;
 }
 static int f16_prepare_chain(const sd_denoiser_weights *w, const Scratch &s, hipStream_t st) {
-    return w->d == 128 ? f16_prepare_chain_d<128>(w, s, st) : f16_prepare_chain_d<256>(w, s, st);
+    return w->d == 128 ? f16_prepare_chain_d<128>(w, s, st) : w->d == 256 ? f16_prepare_chain_d<256>(w, s, st) : f16_prepare_chain_d<512>(w, s, st);
 }
 
-// the unfused row chains run on the fp16 pipe when their split weights were prepared (sampler, hidden_dim 128 / 256;
+// the unfused row chains run on the fp16 pipe when their split weights were prepared (sampler, hidden_dim 128 / 256 / 512;
 // SD_SAMPLER_GEMM=f32 keeps the fp32 kernels)
 static bool chain16_ok(int d, int J) {
     static const char *env = getenv("SD_SAMPLER_GEMM");
     if (env && strcmp(env, "f32") == 0) return false;
-    return (d == 128 || d == 256) && J % 4 == 0;
+    return (d == 128 || d == 256 || d == 512) && J % 4 == 0;
 }
 
 template <typename KV>

@@ -76,7 +76,9 @@ def test_denoiser_vs_oracle(ops, d, J, L, T, M, B):
                                                  (128, 3, 97, 12, 9, 5),
                                                  # split-fp16 kernels (d = 256): shortest / longest horizon of the fp16 attention,
                                                  # odd horizon, horizon past it (fp32 attention over row-major q|k|v), one layer
-                                                 (256, 2, 64, 7, 5, 4), (256, 1, 128, 3, 2, 3), (256, 2, 127, 2, 3, 3), (256, 2, 130, 5, 2, 3)])
+                                                 (256, 2, 64, 7, 5, 4), (256, 1, 128, 3, 2, 3), (256, 2, 127, 2, 3, 3), (256, 2, 130, 5, 2, 3),
+                                                 # unfused chains on the fp16 pipe (long memory, short horizon): d = 512 and 256
+                                                 (512, 2, 10, 30, 2, 4), (256, 2, 10, 40, 7, 4)])
 def test_ddim_sampler_every_step(ops, d, L, T, Mc, B, n_steps):
     """x after EVERY step vs the fp32 CPU oracle loop on identical weights, x_T, context."""
     J = 20
