@@ -1884,7 +1884,11 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     dim3 grid(B * heads), block(256);
-    if (Tq <= 128 && !k_extra && S > 0) {
+    // small batches (the robot: B = 1): one workgroup per (sample, head) instead of one per sample walking its heads
+    // in sequence - the rollout there is a chain of kernel latencies (robot shape: 11.6 -> 9.4 ms per rollout)
+    static const char *penv = getenv("SD_ATT_PIPE_MIN_B");
+    static const int pipe_min_b = penv ? atoi(penv) : 64;
+    if (Tq <= 128 && !k_extra && S > 0 && B >= pipe_min_b) {
         dim3 gridp(B);
 #define SD_ATTNP(HD_)                                                                                            \
     do {                                                                                                         \
