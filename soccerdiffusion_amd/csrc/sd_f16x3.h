@@ -283,38 +283,54 @@ template <int D>
 __device__ __forceinline__ void f16_layer_norm_to_planes(float *sA, const float *ln_w, const float *ln_b, int lane, int wave) {
     using C = PanelCfg<D>;
     constexpr int V4 = D / 64;
+#ifndef SD_LN_ROWS
+#define SD_LN_ROWS 2   // rows per 16-lane group in flight: the DPP reduction chains of independent rows interleave
+#endif
+    constexpr int NR = SD_LN_ROWS;
     const int sub = lane & 15, grp = lane >> 4;
-    for (int row = wave * 4 + grp; row < C::BM; row += 16) {
-        f32x4 v[V4];
-        float s = 0.f;
+    for (int row0 = wave * 4 + grp; row0 < C::BM; row0 += 16 * NR) {
+        f32x4 v[NR][V4];
+        float s[NR], q[NR], mean[NR], rstd[NR];
 #pragma unroll
-        for (int j = 0; j < V4; ++j) {
-            v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + 4 * (sub + 16 * j));
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        }
-        const float mean = row16_sum(s) * (1.0f / D);
-        float q = 0.f;
+        for (int n = 0; n < NR; ++n) {
+            s[n] = 0.f;
 #pragma unroll
-        for (int j = 0; j < V4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[j][e] -= mean;
-                q += v[j][e] * v[j][e];
+            for (int j = 0; j < V4; ++j) {
+                v[n][j] = *reinterpret_cast<const f32x4 *>(sA + (row0 + 16 * n) * C::LDA + 4 * (sub + 16 * j));
+                s[n] += (v[n][j][0] + v[n][j][1]) + (v[n][j][2] + v[n][j][3]);
             }
-        const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / D) + SD_LN_EPS);
-        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) mean[n] = row16_sum(s[n]) * (1.0f / D);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            q[n] = 0.f;
+#pragma unroll
+            for (int j = 0; j < V4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[n][j][e] -= mean[n];
+                    q[n] += v[n][j][e] * v[n][j][e];
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) rstd[n] = 1.0f / sqrtf(row16_sum(q[n]) * (1.0f / D) + SD_LN_EPS);
 #pragma unroll
         for (int j = 0; j < V4; ++j) {
             const int c = 4 * (sub + 16 * j);
             const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + c);
             const f32x4 gb = *reinterpret_cast<const f32x4 *>(ln_b + c);
-            f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = v[j][e] * rstd * gw[e] + gb[e];
-            f16x4 h, l;
-            f16_split4(y, F16_ACT_SCALE, h, l);
-            *reinterpret_cast<f16x4 *>(rowp + c) = h;
-            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
+            for (int n = 0; n < NR; ++n) {
+                f16 *rowp = reinterpret_cast<f16 *>(sA + (row0 + 16 * n) * C::LDA);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = v[n][j][e] * rstd[n] * gw[e] + gb[e];
+                f16x4 h, l;
+                f16_split4(y, F16_ACT_SCALE, h, l);
+                *reinterpret_cast<f16x4 *>(rowp + c) = h;
+                *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
+            }
         }
     }
 }
