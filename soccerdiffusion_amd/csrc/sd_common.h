@@ -100,6 +100,29 @@ typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// two values at a time: the polynomial runs on v_pk_fma_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 u) {
+    const f32x2 z = u * 0.70710678118654752440f;
+    const f32x2 a = {fabsf(z[0]), fabsf(z[1])};
+    const f32x2 d = a * 0.5f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = {0.17087277f, 0.17087277f};
+    p = p * t + (-0.82215223f);
+    p = p * t + 1.48851587f;
+    p = p * t + (-1.13520398f);
+    p = p * t + 0.27886807f;
+    p = p * t + (-0.18628806f);
+    p = p * t + 0.09678418f;
+    p = p * t + 0.37409196f;
+    p = p * t + 1.00002368f;
+    p = p * t + (-1.26551223f);
+    const f32x2 x = (p - a * a) * 1.44269504088896340736f;
+    const f32x2 e = {t[0] * __builtin_amdgcn_exp2f(x[0]), t[1] * __builtin_amdgcn_exp2f(x[1])};
+    const f32x2 w = {z[0] >= 0.f ? 2.0f - e[0] : e[0], z[1] >= 0.f ? 2.0f - e[1] : e[1]};
+    return u * 0.5f * w;
+}
+
 // x*scale as an fp16 pair: hi = fp16(x*scale), lo = fp16(x*scale - hi)  (22 mantissa bits)
 __device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
 #pragma unroll

@@ -267,12 +267,17 @@ __device__ __forceinline__ void f16_gelu_to_planes(float *sA, const f32x16 (&U)[
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = gelu_erf_fast(U[tm][tn][r] * c + bv) * F16_ACT_SCALE;
-                const f16 h = (f16)v;
-                f16 *o = sH + p.row(tm, r) * ROWP + p.col(tn);
-                o[0] = h;
-                o[D] = (f16)(v - (float)h);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 pre = {U[tm][tn][r] * c + bv, U[tm][tn][r + 1] * c + bv};
+                const f32x2 v2 = gelu_erf_fast2(pre) * F16_ACT_SCALE;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = v2[e];
+                    const f16 h = (f16)v;
+                    f16 *o = sH + p.row(tm, r + e) * ROWP + p.col(tn);
+                    o[0] = h;
+                    o[D] = (f16)(v - (float)h);
+                }
             }
     }
 }
