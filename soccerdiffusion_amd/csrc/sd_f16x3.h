@@ -311,12 +311,11 @@ __device__ __forceinline__ void f16_layer_norm_to_planes(float *sA, const float 
         for (int n = 0; n < NR; ++n) {
             q[n] = 0.f;
 #pragma unroll
-            for (int j = 0; j < V4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[n][j][e] -= mean[n];
-                    q[n] += v[n][j][e] * v[n][j][e];
-                }
+            for (int j = 0; j < V4; ++j) {   // whole-vector expressions: packed fp32 instructions
+                v[n][j] = v[n][j] - mean[n];
+                const f32x4 sq = v[n][j] * v[n][j];
+                q[n] += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+            }
         }
 #pragma unroll
         for (int n = 0; n < NR; ++n) rstd[n] = 1.0f / sqrtf(row16_sum(q[n]) * (1.0f / D) + SD_LN_EPS);
@@ -328,9 +327,7 @@ __device__ __forceinline__ void f16_layer_norm_to_planes(float *sA, const float 
 #pragma unroll
             for (int n = 0; n < NR; ++n) {
                 f16 *rowp = reinterpret_cast<f16 *>(sA + (row0 + 16 * n) * C::LDA);
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = v[n][j][e] * rstd[n] * gw[e] + gb[e];
+                const f32x4 y = (v[n][j] * rstd[n]) * gw + gb;
                 f16x4 h, l;
                 f16_split4(y, F16_ACT_SCALE, h, l);
                 *reinterpret_cast<f16x4 *>(rowp + c) = h;
