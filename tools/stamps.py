@@ -21,6 +21,11 @@ NAMES = {1: "load a,h", 2: "K out-proj", 3: "bias+LDS+LN2", 4: "K scores", 5: "s
          15: "K k", 16: "store k", 17: "K v", 18: "store v"}
 
 
+HEAD_NAMES = {1: "x staging + emb weights", 2: "embed MFMA", 3: "+ bias + pe", 4: "h store + LDS + LN1", 5: "K q", 6: "store q",
+              7: "K k", 8: "store k", 9: "K v", 10: "store v"}
+ATT_NAMES = {1: "barrier", 2: "stage K/V", 3: "fetch issue + Q split", 4: "barrier", 5: "S MFMAs", 6: "softmax", 7: "P V", 8: "next unit"}
+
+
 def main():
     B = int(os.environ.get("B", 4096))
     lib = _lib.load()
@@ -61,7 +66,8 @@ def main():
             seg = w0[:, i] - w0[:, prev]
             seg_all = (s[:, :, i] - s[:, :, prev]).max(1).values
             skew = s[:, :, i].max(1).values - s[:, :, i].min(1).values
-            print(f"   {NAMES.get(i, str(i)):26s} {seg.min():8.0f} {seg.quantile(0.1):8.0f} {seg.median():10.0f} {seg.quantile(0.9):9.0f} "
+            names = HEAD_NAMES if l == L else ATT_NAMES if l == L + 1 else NAMES
+            print(f"   {names.get(i, str(i)):26s} {seg.min():8.0f} {seg.quantile(0.1):8.0f} {seg.median():10.0f} {seg.quantile(0.9):9.0f} "
                   f"{100 * seg.median() / life.median():6.1f}%   {seg_all.median():16.0f}  {skew.median():16.0f}")
             prev = i
         # MFMA-pipe occupancy per CU: union of the K-loop intervals of the workgroups that ran there
