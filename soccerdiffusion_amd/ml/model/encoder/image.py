@@ -7,7 +7,8 @@ hand-written: it is the torchvision architecture (absent offline, so restated he
 layer with torchvision's ``state_dict`` keys) built from ``torch.nn`` layers, i.e. MIOpen
 convolutions through PyTorch-ROCm.  Pretrained ImageNet weights cannot be fetched offline
 (``weights=...DEFAULT`` in the reference): load them from a reference checkpoint.
-Parity of the backbone is unpinned (no torchvision here, no reference fixture).
+The Swin-T/S encoders are restated the same way (shifted-window attention with torch ops).
+Parity of the backbones is unpinned (no torchvision here, no reference fixture).
 """
 
 from __future__ import annotations
@@ -101,6 +102,148 @@ class _ResNet(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
+# ---- torchvision.models.swin_transformer (V1), attribute for attribute ------------------------------
+class _SwinMLP(nn.Sequential):          # torchvision.ops.MLP: Linear, GELU, Dropout, Linear, Dropout -> keys mlp.0.*, mlp.3.*
+    def __init__(self, dim: int):
+        super().__init__(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Dropout(0.0), nn.Linear(4 * dim, dim), nn.Dropout(0.0))
+
+
+class _ShiftedWindowAttention(nn.Module):
+    def __init__(self, dim: int, window: int, shift: int, heads: int):
+        super().__init__()
+        self.window, self.shift, self.heads = window, shift, heads
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window - 1) ** 2, heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        coords = torch.stack(torch.meshgrid(torch.arange(window), torch.arange(window), indexing="ij")).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += window - 1
+        rel[:, :, 1] += window - 1
+        rel[:, :, 0] *= 2 * window - 1
+        self.register_buffer("relative_position_index", rel.sum(-1).flatten())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:   # (B, H, W, C)
+        B, H, W, C = x.shape
+        w = self.window
+        pad_r, pad_b = (w - W % w) % w, (w - H % w) % w
+        x = nn.functional.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        _, pH, pW, _ = x.shape
+        sh = [0 if w >= pH else self.shift, 0 if w >= pW else self.shift]   # no shift when the window covers the map
+        if sum(sh) > 0:
+            x = torch.roll(x, shifts=(-sh[0], -sh[1]), dims=(1, 2))
+        nW = (pH // w) * (pW // w)
+        x = x.view(B, pH // w, w, pW // w, w, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, w * w, C)
+        qkv = self.qkv(x).reshape(x.shape[0], x.shape[1], 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * (C // self.heads) ** -0.5, qkv[1], qkv[2]
+        attn = q @ k.transpose(-2, -1)
+        bias = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, -1).permute(2, 0, 1)
+        attn = attn + bias.unsqueeze(0)
+        if sum(sh) > 0:   # tokens that came from different sides of the roll must not see each other
+            mask = x.new_zeros((pH, pW))
+            hs = ((0, -w), (-w, -sh[0]), (-sh[0], None))
+            ws = ((0, -w), (-w, -sh[1]), (-sh[1], None))
+            count = 0
+            for h0, h1 in hs:
+                for w0, w1 in ws:
+                    mask[h0:h1, w0:w1] = count
+                    count += 1
+            mask = mask.view(pH // w, w, pW // w, w).permute(0, 2, 1, 3).reshape(nW, w * w)
+            mask = mask.unsqueeze(1) - mask.unsqueeze(2)
+            mask = mask.masked_fill(mask != 0, -100.0).masked_fill(mask == 0, 0.0)
+            attn = attn.view(B, nW, self.heads, w * w, w * w) + mask.unsqueeze(1).unsqueeze(0)
+            attn = attn.view(-1, self.heads, w * w, w * w)
+        x = (attn.softmax(dim=-1) @ v).transpose(1, 2).reshape(B * nW, w * w, C)
+        x = self.proj(x)
+        x = x.view(B, pH // w, pW // w, w, w, C).permute(0, 1, 3, 2, 4, 5).reshape(B, pH, pW, C)
+        if sum(sh) > 0:
+            x = torch.roll(x, shifts=(sh[0], sh[1]), dims=(1, 2))
+        return x[:, :H, :W, :].contiguous()
+
+
+class _StochasticDepth(nn.Module):       # torchvision.ops.StochasticDepth(p, "row")
+    def __init__(self, p: float):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = 1.0 - self.p
+        noise = torch.empty([x.shape[0]] + [1] * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+        return x * noise.div_(keep)
+
+
+class _SwinBlock(nn.Module):
+    def __init__(self, dim, heads, window, shift, sd_prob):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5)
+        self.attn = _ShiftedWindowAttention(dim, window, shift, heads)
+        self.stochastic_depth = _StochasticDepth(sd_prob)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5)
+        self.mlp = _SwinMLP(dim)
+
+    def forward(self, x):
+        x = x + self.stochastic_depth(self.attn(self.norm1(x)))
+        return x + self.stochastic_depth(self.mlp(self.norm2(x)))
+
+
+class _PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim, eps=1e-5)
+
+    def forward(self, x):   # (B, H, W, C) -> (B, H/2, W/2, 2C)
+        H, W = x.shape[1:3]
+        x = nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[..., 0::2, 0::2, :], x[..., 1::2, 0::2, :], x[..., 0::2, 1::2, :], x[..., 1::2, 1::2, :]], -1)
+        return self.reduction(self.norm(x))
+
+
+class _Permute(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+    def forward(self, x):
+        return x.permute(*self.dims)
+
+
+class _SwinTransformer(nn.Module):
+    """torchvision.models.swin_t / swin_s (patch 4, embed 96, heads 3-6-12-24, window 7), same ``state_dict`` keys."""
+
+    def __init__(self, depths, sd_prob):
+        super().__init__()
+        dim, heads, window = 96, (3, 6, 12, 24), 7
+        layers = [nn.Sequential(nn.Conv2d(3, dim, kernel_size=4, stride=4), _Permute([0, 2, 3, 1]), nn.LayerNorm(dim, eps=1e-5))]
+        total, idx = sum(depths), 0
+        for stage, depth in enumerate(depths):
+            d = dim * 2 ** stage
+            blocks = []
+            for i in range(depth):
+                blocks.append(_SwinBlock(d, heads[stage], window, 0 if i % 2 == 0 else window // 2, sd_prob * idx / (total - 1.0)))
+                idx += 1
+            layers.append(nn.Sequential(*blocks))
+            if stage < len(depths) - 1:
+                layers.append(_PatchMerging(d))
+        self.features = nn.Sequential(*layers)
+        num_features = dim * 2 ** (len(depths) - 1)
+        self.norm = nn.LayerNorm(num_features, eps=1e-5)
+        self.permute = _Permute([0, 3, 1, 2])
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.flatten = nn.Flatten(1)
+        self.head = nn.Linear(num_features, 1000)
+        for m in self.modules():   # torchvision: every Linear trunc_normal(0.02), zero bias
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        return self.head(self.flatten(self.avgpool(self.permute(self.norm(self.features(x))))))
+
+
 class AbstractImageEncoder(nn.Module):
     encoder: nn.Module
 
@@ -144,10 +287,24 @@ class TransformerImageSequenceEncoder(nn.Module):
         return self.transformer_encoder(self.image_encoder(x).contiguous())
 
 
+class SwinTransformerImageEncoder(AbstractImageEncoder):
+    def __init__(self, swin_type: ImageEncoderType, hidden_dim: int):
+        super().__init__()
+        if swin_type == ImageEncoderType.SWIN_TRANSFORMER_TINY:
+            self.encoder = _SwinTransformer((2, 2, 6, 2), 0.2)
+        elif swin_type == ImageEncoderType.SWIN_TRANSFORMER_SMALL:
+            self.encoder = _SwinTransformer((2, 2, 18, 2), 0.3)
+        else:
+            raise ValueError(f"Invalid Swin Transformer type: {swin_type}")
+        self.encoder.head = nn.Linear(self.encoder.head.in_features, hidden_dim)
+
+
 def image_encoder_factory(encoder_type: ImageEncoderType, hidden_dim: int, use_final_avgpool: bool, resolution: int):
     if encoder_type in (ImageEncoderType.RESNET18, ImageEncoderType.RESNET50):
         return ResNetImageEncoder(encoder_type, hidden_dim, use_final_avgpool, resolution)
-    raise NotImplementedError("the Swin image encoders are not available (torchvision is absent; SURVEY §8 f2)")
+    if encoder_type in (ImageEncoderType.SWIN_TRANSFORMER_TINY, ImageEncoderType.SWIN_TRANSFORMER_SMALL):
+        return SwinTransformerImageEncoder(encoder_type, hidden_dim)
+    raise ValueError(f"Invalid image encoder type: {encoder_type}")
 
 
 def image_sequence_encoder_factory(encoder_type: SequenceEncoderType, image_encoder_type: ImageEncoderType, hidden_dim: int,

@@ -169,3 +169,23 @@ def test_image_encoder_state_dict_keys_follow_torchvision():
     assert backbone == 11_176_512  # torchvision resnet18 without its classifier
     r50 = ResNetImageEncoder(ImageEncoderType.RESNET50, 64, True, 224)
     assert sum(p.numel() for p in r50.parameters()) == 23_508_032 + 2048 * 64 + 64
+
+
+def test_swin_image_encoders_follow_torchvision():
+    """swin_t / swin_s restated (image.py:84-98): torchvision's parameter counts and state_dict keys, head -> hidden_dim."""
+    import torch
+
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+    t = image_encoder_factory(ImageEncoderType.SWIN_TRANSFORMER_TINY, 64, True, 224).eval()
+    assert sum(p.numel() for p in t.parameters()) == 28_288_354 - (768 * 1000 + 1000) + 768 * 64 + 64
+    keys = set(t.state_dict())
+    for k in ("encoder.features.0.0.weight", "encoder.features.0.2.bias", "encoder.features.1.1.attn.relative_position_bias_table",
+              "encoder.features.1.1.attn.relative_position_index", "encoder.features.3.0.attn.qkv.weight", "encoder.features.5.5.mlp.3.bias",
+              "encoder.features.6.reduction.weight", "encoder.features.7.1.norm2.weight", "encoder.norm.weight", "encoder.head.bias"):
+        assert k in keys, k
+    with torch.no_grad():
+        y = t(torch.randn(1, 2, 3, 96, 96))   # 96 / 4 = 24 = windows of 7 with padding; later stages smaller than a window
+    assert y.shape == (1, 2, 64) and torch.isfinite(y).all()
+    s = image_encoder_factory(ImageEncoderType.SWIN_TRANSFORMER_SMALL, 64, True, 224)
+    assert sum(p.numel() for p in s.parameters()) == 49_606_258 - (768 * 1000 + 1000) + 768 * 64 + 64

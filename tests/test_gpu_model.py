@@ -99,12 +99,14 @@ def test_scheduler_loop_equals_native_sampler(g1):
     assert rel_err(sched.add_noise(x, noise.cuda(), tt.cuda()), ddim_ref.add_noise(g1["x"], noise, tt, ddim_ref.alphas_cumprod())) < 1e-6
 
 
-def test_swin_image_encoder_is_rejected_loudly(g1):
+def test_swin_image_encoder_builds(g1):
     from soccerdiffusion_amd.ml.model import End2EndDiffusionTransformer
     from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
     from soccerdiffusion_amd.ml.model.encoder.imu import IMUEncoder
 
-    with pytest.raises(NotImplementedError):
-        End2EndDiffusionTransformer(20, 64, False, 1, 20, 5, False, IMUEncoder.OrientationEmbeddingMethod.QUATERNION, 1, 20,
+    m = End2EndDiffusionTransformer(20, 128, False, 1, 20, 5, False, IMUEncoder.OrientationEmbeddingMethod.QUATERNION, 1, 20,
                                     False, 1, 20, True, ImageEncoderType.SWIN_TRANSFORMER_TINY, SequenceEncoderType.TRANSFORMER,
-                                    1, 10, True, 480, False, 2, 16)
+                                    1, 3, True, 96, False, 2, 16).cuda().eval()
+    with torch.no_grad():
+        ctx = m.encode_input_data({"image_data": torch.rand(2, 3, 3, 96, 96, device="cuda")})
+    assert [tuple(c.shape) for c in ctx] == [(2, 3, 128)] and torch.isfinite(ctx[0]).all()
