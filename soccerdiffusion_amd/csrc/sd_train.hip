@@ -7,6 +7,8 @@
 // (add_noise, forward, F.mse_loss, backward, AdamW.step, OneCycleLR.step) at dropout p=0.
 
 #include <math.h>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/soccerdiffusion_hip.h"
 #include "sd_common.h"
@@ -124,6 +126,142 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
     }
 }
 
+// --------------------------------------------------------------------------------------
+// The same product on the fp16 pipe.  The contraction runs over the rows, so an operand scale must be
+// constant over everything that is summed into one accumulator - and gradients have no a-priori magnitude.  Each wave
+// therefore works in sub-chunks of 32 rows: abs-max of the 32 x 64 values of each operand it holds anyway (a wave-wide
+// reduction), two power-of-two scales, split into fp16 hi + lo, 24 fp16 MFMAs into a zero-initialised sub-accumulator,
+// which is then added - un-scaled - to the fp32 accumulator of the whole chunk (block floating point per 32 rows).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                                            float *dW, int ldw, float *db, long R, int N, int K) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = (K + 127) / 128;
+    const int n0 = (blockIdx.x / tiles_k) * 128 + wm * 64;
+    const int k0 = (blockIdx.x % tiles_k) * 128 + wn * 64;
+    const long rbeg = (long)blockIdx.y * TN_RC;
+    long rend = rbeg + TN_RC;
+    if (rend > R) rend = R;
+    if (n0 >= N || k0 >= K) return;  // wave-uniform: this wave's 64 x 64 block is empty
+
+    int ncol[2], kcol[2];
+    bool nok[2], kok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 32 + l31, k = k0 + t * 32 + l31;
+        nok[t] = n < N;
+        kok[t] = k < K;
+        ncol[t] = nok[t] ? n : 0;
+        kcol[t] = kok[t] ? k : 0;
+    }
+    const bool full_cols = n0 + 64 <= N && k0 + 64 <= K;   // wave-uniform
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (long r = rbeg; r < rend; r += 32) {
+        // this lane's rows of step s (16 rows each): r + 16 s + 8 half + e
+        float a[2][2][8], b[2][2][8];
+        const bool full_rows = r + 32 <= rend;   // wave-uniform
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long row = r + 16 * st + 8 * half + e;
+                const bool ok = full_rows || row < rend;
+                const long rr = ok ? row : rbeg;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[st][t][e] = dY[rr * ldy + ncol[t]];
+                    b[st][t][e] = X[rr * ldx + kcol[t]];
+                }
+                if (!(full_rows && full_cols)) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if (!(ok && nok[t])) a[st][t][e] = 0.f;
+                        if (!(ok && kok[t])) b[st][t][e] = 0.f;
+                    }
+                }
+            }
+        float my = 0.f, mx = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    my = fmaxf(my, fabsf(a[st][t][e]));
+                    mx = fmaxf(mx, fabsf(b[st][t][e]));
+                    if (st == 0 || true) bsum[t] += a[st][t][e];
+                }
+        const float sy = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(my)));
+        const float sx = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(mx)));
+        f32x16 sub[2][2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float va = a[st][t][e] * sy, vb = b[st][t][e] * sx;
+                    ah[t][e] = (f16)va;
+                    al[t][e] = (f16)(va - (float)ah[t][e]);
+                    bh[t][e] = (f16)vb;
+                    bl[t][e] = (f16)(vb - (float)bh[t][e]);
+                }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    if (st == 0) sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], zero16, 0, 0, 0);
+                    else sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], sub[tm][tn], 0, 0, 0);
+                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], sub[tm][tn], 0, 0, 0);
+                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], sub[tm][tn], 0, 0, 0);
+                }
+        }
+        const float un = 1.0f / (sy * sx);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = acc[tm][tn] + sub[tm][tn] * un;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int k = k0 + tn * 32 + l31;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n < N) atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r]);
+            }
+        }
+    if (db && (blockIdx.x % tiles_k) == 0 && wn == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const float v = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);
+            const int n = n0 + tm * 32 + l31;
+            if (half == 0 && n < N) atomicAdd(db + n, v);
+        }
+    }
+}
+
 extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,
                              int N, int K, void *stream) {
     if (!dY || !X || !dW || R <= 0 || N <= 0 || K <= 0 || ldy < N || ldx < K || ldw < K)
@@ -131,7 +269,9 @@ extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
     dim3 grid(((N + 127) / 128) * ((K + 127) / 128), (unsigned)((R + TN_RC - 1) / TN_RC));
-    SD_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    static const char *env = getenv("SD_GEMM_TN");   // "f32": the fp32-MFMA kernel (A/B runs)
+    if (env && strcmp(env, "f32") == 0) SD_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    else SD_LAUNCH(gemm_tn16_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
     SD_CHECK_LAUNCH("gemm_tn_kernel");
     return 0;
 }
