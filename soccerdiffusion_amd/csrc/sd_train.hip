@@ -1,7 +1,7 @@
 // Training-side kernels (backward of the denoiser blocks, loss, optimizer) for gfx950.
 // Interface: include/soccerdiffusion_hip.h ("training" section).  Same fragment maps and
-// conventions as sd_kernels.hip; fp32 MFMA throughout (the forward and dX row GEMMs of a training step go
-// through linear() and therefore run on the split-fp16 kernel of sd_f16x3.h).
+// conventions as sd_kernels.hip; fp32 MFMA except the weight-gradient GEMM (gemm_tn16_kernel below); the forward
+// and dX row GEMMs of a training step go through linear() and run on the split-fp16 kernel of sd_f16x3.h.
 //
 // Reference semantics: one training step of soccer_diffusion/ml/training/train.py:204-240
 // (add_noise, forward, F.mse_loss, backward, AdamW.step, OneCycleLR.step) at dropout p=0.
