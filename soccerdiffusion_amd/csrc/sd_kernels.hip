@@ -2199,9 +2199,10 @@ __global__ __launch_bounds__(256) void xattn_fold_kernel(const float *__restrict
                                                          const float *__restrict__ wq, const float *__restrict__ bq,
                                                          const float *__restrict__ wo, float *__restrict__ gv,
                                                          float *__restrict__ cb, long item_rows, int head_rows, int key0,
-                                                         int D, int HD) {
+                                                         int D, int HD, unsigned *maxG, unsigned *maxV) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *Ks = sm, *Vs = sm + FOLD_RB * HD;
+    float mg = 0.f, mv = 0.f;   // abs-max of what this thread writes (the fp16x3 path derives its scales from them)
     const int h = blockIdx.y;
     const long r0 = (long)blockIdx.x * FOLD_RB;
     for (int i = threadIdx.x; i < FOLD_RB * HD; i += 256) {
@@ -2239,7 +2240,10 @@ __global__ __launch_bounds__(256) void xattn_fold_kernel(const float *__restrict
         }
 #pragma unroll
         for (int r = 0; r < FOLD_RB; ++r)
-            if (r0 + r < n_rows) gv[dst[r] * 2 * D + n] = acc[r];
+            if (r0 + r < n_rows) {
+                gv[dst[r] * 2 * D + n] = acc[r];
+                mg = fmaxf(mg, fabsf(acc[r]));
+            }
 #pragma unroll
         for (int r = 0; r < FOLD_RB; ++r) acc[r] = 0.f;
         for (int j = 0; j < HD; j += 4) {
@@ -2252,7 +2256,21 @@ __global__ __launch_bounds__(256) void xattn_fold_kernel(const float *__restrict
         }
 #pragma unroll
         for (int r = 0; r < FOLD_RB; ++r)
-            if (r0 + r < n_rows) gv[dst[r] * 2 * D + D + n] = acc[r];
+            if (r0 + r < n_rows) {
+                gv[dst[r] * 2 * D + D + n] = acc[r];
+                mv = fmaxf(mv, fabsf(acc[r]));
+            }
+    }
+    if (maxG) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+            mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(maxG, __builtin_bit_cast(unsigned, mg));
+            atomicMax(maxV, __builtin_bit_cast(unsigned, mv));
+        }
     }
 }
 
@@ -2513,8 +2531,7 @@ static f16 *f16_wf(const Scratch &s, int l, int d, int which) {   // which: 0 Wo
 static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
     const int d = w->d, L = w->L;
     const size_t gvstride = (size_t)B * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
-    hipError_t e = hipMemsetAsync(s.maxbits, 0, (size_t)(L + 1) * 8 * sizeof(unsigned), st);
-    if (e != hipSuccess) return fail((int)e, "f16_prepare: hipMemsetAsync failed");
+    hipError_t e = hipSuccess;   // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' there
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
@@ -2524,14 +2541,6 @@ static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, in
             SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)rows[m] * d)), dim3(256), 0, st, mats[m], (long)rows[m] * d, mb + m);
             SD_CHECK_LAUNCH("f16_absmax_kernel");
         }
-        if (Mc > 0) {
-            SD_LAUNCH(f16_absmax_gv_kernel, dim3(grid_for((long)B * 64 * 2 * d)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * 64, d,
-                      mb + 4, mb + 5);
-            SD_CHECK_LAUNCH("f16_absmax_gv_kernel");
-        }
-        SD_LAUNCH(f16_absmax_gv_kernel, dim3(grid_for((long)n_steps * 4 * 2 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride,
-                  (long)n_steps * 4, d, mb + 4, mb + 5);
-        SD_CHECK_LAUNCH("f16_absmax_gv_kernel");
     }
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
@@ -2739,6 +2748,7 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         const int hd = d / 4;
         const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
         hipError_t e = hipMemsetAsync(s.gv, 0, L * gvstride * sizeof(float), st);   // unused key slots must be finite
+        if (e == hipSuccess && f16) e = hipMemsetAsync(s.maxbits, 0, (size_t)(L + 1) * 8 * sizeof(unsigned), st);   // abs-max words
         if (e == hipSuccess) e = hipMemsetAsync(s.cb, 0, L * cbstride * sizeof(float), st);
         if (e != hipSuccess) return fail((int)e, "sd_ddim_sample: hipMemsetAsync failed");
         for (int l = 0; l < L; ++l) {
@@ -2747,12 +2757,14 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
                 const long rows = (long)B * Mc;
                 SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((rows + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st,
                           s.kvtmp + (size_t)l * B * Mc * 2 * d, rows, Mc, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w,
-                          s.gv + l * gvstride, s.cb + l * cbstride, 64L, 16, 0, d, hd);
+                          s.gv + l * gvstride, s.cb + l * cbstride, 64L, 16, 0, d, hd, f16 ? s.maxbits + l * 8 + 4 : (unsigned *)nullptr,
+                          f16 ? s.maxbits + l * 8 + 5 : (unsigned *)nullptr);
                 SD_CHECK_LAUNCH("xattn_fold_kernel");
             }
             SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((n_steps + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st,
                       s.kvstep + (size_t)l * kvsstride, (long)n_steps, 1, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w,
-                      s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd);
+                      s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd, f16 ? s.maxbits + l * 8 + 4 : (unsigned *)nullptr,
+                      f16 ? s.maxbits + l * 8 + 5 : (unsigned *)nullptr);
             SD_CHECK_LAUNCH("xattn_fold_kernel");
         }
         if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
