@@ -245,7 +245,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if lib.sd_sampler_mode(D, HEADS, T, MC, J) != 2 else
                      "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate: 22-bit operands; "
-                     "50-step rollout error vs the fp64 oracle 4e-7, the fp32 CPU oracle's own 3.6e-7)",
+                     "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE.json configs[2]: 50-step DDIM sampling, B=%d parallel rollouts per GPU, "
