@@ -51,7 +51,7 @@ def executed_flops_per_traj():
     head = 2 * T * J * D + 6 * T * D * D                                                 # decoder_head_kernel
     attn = L * 4 * T * T * D                                                             # self-attention cores
     once = L * 8 * MC * D * D
-    return {"layer_chain": layer_chain, "step": layer_chain + head + attn, "once": once,
+    return {"layer_chain": layer_chain, "head": head, "step": layer_chain + head + attn, "once": once,
             "rollout": N_DDIM * (layer_chain + head + attn) + once}
 
 
@@ -182,13 +182,19 @@ def main():
         # (executed_flops_per_traj): `achieved` counts the FLOPs the kernel really executes, not the reference's.
         ex = executed_flops_per_traj()
         per_traj_step_dl = ex["layer_chain"]
+        mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
+        # mode 2 runs the head of steps 1.. inside the previous step's last layer launch: those FLOPs and
+        # bytes belong to this kernel class
+        merged = mode == 2 and os.environ.get("SD_MERGE_HEAD", "1") != "0"
+        if merged:
+            per_traj_step_dl += ex["head"] * (N_DDIM - 1) / N_DDIM
+        tail_units = 2 + (4 * (N_DDIM - 1) / N_DDIM if merged else 0)   # a, h in (+ h, q|k|v out), in units of B T d floats
         dl_flops = args.steps * B * N_DDIM * per_traj_step_dl
         dl_s = ms[dl] / 1e3
         achieved = dl_flops / dl_s / 1e12
         total_flops = args.steps * B * N_DDIM * f["total"]
         # mode 2: every product of the layer chain is 3 v_mfma_f32_32x32x16_f16 on split (hi + lo) operands:
         # the matrix pipe executes 3x the algorithmic FLOPs, priced against the fp16 MFMA peak; fc_out (2TdJ) stays fp32
-        mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
         peak, kernel_name, mfma_factor = PEAK_F32_MFMA_TFLOPS, "decoder_layer_kernel<256>", 1.0
         if mode == 2:
             peak, kernel_name, mfma_factor = PEAK_F16_MFMA_TFLOPS, "decoder_layer_f16_kernel<256>", 3.0
@@ -213,9 +219,10 @@ def main():
             # layer writes x only) and read each trajectory's folded cross-attention blocks once
             "hbm": (lambda by: {"algorithmic_bytes_per_launch_avg": by, "achieved": round(by / (dl_s / max(int(cnt[dl]), 1)) / 1e9, 1),
                                 "peak": 8000.0, "unit": "GB/s", "frac": round(by / (dl_s / max(int(cnt[dl]), 1)) / 8e12, 4)})(
-                B * T * D * 4 * ((L - 1) * 6 + 2) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)),
+                B * T * D * 4 * ((L - 1) * 6 + tail_units) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)),
             "executed_mfma_flops_per_algorithmic_flop": mfma_factor,
             "traffic": pmc,
+            "next_step_head_merged_into_last_layer": bool(merged),
             "launches": int(cnt[dl]),
             "avg_launch_ms": round(ms[dl] / max(int(cnt[dl]), 1), 5),
             "flops_per_launch_avg": dl_flops / max(int(cnt[dl]), 1),

@@ -449,6 +449,15 @@ __device__ __forceinline__ void f16_store_qkv(float *qkv, int which, int T, cons
             }
 }
 
+// head of a step: h = x Wemb^T + b + pe on the fp32 MFMA (K = J), then qkv = LN1(h) Wqkv^T + b of layer 0 on the fp16 pipe
+struct F16HeadArgs {
+    DecoderHeadArgs g;
+    const f16 *wf_qkv;
+    const float *sc;     // sc[3] = scale of layer 0's in_proj
+    int qkv_head_major;
+    int h_frag;
+};
+
 struct F16LayerArgs {
     DecoderLayerArgs g;                       // fp32 pointers (h, a, qkv, biases, LN parameters, cb, tail); g.gv unused
     const f16 *wf_o, *wf_1, *wf_2, *wf_qkv;   // split fragment-major weights (wf_qkv: next layer's in_proj, 3 passes)
@@ -458,6 +467,8 @@ struct F16LayerArgs {
     const float *cstep;                       // 4 score biases of the step token
     int qkv_head_major;                       // layout of g.b.qkv (f16_store_qkv) - what attention_f16_head_kernel reads
     int h_frag;                               // g.a.h is in accumulator order (f16_load_h / f16_store_h)
+    int next_head;                            // last layer only: go on with the NEXT step's head on the updated x (head.g.x unused)
+    F16HeadArgs head;
 };
 
 struct F16Scores {
@@ -714,8 +725,19 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
         chain_acc_to_lds<D>(sA, H, p);                        // fp32 rows: fc_out (+ DDIM) stays on the fp32 path
         __syncthreads();
         SD_STAMP(g.slot, 11);
-        panel_fc_out<D>(sA, g, p);
+        if (!fa.next_head) {
+            panel_fc_out<D>(sA, g, p);
+            SD_STAMP(g.slot, 12);
+            return;
+        }
+        // the updated x rows stay in LDS (behind the K-half exchange area, 68 floats per row) and the next step's head
+        // follows at once: no launch, no x round trip, no second ramp-up
+        constexpr int XP = 68;
+        float *xs = sA + 4096;
+        f16_prime<D>(ring, fa.head.wf_qkv + wOff, loff);
+        panel_fc_out<D>(sA, g, p, xs, XP);
         SD_STAMP(g.slot, 12);
+        f16_head_body<D, true>(fa.head, sA, xs, XP, p, ring);
         return;
     } else {
         const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
@@ -743,49 +765,22 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
     }
 }
 
-// head of a step: h = x Wemb^T + b + pe on the fp32 MFMA (K = J), then qkv = LN1(h) Wqkv^T + b of layer 0 on the fp16 pipe
-struct F16HeadArgs {
-    DecoderHeadArgs g;
-    const f16 *wf_qkv;
-    const float *sc;     // sc[3] = scale of layer 0's in_proj
-    int qkv_head_major;
-    int h_frag;
-};
-
-// ONE_WRAP: T >= 64, so the positional index of a row wraps at most once inside a 64-row panel
+// ONE_WRAP: T >= 64, so the positional index of a row wraps at most once inside a 64-row panel.
+// Everything of the head after its x rows sit in LDS (fp32, xs[row * xpitch + j], zero-padded to a multiple of 8 columns);
+// ring: primed with the first fragments of wf_qkv.
 template <int D, bool ONE_WRAP>
-__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kernel(F16HeadArgs fa) {
+__device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, const float *xs, int xpitch, const ChainPos<D> &p,
+                                              F16Ring<D> &ring) {
     using C = PanelCfg<D>;
     constexpr int NK = D / 16, ROWP = 2 * C::LDA;
     constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;
     const DecoderHeadArgs &g = fa.g;
-    extern __shared__ __attribute__((aligned(16))) float sA[];
-    const ChainPos<D> p(g.R);
-    const float *aBase = sA + (p.wm * C::WM + p.l31) * C::LDA + 4 * p.half;
+    const float *aBase = xs + (p.wm * C::WM + p.l31) * xpitch + 4 * p.half;
     const f16 *aH = reinterpret_cast<const f16 *>(sA) + (p.wm * C::WM + p.l31) * ROWP + 8 * p.half;
-    const long wOff = (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM;   // wave-uniform: scalar base + 32-bit lane offset
+    const long wOff = (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM;
     const unsigned loff = (unsigned)p.lane * 8;
     const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc[3]);
-    F16Ring<D> ring;
-    f16_prime<D>(ring, fa.wf_qkv + wOff, loff);
     const int J = g.J, Jp = (J + 7) & ~7;   // <= 64
-    SD_STAMP(SD_STAMP_HEAD_SLOT, 0);
-    // x rows -> panel (fp32, K = J zero-padded), 4 loads in flight per thread and round trip
-    for (int i0 = threadIdx.x; i0 < C::BM * Jp; i0 += 4 * 256) {
-        float xv[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + b * 256;
-            const int row = i / Jp, j = i - row * Jp;
-            xv[b] = (i < C::BM * Jp && row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = i0 + b * 256;
-            const int row = i / Jp, j = i - row * Jp;
-            if (i < C::BM * Jp) sA[row * C::LDA + j] = xv[b];
-        }
-    }
     // embedding weights of all k-steps (J <= 64: at most 8) requested up front
     f32x4 ew[8][C::TN];
 #pragma unroll
@@ -806,7 +801,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         if (ks * 8 >= Jp) break;
         f32x4 af[C::TM];
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * C::LDA + ks * 8);
+        for (int tm = 0; tm < C::TM; ++tm) af[tm] = *reinterpret_cast<const f32x4 *>(aBase + tm * 32 * xpitch + ks * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -857,6 +852,37 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kern
         }
         SD_STAMP(SD_STAMP_HEAD_SLOT, 6 + 2 * pass);
     }
+}
+
+template <int D, bool ONE_WRAP>
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_head_f16_kernel(F16HeadArgs fa) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16;
+    constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;
+    const DecoderHeadArgs &g = fa.g;
+    extern __shared__ __attribute__((aligned(16))) float sA[];
+    const ChainPos<D> p(g.R);
+    F16Ring<D> ring;
+    f16_prime<D>(ring, fa.wf_qkv + (long)__builtin_amdgcn_readfirstlane(p.wn) * WSTREAM, (unsigned)p.lane * 8);
+    const int J = g.J, Jp = (J + 7) & ~7;   // <= 64
+    SD_STAMP(SD_STAMP_HEAD_SLOT, 0);
+    // x rows -> panel (fp32, K = J zero-padded), 4 loads in flight per thread and round trip
+    for (int i0 = threadIdx.x; i0 < C::BM * Jp; i0 += 4 * 256) {
+        float xv[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + b * 256;
+            const int row = i / Jp, j = i - row * Jp;
+            xv[b] = (i < C::BM * Jp && row < p.R_left && j < J) ? g.x[(p.r0 + row) * J + j] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + b * 256;
+            const int row = i / Jp, j = i - row * Jp;
+            if (i < C::BM * Jp) sA[row * C::LDA + j] = xv[b];
+        }
+    }
+    f16_head_body<D, ONE_WRAP>(fa, sA, sA, C::LDA, p, ring);
 }
 
 // ---------------------------------------------------------------------------------------------------

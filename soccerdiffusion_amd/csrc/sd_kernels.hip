@@ -990,8 +990,11 @@ __device__ __forceinline__ void panel_folded_pv(f32x16 (&H)[PanelCfg<D>::TM][Pan
 }
 
 // fc_out (d -> J <= 64) + DDIM update on the panel that holds the final h (see fc_out_kernel)
+// x_lds (optional): the updated x rows are also left in LDS at x_lds[row * x_pitch + j] (zero elsewhere up to column 64),
+// for a kernel that goes on with the next step's embedding
 template <int D>
-__device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &g, const ChainPos<D> &p) {
+__device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &g, const ChainPos<D> &p, float *x_lds = nullptr,
+                                             int x_pitch = 0) {
     using C = PanelCfg<D>;
     constexpr int KH = D / 2;
     const int tm = p.wave & 1, kh = p.wave >> 1;
@@ -1028,6 +1031,8 @@ __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &
         }
     }
     __syncthreads();  // panel consumed: reuse it for the K-half exchange
+    if (x_lds)
+        for (int i = threadIdx.x; i < C::BM * x_pitch; i += 256) x_lds[i] = 0.f;
     if (kh == 1) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
@@ -1059,7 +1064,9 @@ __device__ __forceinline__ void panel_fc_out(float *sA, const DecoderLayerArgs &
                 if (g.eps) g.eps[(p.r0 + row) * J + j] = e;
                 if (xb) {
                     const float x0 = (xv[r] - g.c1 * e) / g.c0;
-                    xb[(unsigned)(row * J + j)] = g.c2 * x0 + g.c3 * e;
+                    const float xn = g.c2 * x0 + g.c3 * e;
+                    xb[(unsigned)(row * J + j)] = xn;
+                    if (x_lds) x_lds[row * x_pitch + j] = xn;
                 }
             }
         }
@@ -2597,7 +2604,11 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
     const int hfrag = !(henv && strcmp(henv, "rows") == 0);
     F16HeadArgs fh{DecoderHeadArgs{x, w->emb_w, w->emb_b, w->pe, l0.n1_w, l0.n1_b, l0.sa_in_w, l0.sa_in_b, s.h, s.qkv, R, T, w->J},
                    f16_wf(s, 0, d, 3), s.scales, hm ? 1 : 0, hfrag};
-    int rc = decoder_head_f16(fh, st);
+    // the head of steps 1.. runs inside the previous step's last layer kernel (SD_MERGE_HEAD=0: always its own launch; A/B runs)
+    static const char *menv = getenv("SD_MERGE_HEAD");
+    const bool merge = !(menv && strcmp(menv, "0") == 0) && T >= 64 && w->J <= 64;
+    int rc = 0;
+    if (i == 0 || !merge) rc = decoder_head_f16(fh, st);
     if (rc) return rc;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
@@ -2618,6 +2629,8 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
             fa.g.fo_b = w->out_b;
             fa.g.x_io = x;
             fa.g.c0 = coef[0]; fa.g.c1 = coef[1]; fa.g.c2 = coef[2]; fa.g.c3 = coef[3];
+            fa.next_head = merge && i + 1 < n_steps;
+            fa.head = fh;
         }
         fa.wf_o = f16_wf(s, l, d, 0);
         fa.wf_1 = f16_wf(s, l, d, 1);
