@@ -76,7 +76,11 @@ if "FETCH_SIZE" in report and "WRITE_SIZE" in report:
     traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_gpu.sh); FETCH_SIZE doubled per the "
                          "gfx950 note in MI355X_MICROARCH.md; KiB units",
                "workload": "bench.py --steps 1 (B=4096)", "dominant_kernel": dom,
-               "decoder_layer_kernel_bytes_per_launch": per[dom]["hbm_bytes_per_launch"] if dom else None, "per_kernel": per}
+               # bench.py's roofline averages over every launch of the layer class: so does this figure
+               "decoder_layer_kernel_bytes_per_launch":
+                   (sum(per[k]["hbm_bytes_per_launch"] * per[k]["dispatches"] for k in layer) / sum(per[k]["dispatches"] for k in layer))
+                   if layer else None,
+               "per_kernel": per}
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("\n== HBM bytes per launch (2 x FETCH + WRITE):")
     for k, v in per.items():
