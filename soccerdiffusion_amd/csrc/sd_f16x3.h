@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
         f16_prime<D>(ring, fa.head.wf_qkv + wOff, loff);
         panel_fc_out<D>(sA, g, p, xs, XP);
         SD_STAMP(g.slot, 12);
-        f16_head_body<D, true>(fa.head, sA, xs, XP, p, ring);
+        f16_head_body<D, true>(fa.head, sA, xs, XP, p, ring, g.slot, 12);
         return;
     } else {
         const float c_q = 1.0f / (F16_ACT_SCALE * fa.sc_next[3]);
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void decoder_layer_f16_ker
 // ring: primed with the first fragments of wf_qkv.
 template <int D, bool ONE_WRAP>
 __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, const float *xs, int xpitch, const ChainPos<D> &p,
-                                              F16Ring<D> &ring) {
+                                              F16Ring<D> &ring, int st_slot = SD_STAMP_HEAD_SLOT, int st_base = 0) {
     using C = PanelCfg<D>;
     constexpr int NK = D / 16, ROWP = 2 * C::LDA;
     constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;
@@ -793,7 +793,7 @@ __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, 
             ew[ks][tn] = t;
         }
     __syncthreads();
-    SD_STAMP(SD_STAMP_HEAD_SLOT, 1);
+    SD_STAMP(st_slot, st_base + 1);
     f32x16 H[C::TM][C::TN];
     chain_zero<D>(H);
 #pragma unroll
@@ -810,7 +810,7 @@ __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, 
                 for (int tn = 0; tn < C::TN; ++tn)
                     H[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], ew[ks][tn][j], H[tm][tn], 0, 0, 0);
     }
-    SD_STAMP(SD_STAMP_HEAD_SLOT, 2);
+    SD_STAMP(st_slot, st_base + 2);
     {   // + bias + positional row.  Position = row index inside its trajectory: ONE modulo per lane, then offsets (< 64 <= T)
         const int pos0 = (int)((p.r0 + p.wm * C::WM + 4 * p.half) % g.T);
 #pragma unroll
@@ -829,7 +829,7 @@ __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, 
                 }
         }
     }
-    SD_STAMP(SD_STAMP_HEAD_SLOT, 3);
+    SD_STAMP(st_slot, st_base + 3);
     if (fa.h_frag) f16_store_h<D>(g.h, H, p);
     else f16_store_acc<D>(g.h, D, 0, H, p);
     __syncthreads();
@@ -837,11 +837,11 @@ __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, 
     __syncthreads();
     f16_layer_norm_to_planes<D>(sA, g.ln_w, g.ln_b, p.lane, p.wave);
     __syncthreads();
-    SD_STAMP(SD_STAMP_HEAD_SLOT, 4);
+    SD_STAMP(st_slot, st_base + 4);
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         f16_gemm<D, true>(H, aH, fa.wf_qkv + (long)pass * C::WAVES_N * WSTREAM + wOff, loff, ring);
-        SD_STAMP(SD_STAMP_HEAD_SLOT, 5 + 2 * pass);
+        SD_STAMP(st_slot, st_base + 5 + 2 * pass);
         if (pass < 2) f16_prime<D>(ring, fa.wf_qkv + (long)(pass + 1) * C::WAVES_N * WSTREAM + wOff, loff);
         f16_unscale<D, false>(H, H, c_q, g.bqkv + pass * D, p);
         if constexpr (C::WN == 64) {
@@ -850,7 +850,7 @@ __device__ __forceinline__ void f16_head_body(const F16HeadArgs &fa, float *sA, 
         } else {
             f16_store_acc<D>(g.qkv, 3 * D, pass * D, H, p);
         }
-        SD_STAMP(SD_STAMP_HEAD_SLOT, 6 + 2 * pass);
+        SD_STAMP(st_slot, st_base + 6 + 2 * pass);
     }
 }
 

@@ -2631,6 +2631,9 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
             fa.g.c0 = coef[0]; fa.g.c1 = coef[1]; fa.g.c2 = coef[2]; fa.g.c3 = coef[3];
             fa.next_head = merge && i + 1 < n_steps;
             fa.head = fh;
+#ifdef SD_STAMPS
+            if (merge && !fa.next_head && n_steps > 1) fa.g.slot = L + 2;   // keep the stamps of the merged launch before it
+#endif
         }
         fa.wf_o = f16_wf(s, l, d, 0);
         fa.wf_1 = f16_wf(s, l, d, 1);

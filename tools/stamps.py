@@ -21,6 +21,9 @@ NAMES = {1: "load a,h", 2: "K out-proj", 3: "bias+LDS+LN2", 4: "K scores", 5: "s
          15: "K k", 16: "store k", 17: "K v", 18: "store v"}
 
 
+# last layer of a step with the next step's head merged in (stamps 13.. = the head's 1.. + 12)
+TAIL_NAMES = {13: "x in LDS + emb weights", 14: "embed MFMA", 15: "+ bias + pe", 16: "h store + LDS + LN1", 17: "K q", 18: "store q",
+              19: "K k", 20: "store k", 21: "K v", 22: "store v"}
 HEAD_NAMES = {1: "x staging + emb weights", 2: "embed MFMA", 3: "+ bias + pe", 4: "h store + LDS + LN1", 5: "K q", 6: "store q",
               7: "K k", 8: "store k", 9: "K v", 10: "store v"}
 ATT_NAMES = {1: "barrier", 2: "stage K/V", 3: "fetch issue + Q split", 4: "barrier", 5: "S MFMAs", 6: "softmax", 7: "P V", 8: "next unit"}
@@ -43,7 +46,7 @@ def main():
     x = torch.randn(B, T, J, device="cuda")
     ctx = torch.randn(B, MC, D, device="cuda")
     wgs = (B * T + 63) // 64
-    buf = torch.zeros(L + 2, max(wgs, B), 4, 32, dtype=torch.int64, device="cuda")   # slot L: head kernel, L+1: attention
+    buf = torch.zeros(L + 3, max(wgs, B), 4, 32, dtype=torch.int64, device="cuda")   # slot L: head kernel, L+1: attention
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())   # warm
     assert fn(buf.data_ptr(), max(wgs, B)) == 0
     ops.ddim_sample(packed, ctx, toks, coef, x.clone())
@@ -66,7 +69,7 @@ def main():
             seg = w0[:, i] - w0[:, prev]
             seg_all = (s[:, :, i] - s[:, :, prev]).max(1).values
             skew = s[:, :, i].max(1).values - s[:, :, i].min(1).values
-            names = HEAD_NAMES if l == L else ATT_NAMES if l == L + 1 else NAMES
+            names = HEAD_NAMES if l == L else ATT_NAMES if l == L + 1 else {**NAMES, **TAIL_NAMES} if l == L - 1 else NAMES
             print(f"   {names.get(i, str(i)):26s} {seg.min():8.0f} {seg.quantile(0.1):8.0f} {seg.median():10.0f} {seg.quantile(0.9):9.0f} "
                   f"{100 * seg.median() / life.median():6.1f}%   {seg_all.median():16.0f}  {skew.median():16.0f}")
             prev = i
