@@ -205,6 +205,11 @@ def main():
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh).get("decoder_layer_kernel_bytes_per_launch")
+        sq = None
+        sq_file = os.path.join(REPO, "profiles", "pmc_sq.json")
+        if os.path.exists(sq_file) and mode == 2:
+            with open(sq_file) as fh:
+                sq = json.load(fh)
         roofline = {
             "bound": "mfma",
             "kernel": kernel_name,
@@ -222,6 +227,10 @@ def main():
                 B * T * D * 4 * ((L - 1) * 6 + tail_units) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)),
             "executed_mfma_flops_per_algorithmic_flop": mfma_factor,
             "traffic": pmc,
+            # the hardware's own count from the committed SQ counter pass (profiles/pmc_sq.json): MFMA-pipe busy cycles over
+            # SIMD-cycles at the clock the kernel really ran at (frac above is priced at the nominal 2.4 GHz)
+            "mfma_busy_pmc": round(sq["decoder_layer_kernel_mfma_busy"], 4) if sq else None,
+            "effective_clock_ghz_pmc": round(sq["decoder_layer_kernel_effective_clock_ghz"], 3) if sq else None,
             "next_step_head_merged_into_last_layer": bool(merged),
             "launches": int(cnt[dl]),
             "avg_launch_ms": round(ms[dl] / max(int(cnt[dl]), 1), 5),
