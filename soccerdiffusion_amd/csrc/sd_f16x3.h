@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
     const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);
     const float c_o = 1.0f / F16_QKV_SCALE;
 
+    SD_STAMP(SD_STAMP_ATT_SLOT, 0);
     // every load of the workgroup is issued before anything is converted
     f32x4 kreg[8], vreg[8], qraw[8];
 #pragma unroll
@@ -1157,6 +1158,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
 #pragma unroll
         for (int i = 0; i < 8; ++i) qraw[i] = *reinterpret_cast<const f32x4 *>(base + qoff + (unsigned)((i >> 1) * 16 + (i & 1) * 4));
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + 256 * i;
@@ -1175,6 +1177,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
             sV[(vc4 * 4 + e) * ATT16H_VP + 128 + vpos] = ll[e];
         }
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 2);
     f16x8 qf[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -1184,7 +1187,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
         qf[ks][0] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         qf[ks][1] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 3);
     __syncthreads();
+    SD_STAMP(SD_STAMP_ATT_SLOT, 4);
     if (wave * 32 >= T) return;   // no barrier follows
     const int kt_valid = (T + 31) / 32;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1213,6 +1218,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
             for (int r = 0; r < 16; ++r) sc[kt][r] = -INFINITY;
         }
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 5);
     {   // keys past T in the last live tile
         const int kt = kt_valid - 1;   // wave-uniform
 #pragma unroll
@@ -1242,6 +1248,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
             sc[kt][r] = pv;
             psum += pv;
         }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 6);
     f32x16 o[2];
     const int n_groups = (T + 15) / 16;   // live 16-key groups
 #pragma unroll
@@ -1266,6 +1273,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
             o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
         }
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 7);
     const float l_tot = psum + __shfl_xor(psum, 32, 64);
     const float inv = c_o / l_tot;
     if (q_ok) {
@@ -1278,6 +1286,192 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
                 *reinterpret_cast<f32x4 *>(op + ft * 32 + 8 * g4 + 4 * half) = t;
             }
     }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 8);
+}
+
+// The same kernel with V^T staged into K's LDS after the scores (one more barrier pair): 34 KB of LDS instead of 68, so
+// 3-4 workgroups per CU instead of 2 keep the HBM queues fed while others compute.
+#ifndef SD_ATT_LV_OCC
+#define SD_ATT_LV_OCC 3
+#endif
+constexpr size_t ATT16LV_LDS = (size_t)(128 * ATT16H_KP > 64 * ATT16H_VP ? 128 * ATT16H_KP : 64 * ATT16H_VP) * sizeof(f16);
+template <bool HM>
+__global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kernel(const float *__restrict__ qkv, int ld_rm, float *__restrict__ out, int ldo,
+                                                                   int T, int heads, float scale_log2e) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) f16 smem16[];
+    f16 *sK = smem16, *sV = smem16;   // V^T takes K's place once the scores are done
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, D = heads * HD;
+    const int qi = wave * 32 + l31;
+    const bool q_ok = qi < T;
+    // workgroup-uniform bases of this head's Q, K, V rows and their row stride
+    const int ld = HM ? HD : ld_rm;
+    const float *base = HM ? qkv + (long)blockIdx.x * 3 * T * HD : qkv + (long)b * T * ld_rm + h * HD;
+    const long k_at = HM ? (long)T * HD : D, v_at = 2 * k_at;
+    const float c_s = scale_log2e / (F16_QKV_SCALE * F16_QKV_SCALE);
+    const float c_o = 1.0f / F16_QKV_SCALE;
+
+    SD_STAMP(SD_STAMP_ATT_SLOT, 0);
+    // every load of the workgroup is issued before anything is converted
+    f32x4 kreg[8], vreg[8], qraw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        const int krow = idx >> 4, kc4 = idx & 15;   // K: 16 pieces per key row
+        const int vrow = idx & 127, vc4 = idx >> 7;  // V: the keys on the lanes (transposed 2-byte LDS writes stay contiguous)
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
+        if (krow < T) a = *reinterpret_cast<const f32x4 *>(base + k_at + (unsigned)(krow * ld + kc4 * 4));
+        if (vrow < T) d = *reinterpret_cast<const f32x4 *>(base + v_at + (unsigned)(vrow * ld + vc4 * 4));
+        kreg[i] = a;
+        vreg[i] = d;
+    }
+    {
+        const unsigned qoff = (unsigned)((q_ok ? qi : 0) * ld + 8 * half);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qraw[i] = *reinterpret_cast<const f32x4 *>(base + qoff + (unsigned)((i >> 1) * 16 + (i & 1) * 4));
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        const int krow = idx >> 4, kc4 = idx & 15;
+        f16x4 hh, ll;
+        f16_split4(kreg[i], F16_QKV_SCALE, hh, ll);
+        *reinterpret_cast<f16x4 *>(sK + krow * ATT16H_KP + kc4 * 4) = hh;
+        *reinterpret_cast<f16x4 *>(sK + krow * ATT16H_KP + HD + kc4 * 4) = ll;
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 2);
+    f16x8 qf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f16x4 h0, l0, h1, l1;
+        f16_split4(qraw[2 * ks], F16_QKV_SCALE, h0, l0);
+        f16_split4(qraw[2 * ks + 1], F16_QKV_SCALE, h1, l1);
+        qf[ks][0] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        qf[ks][1] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 3);
+    __syncthreads();
+    SD_STAMP(SD_STAMP_ATT_SLOT, 4);
+    const bool live = wave * 32 < T;   // a wave without queries still stages V and meets the barriers
+    const int kt_valid = (T + 31) / 32;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 sc[4];
+    if (live) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < kt_valid) {
+            const f16 *kp = sK + (kt * 32 + l31) * ATT16H_KP + 8 * half;
+            f16x8 kf[4][2];   // the tile's 8 fragments in one go: one LDS latency per tile
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks][0] = *reinterpret_cast<const f16x8 *>(kp + ks * 16);
+                kf[ks][1] = *reinterpret_cast<const f16x8 *>(kp + HD + ks * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks == 0) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][1], qf[0][0], zero16, 0, 0, 0);
+                else sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qf[ks][0], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][1], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][0], sc[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = -INFINITY;
+        }
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 5);
+    {   // keys past T in the last live tile
+        const int kt = kt_valid - 1;   // wave-uniform
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+            if (t4 == kt && (T & 31)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t4 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= T) sc[t4][r] = -INFINITY;
+            }
+    }
+    }
+    __syncthreads();   // every wave has its scores: K's LDS is free
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;
+        const int vrow = idx & 127, vc4 = idx >> 7;
+        f16x4 hh, ll;
+        f16_split4(vreg[i], F16_QKV_SCALE, hh, ll);
+        const int k16 = vrow & 15;   // key position inside its 16-key group: the 8 k-slots of a lane half contiguous
+        const int vpos = (vrow & ~15) + (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sV[(vc4 * 4 + e) * ATT16H_VP + vpos] = hh[e];
+            sV[(vc4 * 4 + e) * ATT16H_VP + 128 + vpos] = ll[e];
+        }
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 6);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float m01, m23;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m01) : "v"(m), "v"(sc[0][r]), "v"(sc[1][r]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m23) : "v"(m01), "v"(sc[2][r]), "v"(sc[3][r]));
+        m = m23;
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = m * c_s - 10.0f;   // the 2^10 of F16_P_SCALE rides in the exponent
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sc[kt][r] * c_s - mb);
+            sc[kt][r] = pv;
+            psum += pv;
+        }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 7);
+    __syncthreads();   // V^T staged by everyone
+    if (!live) return;
+    f32x16 o[2];
+    const int n_groups = (T + 15) / 16;   // live 16-key groups
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) {
+        if (gg >= n_groups) break;   // wave-uniform
+        const int kt = gg >> 1, j2 = gg & 1;
+        f16x8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = sc[kt][8 * j2 + e];
+            ph[e] = (f16)t;
+            pl[e] = (f16)(t - (float)ph[e]);
+        }
+        const f16 *vp = sV + l31 * ATT16H_VP + gg * 16 + 8 * half;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const f16x8 vh = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16H_VP);
+            const f16x8 vl = *reinterpret_cast<const f16x8 *>(vp + ft * 32 * ATT16H_VP + 128);
+            if (gg == 0) o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, zero16, 0, 0, 0);
+            else o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[ft], 0, 0, 0);
+            o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[ft], 0, 0, 0);
+            o[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[ft], 0, 0, 0);
+        }
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 8);
+    const float l_tot = psum + __shfl_xor(psum, 32, 64);
+    const float inv = c_o / l_tot;
+    if (q_ok) {
+        float *op = out + ((long)b * T + qi) * ldo + h * HD;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t = {o[ft][4 * g4] * inv, o[ft][4 * g4 + 1] * inv, o[ft][4 * g4 + 2] * inv, o[ft][4 * g4 + 3] * inv};
+                *reinterpret_cast<f32x4 *>(op + ft * 32 + 8 * g4 + 4 * half) = t;
+            }
+    }
+    SD_STAMP(SD_STAMP_ATT_SLOT, 9);
 }
 
 // ---------------------------------------------------------------------------------------------------

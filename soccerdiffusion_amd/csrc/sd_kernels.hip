@@ -674,7 +674,7 @@ __device__ unsigned long long *g_stamp_buf = nullptr;
 __device__ long g_stamp_wgs = 0;
 #define SD_STAMP(slot, i)                                                                                              \
     do {                                                                                                               \
-        if ((threadIdx.x & 63) == 0 && g_stamp_buf)                                                                    \
+        if ((threadIdx.x & 63) == 0 && g_stamp_buf && blockIdx.x < g_stamp_wgs)                                        \
             g_stamp_buf[(((long)(slot) * g_stamp_wgs + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 32 + (i)] =             \
                 __builtin_amdgcn_s_memtime();                                                                          \
     } while (0)
@@ -1375,10 +1375,18 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
 static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s, bool head_major) {
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
-    static const char *env = getenv("SD_ATT16");   // "stream": the per-sample streaming kernel (A/B runs)
+    // default: one workgroup per (sample, head), V^T staged late into K's LDS (35 KB of LDS, 3 workgroups per CU);
+    // A/B runs: "stage2" = K and V^T staged together (69 KB, 2 per CU), "stream" = the per-sample streaming kernel
+    static const char *env = getenv("SD_ATT16");
     if (!head_major && env && strcmp(env, "stream") == 0) {
         SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
         SD_CHECK_LAUNCH("attention_f16_kernel");
+        return 0;
+    }
+    if (!(env && strcmp(env, "stage2") == 0)) {
+        if (head_major) SD_LAUNCH((attention_f16_head_lv_kernel<true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+        else SD_LAUNCH((attention_f16_head_lv_kernel<false>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+        SD_CHECK_LAUNCH("attention_f16_head_lv_kernel");
         return 0;
     }
     static bool attr_set = false;

@@ -142,7 +142,7 @@ def test_fp16x3_sampler_is_fp32_grade(ops):
 
 
 @pytest.mark.parametrize("env", [{"SD_SAMPLER_GEMM": "f32"}, {"SD_QKV": "rows"}, {"SD_QKV": "rows", "SD_ATT16": "stream"},
-                                 {"SD_MERGE_HEAD": "0"}, {"SD_H": "rows"}])
+                                 {"SD_MERGE_HEAD": "0"}, {"SD_H": "rows"}, {"SD_ATT16": "stage2"}])
 def test_sampler_kernel_variants_agree_with_oracle(env):
     """The alternative kernel selections of sd_ddim_sample (fp32-MFMA fold, row-major q|k|v with the per-head or the
     streaming fp16 attention) are read from the environment once per process: run each in a child process against the

@@ -26,7 +26,14 @@ TAIL_NAMES = {13: "x in LDS + emb weights", 14: "embed MFMA", 15: "+ bias + pe",
               19: "K k", 20: "store k", 21: "K v", 22: "store v"}
 HEAD_NAMES = {1: "x staging + emb weights", 2: "embed MFMA", 3: "+ bias + pe", 4: "h store + LDS + LN1", 5: "K q", 6: "store q",
               7: "K k", 8: "store k", 9: "K v", 10: "store v"}
-ATT_NAMES = {1: "barrier", 2: "stage K/V", 3: "fetch issue + Q split", 4: "barrier", 5: "S MFMAs", 6: "softmax", 7: "P V", 8: "next unit"}
+# attention_f16_head_kernel (one workgroup per (sample, head); the default)
+ATT_NAMES = {1: "loads issued", 2: "K/V landed, split, in LDS", 3: "Q split", 4: "barrier", 5: "S MFMAs", 6: "softmax", 7: "P split + PV",
+             8: "normalise + stores issued"}
+ATT_LV_NAMES = {1: "loads issued", 2: "K landed, split, in LDS", 3: "Q split", 4: "barrier", 5: "S MFMAs", 6: "barrier + V^T split, in LDS",
+                7: "softmax", 8: "barrier + P split + PV", 9: "normalise + stores issued"}
+if os.environ.get("SD_ATT16") != "stage2":
+    ATT_NAMES = ATT_LV_NAMES
+ATT_STREAM_NAMES = {1: "barrier", 2: "stage K/V", 3: "fetch issue + Q split", 4: "barrier", 5: "S MFMAs", 6: "softmax", 7: "P V", 8: "next unit"}
 
 
 def main():
@@ -62,7 +69,7 @@ def main():
         life = s[:, :, used[-1]].max(1).values - s[:, :, used[0]].min(1).values
         if not used:
             continue
-        print(f"{'head kernel' if l == L else 'attention (unit 2: 1 barrier, 2 stage, 3 fetch issue+Q, 4 barrier, 5 S, 6 softmax, 7 PV; 8 = 7 of the next unit)' if l == L + 1 else 'layer %d' % l}: workgroup lifetime median {life.median():.0f} cycles")
+        print(f"{'head kernel' if l == L else 'attention_f16_head_kernel (last launch)' if l == L + 1 else 'layer %d' % l}: workgroup lifetime median {life.median():.0f} cycles")
         print(f"   {'phase (ends at stamp)':26s} {'min':>8s} {'p10':>8s} {'wave0 med':>10s} {'p90':>9s} {'share':>7s}   {'slowest-wave med':>16s}  {'skew at end med':>16s}")
         prev = used[0]
         for i in used[1:]:
