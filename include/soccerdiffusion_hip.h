@@ -170,7 +170,9 @@ int sd_op_linear(const float *A, const float *W, const float *bias, const float 
 
 /* Multi-head attention core, unmasked: out[b,i,h*hd:(h+1)*hd] = softmax(q k^T / sqrt(hd)) v.
  * q rows (B*Tq) with row stride ldq; k, v rows (B*S) with row stride ldkv; optional extra
- * key/value row shared by the whole batch (k_extra/v_extra, d floats each, NULL = none). */
+ * key/value row shared by the whole batch (k_extra/v_extra, d floats each, NULL = none).
+ * A packed self-attention buffer (k = q + d, v = q + 2d, ldq = ldkv = 3d, Tq = S <= 128, head dim 64,
+ * no extra row) runs on the split-fp16 MFMA kernel of the sampler (22-bit operands, fp32 accumulate). */
 int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv,
                     const float *k_extra, const float *v_extra, float *out, int ldo,
                     int B, int Tq, int S, int d, int heads, void *stream);

@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
 constexpr size_t ATT16LV_LDS = (size_t)(128 * ATT16H_KP > 64 * ATT16H_VP ? 128 * ATT16H_KP : 64 * ATT16H_VP) * sizeof(f16);
 template <bool HM>
 __global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kernel(const float *__restrict__ qkv, int ld_rm, float *__restrict__ out, int ldo,
-                                                                   int T, int heads, float scale_log2e) {
+                                                                   int T, int heads, float scale_log2e, float *__restrict__ lse2) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) f16 smem16[];
     f16 *sK = smem16, *sV = smem16;   // V^T takes K's place once the scores are done
@@ -1461,6 +1461,8 @@ __global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kern
     SD_STAMP(SD_STAMP_ATT_SLOT, 8);
     const float l_tot = psum + __shfl_xor(psum, 32, 64);
     const float inv = c_o / l_tot;
+    // log2-sum-exp of the scaled scores (the training backward recomputes the probabilities from it): p carries 2^10
+    if (lse2 && q_ok && half == 0) lse2[((long)b * heads + h) * T + qi] = mb + log2f(l_tot);
     if (q_ok) {
         float *op = out + ((long)b * T + qi) * ldo + h * HD;
 #pragma unroll

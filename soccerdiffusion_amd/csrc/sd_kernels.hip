@@ -1372,20 +1372,21 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
 }
 
 // self-attention over qkv [B*T][3d] on the fp16 pipe (head dim 64, T <= 128)
-static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s, bool head_major) {
+static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s, bool head_major,
+                         float *lse2 = nullptr) {
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
     // default: one workgroup per (sample, head), V^T staged late into K's LDS (35 KB of LDS, 3 workgroups per CU);
     // A/B runs: "stage2" = K and V^T staged together (69 KB, 2 per CU), "stream" = the per-sample streaming kernel
     static const char *env = getenv("SD_ATT16");
-    if (!head_major && env && strcmp(env, "stream") == 0) {
+    if (!head_major && !lse2 && env && strcmp(env, "stream") == 0) {
         SD_LAUNCH(attention_f16_kernel, dim3(B), dim3(256), 0, s, qkv, 3 * d, out, d, T, heads, sl2e);
         SD_CHECK_LAUNCH("attention_f16_kernel");
         return 0;
     }
-    if (!(env && strcmp(env, "stage2") == 0)) {
-        if (head_major) SD_LAUNCH((attention_f16_head_lv_kernel<true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
-        else SD_LAUNCH((attention_f16_head_lv_kernel<false>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e);
+    if (lse2 || !(env && strcmp(env, "stage2") == 0)) {
+        if (head_major) SD_LAUNCH((attention_f16_head_lv_kernel<true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2);
+        else SD_LAUNCH((attention_f16_head_lv_kernel<false>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2);
         SD_CHECK_LAUNCH("attention_f16_head_lv_kernel");
         return 0;
     }
@@ -2920,15 +2921,29 @@ extern "C" int sd_op_linear_strided(const float *A, int lda, const float *W, con
     return linear(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, (hipStream_t)stream, lda);
 }
 
+// Self-attention over a packed q|k|v row buffer ([B*T][3d], head dim 64, T <= 128): the fp16x3 kernel of the sampler
+// (SD_ATT_OP=f32: always the fp32-MFMA kernels; A/B runs)
+static bool att_op_f16(const float *q, int ldq, const float *k, const float *v, int ldkv, int ldo, int B, int Tq, int S, int d,
+                       int heads, const float *out) {
+    static const char *env = getenv("SD_ATT_OP");
+    if (env && strcmp(env, "f32") == 0) return false;
+    return q && out && B > 0 && heads > 0 && d == heads * 64 && Tq == S && Tq >= 1 && Tq <= 128 && ldq == 3 * d && ldkv == 3 * d &&
+           ldo == d && k == q + d && v == q + 2 * d;
+}
+
 extern "C" int sd_op_attention_lse(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
                                    int ldo, float *lse2, int B, int Tq, int S, int d, int heads, void *stream) {
     if (!lse2) return fail(SD_E_BADARG, "sd_op_attention_lse: lse2 is required");
+    if (att_op_f16(q, ldq, k, v, ldkv, ldo, B, Tq, S, d, heads, out))
+        return attention_f16(q, out, B, Tq, d, heads, (hipStream_t)stream, false, lse2);
     return attention(q, ldq, k, v, ldkv, nullptr, nullptr, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream, lse2);
 }
 
 extern "C" int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
                                const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
                                void *stream) {
+    if (!k_extra && !v_extra && att_op_f16(q, ldq, k, v, ldkv, ldo, B, Tq, S, d, heads, out))
+        return attention_f16(q, out, B, Tq, d, heads, (hipStream_t)stream, false);
     return attention(q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream);
 }
 

@@ -56,14 +56,31 @@ class _GradSink:
         return z, z
 
 
+# Transposed d x d weight blocks for the dX GEMMs, keyed by the block's address: FusedAdamW fills it with ONE gather over
+# its flat parameter buffer after every step (the weights are final until the next one), instead of one strided copy
+# kernel per block and backward node (41 launches, 3 % of the B=256 step).  An entry is valid while its optimizer is alive
+# and the parameter's version counter is the one seen at the gather (load_state_dict, p.mul_(), ... bump it; a write
+# through ``p.data`` does not - call ``optimizer.refresh_transposes()`` after one).
+_WT_BLOCKS: dict = {}
+
+
+def _transposed_block(W: Tensor, p: int, d: int) -> Tensor:
+    ent = _WT_BLOCKS.get(W.data_ptr() + 4 * p * d * d)
+    if ent is not None:
+        owner, off, bd, pi = ent
+        opt = owner()
+        if opt is not None and bd == d and W.shape[1] == d and opt._wt_params[pi]._version == opt._wt_versions[pi]:
+            return opt.flat_wt[off : off + d * d].view(d, d)
+    return W[p * d : (p + 1) * d].t().contiguous()
+
+
 def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
     """dX[R,d] = dY[R,N] @ W[N,d]: the forward panel kernel on W^T, one pass per d-wide
     column slice of dY (N = d, 2d or 3d), accumulated through the residual input."""
     N, d = W.shape
     out = None
     for p in range(N // d):
-        Wt = W[p * d : (p + 1) * d].t().contiguous()
-        out = ops.linear_strided(dy2d[:, p * d : (p + 1) * d], Wt, res=out, out=out)
+        out = ops.linear_strided(dy2d[:, p * d : (p + 1) * d], _transposed_block(W, p, d), res=out, out=out)
     return out
 
 
@@ -346,6 +363,36 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.flat_m[at : at + k].view(p.shape),
                              "exp_avg_sq": self.flat_v[at : at + k].view(p.shape)}
             at += k
+        # gather index of every d x d block of the (N = k d, d) matrices, transposed (see _WT_BLOCKS)
+        idx, self._wt_blocks, self._wt_params, at, out_at = [], [], [], 0, 0
+        for p in params:
+            k = p.numel()
+            if p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % p.shape[1] == 0:
+                N, d = p.shape
+                idx.append(at + torch.arange(k, dtype=torch.int64).view(N // d, d, d).transpose(1, 2).reshape(-1))
+                for blk in range(N // d):
+                    self._wt_blocks.append((self.flat_param.data_ptr() + 4 * (at + blk * d * d), out_at + blk * d * d, d,
+                                            len(self._wt_params)))
+                self._wt_params.append(p)
+                out_at += k
+            at += k
+        self._wt_index = torch.cat(idx).to(dev) if idx else None
+        self.flat_wt = torch.empty(out_at, dtype=torch.float32, device=dev) if idx else None
+        self._wt_versions = []
+        self.refresh_transposes()
+
+    def refresh_transposes(self) -> None:
+        """Gather W^T of every d x d weight block from the flat parameter buffer (one kernel; see _WT_BLOCKS)."""
+        if self._wt_index is None or not self.flat_param.is_cuda:
+            return
+        import weakref
+        torch.index_select(self.flat_param, 0, self._wt_index, out=self.flat_wt)
+        self._wt_versions = [p._version for p in self._wt_params]
+        if not getattr(self, "_wt_registered", False):
+            owner = weakref.ref(self)
+            for key, off, d, pi in self._wt_blocks:
+                _WT_BLOCKS[key] = (owner, off, d, pi)   # no tensor references: a dead optimizer's entries are inert
+            self._wt_registered = True
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
@@ -364,6 +411,7 @@ class FusedAdamW(torch.optim.Optimizer):
                        g["eps"], g["weight_decay"], self._step)
         for p in g["params"]:
             self.state[p]["step"] = torch.tensor(float(self._step))
+        self.refresh_transposes()
 
     def load_state_dict(self, state_dict):
         views = {id(p): (self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in self.param_groups[0]["params"]}

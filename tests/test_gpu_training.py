@@ -172,3 +172,41 @@ def test_checkpoint_dict_interchange(g1, tmp_path):
                              timesteps=g1["steps_int"].cuda())
     assert abs(float(l1) - float(l3)) < 1e-6
     assert rel_err(opt3.flat_param, opt.flat_param) < 1e-6
+
+
+def test_transposed_weight_blocks_follow_the_optimizer(g1):
+    """The dX GEMMs read W^T blocks that FusedAdamW gathers once per step: they must equal the current weights after
+    every step, and a torch in-place write to a parameter must retire them until the next step."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    m = _build(g1["config"], full=False).cuda()
+    m.load_state_dict(g1["state_dict"])
+    m.train()
+    opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    noise_sched = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    mats = [p for p in m.parameters() if p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % p.shape[1] == 0]
+    assert mats
+
+    def check_all(expect_cached, only=None):
+        for W in (mats if only is None else only):
+            d = W.shape[1]
+            for blk in range(W.shape[0] // d):
+                wt = training._transposed_block(W, blk, d)
+                assert torch.equal(wt, W.detach()[blk * d : (blk + 1) * d].t())
+                cached = wt.data_ptr() >= opt.flat_wt.data_ptr() and wt.data_ptr() < opt.flat_wt.data_ptr() + 4 * opt.flat_wt.numel()
+                assert cached == expect_cached
+
+    check_all(True)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        x0, eps = torch.randn(2, 16, 20, generator=g), torch.randn(2, 16, 20, generator=g)
+        t = torch.randint(0, 1000, (2,), generator=g)
+        training.train_step(m, opt, None, noise_sched, x0.cuda(), context=[g1["ctx"].cuda()], noise=eps.cuda(), timesteps=t.cuda())
+        check_all(True)
+    with torch.no_grad():
+        mats[0].mul_(1.5)          # outside the optimizer: the gathered blocks are stale now
+    check_all(False, only=mats[:1])
+    check_all(True, only=mats[1:])
+    opt.step()
+    check_all(True)
