@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoised joint-trajectories/s, 50-step DDIM, H=100, J=20.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|train] [--batch B]
 
-One "step" = one complete 50-step DDIM rollout of a batch of B trajectories through
-``sd_ddim_sample`` (BASELINE.json config 3: d=256, L=4, 4 heads, T=100, J=20, M=11 memory
-tokens, B=4096 per GPU), inputs resident in HBM.  N>1: one process per GPU (launched by
-torch.distributed.run), every rank samples its own B trajectories — the path shards over
-independent trajectories with no data-path collective (weak scaling); the only
-collectives are the timing barrier and the MAX over ranks of the elapsed time.
+``--mode sample`` (default, BASELINE.json configs[2]): one "step" = one complete 50-step DDIM rollout of a batch of
+B = 4096 trajectories per GPU through ``sd_ddim_sample`` (d=256, L=4, 4 heads, T=100, J=20, M=11 memory tokens),
+inputs resident in HBM.  Ranks sample independent trajectories: no data-path collective (weak scaling).
 
-Prints ONE JSON line (rank 0) with the contract keys plus ``roofline`` and ``cpu_baseline``.
+``--mode train`` (BASELINE.json configs[1] / [3]): one "step" = one training iteration of the decoder-pretraining
+path (add_noise, forward, MSE, backward, RCCL all-reduce of the flat gradient, AdamW, OneCycleLR) at B = 256
+trajectories per GPU through ``training.train_step`` (weak scaling, one collective per step).
+
+N > 1: one process per GPU.  Under ``torch.distributed.run`` (WORLD_SIZE set) this process is one rank; started
+plainly as ``python bench.py --gpus N`` the parent launches N fresh ranks itself BEFORE it touches the GPU and exits
+with their exit code.  A world size that disagrees with ``--gpus`` is an error, never a silent 1-GPU run.
+
+Prints ONE JSON line (rank 0) with the contract keys plus ``roofline`` and ``cpu_baseline``; at N = 1 in sample mode
+the line also carries the hipGraph replay of the same rollout, north_star's B = 256 sampling shape and the C2
+training step (each timed after the headline region).
 """
 
 from __future__ import annotations
@@ -19,19 +26,21 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 D, L, HEADS, T, J, MC, N_DDIM = 256, 4, 4, 100, 20, 10, 50
 M = MC + 1
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2516.8  # MI355X_MICROARCH.md: BF16/F16 MFMA dense (~2.5 PF = 16 x the fp32 matrix rate)
+PEAK_HBM_GBS = 8000.0
+FUSED_BYTES_PER_TRAJ_STEP = 2 * T * J * 4 + M * D * 4   # x in + eps out + memory = 27 264 B
+TRAIN_B = 256
 
 
 def flops_per_traj_step():
@@ -45,7 +54,7 @@ def flops_per_traj_step():
 
 def executed_flops_per_traj():
     """FLOPs this implementation executes per trajectory: the sampler caches the memory K/V over the rollout and
-    folds the cross-attention Q and out projections into them (DESIGN.md 5.3), so per step and layer the 16 T d^2 of
+    folds the cross-attention Q and out projections into them (DESIGN.md 5.5), so per step and layer the 16 T d^2 of
     row GEMMs become 12 T d^2 + 4 T d (heads*M); the fold itself is 8 Mc d^2 per layer, once."""
     layer_chain = (L * 12 - 6) * T * D * D + L * 4 * T * D * HEADS * M + 2 * T * D * J   # decoder_layer_kernel, L launches
     head = 2 * T * J * D + 6 * T * D * D                                                 # decoder_head_kernel
@@ -55,19 +64,73 @@ def executed_flops_per_traj():
             "rollout": N_DDIM * (layer_chain + head + attn) + once}
 
 
+def layer_kernel_algorithmic_flops_per_traj_step(merged: bool):
+    """SURVEY §8(d) FLOPs owned by the L launches of the layer kernel in one DDIM step, per trajectory: all row GEMMs
+    of the reference algorithm (16 T d^2 per layer, the two cross-attention projections the fold removes INCLUDED -
+    algorithmic, not executed), the cross-attention cores 4 T M d, fc_out 2 T d J and - when the next step's head runs
+    inside the last layer's launch - its embedding 2 T J d; layer 0's LN1+QKV (6 T d^2) of the FIRST step belongs to
+    decoder_head_kernel."""
+    f = L * 16 * T * D * D + L * 4 * T * M * D + 2 * T * D * J
+    if merged:
+        f += 2 * T * J * D - (6 * T * D * D + 2 * T * J * D) / N_DDIM
+    else:
+        f -= 6 * T * D * D
+    return f
+
+
+def physical_cores() -> int:
+    """Distinct (package, core) pairs among the CPUs this process may run on."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as fh:
+                core = fh.read().strip()
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as fh:
+                pkg = fh.read().strip()
+            seen.add((pkg, core))
+        except OSError:
+            seen.add(("?", str(c)))
+    return max(1, len(seen))
+
+
+def cpu_quota() -> float:
+    """CPUs this process may actually use: the cgroup quota when there is one (a box's affinity mask can list every
+    host CPU while the container is throttled to a fraction of them), else the affinity count."""
+    n = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            with open(path) as fh:
+                quota, period = fh.read().split()[:2]
+            if quota != "max":
+                n = min(n, float(quota) / float(period))
+        except (OSError, ValueError):
+            pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            q = float(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            per = float(fh.read())
+        if q > 0:
+            n = min(n, q / per)
+    except (OSError, ValueError):
+        pass
+    return max(1.0, n)
+
+
 def cpu_baseline(sd, seconds_budget=25.0):
-    """The CPU oracle (a stock-PyTorch restatement of the reference path, validated against
-    the reference's own modules) on the host cores of this box: a bounded sample of the
-    same workload."""
+    """the CPU oracle (a stock-PyTorch restatement of the reference path, validated against the
+    reference's own modules) on the host cores of this box, fp32, no_grad, B = 256: the thread count is the fastest of
+    a short sweep (one denoiser step each: more threads than the container's CPU share only thrash), then one more
+    warm-up step and as many timed steps of the 50-step rollout as the budget allows (a bounded sample of the same
+    workload)."""
+    import torch
     from oracle import ddim_ref
     from oracle import denoiser_ref as ref
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    Bc = 32
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(Bc, T, J, generator=g)
+    phys, quota = physical_cores(), cpu_quota()
+    Bc = 256
+    x = torch.randn(Bc, T, J, generator=torch.Generator().manual_seed(1234))
     ctx = torch.randn(Bc, MC, D, generator=torch.Generator().manual_seed(1235))
     acp = ddim_ref.alphas_cumprod()
     ts = ddim_ref.timesteps(N_DDIM).tolist()
@@ -77,7 +140,19 @@ def cpu_baseline(sd, seconds_budget=25.0):
             eps = ref.forward_with_context(sd, [ctx], x, torch.full((Bc,), t, dtype=torch.int64))
         return ddim_ref.step(eps, t, x, N_DDIM, acp)
 
-    x = one(x, ts[0])  # warm-up (thread pool, allocator)
+    cands = sorted({c for c in (8, 16, 32, 64, int(quota), phys) if 1 <= c <= phys})
+    sweep, t_sweep = {}, time.perf_counter()
+    for c in cands:
+        torch.set_num_threads(c)
+        one(x, ts[0])                      # thread-pool spin-up at this width
+        t0 = time.perf_counter()
+        one(x, ts[0])
+        sweep[c] = time.perf_counter() - t0
+        if time.perf_counter() - t_sweep > 20.0:
+            break
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    x = one(x, ts[0])  # warm-up at the chosen width
     t0 = time.perf_counter()
     done = 0
     for t in ts:
@@ -87,30 +162,158 @@ def cpu_baseline(sd, seconds_budget=25.0):
             break
     dt = time.perf_counter() - t0
     return {
-        "value": Bc * (done / N_DDIM) / dt,
+        "value": round(Bc * (done / N_DDIM) / dt, 3),
         "unit": "trajectories/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"B={Bc} trajectories x {done} of {N_DDIM} DDIM steps (d={D}, L={L}, T={T}, J={J}, M={M}), "
-                  f"oracle/denoiser_ref.py on {threads} torch threads, fp32",
+        "seconds_per_denoiser_step": round(dt / done, 4),
+        "thread_sweep_seconds_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
+        "sample": f"B={Bc} trajectories x {done} of {N_DDIM} DDIM steps after warm-up (d={D}, L={L}, T={T}, J={J}, M={M}), "
+                  f"oracle/denoiser_ref.py + oracle/ddim_ref.py, fp32, no_grad, {threads} torch threads (fastest of the sweep; "
+                  f"this box: {phys} physical cores in the affinity mask, cgroup CPU quota {quota:g})",
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, rendezvous on
+    127.0.0.1) before this process makes any GPU call, and hand their exit code back."""
+    import torch
+
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# training leg (BASELINE configs[1]: C2; configs[3]: C2 x N with the RCCL gradient all-reduce)
+# ------------------------------------------------------------------------------------------------------------------
+C2_PARAMS = dict(hidden_dim=D, action_context_length=100, trajectory_prediction_length=T, epochs=1, batch_size=TRAIN_B,
+                 lr=1e-4, train_denoising_timesteps=1000, image_context_length=10, imu_context_length=100,
+                 num_imu_encoder_layers=2, joint_state_context_length=100, num_normalization_samples=1000, num_joints=J,
+                 use_action_history=False, num_action_history_encoder_layers=2, use_imu=False,
+                 imu_orientation_embedding_method="quaternion", use_joint_states=False, joint_state_encoder_layers=2,
+                 use_images=False, image_sequence_encoder_type="transformer", image_encoder_type="resnet18",
+                 num_image_sequence_encoder_layers=1, num_decoder_layers=L, distill_teacher_inference_steps=30,
+                 use_gamestate=False, encoder_patch_size=10)
+
+
+class TrainLeg:
+    """C2: decoder d=256 L=4, B trajectories per GPU of horizon 100 x 20 joints, memory = 10 random context tokens + the
+    step token (the reference's --decoder-pretraining path, train.py:221-224), dropout as `dropout` (the reference
+    trains with torch's default 0.1)."""
+
+    def __init__(self, dev, rank, world, batch, total_steps, dropout=0.1):
+        import torch
+        from soccerdiffusion_amd import cli, training
+        from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+        self.torch, self.training, self.world, self.B, self.dev = torch, training, world, batch, dev
+        torch.manual_seed(0)   # every rank builds the same replica ...
+        self.model = cli.build_model(C2_PARAMS).to(dev).train()
+        if hasattr(self.model, "set_dropout"):
+            self.model.set_dropout(dropout)
+        self.dropout = dropout if hasattr(self.model, "set_dropout") else 0.0
+        self.opt = training.FusedAdamW(self.model.parameters(), lr=1e-4)
+        if world > 1:   # ... and rank 0's parameters are broadcast anyway (cli.cmd_train does the same)
+            training.broadcast_parameters(self.opt, self.model)
+        self.lr = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=1e-4, total_steps=total_steps + 8)
+        self.ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+        self.g = torch.Generator(device=dev).manual_seed(1 + rank)
+        self.x0 = torch.randn(batch, T, J, device=dev, generator=self.g)
+        self.ctx = [torch.randn(batch, MC, D, device=dev, generator=self.g)]
+
+    def step(self):
+        return self.training.train_step(self.model, self.opt, self.lr, self.ns, self.x0, context=self.ctx,
+                                        world_size=self.world, generator=self.g)
+
+    def allreduce_ms(self, iters=10):
+        """The gradient exchange alone (flat fp32 buffer, sum + mean) timed with events on the current stream."""
+        torch = self.torch
+        if self.world <= 1:
+            return 0.0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.training.allreduce_gradients(self.opt, self.world)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(iters):
+            self.training.allreduce_gradients(self.opt, self.world)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+
+def time_train(leg: TrainLeg, steps: int, warmup: int, dist):
+    torch = leg.torch
+    for _ in range(warmup):
+        leg.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = leg.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=leg.dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, float(loss)
+
+
+def train_record(elapsed, steps, world, B, loss, allreduce_ms, dropout, n_params):
+    f = flops_per_traj_step()["total"]
+    tf = 3 * f * B * world * steps / elapsed / 1e12
+    return {
+        "value": round(world * B * steps / elapsed, 1), "unit": "trajectories/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "batch_per_gpu": B, "n_gpus": world,
+        "algorithmic_tflops": round(tf, 2),   # 3 x F_step (SURVEY 8(d)) per trajectory: forward + backward
+        "algorithmic_tflops_per_gpu": round(tf / world, 2),
+        "frac_of_f16_mfma_peak": round(tf / world / PEAK_F16_MFMA_TFLOPS, 4),
+        "frac_of_f32_mfma_peak": round(tf / world / PEAK_F32_MFMA_TFLOPS, 4),
+        "allreduce_ms": round(allreduce_ms, 4), "allreduce_bytes": 4 * n_params,
+        "dropout_p": dropout, "final_loss": round(loss, 6),
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU per rollout")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 3 rollouts / 30 training steps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 1 rollout / 5 training steps)")
+    ap.add_argument("--mode", choices=("sample", "train"), default="sample")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU per step (default 4096 sample / 256 train)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="sample mode: skip the hipGraph / B=256 / training sub-records")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))   # nothing below has run: this process never touched the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}` "
+                         f"or plainly as `python bench.py --gpus {args.gpus}`")
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
@@ -120,12 +323,60 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    try:
+        if args.mode == "train":
+            run_train(args, rank, world, dev, dist)
+        else:
+            run_sample(args, rank, world, dev, dist)
+    finally:
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
 
-    from soccerdiffusion_amd.synthetic import synthetic_state_dict
+
+def run_train(args, rank, world, dev, dist):
+    steps = args.steps if args.steps is not None else 30
+    warmup = args.warmup if args.warmup is not None else 5
+    B = args.batch or TRAIN_B
+    leg = TrainLeg(dev, rank, world, B, steps + warmup, dropout=args.dropout)
+    elapsed, loss = time_train(leg, steps, warmup, dist)
+    ar = leg.allreduce_ms()
+    if rank != 0:
+        return
+    rec = train_record(elapsed, steps, world, B, loss, ar, leg.dropout, leg.opt.flat_param.numel())
+    line = {
+        "metric": "training trajectories/s (fwd + bwd + AdamW per trajectory; denoiser d=256 L=4, H=100, J=20)",
+        "value": rec["value"], "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; attention backward on the fp32 MFMA)",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{1 if world == 1 else 3}]: one training step (add_noise, forward, MSE, backward, "
+                               f"{'RCCL all-reduce of the flat fp32 gradient, ' if world > 1 else ''}AdamW, OneCycleLR) of the transformer "
+                               f"denoiser d=256 L=4 heads=4, B={B} trajectories per GPU, horizon T=100, J=20, memory M=11 "
+                               f"(decoder-pretraining path, reference train.py:204-240), dropout p={rec['dropout_p']}",
+                   "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "joints": J, "hidden_dim": D, "decoder_layers": L,
+                   "memory_tokens": M, "parallelism": f"dp{world}" + (" (one flat-gradient all-reduce per step)" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "kernel": "whole training step (no single dominant kernel: profiles/)",
+                     "achieved": rec["algorithmic_tflops_per_gpu"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": rec["frac_of_f16_mfma_peak"], "traffic": None,
+                     "definition": "3 x F_step (SURVEY 8(d)) x trajectories / wall time, per GPU"},
+        "train": rec,
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
+def run_sample(args, rank, world, dev, dist):
+    import numpy as np  # noqa: F401
+    import torch
+
     from soccerdiffusion_amd import _lib, ops
+    from soccerdiffusion_amd.synthetic import synthetic_state_dict
 
+    steps = args.steps if args.steps is not None else 3
+    warmup = args.warmup if args.warmup is not None else 1
     lib = _lib.load()
-    B = args.batch
+    B = args.batch or 4096
     sd = synthetic_state_dict(D, J, L, seed=7)
     packed = ops.pack_denoiser(sd, dev, heads=HEADS, max_len=T)
     ts = ops.ddim_timesteps(N_DDIM)
@@ -136,12 +387,13 @@ def main():
     x_T = torch.randn(B, T, J, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
     ctx = torch.randn(B, MC, D, generator=torch.Generator().manual_seed(1235 + rank)).to(dev)
     x = torch.empty_like(x_T)
+    guard = torch.zeros(1, dtype=torch.int32, device=dev)   # range-guard word of sd_ddim_sample_ex, read after the timed region
 
     def rollout():
         x.copy_(x_T)
-        ops.ddim_sample(packed, ctx, toks, coef, x, inplace=True)
+        ops.ddim_sample(packed, ctx, toks, coef, x, inplace=True, status=guard)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         rollout()
     timing = not args.no_kernel_timing
     torch.cuda.synchronize()
@@ -151,7 +403,7 @@ def main():
     if timing:
         lib.sd_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         rollout()
     torch.cuda.synchronize()
     if dist:
@@ -164,119 +416,220 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(x).all(), "sampler produced non-finite values"
+    assert int(guard.item()) == 0, "sampler range guard tripped: non-finite sample"
 
+    mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
     roofline = None
     if timing:
         n = len(_lib.KERNEL_CLASSES)
         ms = (C.c_double * n)()
         cnt = (C.c_long * n)()
         _lib.check(lib.sd_profile_collect(ms, cnt, n), "sd_profile_collect")
-        f = flops_per_traj_step()
-        names = _lib.KERNEL_CLASSES
-        dl = names.index("decoder_layer_kernel")
-        # Dominant kernel: decoder_layer_kernel, one launch per (DDIM step, layer).  Per trajectory it does the row
-        # GEMMs of SURVEY 8(d) except layer 0's LN1+QKV, which decoder_head_kernel does (10Td^2 per layer + the next
-        # layer's 6Td^2 QKV for all but the last), the cross-attention cores 4TMd and, in the last layer, fc_out
-        # 2TdJ.  Summed over the L launches of a step:
-        # In the sampler the Q and out projections of the cross-attention are folded into the cached memory
-        # (executed_flops_per_traj): `achieved` counts the FLOPs the kernel really executes, not the reference's.
-        ex = executed_flops_per_traj()
-        per_traj_step_dl = ex["layer_chain"]
-        mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
-        # mode 2 runs the head of steps 1.. inside the previous step's last layer launch: those FLOPs and
-        # bytes belong to this kernel class
-        merged = mode == 2 and os.environ.get("SD_MERGE_HEAD", "1") != "0"
-        if merged:
-            per_traj_step_dl += ex["head"] * (N_DDIM - 1) / N_DDIM
-        tail_units = 2 + (4 * (N_DDIM - 1) / N_DDIM if merged else 0)   # a, h in (+ h, q|k|v out), in units of B T d floats
-        dl_flops = args.steps * B * N_DDIM * per_traj_step_dl
-        dl_s = ms[dl] / 1e3
-        achieved = dl_flops / dl_s / 1e12
-        total_flops = args.steps * B * N_DDIM * f["total"]
-        # mode 2: every product of the layer chain is 3 v_mfma_f32_32x32x16_f16 on split (hi + lo) operands:
-        # the matrix pipe executes 3x the algorithmic FLOPs, priced against the fp16 MFMA peak; fc_out (2TdJ) stays fp32
-        peak, kernel_name, mfma_factor = PEAK_F32_MFMA_TFLOPS, "decoder_layer_kernel<256>", 1.0
-        if mode == 2:
-            peak, kernel_name, mfma_factor = PEAK_F16_MFMA_TFLOPS, "decoder_layer_f16_kernel<256>", 3.0
-        alg_tflops = achieved
-        achieved = achieved * mfma_factor
-        pmc = None
-        pmc_file = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
-            with open(pmc_file) as fh:
-                pmc = json.load(fh).get("decoder_layer_kernel_bytes_per_launch")
-        sq = None
-        sq_file = os.path.join(REPO, "profiles", "pmc_sq.json")
-        if os.path.exists(sq_file) and mode == 2:
-            with open(sq_file) as fh:
-                sq = json.load(fh)
-        roofline = {
-            "bound": "mfma",
-            "kernel": kernel_name,
-            "achieved": round(achieved, 2),
-            "peak": peak,
-            "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4),
-            "sampler_mode": {0: "fp32 MFMA", 1: "fp32 MFMA, folded cross-attention",
-                             2: "fp16x3 split-operand MFMA (fp32 accumulate), folded cross-attention"}[mode],
-            "algorithmic_tflops": round(alg_tflops, 2),   # executed FLOPs counted once; the fp32 MFMA peak is 157.3
-            # the same kernel against the HBM roof: per launch it must read a and h, write h and the next q|k|v (the last
-            # layer writes x only) and read each trajectory's folded cross-attention blocks once
-            "hbm": (lambda by: {"algorithmic_bytes_per_launch_avg": by, "achieved": round(by / (dl_s / max(int(cnt[dl]), 1)) / 1e9, 1),
-                                "peak": 8000.0, "unit": "GB/s", "frac": round(by / (dl_s / max(int(cnt[dl]), 1)) / 8e12, 4)})(
-                B * T * D * 4 * ((L - 1) * 6 + tail_units) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)),
-            "executed_mfma_flops_per_algorithmic_flop": mfma_factor,
-            "traffic": pmc,
-            # the hardware's own count from the committed SQ counter pass (profiles/pmc_sq.json): MFMA-pipe busy cycles over
-            # SIMD-cycles at the clock the kernel really ran at (frac above is priced at the nominal 2.4 GHz)
-            "mfma_busy_pmc": round(sq["decoder_layer_kernel_mfma_busy"], 4) if sq else None,
-            "effective_clock_ghz_pmc": round(sq["decoder_layer_kernel_effective_clock_ghz"], 3) if sq else None,
-            "next_step_head_merged_into_last_layer": bool(merged),
-            "launches": int(cnt[dl]),
-            "avg_launch_ms": round(ms[dl] / max(int(cnt[dl]), 1), 5),
-            "flops_per_launch_avg": dl_flops / max(int(cnt[dl]), 1),
-            "kernel_time_share": {k: round(ms[i] / 1e3 / elapsed, 4) for i, k in enumerate(names)},
-            "whole_path": {   # executed = what the GPU did; reference_algorithm = SURVEY 8(d) F_step x 50 over the same time
-                "achieved": round(mfma_factor * args.steps * B * ex["rollout"] / elapsed / 1e12, 2),
-                "frac": round(mfma_factor * args.steps * B * ex["rollout"] / elapsed / 1e12 / peak, 4),
-                "algorithmic_tflops": round(args.steps * B * ex["rollout"] / elapsed / 1e12, 2),
-                "flops_per_trajectory": ex["rollout"],
-                "reference_algorithm_tflops": round(total_flops / elapsed / 1e12, 2),
-                "reference_flops_per_trajectory": N_DDIM * f["total"],
-            },
-        }
+        roofline = sample_roofline(ms, cnt, steps, B, elapsed, mode)
 
-    if rank == 0:
-        value = world * B * args.steps / elapsed
-        line = {
-            "metric": "denoised joint-trajectories/s (50-step DDIM, H=100, J=20)",
-            "value": round(value, 2),
-            "unit": "trajectories/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if lib.sd_sampler_mode(D, HEADS, T, MC, J) != 2 else
-                     "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate: 22-bit operands; "
-                     "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
-            "data": "synthetic",
-            "config": {
-                "workload": "BASELINE.json configs[2]: 50-step DDIM sampling, B=%d parallel rollouts per GPU, "
-                            "transformer denoiser d=256 L=4 heads=4, horizon T=100, J=20, memory M=11 "
-                            "(10 context tokens + step token); one step = one full rollout" % B,
-                "batch_per_gpu": B, "ddim_steps": N_DDIM, "horizon": T, "joints": J, "hidden_dim": D,
-                "decoder_layers": L, "memory_tokens": M, "parallelism": f"dp{world} (independent rollouts, no collective)",
-            },
-            "roofline": roofline,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd),
-        }
-        print(json.dumps(line), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return
+    extras = {}
+    if world == 1 and not args.no_extras:
+        extras = sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev)
+    value = world * B * steps / elapsed
+    line = {
+        "metric": "denoised joint-trajectories/s (50-step DDIM, H=100, J=20)",
+        "value": round(value, 2),
+        "unit": "trajectories/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if mode != 2 else
+                 "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate: 22-bit operands; "
+                 "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: 50-step DDIM sampling, B=%d parallel rollouts per GPU, "
+                        "transformer denoiser d=256 L=4 heads=4, horizon T=100, J=20, memory M=11 "
+                        "(10 context tokens + step token); one step = one full rollout; the timed region issues the rollout's "
+                        "launches eagerly with a HIP-event pair around each (the roofline leg); the hipGraph replay of the same "
+                        "rollout is timed right after it (`hipgraph`)" % B,
+            "batch_per_gpu": B, "ddim_steps": N_DDIM, "horizon": T, "joints": J, "hidden_dim": D,
+            "decoder_layers": L, "memory_tokens": M, "parallelism": f"dp{world} (independent rollouts, no collective)",
+        },
+        "roofline": roofline,
+        **extras,
+        "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd),
+    }
+    print(json.dumps(line), flush=True)
+
+
+def sample_roofline(ms, cnt, steps, B, elapsed, mode):
+    from soccerdiffusion_amd import _lib
+
+    names = _lib.KERNEL_CLASSES
+    dl = names.index("decoder_layer_kernel")
+    at = names.index("attention_kernel")
+    f = flops_per_traj_step()
+    ex = executed_flops_per_traj()
+    # mode 2 runs the head of steps 1.. inside the previous step's last layer launch
+    merged = mode == 2 and os.environ.get("SD_MERGE_HEAD", "1") != "0"
+    launches = max(int(cnt[dl]), 1)
+    dl_s = ms[dl] / 1e3
+    avg_s = dl_s / launches
+    # --- ALGORITHMIC FLOPs of the dominant kernel / its time ---------------------------------------
+    alg_per_traj_step = layer_kernel_algorithmic_flops_per_traj_step(merged)
+    alg_flops = steps * B * N_DDIM * alg_per_traj_step
+    achieved = alg_flops / dl_s / 1e12
+    # --- what the matrix pipe executed: folded projections removed, every product as 3 fp16 MFMAs in mode 2 ----
+    exe_per_traj_step = ex["layer_chain"] + (ex["head"] * (N_DDIM - 1) / N_DDIM if merged else 0)
+    mfma_factor = 3.0 if mode == 2 else 1.0
+    executed = mfma_factor * steps * B * N_DDIM * exe_per_traj_step / dl_s / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS if mode == 2 else PEAK_F32_MFMA_TFLOPS
+    kernel_name = "decoder_layer_f16_kernel<256>" if mode == 2 else "decoder_layer_kernel<256>"
+    # --- HBM: this design's own per-launch bytes (a + h read, h + next q|k|v written, folded blocks read once) ----
+    tail_units = 2 + (4 * (N_DDIM - 1) / N_DDIM if merged else 0)
+    design_bytes = B * T * D * 4 * ((L - 1) * 6 + tail_units) / L + B * 64 * 2 * D * 4 * (1 if mode else 0)
+    prof = profiles_record()
+    traffic = prof.get("decoder_layer_kernel_bytes_per_launch") if prof else None
+    att_traffic = prof.get("attention_kernel_bytes_per_launch") if prof else None
+    fused_alg_bytes_per_step = B * FUSED_BYTES_PER_TRAJ_STEP + 10.59e6   # fused step + fp32 weights once per step
+    hbm = {
+        "algorithmic_bytes_per_launch_this_design": design_bytes,
+        "achieved": round(design_bytes / avg_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": round(design_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+        "fused_algorithmic_bytes_per_ddim_step": fused_alg_bytes_per_step,
+    }
+    if traffic:
+        hbm["traffic_over_this_design"] = round(traffic / design_bytes, 3)
+        if att_traffic:
+            hbm["traffic_over_algorithmic"] = round(L * (traffic + att_traffic) / fused_alg_bytes_per_step, 1)
+            hbm["traffic_bytes_per_trajectory_step"] = round(L * (traffic + att_traffic) / 4096, 1)
+    return {
+        "bound": "mfma",
+        "kernel": kernel_name,
+        "achieved": round(achieved, 2),          # SURVEY 8(d) algorithmic FLOPs of this kernel class / its time
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4),
+        "traffic": traffic,                      # HBM bytes per launch from the committed PMC passes (see from_profiles)
+        "definition": "algorithmic FLOPs (SURVEY 8(d): 16Td^2 + 4TMd per layer + fc_out/embedding, folded projections "
+                      "counted) of the L launches per DDIM step / summed HIP-event durations of those launches",
+        "algorithmic_flops_per_launch_avg": alg_flops / launches,
+        "launches": launches,
+        "avg_launch_ms": round(avg_s * 1e3, 5),
+        "sampler_mode": {0: "fp32 MFMA", 1: "fp32 MFMA, folded cross-attention",
+                         2: "fp16x3 split-operand MFMA (fp32 accumulate), folded cross-attention"}[mode],
+        # pipe occupancy, NOT useful work: executed products x 3 MFMAs each against the fp16 peak
+        "mfma_pipe_occupancy": round(executed / peak, 4),
+        "executed_mfma_tflops": round(executed, 2),
+        "executed_mfma_flops_per_algorithmic_flop": round(mfma_factor * exe_per_traj_step / alg_per_traj_step, 3),
+        "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),   # what the split-fp16 design buys over an exact-fp32 MFMA
+        "next_step_head_merged_into_last_layer": bool(merged),
+        "hbm": hbm,
+        "kernel_time_share": {k: round(ms[i] / 1e3 / elapsed, 4) for i, k in enumerate(names)},
+        "attention_kernel": {"launches": int(cnt[at]), "avg_launch_ms": round(ms[at] / max(int(cnt[at]), 1), 5),
+                             "algorithmic_tflops": round(steps * B * N_DDIM * L * 4 * T * T * D / max(ms[at] / 1e3, 1e-9) / 1e12, 2)},
+        "whole_path": {   # SURVEY 8(d) F_step x 50 over the wall time of the timed region
+            "achieved": round(steps * B * N_DDIM * f["total"] / elapsed / 1e12, 2),
+            "frac": round(steps * B * N_DDIM * f["total"] / elapsed / 1e12 / peak, 4),
+            "flops_per_trajectory": N_DDIM * f["total"],
+            "executed_flops_per_trajectory": ex["rollout"],
+        },
+        "from_profiles": prof,
+    }
+
+
+def profiles_record():
+    """Counter-derived figures read from the committed profile summaries (profiles/*.json): measured by rocprofv3 on
+    ANOTHER box and run than this line, so they are evidence with provenance, not live measurements."""
+    out = {}
+    p = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        with open(p) as fh:
+            t = json.load(fh)
+        out["decoder_layer_kernel_bytes_per_launch"] = t.get("decoder_layer_kernel_bytes_per_launch")
+        out["attention_kernel_bytes_per_launch"] = t.get("attention_kernel_bytes_per_launch")
+        if out["attention_kernel_bytes_per_launch"] is None:
+            for k, v in t.get("per_kernel", {}).items():
+                if k.startswith("attention_f16"):
+                    out["attention_kernel_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
+        out["traffic_source"] = t.get("source")
+        out["traffic_round"] = t.get("round", "r01")
+    p = os.path.join(REPO, "profiles", "pmc_sq.json")
+    if os.path.exists(p):
+        with open(p) as fh:
+            s = json.load(fh)
+        out["mfma_busy_pmc"] = round(s["decoder_layer_kernel_mfma_busy"], 4)
+        out["effective_clock_ghz_pmc"] = round(s["decoder_layer_kernel_effective_clock_ghz"], 3)
+        out["sq_source"] = s.get("source")
+        out["sq_round"] = s.get("round", "r01")
+    if out:
+        out["note"] = "from committed rocprofv3 passes (profiles/), a different box and run than this line"
+    return out or None
+
+
+def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
+    """After the headline region, N = 1: (a) the same rollout replayed from a hipGraph (BASELINE configs[2] names a
+    hipGraph-captured step), checked bit for bit against the eager result; (b) north_star's B = 256 sampling shape;
+    (c) the C2 training step."""
+    import torch
+
+    out = {}
+    B = x_T.shape[0]
+    # (a) hipGraph replay at the headline batch
+    try:
+        gs = ops.GraphedSampler(packed, B, T, MC, toks, coef)
+        y = gs(ctx, x_T)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(y, x))
+        n = 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gs.replay_into(ctx, x_T)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["hipgraph"] = {"ms_per_rollout": round(dt * 1e3, 3), "value": round(B / dt, 2), "unit": "trajectories/s",
+                           "replays_timed": n, "bit_identical_to_eager": same}
+        del gs
+    except Exception as e:  # noqa: BLE001 - a sub-record must not take the headline down
+        out["hipgraph"] = {"error": repr(e)[:300]}
+    # (b) B = 256 (north_star's sampling shape), hipGraph replay and eager
+    try:
+        Bs = 256
+        xs, cs = x_T[:Bs].contiguous(), ctx[:Bs].contiguous()
+        gs = ops.GraphedSampler(packed, Bs, T, MC, toks, coef)
+        gs(cs, xs)
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gs.replay_into(cs, xs)
+        torch.cuda.synchronize()
+        dg = (time.perf_counter() - t0) / n
+        xe = torch.empty_like(xs)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            xe.copy_(xs)
+            ops.ddim_sample(packed, cs, toks, coef, xe, inplace=True)
+        torch.cuda.synchronize()
+        de = (time.perf_counter() - t0) / n
+        out["b256"] = {"workload": "north_star shape: B=256, 50 DDIM steps, T=100, J=20 (one rollout = one step)",
+                       "hipgraph_ms_per_rollout": round(dg * 1e3, 3), "eager_ms_per_rollout": round(de * 1e3, 3),
+                       "value": round(Bs / min(dg, de), 2), "unit": "trajectories/s",
+                       "algorithmic_tflops": round(Bs * N_DDIM * flops_per_traj_step()["total"] / min(dg, de) / 1e12, 2)}
+        del gs
+    except Exception as e:  # noqa: BLE001
+        out["b256"] = {"error": repr(e)[:300]}
+    # (c) C2 training step on this GPU
+    try:
+        leg = TrainLeg(dev, 0, 1, TRAIN_B, 40)
+        elapsed, loss = time_train(leg, 30, 5, None)
+        out["train"] = train_record(elapsed, 30, 1, TRAIN_B, loss, 0.0, leg.dropout, leg.opt.flat_param.numel())
+        out["train"]["workload"] = "BASELINE.json configs[1]: C2 training step, B=256, d=256 L=4 T=100 J=20 M=11 (bench.py --mode train)"
+    except Exception as e:  # noqa: BLE001
+        out["train"] = {"error": repr(e)[:300]}
+    return out
 
 
 if __name__ == "__main__":

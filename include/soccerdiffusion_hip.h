@@ -160,6 +160,21 @@ int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *
                    const float *coef, float *x, float *trace, float *workspace,
                    int B, int T, int Mc, int n_steps, void *stream);
 
+/* sd_ddim_sample with a range guard and a kernel-selection cap (same loop, same reference call sites).
+ *   status (DEVICE pointer to one int32, or NULL): zeroed at the start of the call; at its end a pass over the sample
+ *     ORs SD_STATUS_NONFINITE into it when any value of x is inf / NaN.  The split-fp16 kernels of mode 2 use fixed
+ *     power-of-two activation scales (8 for LayerNorm / attention / GELU outputs): a value with |8 v| >= 65520 becomes an
+ *     fp16 infinity, its products NaN, and the NaN stays in its trajectory down to x - so a set bit means "operand
+ *     range of mode 2 exceeded (e.g. a LayerNorm weight in the thousands) or non-finite input", never silently wrong
+ *     finite numbers.  No synchronisation: read the word after the stream has drained.
+ *   max_mode: -1 = automatic (sd_sampler_mode); 0 / 1 / 2 = never use a mode above this one.  max_mode <= 1 also keeps
+ *     the memory K/V projections on the exact-fp32 MFMA: the rerun path after a set status bit
+ *     (soccerdiffusion_amd.ops.ddim_sample_guarded does exactly that). */
+#define SD_STATUS_NONFINITE 1
+int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                      const float *coef, float *x, float *trace, float *workspace,
+                      int B, int T, int Mc, int n_steps, int32_t *status, int max_mode, void *stream);
+
 /* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
 
 /* out[R,N] = act(LN?(A)[R,d] @ W[N,d]^T + bias) (+ res).  ln_w/ln_b NULL = no LayerNorm;

@@ -124,6 +124,10 @@ def open_database(path: str, params: dict):
 
 
 def data_source(args, params: dict, device) -> DataSource:
+    chosen = [n for n in ("db", "data", "synthetic") if getattr(args, n, None) is not None]
+    if len(chosen) != 1:
+        raise SystemExit("give exactly one data source: --db FILE (the reference's SQLite database), --data FILE.pt "
+                         f"or --synthetic N (got: {', '.join('--' + c for c in chosen) or 'none'})")
     if getattr(args, "db", None):
         return DataSource(dataset=open_database(args.db, params), device=device)
     return DataSource(tensors=load_data(args, params), device=device)
@@ -136,6 +140,23 @@ def load_data(args, params: dict) -> dict:
             raise SystemExit("--data file must hold a dict with a 'joint_command' (N, T, J) tensor")
         return data
     return synthetic_dataset(args.synthetic, params, seed=args.seed)
+
+
+def shard_plan(n_total: int, batch_size: int, rank: int, world: int):
+    """Sample indices of this rank and the number of optimizer steps per epoch, the SAME on every rank.
+
+    world == 1: all samples, ceil(n / bs) steps, the last batch may be short (the reference's DataLoader default,
+    train.py:199-201).  world > 1: every rank owns exactly n_total // world samples (every world-th one; the
+    n_total % world trailing samples are dropped) and runs floor(per_rank / bs) full batches - at least one, possibly
+    short, when per_rank < bs - so that every rank issues the same number of all-reduces and OneCycleLR gets the same
+    total_steps everywhere."""
+    if world <= 1:
+        return torch.arange(n_total), max(1, math.ceil(n_total / batch_size))
+    per_rank = n_total // world
+    if per_rank == 0:
+        raise SystemExit(f"{n_total} samples cannot be sharded over {world} ranks")
+    shard = torch.arange(rank, per_rank * world, world)
+    return shard, max(1, per_rank // batch_size)
 
 
 def _dist_env():
@@ -164,10 +185,15 @@ def cmd_train(args) -> int:
     if args.config is not None:
         with open(args.config) as f:
             config_params = yaml.safe_load(f)
-        for key, value in config_params.items():  # the YAML wins; differences are warned (train.py:57-70)
-            if key in params and params[key] != value:
-                logger.warning("parameter %s differs: checkpoint %r, config %r (using the config)", key, params[key], value)
-            params[key] = value
+        if checkpoint is not None:  # train.py:57-70: differences are warned, then the YAML REPLACES the checkpoint's dict
+            logger.warning("Both a configuration file and a checkpoint are provided. "
+                           "The configuration file will be used for the hyperparameters.")
+            for key, value in config_params.items():
+                if key not in params:
+                    logger.warning("Key '%s' is not present in the checkpoint", key)
+                elif value != params[key]:
+                    logger.warning("Key '%s' has a different value in the checkpoint: %r != %r", key, params[key], value)
+        params = dict(config_params)
     if params["train_denoising_timesteps"] != 1000:
         raise SystemExit("train_denoising_timesteps must be 1000 (the scheduler table length; see scheduler.py)")
 
@@ -179,6 +205,7 @@ def cmd_train(args) -> int:
 
     mean, std = fit_rows(source.batch(norm_idx)["joint_command"].cpu())  # train.py:108-110
 
+    torch.manual_seed(args.seed)  # the same initial replica on every rank ...
     model = build_model(params).to(device)
     model.mean.copy_(mean)
     model.std.copy_(std)
@@ -188,13 +215,16 @@ def cmd_train(args) -> int:
         pre = torch.load(args.pretrained_decoder, map_location="cpu", weights_only=True)
         model.load_state_dict(pre["model_state_dict"], strict=False)
     model.train()
+    if hasattr(model, "set_dropout"):
+        model.set_dropout(args.dropout)
 
     optimizer = training.FusedAdamW(model.parameters(), lr=params["lr"])
     if checkpoint is not None and "optimizer_state_dict" in checkpoint:
         optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    if world > 1:  # ... and rank 0's parameters, moments and buffers are what every rank starts from, whatever happened above
+        training.broadcast_parameters(optimizer, model)
     bs = params["batch_size"]
-    shard = torch.arange(rank, n_total, world)  # each rank owns every world-th sample
-    steps_per_epoch = max(1, math.ceil(len(shard) / bs))
+    shard, steps_per_epoch = shard_plan(n_total, bs, rank, world)
     lr_scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=params["lr"], total_steps=params["epochs"] * steps_per_epoch)
     scheduler = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
     scheduler.config["num_train_timesteps"] = params["train_denoising_timesteps"]
@@ -204,8 +234,6 @@ def cmd_train(args) -> int:
         order = shard[torch.randperm(len(shard), generator=gen)]
         for i in range(steps_per_epoch):
             idx = order[i * bs : (i + 1) * bs]
-            if world > 1 and len(idx) < bs and i > 0:
-                continue  # keep ranks in lock step: a short last batch would desynchronise the all-reduce
             batch = source.batch(idx)
             targets = ops.normalize(batch["joint_command"].contiguous(), model.mean, model.std)
             if args.decoder_pretraining:
@@ -270,8 +298,7 @@ def cmd_distill(args) -> int:
     source = data_source(args, params, device)
     n_total = source.n
     bs = params["batch_size"]
-    shard = torch.arange(rank, n_total, world)
-    steps_per_epoch = max(1, math.ceil(len(shard) / bs))
+    shard, steps_per_epoch = shard_plan(n_total, bs, rank, world)
     lr_scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=params["lr"], total_steps=params["epochs"] * steps_per_epoch)
     dev_gen = torch.Generator(device=device).manual_seed(args.seed + 1000 * rank)
     n_teacher = params["distill_teacher_inference_steps"]
@@ -280,8 +307,6 @@ def cmd_distill(args) -> int:
         mean_loss = 0.0
         for i in range(steps_per_epoch):
             idx = order[i * bs : (i + 1) * bs]
-            if world > 1 and len(idx) < bs and i > 0:
-                continue
             batch = source.batch(idx)
             noisy = torch.randn(batch["joint_command"].shape, device=device, generator=dev_gen)
             optimizer.zero_grad()
@@ -351,7 +376,7 @@ def cmd_sample(args) -> int:
 
 
 def params_need_context(params: dict) -> bool:
-    return any(params.get(k, False) for k in ("use_action_history", "use_imu", "use_joint_states", "use_gamestate"))
+    return any(params.get(k, False) for k in ("use_action_history", "use_imu", "use_joint_states", "use_images", "use_gamestate"))
 
 
 def main(argv: Optional[list] = None) -> int:
@@ -364,6 +389,8 @@ def main(argv: Optional[list] = None) -> int:
     tr.add_argument("--output", "-o", type=str, default="trajectory_transformer_model.pth", help="Path to save the model")
     tr.add_argument("--decoder-pretraining", action="store_true", help="Train the decoder only, on random context")
     tr.add_argument("--pretrained-decoder", type=str, default=None, help="Checkpoint whose decoder weights are loaded (strict=False)")
+    tr.add_argument("--dropout", type=float, default=0.1, help="dropout probability of the transformer layers in training "
+                    "(the reference never sets it: torch's default 0.1, decoder.py:26-33); 0 = the parity path")
     sa = sub.add_parser("sample", help="sample trajectories from a checkpoint (flags of the reference's plot.py)")
     sa.add_argument("checkpoint", type=str, help="Path to the checkpoint to load")
     sa.add_argument("--steps", type=int, default=30, help="Number of denoising steps")
@@ -376,7 +403,7 @@ def main(argv: Optional[list] = None) -> int:
     for p in (tr, sa, di):
         p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
         p.add_argument("--db", type=str, default=None, help="SQLite database in the reference's schema (SOCCER_DIFFUSION_DB_PATH of the reference)")
-        p.add_argument("--synthetic", type=int, default=2048, help="number of synthetic sine-wave samples when --data is absent")
+        p.add_argument("--synthetic", type=int, default=None, metavar="N", help="train / sample on N synthetic sine-wave samples")
         p.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():

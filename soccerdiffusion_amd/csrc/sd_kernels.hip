@@ -242,6 +242,8 @@ static int launch_panel(const float *A, int lda, const float *W, const float *bi
 
 int linear16(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
              float *out, int R, int N, int d, int act, hipStream_t s, int lda);
+int linear32(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+             float *out, int R, int N, int d, int act, hipStream_t s, int lda);
 
 int linear(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
            float *out, int R, int N, int d, int act, hipStream_t s, int lda) {
@@ -253,6 +255,17 @@ int linear(const float *A, const float *W, const float *bias, const float *ln_w,
         static const char *env = getenv("SD_LINEAR");
         if (!(env && strcmp(env, "f32") == 0)) return linear16(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);
     }
+    return linear32(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);
+}
+
+// the same layer on v_mfma_f32_32x32x2_f32 only (exact fp32 fma chain, no operand range limits): the sampler's
+// range-guard fallback (sd_ddim_sample_ex, max_mode <= 1) projects the memory keys / values with it
+int linear32(const float *A, const float *W, const float *bias, const float *ln_w, const float *ln_b, const float *res,
+             float *out, int R, int N, int d, int act, hipStream_t s, int lda) {
+    if (lda == 0) lda = d;
+    if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "linear: row stride must be >= d and a multiple of 4");
+    if (!A || !W || !out || R <= 0 || N <= 0) return fail(SD_E_BADARG, "linear: null pointer or empty shape");
+    if (N % d != 0) return fail(SD_E_BADDIM, "linear: N must be a multiple of d");
     switch (d) {
         case 64: return launch_panel<64>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
         case 128: return launch_panel<128>(A, lda, W, bias, ln_w, ln_b, res, out, R, N, act, s);
@@ -2332,6 +2345,41 @@ __global__ void copy_rows_kernel(const float *__restrict__ src, long src_stride,
     }
 }
 
+// Zero-fill of workspace regions as a KERNEL, not hipMemsetAsync: memset nodes captured into a hipGraph were observed
+// (ROCm 7.2, gfx950) to replay with a garbage fill byte - the range-guard word read 0x58585858 / 0x80808080 after a
+// replay, and the abs-max words behind the fp16 scales were hit the same way (a replay then differed from the eager
+// rollout in the last bits).  A kernel node has no such problem.  n16 = number of 16-byte pieces.
+__global__ void zero_fill_kernel(f32x4 *__restrict__ p, long n16) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p[i] = z;
+}
+__global__ void zero_words_kernel(unsigned *__restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+// bytes: a multiple of 4; 16-byte aligned regions go through the wide kernel
+static int zero_async(void *ptr, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && bytes % 16 == 0) {
+        SD_LAUNCH(zero_fill_kernel, dim3(grid_for((long)(bytes / 16))), dim3(256), 0, st, reinterpret_cast<f32x4 *>(ptr), (long)(bytes / 16));
+    } else {
+        SD_LAUNCH(zero_words_kernel, dim3(grid_for((long)(bytes / 4))), dim3(256), 0, st, reinterpret_cast<unsigned *>(ptr), (long)(bytes / 4));
+    }
+    SD_CHECK_LAUNCH("zero_fill_kernel");
+    return 0;
+}
+
+// Range guard of the sampler: ORs `bit` into *status when any value is not finite.  The split-fp16 kernels use fixed
+// activation scales (sd_f16x3.h): |8 x| >= 65520 becomes an fp16 infinity, its lo part -inf, their products NaN, and a
+// NaN stays in its trajectory's rows down to x - so one pass over the sample is a complete detector (33 MB at B = 4096).
+__global__ void finite_check_kernel(const float *__restrict__ x, long n, int *status, int bit) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[i]);
+        bad |= (u & 0x7f800000u) == 0x7f800000u;   // exponent all ones: inf or NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, bit);
+}
+
 
 // ======================================================================================
 // Layer drivers
@@ -2440,8 +2488,7 @@ static f16 *f16_wfc(const Scratch &s, int l, int d, int which) { return s.wfc + 
 template <int D>
 static int f16_prepare_chain_d(const sd_denoiser_weights *w, const Scratch &s, hipStream_t st) {
     const int d = w->d, L = w->L;
-    hipError_t e = hipMemsetAsync(s.mbc, 0, (size_t)L * 8 * sizeof(unsigned), st);
-    if (e != hipSuccess) return fail((int)e, "f16_prepare_chain: hipMemsetAsync failed");
+    if (int rz = zero_async(s.mbc, (size_t)L * 8 * sizeof(unsigned), st)) return rz;
     for (int pass = 0; pass < 2; ++pass)
         for (int l = 0; l < L; ++l) {
             const sd_layer_weights &lw = w->layers[l];
@@ -2550,7 +2597,7 @@ static f16 *f16_wf(const Scratch &s, int l, int d, int which) {   // which: 0 Wo
 static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
     const int d = w->d, L = w->L;
     const size_t gvstride = (size_t)B * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
-    hipError_t e = hipSuccess;   // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' there
+    // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' there
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
@@ -2581,9 +2628,9 @@ static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, in
                       s.v16 + (size_t)l * B * 4 * blk, sc + 5);
             SD_CHECK_LAUNCH("f16_pack_v_kernel");
         } else {   // no context rows: the per-trajectory blocks are all zero
-            e = hipMemsetAsync(s.g16 + (size_t)l * B * 4 * blk, 0, (size_t)B * 4 * blk * sizeof(f16), st);
-            if (e == hipSuccess) e = hipMemsetAsync(s.v16 + (size_t)l * B * 4 * blk, 0, (size_t)B * 4 * blk * sizeof(f16), st);
-            if (e != hipSuccess) return fail((int)e, "f16_prepare: hipMemsetAsync failed");
+            int rz = zero_async(s.g16 + (size_t)l * B * 4 * blk, (size_t)B * 4 * blk * sizeof(f16), st);
+            if (!rz) rz = zero_async(s.v16 + (size_t)l * B * 4 * blk, (size_t)B * 4 * blk * sizeof(f16), st);
+            if (rz) return rz;
         }
         SD_LAUNCH((f16_pack_g_kernel<256>), dim3(grid_for((long)n_steps * 4 * 16 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride,
                   (long)n_steps, 1, Mc, mb + 4, s.gstep16 + (size_t)l * n_steps * 4 * blk, Mc > 0 ? (float *)nullptr : sc + 4);
@@ -2743,10 +2790,18 @@ extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
 extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
                               const float *coef, float *x, float *trace, float *workspace, int B, int T, int Mc,
                               int n_steps, void *stream) {
+    return sd_ddim_sample_ex(w, ctx, step_tokens, coef, x, trace, workspace, B, T, Mc, n_steps, nullptr, -1, stream);
+}
+
+extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                                 const float *coef, float *x, float *trace, float *workspace, int B, int T, int Mc,
+                                 int n_steps, int32_t *status, int max_mode, void *stream) {
     int rc = check_denoiser(w);
     if (rc) return rc;
     if (!step_tokens || !coef || !x || !workspace || B <= 0 || T <= 0 || Mc < 0 || n_steps <= 0 || (Mc > 0 && !ctx))
         return fail(SD_E_BADARG, "sd_ddim_sample: null pointer or empty shape");
+    if (max_mode < -1 || max_mode > 2) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode must be -1, 0, 1 or 2");
+    if (max_mode < 0) max_mode = 2;
     if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T, L = w->L;
@@ -2755,19 +2810,23 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
     // [Mk][2d] block, Mk = Mc + 1) and of all n_steps step tokens, per layer
     const int Mk = Mc + 1;
     const size_t kvstride = (size_t)B * Mk * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
-    const bool fold = fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
+    const bool fold = max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
     const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
-    const bool f16 = fold && f16_ok(d, w->J) && s.wf != nullptr;
-    const bool chain16 = !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
+    const bool f16 = max_mode >= 2 && fold && f16_ok(d, w->J) && s.wf != nullptr;
+    const bool chain16 = max_mode >= 2 && !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
+    if (status) {
+        if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
+    }
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
+        auto lin = max_mode >= 2 ? linear : linear32;
         if (Mc > 0) {
-            rc = linear(ctx, wkv, bkv, nullptr, nullptr, nullptr, s.kvtmp + (size_t)l * B * Mc * 2 * d, B * Mc, 2 * d, d, 0, st);
+            rc = lin(ctx, wkv, bkv, nullptr, nullptr, nullptr, s.kvtmp + (size_t)l * B * Mc * 2 * d, B * Mc, 2 * d, d, 0, st, 0);
             if (rc) return rc;
         }
-        rc = linear(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_steps, 2 * d, d, 0, st);
+        rc = lin(step_tokens, wkv, bkv, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_steps, 2 * d, d, 0, st, 0);
         if (rc) return rc;
     }
     if (chain16 && (rc = f16_prepare_chain(w, s, st))) return rc;
@@ -2775,10 +2834,10 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
         // the memory is fixed over the rollout: fold Wq into its keys and Woc into its values once
         const int hd = d / 4;
         const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
-        hipError_t e = hipMemsetAsync(s.gv, 0, L * gvstride * sizeof(float), st);   // unused key slots must be finite
-        if (e == hipSuccess && f16) e = hipMemsetAsync(s.maxbits, 0, (size_t)(L + 1) * 8 * sizeof(unsigned), st);   // abs-max words
-        if (e == hipSuccess) e = hipMemsetAsync(s.cb, 0, L * cbstride * sizeof(float), st);
-        if (e != hipSuccess) return fail((int)e, "sd_ddim_sample: hipMemsetAsync failed");
+        int rz = zero_async(s.gv, L * gvstride * sizeof(float), st);   // unused key slots must be finite
+        if (!rz && f16) rz = zero_async(s.maxbits, (size_t)(L + 1) * 8 * sizeof(unsigned), st);   // abs-max words
+        if (!rz) rz = zero_async(s.cb, L * cbstride * sizeof(float), st);
+        if (rz) return rz;
         for (int l = 0; l < L; ++l) {
             const sd_layer_weights &lw = w->layers[l];
             if (Mc > 0) {
@@ -2828,6 +2887,11 @@ extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, co
                                1L, (int)n);
             SD_CHECK_LAUNCH("copy_rows_kernel");
         }
+    }
+    if (status) {
+        const long n = (long)R * w->J;
+        SD_LAUNCH(finite_check_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, status, SD_STATUS_NONFINITE);
+        SD_CHECK_LAUNCH("finite_check_kernel");
     }
     return 0;
 }

@@ -149,6 +149,9 @@ class End2EndDiffusionTransformer(nn.Module):
             if key not in cache:
                 cache.clear()  # one shape at a time: a graph pins its workspace
                 cache[key] = ops.GraphedSampler(packed, B, T, Mc, self.step_encoding.table(ts, x_T.device), coef)
-            return cache[key](ctx, x_T)
+            out = cache[key](ctx, x_T)
+            if int(cache[key].status.item()) == 0:
+                return out
+            # range guard tripped (ops.ddim_sample_guarded): fall through to the guarded eager path
         tokens = self.step_encoding.table(ts, x_T.device)
-        return ops.ddim_sample(packed, ctx, tokens, coef, x_T.contiguous(), trace=return_trace)
+        return ops.ddim_sample_guarded(packed, ctx, tokens, coef, x_T.contiguous(), trace=return_trace)

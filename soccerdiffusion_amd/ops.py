@@ -296,18 +296,24 @@ def ddim_step(eps: Tensor, x: Tensor, coef4) -> Tensor:
     return out
 
 
+STATUS_NONFINITE = 1  # SD_STATUS_NONFINITE
+
+
 class GraphedSampler:
     """The whole rollout (n_steps x (L x 2 + 3) kernel launches of ``sd_ddim_sample``) captured
     once into a hipGraph and replayed: removes the per-launch host cost, which dominates at
     small batch (the robot's B = 1, 30-step rollout).  Static shapes; the inputs are copied
-    into the captured buffers before every replay."""
+    into the captured buffers before every replay.  ``status`` (one int32 on the device) is
+    the range-guard word of ``sd_ddim_sample_ex``, rewritten by every replay."""
 
-    def __init__(self, packed: _Packed, B: int, T: int, Mc: int, step_tokens: Tensor, coef: np.ndarray):
+    def __init__(self, packed: _Packed, B: int, T: int, Mc: int, step_tokens: Tensor, coef: np.ndarray, max_mode: int = -1):
         dev = step_tokens.device
         self.packed, self.coef = packed, np.ascontiguousarray(coef, dtype=np.float32)
         self.tokens = step_tokens.contiguous()
+        self.max_mode = int(max_mode)
         self.x = torch.zeros(B, T, packed.J, dtype=torch.float32, device=dev)
         self.ctx = torch.zeros(B, Mc, packed.d, dtype=torch.float32, device=dev) if Mc > 0 else None
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         lib = _lib.load()
         self.ws = torch.empty(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, len(self.coef)),
                               dtype=torch.float32, device=dev)
@@ -323,23 +329,32 @@ class GraphedSampler:
 
     def _run(self):
         B, T, _ = self.x.shape
-        check(_lib.load().sd_ddim_sample(C.byref(self.packed.struct), _ptr(self.ctx), self.tokens.data_ptr(),
-                                         self.coef.ctypes.data_as(_lib.c_float_p), self.x.data_ptr(), None,
-                                         self.ws.data_ptr(), B, T, 0 if self.ctx is None else self.ctx.shape[1],
-                                         len(self.coef), _stream()), "sd_ddim_sample")
+        check(_lib.load().sd_ddim_sample_ex(C.byref(self.packed.struct), _ptr(self.ctx), self.tokens.data_ptr(),
+                                            self.coef.ctypes.data_as(_lib.c_float_p), self.x.data_ptr(), None,
+                                            self.ws.data_ptr(), B, T, 0 if self.ctx is None else self.ctx.shape[1],
+                                            len(self.coef), self.status.data_ptr(), self.max_mode, _stream()),
+              "sd_ddim_sample_ex")
 
-    def __call__(self, ctx: Optional[Tensor], x_T: Tensor) -> Tensor:
+    def replay_into(self, ctx: Optional[Tensor], x_T: Tensor) -> Tensor:
+        """Copies the inputs into the captured buffers, replays, and returns the captured x buffer itself
+        (overwritten by the next replay)."""
         self.x.copy_(x_T)
         if self.ctx is not None:
             self.ctx.copy_(ctx)
         self.graph.replay()
-        return self.x.clone()
+        return self.x
+
+    def __call__(self, ctx: Optional[Tensor], x_T: Tensor) -> Tensor:
+        return self.replay_into(ctx, x_T).clone()
 
 
 def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
-                trace: bool = False, inplace: bool = False):
+                trace: bool = False, inplace: bool = False, status: Optional[Tensor] = None, max_mode: int = -1):
     """The reference's sampling loop (ml/inference/plot.py:122-131, ml/training/distill.py:179-189)
-    as ONE native call.  Returns the sample, or (sample, per-step trace) when ``trace``."""
+    as ONE native call.  Returns the sample, or (sample, per-step trace) when ``trace``.
+    ``status`` (int32 tensor of one element on the device) receives the range-guard word of
+    ``sd_ddim_sample_ex`` - not read here, so the call stays asynchronous; ``max_mode`` caps the kernel selection
+    (see ``ddim_sample_guarded``)."""
     lib = _lib.load()
     _req(x_T, "x_T"); _req(step_tokens, "step_tokens")
     B, T, J = x_T.shape
@@ -353,13 +368,43 @@ def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coe
     coef = np.ascontiguousarray(coef, dtype=np.float32)
     if coef.shape != (n_steps, 4):
         raise ValueError("coef must be (n_steps, 4)")
+    if status is not None:
+        _req(status, "status", torch.int32)
     x = x_T if inplace else x_T.clone()
     tr = torch.empty(n_steps, B, T, J, dtype=torch.float32, device=x.device) if trace else None
     ws = workspace(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, n_steps), x.device)
-    check(lib.sd_ddim_sample(C.byref(packed.struct), _ptr(ctx), step_tokens.data_ptr(),
-                             coef.ctypes.data_as(_lib.c_float_p), x.data_ptr(), _ptr(tr), ws.data_ptr(),
-                             B, T, Mc, n_steps, _stream()), "sd_ddim_sample")
+    check(lib.sd_ddim_sample_ex(C.byref(packed.struct), _ptr(ctx), step_tokens.data_ptr(),
+                                coef.ctypes.data_as(_lib.c_float_p), x.data_ptr(), _ptr(tr), ws.data_ptr(),
+                                B, T, Mc, n_steps, _ptr(status), int(max_mode), _stream()), "sd_ddim_sample_ex")
     return (x, tr) if trace else x
+
+
+def ddim_sample_guarded(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
+                        trace: bool = False):
+    """``ddim_sample`` with the range guard read back (one host synchronisation): when the split-fp16 kernels of
+    sampler mode 2 were driven out of their operand range (|8 v| >= 65520 for a LayerNorm / attention / GELU output -
+    e.g. a checkpoint with LayerNorm weights in the thousands), the rollout is repeated on the exact-fp32 MFMA kernels
+    (``max_mode`` 1), which have no such limit.  Raises if that result is not finite either (non-finite inputs)."""
+    import warnings
+
+    status = torch.zeros(1, dtype=torch.int32, device=x_T.device)
+    out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status)
+    if int(status.item()) == 0:
+        return out
+    mode = _lib.load().sd_sampler_mode(packed.d, packed.heads, x_T.shape[1], 0 if ctx is None else ctx.shape[1], packed.J)
+    if mode < 2 and _chain16_possible(packed):
+        mode = 2   # the unfused row chains run on the split-fp16 pipe as well
+    if mode >= 2:
+        warnings.warn("sd_ddim_sample: the split-fp16 kernels left their operand range (non-finite sample); "
+                      "repeating the rollout on the fp32-MFMA kernels", RuntimeWarning, stacklevel=2)
+        out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=1)
+        if int(status.item()) == 0:
+            return out
+    raise FloatingPointError("sd_ddim_sample produced non-finite values on the fp32 kernels too: the inputs or the weights are not finite")
+
+
+def _chain16_possible(packed: _Packed) -> bool:
+    return packed.d in (128, 256, 512) and packed.J % 4 == 0
 
 
 # ---- single ops (unit parity tests) ----------------------------------------------------

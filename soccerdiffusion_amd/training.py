@@ -426,6 +426,35 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = max(steps) if steps else 0
 
 
+def broadcast_parameters(optimizer: FusedAdamW, model=None, src: int = 0, group=None) -> None:
+    """Data-parallel start: every rank takes rank ``src``'s replica - the optimizer's flat parameter buffer and both
+    moment buffers (three broadcasts), plus every tensor of ``model`` the optimizer does not own (buffers such as
+    ``mean`` / ``std`` and BatchNorm statistics, frozen parameters).  Without it replicas that were initialised from
+    different RNG states would apply the averaged gradient to different weights and drift apart silently."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return
+    for buf in (optimizer.flat_param, optimizer.flat_m, optimizer.flat_v):
+        dist.broadcast(buf, src=src, group=group)
+    step = torch.tensor([optimizer._step], dtype=torch.int64, device=optimizer.flat_param.device)
+    dist.broadcast(step, src=src, group=group)
+    optimizer._step = int(step.item())
+    if model is not None:
+        lo = optimizer.flat_param.data_ptr()
+        hi = lo + 4 * optimizer.flat_param.numel()
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.numel() == 0 or lo <= t.data_ptr() < hi:
+                continue
+            if t.dtype == torch.int64 and t.dim() == 0:   # BatchNorm's num_batches_tracked
+                tmp = t.detach().reshape(1).clone()
+                dist.broadcast(tmp, src=src, group=group)
+                t.data.copy_(tmp.reshape(()))
+            else:
+                dist.broadcast(t.detach(), src=src, group=group)
+    optimizer.refresh_transposes()
+
+
 def allreduce_gradients(optimizer: FusedAdamW, world_size: int, group=None) -> None:
     """Data-parallel gradient exchange: ONE sum all-reduce of the flat fp32 gradient buffer
     over RCCL/xGMI (gloo on CPU tests), then the mean.  The reference is single-device."""
