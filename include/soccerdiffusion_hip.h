@@ -222,6 +222,37 @@ int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v,
                         int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
                         float *dv, int lddkv, int B, int Tq, int S, int d, int heads, void *stream);
 
+/* ---- dropout (training) -----------------------------------------------------------------------------------------
+ * The reference trains with torch's default dropout p = 0.1 (soccer_diffusion/ml/model/decoder.py:26-33 and
+ * encoder/base.py:29-40 never set it; train.py never calls .eval()): on the attention probabilities
+ * (nn.MultiheadAttention), after each attention out-projection (dropout1 / dropout2), after the GELU and after linear2
+ * (dropout / dropout3).  ONE counter-based mask for every kernel, nothing stored: element (row, col) of the logical
+ * (rows x width) tensor of site `site` is kept iff word (col & 3) of Philox4x32-10(counter = {quad lo, quad hi, site lo,
+ * site hi}, key = seed) >= p * 2^32, quad = (row * ceil4(width) + col) >> 2; kept values are scaled by 1 / (1 - p).
+ * The backward entry points regenerate the mask from the same (p, seed, site).  p = 0 is the parity path. */
+
+/* out = x o mask (forward of a stand-alone site; backward of a fused one: dy o mask).  out may alias x. */
+int sd_op_dropout(const float *x, float *out, long rows, int width, float p, uint64_t seed, uint64_t site, void *stream);
+/* mask[rows, width] = 0 or 1 / (1 - p): what the kernels apply (tests hand it to the oracle). */
+int sd_op_dropout_mask(float *mask, long rows, int width, float p, uint64_t seed, uint64_t site, void *stream);
+/* out = gelu(pre) o mask;  dpre = dy o mask o gelu'(pre)   (FFN: linear2(dropout(gelu(linear1 x)))) */
+int sd_op_gelu_dropout_fwd(const float *pre, float *out, long rows, int width, float p, uint64_t seed, uint64_t site, void *stream);
+int sd_op_gelu_dropout_bwd(const float *dy, const float *pre, float *dpre, long rows, int width, float p, uint64_t seed,
+                           uint64_t site, void *stream);
+/* out[R,N] = res + dropout(A[R,d] W[N,d]^T + bias), mask rows = R, width = N (x + dropout1(sa_block(x)) etc.);
+ * A may have a row stride lda >= d (0 = d).  res is required and may alias out. */
+int sd_op_linear_dropout(const float *A, int lda, const float *W, const float *bias, const float *res, float *out, int R,
+                         int N, int d, float p, uint64_t seed, uint64_t site, void *stream);
+/* sd_op_attention_lse / sd_op_attention_bwd with dropout on the probabilities: O = (softmax(S) o mask) V, the softmax
+ * normaliser and lse2 are those of the un-dropped probabilities; mask rows = (b * heads + h) * Tq + q, width = S. */
+int sd_op_attention_lse_dropout(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                                int ldo, float *lse2, int B, int Tq, int S, int d, int heads, float p, uint64_t seed,
+                                uint64_t site, void *stream);
+int sd_op_attention_bwd_dropout(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
+                                int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
+                                float *dv, int lddkv, int B, int Tq, int S, int d, int heads, float p, uint64_t seed,
+                                uint64_t site, void *stream);
+
 /* dW[N,K] += dY[R,N]^T X[R,K];  db[N] += column sums of dY (db may be NULL).  Accumulates
  * with fp32 atomics: zero dW/db first (summation order is not fixed). */
 int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,

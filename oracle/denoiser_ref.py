@@ -72,8 +72,25 @@ def gelu_erf(u: Tensor) -> Tensor:
     return 0.5 * u * (1.0 + torch.erf(u / math.sqrt(2.0)))
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
-    """softmax(q k^T / sqrt(hd)) v per head, unmasked.  q (B,T,d); k,v (B,S,d)."""
+# Dropout sites of one layer, in torch's forward order (nn.TransformerDecoderLayer._sa_block / _mha_block / _ff_block
+# and nn.MultiheadAttention): probabilities of the self-attention, its out-projection (dropout1), probabilities of the
+# cross-attention, its out-projection (dropout2), the activation (dropout) and linear2 (dropout3; dropout2 in an encoder
+# layer).  The reference trains with torch's default p = 0.1 at all of them (decoder.py:26-33, encoder/base.py:29-40).
+# ``masks`` is None (p = 0: the golden-vector path) or a callable (kind, shape) -> multiplier tensor (0 or 1/(1-p)) that
+# the caller builds - the tests pass the very masks the HIP kernels regenerate from their Philox counter.
+SITE_SA_PROBS, SITE_SA_OUT, SITE_CA_PROBS, SITE_CA_OUT, SITE_FFN_ACT, SITE_FFN_OUT = range(6)
+
+
+def _drop(v: Tensor, masks, kind: int) -> Tensor:
+    if masks is None:
+        return v
+    m = masks(kind, tuple(v.shape))
+    return v if m is None else v * m.to(v.dtype)
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, masks=None, kind: int = SITE_SA_PROBS) -> Tensor:
+    """softmax(q k^T / sqrt(hd)) v per head, unmasked.  q (B,T,d); k,v (B,S,d).  Dropout acts on the probabilities
+    (B, heads, T, S) after the softmax, as in torch's scaled-dot-product path."""
     B, T, d = q.shape
     S = k.shape[1]
     hd = d // heads
@@ -81,18 +98,19 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
     kh = k.view(B, S, heads, hd).transpose(1, 2)
     vh = v.view(B, S, heads, hd).transpose(1, 2)
     p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), dim=-1)
+    p = _drop(p, masks, kind)
     return (p @ vh).transpose(1, 2).reshape(B, T, d)
 
 
-def self_attn_block(sd, pre: str, h: Tensor, heads: int, dt) -> Tensor:
+def self_attn_block(sd, pre: str, h: Tensor, heads: int, dt, masks=None) -> Tensor:
     d = h.shape[-1]
     n = layer_norm(h, _w(sd, pre + "norm1.weight", dt), _w(sd, pre + "norm1.bias", dt))
     qkv = n @ _w(sd, pre + "self_attn.in_proj_weight", dt).T + _w(sd, pre + "self_attn.in_proj_bias", dt)
-    a = attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads)
-    return h + a @ _w(sd, pre + "self_attn.out_proj.weight", dt).T + _w(sd, pre + "self_attn.out_proj.bias", dt)
+    a = attention(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads, masks, SITE_SA_PROBS)
+    return h + _drop(a @ _w(sd, pre + "self_attn.out_proj.weight", dt).T + _w(sd, pre + "self_attn.out_proj.bias", dt), masks, SITE_SA_OUT)
 
 
-def cross_attn_block(sd, pre: str, h: Tensor, memory: Tensor, heads: int, dt) -> Tensor:
+def cross_attn_block(sd, pre: str, h: Tensor, memory: Tensor, heads: int, dt, masks=None) -> Tensor:
     d = h.shape[-1]
     w = _w(sd, pre + "multihead_attn.in_proj_weight", dt)
     b = _w(sd, pre + "multihead_attn.in_proj_bias", dt)
@@ -100,14 +118,15 @@ def cross_attn_block(sd, pre: str, h: Tensor, memory: Tensor, heads: int, dt) ->
     q = n @ w[:d].T + b[:d]
     k = memory @ w[d : 2 * d].T + b[d : 2 * d]  # memory is NOT normalised
     v = memory @ w[2 * d :].T + b[2 * d :]
-    a = attention(q, k, v, heads)
-    return h + a @ _w(sd, pre + "multihead_attn.out_proj.weight", dt).T + _w(sd, pre + "multihead_attn.out_proj.bias", dt)
+    a = attention(q, k, v, heads, masks, SITE_CA_PROBS)
+    return h + _drop(a @ _w(sd, pre + "multihead_attn.out_proj.weight", dt).T + _w(sd, pre + "multihead_attn.out_proj.bias", dt),
+                     masks, SITE_CA_OUT)
 
 
-def ffn_block(sd, pre: str, h: Tensor, norm: str, dt) -> Tensor:
+def ffn_block(sd, pre: str, h: Tensor, norm: str, dt, masks=None) -> Tensor:
     n = layer_norm(h, _w(sd, pre + norm + ".weight", dt), _w(sd, pre + norm + ".bias", dt))
-    u = gelu_erf(n @ _w(sd, pre + "linear1.weight", dt).T + _w(sd, pre + "linear1.bias", dt))
-    return h + u @ _w(sd, pre + "linear2.weight", dt).T + _w(sd, pre + "linear2.bias", dt)
+    u = _drop(gelu_erf(n @ _w(sd, pre + "linear1.weight", dt).T + _w(sd, pre + "linear1.bias", dt)), masks, SITE_FFN_ACT)
+    return h + _drop(u @ _w(sd, pre + "linear2.weight", dt).T + _w(sd, pre + "linear2.bias", dt), masks, SITE_FFN_OUT)
 
 
 def _num_layers(sd: Mapping[str, Tensor], stem: str) -> int:
@@ -127,10 +146,12 @@ def denoiser_forward(
     prefix: str = "diffusion_action_generator.",
     dtype: torch.dtype = torch.float32,
     heads: int = NUM_HEADS,
+    dropout_masks=None,
 ) -> Tensor:
     """DiffusionActionGenerator.forward — soccer_diffusion/ml/model/decoder.py:38-54.
 
-    x (B,T,J) noisy trajectory, memory (B,M,d) context tokens incl. the step token."""
+    x (B,T,J) noisy trajectory, memory (B,M,d) context tokens incl. the step token.
+    ``dropout_masks``: None, or a callable (layer, kind, shape) -> multiplier tensor (training-mode forward)."""
     dt = dtype
     x = x.to("cpu", dt)
     memory = memory.to("cpu", dt)
@@ -142,9 +163,10 @@ def denoiser_forward(
     stem = prefix + "transformer_decoder.layers."
     for l in range(_num_layers(sd, stem)):  # decoder.py:52
         pre = f"{stem}{l}."
-        h = self_attn_block(sd, pre, h, heads, dt)
-        h = cross_attn_block(sd, pre, h, memory, heads, dt)
-        h = ffn_block(sd, pre, h, "norm3", dt)
+        mk = None if dropout_masks is None else (lambda kind, shape, l=l: dropout_masks(l, kind, shape))
+        h = self_attn_block(sd, pre, h, heads, dt, mk)
+        h = cross_attn_block(sd, pre, h, memory, heads, dt, mk)
+        h = ffn_block(sd, pre, h, "norm3", dt, mk)
     return h @ _w(sd, prefix + "fc_out.weight", dt).T + _w(sd, prefix + "fc_out.bias", dt)  # decoder.py:54
 
 
@@ -200,13 +222,14 @@ def encode_input_data(sd: Mapping[str, Tensor], input_data: Mapping[str, Tensor]
 
 
 def forward_with_context(
-    sd: Mapping[str, Tensor], context: Sequence[Tensor], noisy: Tensor, step: Tensor, dtype: torch.dtype = torch.float32
+    sd: Mapping[str, Tensor], context: Sequence[Tensor], noisy: Tensor, step: Tensor, dtype: torch.dtype = torch.float32,
+    dropout_masks=None,
 ) -> Tensor:
     """End2EndDiffusionTransformer.forward_with_context — soccer_diffusion/ml/model/model.py:159-179."""
     d = sd["diffusion_action_generator.embedding.weight"].shape[0]
     tok = step_token(step.cpu(), sd["step_encoding.token"].cpu().float(), d)  # model.py:173
     mem = torch.cat([c.to("cpu", dtype) for c in context] + [tok.to(dtype)], dim=1)  # model.py:176
-    return denoiser_forward(sd, noisy, mem, dtype=dtype)  # model.py:179
+    return denoiser_forward(sd, noisy, mem, dtype=dtype, dropout_masks=dropout_masks)  # model.py:179
 
 
 def forward(sd, input_data, noisy, step, dtype=torch.float32) -> Tensor:
@@ -214,15 +237,16 @@ def forward(sd, input_data, noisy, step, dtype=torch.float32) -> Tensor:
     return forward_with_context(sd, encode_input_data(sd, input_data, dtype), noisy, step, dtype)
 
 
-def train_loss_and_grads(sd, noisy, step, noise, context=None, input_data=None, dtype=torch.float32):
-    """Loss and per-parameter gradients of one reference training step at dropout p=0:
-    ``mse_loss(model(...), noise)`` + ``backward`` — soccer_diffusion/ml/training/train.py:221-238.
+def train_loss_and_grads(sd, noisy, step, noise, context=None, input_data=None, dtype=torch.float32, dropout_masks=None):
+    """Loss and per-parameter gradients of one reference training step:
+    ``mse_loss(model(...), noise)`` + ``backward`` — soccer_diffusion/ml/training/train.py:221-238; dropout p = 0
+    unless ``dropout_masks`` (decoder sites only, see denoiser_forward) hands in the masks to apply.
     Exactly one of ``context`` (decoder-pretraining path, train.py:221-224) and
     ``input_data`` (full model, train.py:226) is given.  Returns (pred, loss, grads)."""
     leaf = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k not in ("mean", "std")) for k, v in sd.items()}
     with torch.enable_grad():
         if context is not None:
-            pred = forward_with_context(leaf, context, noisy, step, dtype)
+            pred = forward_with_context(leaf, context, noisy, step, dtype, dropout_masks=dropout_masks)
         else:
             pred = forward(leaf, input_data, noisy, step, dtype)
         loss = torch.nn.functional.mse_loss(pred, noise.to(dtype))

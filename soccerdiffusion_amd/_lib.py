@@ -76,6 +76,17 @@ SIGNATURES = {
     "sd_op_attention_lse": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "sd_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]),
+    "sd_op_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_dropout_mask": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_gelu_dropout_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_gelu_dropout_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_linear_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_attention_lse_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 +
+                                    [C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_op_attention_bwd_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 +
+                                    [C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sd_op_gemm_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_long, C.c_int, C.c_void_p]),
     "sd_op_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_long, C.c_int, C.c_void_p]),

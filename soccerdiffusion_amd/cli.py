@@ -215,8 +215,7 @@ def cmd_train(args) -> int:
         pre = torch.load(args.pretrained_decoder, map_location="cpu", weights_only=True)
         model.load_state_dict(pre["model_state_dict"], strict=False)
     model.train()
-    if hasattr(model, "set_dropout"):
-        model.set_dropout(args.dropout)
+    model.set_dropout(args.dropout, seed=args.seed + 7919 * rank)   # every rank its own mask stream
 
     optimizer = training.FusedAdamW(model.parameters(), lr=params["lr"])
     if checkpoint is not None and "optimizer_state_dict" in checkpoint:
@@ -285,10 +284,15 @@ def cmd_distill(args) -> int:
 
     teacher = build_model(params).to(device)
     teacher.load_state_dict(checkpoint["model_state_dict"])
-    teacher.eval()
+    # distill.py:127-131 never calls teacher_model.eval(): the reference's teacher rollout (and its context encoders) run
+    # with dropout 0.1 live.  --teacher-dropout reproduces that (a Python loop over the training kernels); the default
+    # is the clean teacher on the native sampler.
+    teacher.train(args.teacher_dropout)
+    teacher.set_dropout(args.dropout if args.teacher_dropout else 0.0, seed=args.seed + 104729 + 7919 * rank)
     student = build_model(params).to(device)
     student.load_state_dict(checkpoint["model_state_dict"])
     student.train()
+    student.set_dropout(args.dropout, seed=args.seed + 7919 * rank)
     # the student's context encoders never see a gradient (the context comes from the teacher under
     # no_grad), so torch's AdamW leaves them untouched; the flat optimizer therefore only owns the rest
     trainable = [p for n, p in student.named_parameters() if n.startswith(("diffusion_action_generator.", "step_encoding."))]
@@ -315,7 +319,7 @@ def cmd_distill(args) -> int:
                     embedded = teacher.encode_input_data({k: batch[k].contiguous() for k in CONTEXT_KEYS if k in batch})
                 else:
                     embedded = [torch.randn(len(idx), 10, params["hidden_dim"], device=device, generator=dev_gen)]
-                target = teacher.sample(embedded, noisy, n_teacher)
+                target = teacher.sample(embedded, noisy, n_teacher, with_dropout=args.teacher_dropout)
             pred = student.forward_with_context(embedded, noisy, torch.zeros(len(idx), device=device))
             loss = training.mse_loss(pred, target)
             loss.backward()
@@ -400,6 +404,9 @@ def main(argv: Optional[list] = None) -> int:
     di.add_argument("config", type=str, help="Path to the training configuration file")
     di.add_argument("checkpoint", type=str, help="Path to the checkpoint to load for the teacher model")
     di.add_argument("--output", "-o", type=str, default="distilled_trajectory_transformer_model.pth", help="Path to save the distilled model")
+    di.add_argument("--dropout", type=float, default=0.1, help="dropout probability of the student (and of the teacher with --teacher-dropout)")
+    di.add_argument("--teacher-dropout", action="store_true", help="leave the teacher in train mode during its rollout, as the "
+                    "reference's distill.py does (it never calls teacher_model.eval())")
     for p in (tr, sa, di):
         p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
         p.add_argument("--db", type=str, default=None, help="SQLite database in the reference's schema (SOCCER_DIFFUSION_DB_PATH of the reference)")

@@ -142,6 +142,57 @@ __device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
     return ldexpf(1.0f, 14 - e);
 }
 
+// --------------------------------------------------------------------------------------
+// Dropout (training only; reference: torch's default p = 0.1 inside nn.TransformerDecoderLayer / EncoderLayer and
+// nn.MultiheadAttention, soccer_diffusion/ml/model/decoder.py:26-33 never overrides it).  ONE mask function for every
+// kernel: element (row, col) of the logical (rows x width) tensor of dropout site `site` is kept iff word
+// (col & 3) of Philox4x32-10(counter = {quad lo, quad hi, site lo, site hi}, key = seed) is >= thresh, with
+// quad = (row * ceil4(width) + col) >> 2 - rows are padded to a multiple of 4 columns so that 4 consecutive columns of
+// a row always come from one Philox call, whatever the width (attention rows have S = 11 keys).  Nothing is stored: the
+// backward kernels regenerate the mask from (seed, site).  Kept values are scaled by 1 / (1 - p).
+// --------------------------------------------------------------------------------------
+struct DropoutArgs {
+    unsigned thresh;      // keep iff word >= thresh;  0 = no dropout
+    float scale;          // 1 / (1 - p)
+    unsigned seed_lo, seed_hi, site_lo, site_hi;
+};
+
+static inline DropoutArgs make_dropout(float p, uint64_t seed, uint64_t site) {
+    DropoutArgs a;
+    double t = (double)p * 4294967296.0;
+    a.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+    a.scale = p <= 0.f ? 1.0f : 1.0f / (1.0f - p);
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.site_lo = (unsigned)site; a.site_hi = (unsigned)(site >> 32);
+    return a;
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&w)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+
+// multipliers (0 or 1/(1-p)) of the 4 elements of quad `quad` (= padded flat index >> 2)
+__device__ __forceinline__ f32x4 dropout_quad(const DropoutArgs &a, unsigned long quad) {
+    unsigned w[4];
+    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), a.site_lo, a.site_hi, a.seed_lo, a.seed_hi, w);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = w[e] >= a.thresh ? a.scale : 0.f;
+    return m;
+}
+
 static inline unsigned grid_for(long n, int block = 256) {
     long g = (n + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;

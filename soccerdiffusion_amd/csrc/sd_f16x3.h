@@ -1295,9 +1295,12 @@ __global__ __launch_bounds__(256, 2) void attention_f16_head_kernel(const float 
 #define SD_ATT_LV_OCC 3
 #endif
 constexpr size_t ATT16LV_LDS = (size_t)(128 * ATT16H_KP > 64 * ATT16H_VP ? 128 * ATT16H_KP : 64 * ATT16H_VP) * sizeof(f16);
-template <bool HM>
+// DROP (training forward): dropout on the probabilities, see attention_kernel; instantiated for HM = false only, so the
+// sampler's kernel (register-tight at 3 workgroups per CU) is untouched.
+template <bool HM, bool DROP = false>
 __global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kernel(const float *__restrict__ qkv, int ld_rm, float *__restrict__ out, int ldo,
-                                                                   int T, int heads, float scale_log2e, float *__restrict__ lse2) {
+                                                                   int T, int heads, float scale_log2e, float *__restrict__ lse2,
+                                                                   DropoutArgs da = DropoutArgs{}) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) f16 smem16[];
     f16 *sK = smem16, *sV = smem16;   // V^T takes K's place once the scores are done
@@ -1431,6 +1434,22 @@ __global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kern
             sc[kt][r] = pv;
             psum += pv;
         }
+    if constexpr (DROP) {
+        if (live) {
+            const unsigned long mrow = ((unsigned long)b * heads + h) * T + (q_ok ? qi : 0);
+            const unsigned long wq = (unsigned long)((T + 3) >> 2);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                if (kt < kt_valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 m4 = dropout_quad(da, mrow * wq + (unsigned long)((kt * 32 + 8 * g + 4 * half) >> 2));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[kt][4 * g + e] *= m4[e];
+                    }
+                }
+        }
+    }
     SD_STAMP(SD_STAMP_ATT_SLOT, 7);
     __syncthreads();   // V^T staged by everyone
     if (!live) return;
@@ -1548,11 +1567,14 @@ __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const
     }
 }
 
-template <int D, bool HAS_LN, int ACT, bool HAS_RES>
+// DROP (training): out = res + dropout(A W^T + bias) - torch's x + dropout1(sa_block(x)) / x + dropout2(ff_block(x)); the mask
+// is applied to the quad-transposed values (4 consecutive columns of one row = one Philox call, sd_common.h) and the
+// residual is then added from a 16-byte load.
+template <int D, bool HAS_LN, int ACT, bool HAS_RES, bool DROP = false>
 __global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, const float *__restrict__ ln_w,
                                                             const float *__restrict__ ln_b, const float *res, float *out, int R,
-                                                            int N, int lda) {
+                                                            int N, int lda, DropoutArgs da = DropoutArgs{}) {
     using C = PanelCfg<D>;
     constexpr int NK = D / 16, ROWP = 2 * C::LDA;
     extern __shared__ __attribute__((aligned(16))) float sA[];
@@ -1673,7 +1695,7 @@ __global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[tm][tn][4 * g + e] * inv[tm][g][e] + bv;
-                        if constexpr (HAS_RES) {
+                        if constexpr (HAS_RES && !DROP) {
                             const long row = r0 + wm * C::WM + tm * 32 + 8 * g + 4 * half + e;
                             v += (full_panel || row < R) ? res[row * N + col] : 0.f;
                         }
@@ -1682,7 +1704,13 @@ __global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restri
                     }
                     quad_transpose(x[0], x[1], x[2], x[3], lane);
                     if (full_panel || orow + 8 * g < R) {
-                        const f32x4 v4 = {x[0], x[1], x[2], x[3]};
+                        f32x4 v4 = {x[0], x[1], x[2], x[3]};
+                        if constexpr (DROP) {
+                            const long row = orow + 8 * g;
+                            const int c0 = n0 + wn * C::WN + tn * 32 + (l31 & ~3);
+                            v4 = v4 * dropout_quad(da, ((unsigned long)row * (unsigned long)((N + 3) >> 2)) + (unsigned long)(c0 >> 2));
+                            if constexpr (HAS_RES) v4 = v4 + *reinterpret_cast<const f32x4 *>(res + row * N + c0);
+                        }
                         *reinterpret_cast<f32x4 *>(op + (long)(8 * g) * N) = v4;
                     }
                 }

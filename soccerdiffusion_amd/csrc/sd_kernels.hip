@@ -1327,11 +1327,23 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
 
 template <int D>
 static int launch_panel16(const float *A, int lda, const float *W, const float *bias, const float *ln_w, const float *ln_b,
-                          const float *res, float *out, int R, int N, int act, hipStream_t s) {
+                          const float *res, float *out, int R, int N, int act, hipStream_t s, const DropoutArgs &da = DropoutArgs{}) {
     using C = PanelCfg<D>;
     ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
     dim3 grid((R + C::BM - 1) / C::BM), block(256);
     const size_t lds = C::LDS_BYTES + C::BM * sizeof(float);
+    if (da.thresh) {   // training: out = res + dropout(A W^T + bias)
+        if (ln_w || act != 0 || !res || N % 4 != 0) return fail(SD_E_BADARG, "sd_op_linear_dropout: needs res, no LayerNorm, no activation, N % 4 == 0");
+        auto kfn = panel_gemm16_kernel<D, false, 0, true, true>;
+        static bool attr_set = false;
+        if (lds > 64 * 1024 && !attr_set) {
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda, da);
+        SD_CHECK_LAUNCH("panel_gemm16_kernel");
+        return 0;
+    }
 #define SD_PANEL16(LN_, ACT_, RES_)                                                                            \
     do {                                                                                                       \
         auto kfn = panel_gemm16_kernel<D, LN_, ACT_, RES_>;                                                    \
@@ -1340,7 +1352,7 @@ static int launch_panel16(const float *A, int lda, const float *W, const float *
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda);                      \
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda, DropoutArgs{});       \
     } while (0)
     const bool ln = ln_w != nullptr;
     const bool rs = res != nullptr;
@@ -1367,6 +1379,24 @@ int linear16(const float *A, const float *W, const float *bias, const float *ln_
     return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
 }
 
+extern "C" int sd_op_linear_dropout(const float *A, int lda, const float *W, const float *bias, const float *res, float *out, int R,
+                                    int N, int d, float p, uint64_t seed, uint64_t site, void *stream) {
+    if (!A || !W || !out || !res || R <= 0 || N <= 0 || N % d != 0) return fail(SD_E_BADARG, "sd_op_linear_dropout: bad argument");
+    if (!(p >= 0.f) || !(p < 1.f)) return fail(SD_E_BADARG, "sd_op_linear_dropout: p must be in [0, 1)");
+    if (lda == 0) lda = d;
+    if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "sd_op_linear_dropout: row stride must be >= d and a multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    if (p == 0.f) return linear(A, W, bias, nullptr, nullptr, res, out, R, N, d, 0, s, lda);
+    const DropoutArgs da = make_dropout(p, seed, site);
+    switch (d) {
+        case 64: return launch_panel16<64>(A, lda, W, bias, nullptr, nullptr, res, out, R, N, 0, s, da);
+        case 128: return launch_panel16<128>(A, lda, W, bias, nullptr, nullptr, res, out, R, N, 0, s, da);
+        case 256: return launch_panel16<256>(A, lda, W, bias, nullptr, nullptr, res, out, R, N, 0, s, da);
+        case 512: return launch_panel16<512>(A, lda, W, bias, nullptr, nullptr, res, out, R, N, 0, s, da);
+    }
+    return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+}
+
 static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     if (fa.g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer_f16: empty shape");
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
@@ -1386,9 +1416,15 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
 
 // self-attention over qkv [B*T][3d] on the fp16 pipe (head dim 64, T <= 128)
 static int attention_f16(const float *qkv, float *out, int B, int T, int d, int heads, hipStream_t s, bool head_major,
-                         float *lse2 = nullptr) {
+                         float *lse2 = nullptr, const DropoutArgs &da = DropoutArgs{}) {
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     const float sl2e = (1.0f / sqrtf(64.0f)) * 1.44269504088896340736f;
+    if (da.thresh) {   // training forward with dropout on the probabilities: row-major q|k|v only
+        if (head_major) return fail(SD_E_BADARG, "attention_f16: dropout needs the row-major q|k|v layout");
+        SD_LAUNCH((attention_f16_head_lv_kernel<false, true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2, da);
+        SD_CHECK_LAUNCH("attention_f16_head_lv_kernel");
+        return 0;
+    }
     // default: one workgroup per (sample, head), V^T staged late into K's LDS (35 KB of LDS, 3 workgroups per CU);
     // A/B runs: "stage2" = K and V^T staged together (69 KB, 2 per CU), "stream" = the per-sample streaming kernel
     static const char *env = getenv("SD_ATT16");
@@ -1398,8 +1434,8 @@ static int attention_f16(const float *qkv, float *out, int B, int T, int d, int 
         return 0;
     }
     if (lse2 || !(env && strcmp(env, "stage2") == 0)) {
-        if (head_major) SD_LAUNCH((attention_f16_head_lv_kernel<true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2);
-        else SD_LAUNCH((attention_f16_head_lv_kernel<false>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2);
+        if (head_major) SD_LAUNCH((attention_f16_head_lv_kernel<true>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2, DropoutArgs{});
+        else SD_LAUNCH((attention_f16_head_lv_kernel<false>), dim3(B * heads), dim3(256), ATT16LV_LDS, s, qkv, 3 * d, out, d, T, heads, sl2e, lse2, DropoutArgs{});
         SD_CHECK_LAUNCH("attention_f16_head_lv_kernel");
         return 0;
     }
@@ -1537,13 +1573,15 @@ struct AttnCfg {
     static constexpr size_t LDS_BYTES = (size_t)KC * (LDK + LDV) * sizeof(float);
 };
 
-template <int HD>
+// DROP (training): dropout on the attention probabilities (torch nn.MultiheadAttention dropout): the normaliser uses
+// the un-dropped probabilities, O = (P o m) V; mask row = (sample, head, query), column = key (sd_common.h).
+template <int HD, bool DROP = false>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, int ldq,
                                                          const float *__restrict__ k, const float *__restrict__ v,
                                                          int ldkv, const float *__restrict__ k_extra,
                                                          const float *__restrict__ v_extra, float *__restrict__ out,
                                                          int ldo, int Tq, int S, int heads, float scale_log2e,
-                                                         float *__restrict__ lse2) {
+                                                         float *__restrict__ lse2, DropoutArgs da = DropoutArgs{}) {
     using C = AttnCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S_all = S + (k_extra ? 1 : 0);
@@ -1650,6 +1688,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
                     sc[kt][r] = p;
                     psum += p;
                 }
+            if constexpr (DROP) {
+                const int qi = q0 + l31;
+                const unsigned long mrow = ((unsigned long)b * heads + h) * Tq + (qi < Tq ? qi : 0);
+                const unsigned long wq = (unsigned long)((S_all + 3) >> 2);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    if (kt < kt_valid) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 m4 = dropout_quad(da, mrow * wq + (unsigned long)((kc0 + kt * 32 + 8 * g + 4 * half) >> 2));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sc[kt][4 * g + e] *= m4[e];
+                        }
+                    }
+            }
             l_part = l_part * alpha + psum;
 #pragma unroll
             for (int ft = 0; ft < C::FT; ++ft)
@@ -1903,7 +1956,7 @@ __global__ __launch_bounds__(256, (HD <= 64 ? 2 : 1)) void attention_pipe_kernel
 
 static int attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,
                      const float *v_extra, float *out, int ldo, int B, int Tq, int S, int d, int heads,
-                     hipStream_t s, float *lse2 = nullptr) {
+                     hipStream_t s, float *lse2 = nullptr, const DropoutArgs &da = DropoutArgs{}) {
     if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || S < 0 || heads <= 0)
         return fail(SD_E_BADARG, "attention: null pointer or empty shape");
     if ((k_extra == nullptr) != (v_extra == nullptr)) return fail(SD_E_BADARG, "attention: k_extra/v_extra mismatch");
@@ -1917,7 +1970,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     // in sequence - the rollout there is a chain of kernel latencies (robot shape: 11.6 -> 9.4 ms per rollout)
     static const char *penv = getenv("SD_ATT_PIPE_MIN_B");
     static const int pipe_min_b = penv ? atoi(penv) : 64;
-    if (Tq <= 128 && !k_extra && S > 0 && B >= pipe_min_b) {
+    if (Tq <= 128 && !k_extra && S > 0 && B >= pipe_min_b && !da.thresh) {
         dim3 gridp(B);
 #define SD_ATTNP(HD_)                                                                                            \
     do {                                                                                                         \
@@ -1943,17 +1996,17 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     }
 #define SD_ATTN(HD_)                                                                                             \
     do {                                                                                                         \
-        auto kfn = attention_kernel<HD_>;                                                                        \
+        auto kfn = da.thresh ? attention_kernel<HD_, true> : attention_kernel<HD_, false>;                       \
         const int s_all = S + (k_extra ? 1 : 0);                                                                 \
         const int rows_cap = std::min((int)AttnCfg<HD_>::KC, ((s_all + 31) / 32) * 32);                           \
         const size_t lds = (size_t)rows_cap * (AttnCfg<HD_>::LDK + AttnCfg<HD_>::LDV) * sizeof(float);           \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
+        static bool attr_set[2] = {false, false};                                                                \
+        if (!attr_set[da.thresh ? 1 : 0]) {                                                                      \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                       (int)AttnCfg<HD_>::LDS_BYTES);                                             \
-            attr_set = true;                                                                                     \
+            attr_set[da.thresh ? 1 : 0] = true;                                                                  \
         }                                                                                                        \
-        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e, lse2); \
+        SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, k_extra, v_extra, out, ldo, Tq, S, heads, sl2e, lse2, da); \
     } while (0)
     switch (hd) {
         case 16: SD_ATTN(16); break;
@@ -2997,10 +3050,18 @@ static bool att_op_f16(const float *q, int ldq, const float *k, const float *v, 
 
 extern "C" int sd_op_attention_lse(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
                                    int ldo, float *lse2, int B, int Tq, int S, int d, int heads, void *stream) {
+    return sd_op_attention_lse_dropout(q, ldq, k, v, ldkv, out, ldo, lse2, B, Tq, S, d, heads, 0.f, 0, 0, stream);
+}
+
+extern "C" int sd_op_attention_lse_dropout(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,
+                                           int ldo, float *lse2, int B, int Tq, int S, int d, int heads, float p, uint64_t seed,
+                                           uint64_t site, void *stream) {
     if (!lse2) return fail(SD_E_BADARG, "sd_op_attention_lse: lse2 is required");
+    if (!(p >= 0.f) || !(p < 1.f)) return fail(SD_E_BADARG, "sd_op_attention_lse_dropout: p must be in [0, 1)");
+    const DropoutArgs da = make_dropout(p, seed, site);
     if (att_op_f16(q, ldq, k, v, ldkv, ldo, B, Tq, S, d, heads, out))
-        return attention_f16(q, out, B, Tq, d, heads, (hipStream_t)stream, false, lse2);
-    return attention(q, ldq, k, v, ldkv, nullptr, nullptr, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream, lse2);
+        return attention_f16(q, out, B, Tq, d, heads, (hipStream_t)stream, false, lse2, da);
+    return attention(q, ldq, k, v, ldkv, nullptr, nullptr, out, ldo, B, Tq, S, d, heads, (hipStream_t)stream, lse2, da);
 }
 
 extern "C" int sd_op_attention(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *k_extra,

@@ -431,6 +431,83 @@ extern "C" int sd_op_gelu_bwd(const float *dy, const float *pre, float *dpre, lo
     return 0;
 }
 
+// --------------------------------------------------------------------------------------
+// Dropout (sd_common.h: one Philox mask function for every kernel).  The elementwise forms: out = x o m (also the
+// backward of a fused-epilogue site: dy o m), the mask itself (tests hand it to the oracle), and GELU with the
+// dropout that follows it in the FFN (torch: linear2(dropout(activation(linear1(x))))).
+// One thread per quad = 4 consecutive columns of one row = one Philox call.
+// --------------------------------------------------------------------------------------
+template <int MODE>   // 0: out = x o m;  1: mask only;  2: out = gelu(x) o m;  3: dpre = dy o m o gelu'(pre)
+__global__ void dropout_quads_kernel(const float *__restrict__ x, const float *__restrict__ pre, float *__restrict__ out, long rows,
+                                     int width, DropoutArgs da) {
+    const int wq = (width + 3) >> 2;
+    const long nq = rows * wq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / wq;
+        const int c0 = (int)(i - row * wq) * 4;
+        const f32x4 m = dropout_quad(da, (unsigned long)i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c0 + e >= width) break;
+            const long at = row * width + c0 + e;
+            float v;
+            if (MODE == 0) v = x[at] * m[e];
+            else if (MODE == 1) v = m[e];
+            else if (MODE == 2) v = gelu_erf(x[at]) * m[e];
+            else {
+                const float u = pre[at];
+                const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+                const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+                v = x[at] * m[e] * (cdf + u * pdf);
+            }
+            out[at] = v;
+        }
+    }
+}
+
+static int dropout_args_ok(float p, const char *what) {
+    if (!(p >= 0.f) || !(p < 1.f)) return fail(SD_E_BADARG, what);
+    return 0;
+}
+
+extern "C" int sd_op_dropout(const float *x, float *out, long rows, int width, float p, uint64_t seed, uint64_t site, void *stream) {
+    if (!x || !out || rows <= 0 || width <= 0) return fail(SD_E_BADARG, "sd_op_dropout: bad argument");
+    if (int rc = dropout_args_ok(p, "sd_op_dropout: p must be in [0, 1)")) return rc;
+    SD_LAUNCH(dropout_quads_kernel<0>, dim3(grid_for(rows * ((width + 3) / 4))), dim3(256), 0, (hipStream_t)stream, x, nullptr, out, rows,
+              width, make_dropout(p, seed, site));
+    SD_CHECK_LAUNCH("dropout_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_dropout_mask(float *mask, long rows, int width, float p, uint64_t seed, uint64_t site, void *stream) {
+    if (!mask || rows <= 0 || width <= 0) return fail(SD_E_BADARG, "sd_op_dropout_mask: bad argument");
+    if (int rc = dropout_args_ok(p, "sd_op_dropout_mask: p must be in [0, 1)")) return rc;
+    SD_LAUNCH(dropout_quads_kernel<1>, dim3(grid_for(rows * ((width + 3) / 4))), dim3(256), 0, (hipStream_t)stream, nullptr, nullptr, mask,
+              rows, width, make_dropout(p, seed, site));
+    SD_CHECK_LAUNCH("dropout_mask_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_gelu_dropout_fwd(const float *pre, float *out, long rows, int width, float p, uint64_t seed, uint64_t site,
+                                      void *stream) {
+    if (!pre || !out || rows <= 0 || width <= 0) return fail(SD_E_BADARG, "sd_op_gelu_dropout_fwd: bad argument");
+    if (int rc = dropout_args_ok(p, "sd_op_gelu_dropout_fwd: p must be in [0, 1)")) return rc;
+    SD_LAUNCH(dropout_quads_kernel<2>, dim3(grid_for(rows * ((width + 3) / 4))), dim3(256), 0, (hipStream_t)stream, pre, nullptr, out, rows,
+              width, make_dropout(p, seed, site));
+    SD_CHECK_LAUNCH("gelu_dropout_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_gelu_dropout_bwd(const float *dy, const float *pre, float *dpre, long rows, int width, float p, uint64_t seed,
+                                      uint64_t site, void *stream) {
+    if (!dy || !pre || !dpre || rows <= 0 || width <= 0) return fail(SD_E_BADARG, "sd_op_gelu_dropout_bwd: bad argument");
+    if (int rc = dropout_args_ok(p, "sd_op_gelu_dropout_bwd: p must be in [0, 1)")) return rc;
+    SD_LAUNCH(dropout_quads_kernel<3>, dim3(grid_for(rows * ((width + 3) / 4))), dim3(256), 0, (hipStream_t)stream, dy, pre, dpre, rows,
+              width, make_dropout(p, seed, site));
+    SD_CHECK_LAUNCH("gelu_dropout_bwd_kernel");
+    return 0;
+}
+
 // F.mse_loss(pred, target) (mean) and its gradient 2 (pred - target) / n  (train.py:229)
 __global__ void mse_kernel(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ grad,
                            double *partial, long n, float scale) {
@@ -577,7 +654,10 @@ struct AttnBwdCfg {
     static constexpr size_t LDS_BYTES = LDS_FLOATS * sizeof(float);
 };
 
-template <int HD>
+// DROP: the forward dropped probabilities (P_d = P o m, O = P_d V).  Then dV = P_d^T dO, dP = (V dO^T) o m,
+// dS = P o (dP - delta) / sqrt(hd) with the same delta_q = sum_f dO O (= sum_k dP_d P_d); the mask is regenerated
+// from (seed, site): row (b, h, q), column = key, 4 consecutive keys (registers 4g..4g+3) per Philox call.
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restrict__ q, int ldq,
                                                              const float *__restrict__ k,
                                                              const float *__restrict__ v, int ldkv,
@@ -585,7 +665,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
                                                              const float *__restrict__ dO, int lddo,
                                                              const float *__restrict__ lse2, float *dq, int lddq,
                                                              float *dk, float *dv, int lddkv, int Tq, int S, int heads,
-                                                             float scale) {
+                                                             float scale, DropoutArgs da) {
     using C = AttnBwdCfg<HD>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sQ = smem;
@@ -687,12 +767,25 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
                             dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[st][j], dsT, 0, 0, 0);  // dP^T
                         }
                     }
+                    f32x4 dm[4];
+                    if constexpr (DROP) {
+                        const unsigned long mrow = ((unsigned long)b * heads + h) * Tq + (q_ok ? qi : 0);
+                        const unsigned long wq = (unsigned long)((S + 3) >> 2);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) dm[g] = dropout_quad(da, mrow * wq + (unsigned long)((kc0 + kt * 32 + 8 * g + 4 * half) >> 2));
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kc0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const float p = (key < S && q_ok) ? exp2f(pT[r] * sl2e - lse) : 0.f;
-                        pT[r] = p;
-                        dsT[r] = p * (dsT[r] - delta) * scale;
+                        if constexpr (DROP) {
+                            const float mk = dm[r >> 2][r & 3];
+                            pT[r] = p * mk;                                  // P_d: what dV contracts
+                            dsT[r] = p * (dsT[r] * mk - delta) * scale;
+                        } else {
+                            pT[r] = p;
+                            dsT[r] = p * (dsT[r] - delta) * scale;
+                        }
                     }
                     // dQ^T += K^T dS^T : A = K^T[feature l31][key] read as K[key][feature]
 #pragma unroll
@@ -769,6 +862,16 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
 extern "C" int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
                                    int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
                                    float *dv, int lddkv, int B, int Tq, int S, int d, int heads, void *stream) {
+    return sd_op_attention_bwd_dropout(q, ldq, k, v, ldkv, o, ldo, dO, lddo, lse2, dq, lddq, dk, dv, lddkv, B, Tq, S, d, heads, 0.f, 0, 0,
+                                       stream);
+}
+
+extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
+                                           int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
+                                           float *dv, int lddkv, int B, int Tq, int S, int d, int heads, float p, uint64_t seed,
+                                           uint64_t site, void *stream) {
+    if (int rc = dropout_args_ok(p, "sd_op_attention_bwd_dropout: p must be in [0, 1)")) return rc;
+    const DropoutArgs da = make_dropout(p, seed, site);
     if (!q || !k || !v || !o || !dO || !lse2 || !dq || !dk || !dv || B <= 0 || Tq <= 0 || S <= 0 || heads <= 0)
         return fail(SD_E_BADARG, "sd_op_attention_bwd: bad argument");
     if (d % heads != 0) return fail(SD_E_BADDIM, "attention: d not divisible by heads");
@@ -779,15 +882,15 @@ extern "C" int sd_op_attention_bwd(const float *q, int ldq, const float *k, cons
     dim3 grid(B * heads), block(256);
 #define SD_ATTNB(HD_)                                                                                            \
     do {                                                                                                         \
-        auto kfn = attention_bwd_kernel<HD_>;                                                                    \
+        auto kfn = da.thresh ? attention_bwd_kernel<HD_, true> : attention_bwd_kernel<HD_, false>;               \
         const size_t lds = AttnBwdCfg<HD_>::LDS_BYTES;                                                           \
-        static bool attr_set = false;                                                                            \
-        if (lds > 64 * 1024 && !attr_set) {                                                                      \
+        static bool attr_set[2] = {false, false};                                                                \
+        if (lds > 64 * 1024 && !attr_set[da.thresh ? 1 : 0]) {                                                   \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            attr_set = true;                                                                                     \
+            attr_set[da.thresh ? 1 : 0] = true;                                                                  \
         }                                                                                                        \
         SD_LAUNCH(kfn, grid, block, lds, s, q, ldq, k, v, ldkv, o, ldo, dO, lddo, lse2, dq, lddq, dk, dv, lddkv, Tq, S, \
-                  heads, scale);                                                                                 \
+                  heads, scale, da);                                                                             \
     } while (0)
     switch (hd) {
         case 16: SD_ATTNB(16); break;

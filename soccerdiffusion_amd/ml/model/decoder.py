@@ -24,6 +24,10 @@ class DiffusionActionGenerator(PackedWeightsMixin, nn.Module):
         self.positional_encoding = PositionalEncoding(hidden_dim, max_seq_len)
         self.transformer_decoder = LayerStack(hidden_dim, num_layers, cross=True)
         self.fc_out = LinearParams(num_joints, hidden_dim)
+        from ...training import Dropout
+
+        # torch's default: the reference builds nn.TransformerDecoderLayer without a dropout argument (decoder.py:26-33)
+        self.dropout = Dropout(p=0.1)
 
     def packed(self):
         def build():
@@ -35,8 +39,9 @@ class DiffusionActionGenerator(PackedWeightsMixin, nn.Module):
 
     def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         """x (B, T, J) noisy actions; context (B, M, d) memory tokens -> predicted noise (B, T, J)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from ...training import denoiser_forward_autograd  # backward kernels
+        tape = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if tape or (self.training and self.dropout.p > 0.0):   # dropout follows module.training, not the grad mode (torch)
+            from ...training import denoiser_forward_autograd  # training kernels (+ backward)
 
             return denoiser_forward_autograd(self, x, context)
         return ops.denoiser_forward(self.packed(), x.contiguous(), context.contiguous())

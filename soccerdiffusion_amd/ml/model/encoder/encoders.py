@@ -25,6 +25,9 @@ class BaseEncoder(PackedWeightsMixin, nn.Module):
         self.embedding = LinearParams(hidden_dim, input_dim, patch_size)  # Conv1d weight (d, C, p)
         self.positional_encoding = PositionalEncoding(hidden_dim, max_seq_len)
         self.transformer_encoder = LayerStack(hidden_dim, num_layers, cross=False)
+        from ....training import Dropout
+
+        self.dropout = Dropout(p=0.1)  # torch's default (the reference's nn.TransformerEncoderLayer, encoder/base.py:29-40)
 
     def packed(self):
         def build():
@@ -35,7 +38,8 @@ class BaseEncoder(PackedWeightsMixin, nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (B, S, input_dim) -> context tokens (B, S // patch, hidden_dim)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        tape = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if tape or (self.training and self.dropout.p > 0.0):
             from ....training import encoder_forward_autograd
 
             return encoder_forward_autograd(self, x)

@@ -107,6 +107,30 @@ class End2EndDiffusionTransformer(nn.Module):
         return self.diffusion_action_generator(x, memory)
 
     # ---- extras ------------------------------------------------------------------------
+    def dropout_stacks(self):
+        """The transformer stacks that carry dropout (decoder + every enabled context encoder), in a fixed order."""
+        from .encoder.encoders import BaseEncoder
+
+        stacks = [self.diffusion_action_generator]
+        for m in self.modules():
+            if isinstance(m, BaseEncoder):
+                stacks.append(m)
+        return stacks
+
+    def set_dropout(self, p: float, seed: Optional[int] = None) -> "End2EndDiffusionTransformer":
+        """Dropout probability of every transformer layer (live in ``train()`` mode only).  The reference never sets it,
+        i.e. trains with torch's default 0.1 - also the default here; 0 selects the parity path (golden gradients).
+        ``seed`` keys the Philox masks (default: ``torch.initial_seed()`` at first use; give every data-parallel rank
+        its own).  The ResNet / Swin image backbones (torch.nn modules) are not affected."""
+        if not 0.0 <= p < 1.0:
+            raise ValueError("dropout probability must be in [0, 1)")
+        for i, m in enumerate(self.dropout_stacks()):
+            m.dropout.p = float(p)
+            m.dropout.salt = i
+            if seed is not None:
+                m.dropout.seed = int(seed)
+        return self
+
     def _assemble_memory(self, context, step, B, device) -> torch.Tensor:
         grad_path = torch.is_grad_enabled() and any(c.requires_grad for c in context)
         if grad_path or (torch.is_grad_enabled() and self.step_encoding.token.requires_grad):
@@ -131,10 +155,26 @@ class End2EndDiffusionTransformer(nn.Module):
 
     @torch.no_grad()
     def sample(self, context: Sequence[torch.Tensor], x_T: torch.Tensor, num_inference_steps: int,
-               return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None, use_graph: bool = False):
+               return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None, use_graph: bool = False,
+               with_dropout: bool = False):
         """The reference's denoising loop (plot.py:122-131 / distill.py:179-189 / ros.py:301-310)
         as one native call: n x (denoiser forward + DDIM update) with the context K/V cached.
-        ``use_graph`` replays the rollout from a hipGraph captured for this (B, T, M, n) shape."""
+        ``use_graph`` replays the rollout from a hipGraph captured for this (B, T, M, n) shape.
+        The native rollout has no dropout (inference).  ``with_dropout=True`` on a model in ``train()`` mode instead
+        steps through ``forward_with_context`` + the scheduler update like the reference's loop does, dropout live in
+        every call - what distill.py's teacher, which is never put into eval mode, actually computes (distill.py:127-189)."""
+        if with_dropout and self.training and self.diffusion_action_generator.dropout.p > 0.0:
+            from ...scheduler import DDIMScheduler
+
+            sch = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+            sch.set_timesteps(num_inference_steps)
+            x, trace = x_T, []
+            for t in sch.timesteps.tolist():
+                eps = self.forward_with_context(context, x, torch.full((x.shape[0],), t, dtype=torch.int64, device=x.device))
+                x = sch.step(eps, t, x).prev_sample
+                if return_trace:
+                    trace.append(x)
+            return (x, torch.stack(trace)) if return_trace else x
         ts = ops.ddim_timesteps(num_inference_steps)
         acp = ops.alphas_cumprod() if alphas_cumprod is None else alphas_cumprod
         coef = ops.ddim_coefficients(ts, acp, num_inference_steps)

@@ -495,9 +495,75 @@ def linear_strided(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, res: Opt
     return out
 
 
-def attention_lse(q: Tensor, k: Tensor, v: Tensor, heads: int):
+# ---- dropout (training; one Philox mask function shared by every kernel, include/soccerdiffusion_hip.h) ----------------
+def _drop(drop) -> tuple:
+    """(p, seed, site) -> ctypes-ready triple; None = no dropout."""
+    if drop is None:
+        return 0.0, 0, 0
+    p, seed, site = drop
+    return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout(x: Tensor, drop, out: Optional[Tensor] = None) -> Tensor:
+    """x o mask over the last dim as the mask width (rows = everything else)."""
+    lib = _lib.load()
+    _req(x, "x")
+    width = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_dropout(x.data_ptr(), out.data_ptr(), x.numel() // width, width, p, seed, site, _stream()), "sd_op_dropout")
+    return out
+
+
+def dropout_mask(rows: int, width: int, drop, device) -> Tensor:
+    """The (rows, width) multiplier tensor (0 or 1/(1-p)) the kernels apply for this (p, seed, site)."""
+    lib = _lib.load()
+    mask = torch.empty(rows, width, dtype=torch.float32, device=device)
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_dropout_mask(mask.data_ptr(), rows, width, p, seed, site, _stream()), "sd_op_dropout_mask")
+    return mask
+
+
+def gelu_dropout_fwd(pre: Tensor, drop) -> Tensor:
+    lib = _lib.load()
+    _req(pre, "pre")
+    out = torch.empty_like(pre)
+    width = pre.shape[-1]
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_gelu_dropout_fwd(pre.data_ptr(), out.data_ptr(), pre.numel() // width, width, p, seed, site, _stream()),
+          "sd_op_gelu_dropout_fwd")
+    return out
+
+
+def gelu_dropout_bwd(dy: Tensor, pre: Tensor, drop) -> Tensor:
+    lib = _lib.load()
+    _req(dy, "dy"); _req(pre, "pre")
+    out = torch.empty_like(pre)
+    width = pre.shape[-1]
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_gelu_dropout_bwd(dy.data_ptr(), pre.data_ptr(), out.data_ptr(), pre.numel() // width, width, p, seed, site,
+                                     _stream()), "sd_op_gelu_dropout_bwd")
+    return out
+
+
+def linear_dropout(A: Tensor, W: Tensor, bias: Optional[Tensor], res: Tensor, drop, out: Optional[Tensor] = None) -> Tensor:
+    """out = res + dropout(A W^T + bias): the fused epilogue of the split-fp16 panel GEMM."""
+    lib = _lib.load()
+    _req(A, "A"); _req(W, "W"); _req(res, "res")
+    R, d = A.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(R, N, dtype=torch.float32, device=A.device)
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_linear_dropout(A.data_ptr(), d, W.data_ptr(), _ptr(bias), res.data_ptr(), out.data_ptr(), R, N, d, p, seed, site,
+                                   _stream()), "sd_op_linear_dropout")
+    return out
+
+
+def attention_lse(q: Tensor, k: Tensor, v: Tensor, heads: int, drop=None):
     """Forward attention that also returns lse2 (B, heads, Tq).  q (B,Tq,d), k/v (B,S,d) may be
-    column-slice views of packed buffers."""
+    column-slice views of packed buffers.  ``drop`` = (p, seed, site): dropout on the probabilities."""
     lib = _lib.load()
     qp, ldq = _rows(q, "q"); kp, ldk = _rows(k, "k"); vp, ldv = _rows(v, "v")
     if ldk != ldv:
@@ -506,13 +572,14 @@ def attention_lse(q: Tensor, k: Tensor, v: Tensor, heads: int):
     S = k.shape[1]
     out = torch.empty(B, Tq, d, dtype=torch.float32, device=q.device)
     lse = torch.empty(B, heads, Tq, dtype=torch.float32, device=q.device)
-    check(lib.sd_op_attention_lse(qp, ldq, kp, vp, ldk, out.data_ptr(), d, lse.data_ptr(), B, Tq, S, d, heads, _stream()),
-          "sd_op_attention_lse")
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_attention_lse_dropout(qp, ldq, kp, vp, ldk, out.data_ptr(), d, lse.data_ptr(), B, Tq, S, d, heads, p, seed, site,
+                                          _stream()), "sd_op_attention_lse")
     return out, lse
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, dO: Tensor, lse: Tensor, dq: Tensor, dk: Tensor, dv: Tensor,
-                  heads: int) -> None:
+                  heads: int, drop=None) -> None:
     lib = _lib.load()
     qp, ldq = _rows(q, "q"); kp, ldk = _rows(k, "k"); vp, ldv = _rows(v, "v")
     op, ldo = _rows(o, "o"); dop, lddo = _rows(dO, "dO")
@@ -521,8 +588,9 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, dO: Tensor, lse: T
         raise ValueError("k/v (and dk/dv) must share a row stride")
     B, Tq, d = q.shape
     S = k.shape[1]
-    check(lib.sd_op_attention_bwd(qp, ldq, kp, vp, ldk, op, ldo, dop, lddo, lse.data_ptr(), dqp, lddq, dkp, dvp, lddk,
-                                  B, Tq, S, d, heads, _stream()), "sd_op_attention_bwd")
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_attention_bwd_dropout(qp, ldq, kp, vp, ldk, op, ldo, dop, lddo, lse.data_ptr(), dqp, lddq, dkp, dvp, lddk,
+                                          B, Tq, S, d, heads, p, seed, site, _stream()), "sd_op_attention_bwd")
 
 
 def gemm_tn(dY: Tensor, X: Tensor, dW: Tensor, db: Optional[Tensor] = None) -> None:

@@ -4,9 +4,11 @@ buffers, and the data-parallel gradient all-reduce.
 
 Reference semantics: one iteration of soccer_diffusion/ml/training/train.py:204-240
 (normalise, t ~ randint, eps ~ randn, add_noise, forward, F.mse_loss, backward,
-AdamW(lr).step, OneCycleLR.step) with dropout p = 0 — the reference trains with torch's
-default dropout 0.1; parity is only defined without it, and this
-implementation has no dropout.
+AdamW(lr).step, OneCycleLR.step).  The reference trains with torch's default dropout 0.1
+(decoder.py:26-33 / encoder/base.py:29-40 never set it, train.py never calls .eval()):
+``Dropout`` below reproduces it at torch's four kinds of sites with a counter-based Philox
+mask that the backward kernels regenerate (nothing is stored); p = 0 is the parity path
+(bit-level parity with torch's own mask stream is not defined: a different generator).
 
 torch.autograd is used as the tape only (plumbing): each node below is one reference
 block, its forward and backward are calls into libsoccerdiffusion_hip.so.
@@ -84,16 +86,54 @@ def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
     return out
 
 
+# ---- dropout sites (torch: nn.MultiheadAttention.dropout, TransformerDecoderLayer.dropout1/2/3 and .dropout) ----------
+SITE_SA_PROBS, SITE_SA_OUT, SITE_CA_PROBS, SITE_CA_OUT, SITE_FFN_ACT, SITE_FFN_OUT = range(6)
+
+
+class Dropout:
+    """Dropout configuration of one transformer stack (the decoder or one context encoder).
+
+    ``p`` defaults to torch's 0.1, as in the reference, and is live only in ``module.train()`` mode.  ``seed`` keys
+    the Philox mask; every forward call of the stack draws a fresh call index, and a site is
+    ``(call << 24) | (salt << 12) | (layer << 4) | kind``, so masks never repeat across calls, stacks, layers or
+    sites.  ``for_call()`` returns the per-call object the autograd nodes use (``None`` when dropout is off)."""
+
+    def __init__(self, p: float = 0.1, seed: Optional[int] = None, salt: int = 0):
+        self.p, self.seed, self.salt, self.calls = float(p), seed, int(salt), 0
+
+    def for_call(self, training: bool):
+        if not training or self.p <= 0.0:
+            return None
+        if self.seed is None:
+            self.seed = int(torch.initial_seed())
+        self.calls += 1
+        return _DropCall(self.p, self.seed, (self.calls << 24) | (self.salt << 12))
+
+
+class _DropCall:
+    __slots__ = ("p", "seed", "base")
+
+    def __init__(self, p, seed, base):
+        self.p, self.seed, self.base = p, seed, base
+
+    def site(self, layer: int, kind: int) -> tuple:
+        return (self.p, self.seed, self.base | (layer << 4) | kind)
+
+
 class _LNLinear(Function):
-    """y = act(LayerNorm(x) W^T + b) — LN1+QKV, LN2+Q, LN3+FFN1(+GELU)."""
+    """y = act(LayerNorm(x) W^T + b) — LN1+QKV, LN2+Q, LN3+FFN1(+GELU [+ dropout])."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None):
+    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None, drop=None):
         x2 = x.reshape(-1, x.shape[-1])
         pre = ops.linear(x2, W, b, ln=(ln_w, ln_b))
-        y = ops.gelu_fwd(pre) if gelu else pre
+        if gelu:
+            y = ops.gelu_dropout_fwd(pre, drop) if drop is not None else ops.gelu_fwd(pre)
+        else:
+            y = pre
         ctx.save_for_backward(x2, ln_w, ln_b, W, pre if gelu else None)
         ctx.gelu = gelu
+        ctx.drop = drop
         ctx.shape = x.shape
         ctx.sink = sink if sink is not None else _GradSink()
         return y.view(*x.shape[:-1], W.shape[0])
@@ -102,36 +142,46 @@ class _LNLinear(Function):
     def backward(ctx, dy):
         x2, ln_w, ln_b, W, pre = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
-        dpre = ops.gelu_bwd(dy2, pre) if ctx.gelu else dy2
+        if ctx.gelu:
+            dpre = ops.gelu_dropout_bwd(dy2, pre, ctx.drop) if ctx.drop is not None else ops.gelu_bwd(dy2, pre)
+        else:
+            dpre = dy2
         n, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b)  # recomputed, not stored
         (dg, rg), (dbeta, rbeta) = ctx.sink.target(0, ln_w), ctx.sink.target(1, ln_w)
         (dW, rW), (db, rb) = ctx.sink.target(2, W), ctx.sink.target(3, W[:, 0])
         ops.gemm_tn(dpre, n, dW, db)
         dn = _dx_through_weight(dpre, W)
         dx = ops.layernorm_bwd_into(dn, x2, mean, rstd, ln_w, dg, dbeta)
-        return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None
+        return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None, None
 
 
 class _LinearRes(Function):
-    """y = res + a W^T + b — attention out-projection and FFN2 with the residual add."""
+    """y = res + dropout(a W^T + b) — attention out-projection and FFN2 with the residual add
+    (torch: x + dropout1(sa_block(x)), x + dropout3(ff_block(x)))."""
 
     @staticmethod
-    def forward(ctx, a, W, b, res, sink=None):
+    def forward(ctx, a, W, b, res, sink=None, drop=None):
         a2 = a.reshape(-1, a.shape[-1])
         ctx.save_for_backward(a2, W)
         ctx.shape = a.shape
+        ctx.drop = drop
         ctx.sink = sink if sink is not None else _GradSink()
-        y = ops.linear(a2, W, b, res=res.reshape(-1, W.shape[0]).contiguous())
+        res2 = res.reshape(-1, W.shape[0]).contiguous()
+        if drop is not None:
+            y = ops.linear_dropout(a2.contiguous(), W, b, res2, drop)
+        else:
+            y = ops.linear(a2, W, b, res=res2)
         return y.view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         a2, W = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
+        dym = ops.dropout(dy2, ctx.drop) if ctx.drop is not None else dy2   # gradient of the dropped branch; the residual gets dy
         (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
-        ops.gemm_tn(dy2, a2, dW, db)
-        da = _dx_through_weight(dy2, W)
-        return da.view(ctx.shape), rW, rb, dy, None
+        ops.gemm_tn(dym, a2, dW, db)
+        da = _dx_through_weight(dym, W)
+        return da.view(ctx.shape), rW, rb, dy, None, None
 
 
 class _Linear(Function):
@@ -159,11 +209,12 @@ class _SelfAttention(Function):
     """softmax(q k^T / sqrt(hd)) v on a packed (B, T, 3d) q|k|v buffer."""
 
     @staticmethod
-    def forward(ctx, qkv, heads: int):
+    def forward(ctx, qkv, heads: int, drop=None):
         d = qkv.shape[-1] // 3
-        out, lse = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads)
+        out, lse = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads, drop)
         ctx.save_for_backward(qkv, out, lse)
         ctx.heads = heads
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -172,19 +223,20 @@ class _SelfAttention(Function):
         d = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
         ops.attention_bwd(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], out, dO.contiguous(), lse,
-                          dqkv[..., :d], dqkv[..., d : 2 * d], dqkv[..., 2 * d :], ctx.heads)
-        return dqkv, None
+                          dqkv[..., :d], dqkv[..., d : 2 * d], dqkv[..., 2 * d :], ctx.heads, ctx.drop)
+        return dqkv, None, None
 
 
 class _CrossAttention(Function):
     """Queries (B, T, d) against packed memory keys|values (B, M, 2d)."""
 
     @staticmethod
-    def forward(ctx, q, kv, heads: int):
+    def forward(ctx, q, kv, heads: int, drop=None):
         d = q.shape[-1]
-        out, lse = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads)
+        out, lse = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads, drop)
         ctx.save_for_backward(q, kv, out, lse)
         ctx.heads = heads
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -192,8 +244,8 @@ class _CrossAttention(Function):
         q, kv, out, lse = ctx.saved_tensors
         d = q.shape[-1]
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        ops.attention_bwd(q, kv[..., :d], kv[..., d:], out, dO.contiguous(), lse, dq, dkv[..., :d], dkv[..., d:], ctx.heads)
-        return dq, dkv, None
+        ops.attention_bwd(q, kv[..., :d], kv[..., d:], out, dO.contiguous(), lse, dq, dkv[..., :d], dkv[..., d:], ctx.heads, ctx.drop)
+        return dq, dkv, None, None
 
 
 class _PatchEmbed(Function):
@@ -289,12 +341,16 @@ def step_token_autograd(step_module, steps: Tensor) -> Tensor:
     return _StepTokenFn.apply(steps, step_module._freq, step_module.token)
 
 
-def _layer(lp, h, heads, memory=None, ffn_norm=None):
+def _layer(lp, h, heads, memory=None, ffn_norm=None, dc=None, li: int = 0):
+    """One pre-norm layer; ``dc`` (a _DropCall or None) turns on dropout at torch's sites of layer ``li``."""
+    def site(kind):
+        return dc.site(li, kind) if dc is not None else None
+
     sa, n1 = lp.self_attn, lp.norm1
     qkv = _LNLinear.apply(h, n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias, False,
                           _GradSink(n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias))
-    a = _SelfAttention.apply(qkv, heads)
-    h = _LinearRes.apply(a, sa.out_proj.weight, sa.out_proj.bias, h, _GradSink(sa.out_proj.weight, sa.out_proj.bias))
+    a = _SelfAttention.apply(qkv, heads, site(SITE_SA_PROBS))
+    h = _LinearRes.apply(a, sa.out_proj.weight, sa.out_proj.bias, h, _GradSink(sa.out_proj.weight, sa.out_proj.bias), site(SITE_SA_OUT))
     if memory is not None:
         d = h.shape[-1]
         ca, n2 = lp.multihead_attn, lp.norm2
@@ -302,11 +358,11 @@ def _layer(lp, h, heads, memory=None, ffn_norm=None):
         q = _LNLinear.apply(h, n2.weight, n2.bias, w[:d], b[:d], False,
                             _GradSink(n2.weight, n2.bias, (w, slice(0, d)), (b, slice(0, d))))
         kv = _Linear.apply(memory, w[d:], b[d:], _GradSink((w, slice(d, 3 * d)), (b, slice(d, 3 * d))))  # memory is NOT layer-normed
-        a = _CrossAttention.apply(q, kv, heads)
-        h = _LinearRes.apply(a, ca.out_proj.weight, ca.out_proj.bias, h, _GradSink(ca.out_proj.weight, ca.out_proj.bias))
+        a = _CrossAttention.apply(q, kv, heads, site(SITE_CA_PROBS))
+        h = _LinearRes.apply(a, ca.out_proj.weight, ca.out_proj.bias, h, _GradSink(ca.out_proj.weight, ca.out_proj.bias), site(SITE_CA_OUT))
     u = _LNLinear.apply(h, ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias, True,
-                        _GradSink(ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias))
-    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias))
+                        _GradSink(ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias), site(SITE_FFN_ACT))
+    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias), site(SITE_FFN_OUT))
 
 
 def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
@@ -315,8 +371,9 @@ def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
     pe = gen.positional_encoding.pe[0, :T].contiguous()
     h = _PatchEmbed.apply(x, gen.embedding.weight, gen.embedding.bias, pe)
     memory = memory.contiguous()
-    for lp in gen.transformer_decoder.layers:
-        h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3)
+    dc = gen.dropout.for_call(gen.training)
+    for li, lp in enumerate(gen.transformer_decoder.layers):
+        h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3, dc=dc, li=li)
     return _FcOut.apply(h, gen.fc_out.weight, gen.fc_out.bias)
 
 
@@ -325,8 +382,9 @@ def encoder_forward_autograd(enc, x: Tensor) -> Tensor:
     n = x.shape[1] // enc.patch_size
     pe = enc.positional_encoding.pe[0, :n].contiguous()
     h = _PatchEmbed.apply(x, enc.embedding.weight, enc.embedding.bias, pe)
-    for lp in enc.transformer_encoder.layers:
-        h = _layer(lp, h, enc.num_heads, memory=None, ffn_norm=lp.norm2)
+    dc = enc.dropout.for_call(enc.training)
+    for li, lp in enumerate(enc.transformer_encoder.layers):
+        h = _layer(lp, h, enc.num_heads, memory=None, ffn_norm=lp.norm2, dc=dc, li=li)
     return h
 
 

@@ -63,7 +63,7 @@ def test_gradients_reach_the_backbone():
     from soccerdiffusion_amd.training import FusedAdamW, train_step
 
     dev = torch.device("cuda:0")
-    m = _model(dev).train()
+    m = _model(dev).train().set_dropout(0.0)
     opt = FusedAdamW(m.parameters(), lr=1e-3)
     sch = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
     B, F, R = 4, 3, 64

@@ -12,6 +12,11 @@ from oracle import ddim_ref
 from oracle import denoiser_ref as ref
 from test_gpu_model import _build
 
+
+def _build0(c, full):
+    """The parity path: dropout p = 0 (the golden gradients and the oracle's autograd have none)."""
+    return _build(c, full).set_dropout(0.0)
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
@@ -35,7 +40,7 @@ def _check_grads(model, golden_grads):
 def test_decoder_pretraining_step_gradients_golden(g1):
     from soccerdiffusion_amd import training
 
-    m = _build(g1["config"], full=False).cuda()
+    m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
     tr = g1["train"]
@@ -50,7 +55,7 @@ def test_decoder_pretraining_step_gradients_golden(g1):
 def test_full_model_step_gradients_golden(g2):
     from soccerdiffusion_amd import training
 
-    m = _build(g2["config"], full=True).cuda()
+    m = _build0(g2["config"], full=True).cuda()
     m.load_state_dict(g2["state_dict"])
     m.train()
     tr = g2["train"]
@@ -69,7 +74,7 @@ def test_c2_shape_gradients_vs_oracle():
 
     c = dict(d=256, J=20, L=4, T=100)
     sd = synthetic_state_dict(256, 20, 4, seed=5)
-    m = _build(c, full=False).cuda()
+    m = _build0(c, full=False).cuda()
     m.load_state_dict(sd)
     g = torch.Generator().manual_seed(3)
     B = 3
@@ -91,7 +96,7 @@ def test_fused_adamw_onecycle_matches_torch(g1):
     from soccerdiffusion_amd import training
     from soccerdiffusion_amd.scheduler import DDIMScheduler
 
-    m = _build(g1["config"], full=False).cuda()
+    m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
     opt = training.FusedAdamW(m.parameters(), lr=1e-3)
@@ -135,7 +140,7 @@ def test_checkpoint_dict_interchange(g1, tmp_path):
     OneCycleLR accept the optimizer and lr-scheduler entries."""
     from soccerdiffusion_amd import training
 
-    m = _build(g1["config"], full=False).cuda()
+    m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
     opt = training.FusedAdamW(m.parameters(), lr=1e-4)
@@ -153,14 +158,14 @@ def test_checkpoint_dict_interchange(g1, tmp_path):
     back = torch.load(path, weights_only=True)  # the reference always loads with weights_only=True
     assert set(back) == {"model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict", "hyperparams", "current_epoch"}
     # torch's AdamW on a same-shaped model accepts the optimizer state
-    m2 = _build(g1["config"], full=False)
+    m2 = _build0(g1["config"], full=False)
     m2.load_state_dict(back["model_state_dict"])
     topt = torch.optim.AdamW(m2.parameters(), lr=1e-4)
     topt.load_state_dict(back["optimizer_state_dict"])
     first = next(iter(topt.state.values()))
     assert set(first) >= {"step", "exp_avg", "exp_avg_sq"} and float(first["step"]) == 2.0
     # and our optimizer resumes from it
-    m3 = _build(g1["config"], full=False).cuda()
+    m3 = _build0(g1["config"], full=False).cuda()
     m3.load_state_dict(back["model_state_dict"])
     opt3 = training.FusedAdamW(m3.parameters(), lr=1e-4)
     opt3.load_state_dict(back["optimizer_state_dict"])
@@ -180,7 +185,7 @@ def test_transposed_weight_blocks_follow_the_optimizer(g1):
     from soccerdiffusion_amd import training
     from soccerdiffusion_amd.scheduler import DDIMScheduler
 
-    m = _build(g1["config"], full=False).cuda()
+    m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
     opt = training.FusedAdamW(m.parameters(), lr=1e-3)
