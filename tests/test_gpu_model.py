@@ -63,6 +63,7 @@ def test_full_model_forward_golden(g2):
 def test_step_broadcast_and_mismatch(g1):
     m = _build(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
+    m.eval()   # a freshly built module is in train() mode: dropout 0.1 would be live, as in the reference
     with torch.no_grad():
         one = m.forward_with_context([g1["ctx"][:1].cuda()], g1["x"][:1].cuda(), torch.tensor([900], device="cuda"))
         assert rel_err(one, g1["eps_int"][:1]) < TOL  # (1,) step at B=1 as ros.py:306 passes it
