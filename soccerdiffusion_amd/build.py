@@ -29,6 +29,16 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 with gfx950 support)")
 
 
+def _obj(src: str) -> str:
+    return os.path.join(LIB_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _deps(src: str) -> list:
+    """sd_f16x3.h is included by sd_kernels.hip only."""
+    hdr = [h for h in HDR if not (h.endswith("sd_f16x3.h") and not src.endswith("sd_kernels.hip"))]
+    return [src] + hdr
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -36,21 +46,40 @@ def is_stale() -> bool:
     return any(os.path.getmtime(f) > t for f in SRC + HDR)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wno-unused-value",
-           "-I", os.path.join(REPO, "include"), *SRC, "-o", LIB + ".tmp"]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+def _run(cmd: list, what: str, verbose: bool) -> None:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building " + LIB)
-    os.replace(LIB + ".tmp", LIB)
+        raise RuntimeError("hipcc failed " + what)
     if verbose:
         sys.stderr.write(res.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per translation unit (recompiled only when it or a header it includes changed; the two compile in
+    parallel), then one link.  The units share host functions only - no relocatable device code is needed."""
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wno-unused-value", "-I", os.path.join(REPO, "include")]
+    if verbose:
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    jobs = []
+    for src in SRC:
+        obj = _obj(src)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(f) > os.path.getmtime(obj) for f in _deps(src)):
+            jobs.append((src, subprocess.Popen([hipcc(), *flags, "-c", src, "-o", obj + ".tmp"], stdout=subprocess.PIPE,
+                                               stderr=subprocess.PIPE, text=True)))
+    for src, proc in jobs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            sys.stderr.write(out + err)
+            raise RuntimeError("hipcc failed compiling " + src)
+        os.replace(_obj(src) + ".tmp", _obj(src))
+        if verbose:
+            sys.stderr.write(err)
+    _run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *[_obj(s) for s in SRC], "-o", LIB + ".tmp"], "linking " + LIB, verbose)
+    os.replace(LIB + ".tmp", LIB)
     return LIB
 
 

@@ -36,6 +36,26 @@ def test_gemm_tn(ops, R, N, K):
     assert rel_err(dW, 2 * (dY.double().T @ X.double())) < TOL
 
 
+def test_gemm_tn_staged_kernel_slices_and_dynamic_range(ops):
+    """The LDS-staged kernel (N, K multiples of 128): operands that are column slices of packed (R, 3d) buffers, rows
+    whose magnitudes span 1e-6 .. 1e+3 (block floating point per 32-row slab: gradients have no a-priori scale), a row
+    count that is not a multiple of the slab, and agreement with the register-staged kernel's numerics class (fp64 ref)."""
+    R, d = 1237, 256
+    g = torch.Generator().manual_seed(7)
+    big = torch.randn(R, 3 * d, generator=g)
+    mag = 10.0 ** (torch.rand(R, 1, generator=g) * 9 - 6)
+    big = (big * mag).cuda()
+    X = (torch.randn(R, 2 * d, generator=g) * 10.0 ** (torch.rand(R, 1, generator=g) * 4 - 2)).cuda()
+    for sl, xs in ((slice(0, d), slice(0, d)), (slice(d, 3 * d), slice(d, 2 * d)), (slice(0, 3 * d), slice(0, 2 * d))):
+        dY, Xs = big[:, sl], X[:, xs]
+        N, K = dY.shape[1], Xs.shape[1]
+        dW = torch.zeros(N, K, device="cuda")
+        db = torch.zeros(N, device="cuda")
+        ops.gemm_tn(dY, Xs, dW, db)
+        assert rel_err(dW, dY.double().cpu().T @ Xs.double().cpu()) < 1e-6
+        assert rel_err(db, dY.double().cpu().sum(0)) < 1e-5
+
+
 def test_gemm_tn_column_slices(ops):
     R, d = 300, 64
     big = _rand(R, 3 * d, seed=1).cuda()
