@@ -209,7 +209,7 @@ class TrainLeg:
     step token (the reference's --decoder-pretraining path, train.py:221-224), dropout as `dropout` (the reference
     trains with torch's default 0.1)."""
 
-    def __init__(self, dev, rank, world, batch, total_steps, dropout=0.1):
+    def __init__(self, dev, rank, world, batch, total_steps, dropout=0.1, graph=True):
         import torch
         from soccerdiffusion_amd import cli, training
         from soccerdiffusion_amd.scheduler import DDIMScheduler
@@ -228,10 +228,19 @@ class TrainLeg:
         self.g = torch.Generator(device=dev).manual_seed(1 + rank)
         self.x0 = torch.randn(batch, T, J, device=dev, generator=self.g)
         self.ctx = [torch.randn(batch, MC, D, device=dev, generator=self.g)]
+        self.graphed = None
+        if graph:   # the step replayed from a hipGraph (training.GraphedTrainStep); the first two calls run eagerly
+            self.graphed = training.GraphedTrainStep(self.model, self.opt, self.lr, self.ns, world_size=world, generator=self.g)
 
     def step(self):
+        if self.graphed is not None:
+            return self.graphed(self.x0, context=self.ctx)
         return self.training.train_step(self.model, self.opt, self.lr, self.ns, self.x0, context=self.ctx,
                                         world_size=self.world, generator=self.g)
+
+    def close(self):
+        if self.graphed is not None:
+            self.graphed.close()
 
     def allreduce_ms(self, iters=10):
         """The gradient exchange alone (flat fp32 buffer, sum + mean) timed with events on the current stream."""
@@ -296,6 +305,7 @@ def main():
     ap.add_argument("--mode", choices=("sample", "train"), default="sample")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU per step (default 4096 sample / 256 train)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference: 0.1)")
+    ap.add_argument("--no-graph", action="store_true", help="train mode: issue the step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="sample mode: skip the hipGraph / B=256 / training sub-records")
@@ -338,9 +348,10 @@ def run_train(args, rank, world, dev, dist):
     steps = args.steps if args.steps is not None else 30
     warmup = args.warmup if args.warmup is not None else 5
     B = args.batch or TRAIN_B
-    leg = TrainLeg(dev, rank, world, B, steps + warmup, dropout=args.dropout)
-    elapsed, loss = time_train(leg, steps, warmup, dist)
+    leg = TrainLeg(dev, rank, world, B, steps + warmup, dropout=args.dropout, graph=not args.no_graph)
+    elapsed, loss = time_train(leg, steps, max(warmup, 3 if leg.graphed is not None else 0), dist)   # capture happens on call 3
     ar = leg.allreduce_ms()
+    leg.close()
     if rank != 0:
         return
     rec = train_record(elapsed, steps, world, B, loss, ar, leg.dropout, leg.opt.flat_param.numel())
@@ -353,7 +364,8 @@ def run_train(args, rank, world, dev, dist):
         "config": {"workload": f"BASELINE.json configs[{1 if world == 1 else 3}]: one training step (add_noise, forward, MSE, backward, "
                                f"{'RCCL all-reduce of the flat fp32 gradient, ' if world > 1 else ''}AdamW, OneCycleLR) of the transformer "
                                f"denoiser d=256 L=4 heads=4, B={B} trajectories per GPU, horizon T=100, J=20, memory M=11 "
-                               f"(decoder-pretraining path, reference train.py:204-240), dropout p={rec['dropout_p']}",
+                               f"(decoder-pretraining path, reference train.py:204-240), dropout p={rec['dropout_p']}, "
+                               f"{'the step replayed from a hipGraph' if leg.graphed is not None else 'launches issued eagerly'}",
                    "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "joints": J, "hidden_dim": D, "decoder_layers": L,
                    "memory_tokens": M, "parallelism": f"dp{world}" + (" (one flat-gradient all-reduce per step)" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": "whole training step (no single dominant kernel: profiles/)",
@@ -625,7 +637,9 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
     try:
         leg = TrainLeg(dev, 0, 1, TRAIN_B, 40)
         elapsed, loss = time_train(leg, 30, 5, None)
+        leg.close()
         out["train"] = train_record(elapsed, 30, 1, TRAIN_B, loss, 0.0, leg.dropout, leg.opt.flat_param.numel())
+        out["train"]["hipgraph"] = leg.graphed is not None
         out["train"]["workload"] = "BASELINE.json configs[1]: C2 training step, B=256, d=256 L=4 T=100 J=20 M=11 (bench.py --mode train)"
     except Exception as e:  # noqa: BLE001
         out["train"] = {"error": repr(e)[:300]}

@@ -282,6 +282,17 @@ int sd_mse_loss(const float *pred, const float *target, float *loss, float *grad
 int sd_adamw_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, long step, void *stream);
 
+/* The same update with its seven scalars in DEVICE memory (hyper7[0..6] = 1 - lr*wd, 1 - beta1, beta2, 1 - beta2,
+ * lr / (1 - beta1^step), sqrt(1 - beta2^step), eps; sd_adamw_hyper fills a HOST array with them): kernel arguments are
+ * frozen in a captured hipGraph, the learning rate (OneCycleLR), beta1 and the bias corrections change every step. */
+int sd_adamw_step_dev(float *p, const float *g, float *m, float *v, long n, const float *hyper7_dev, void *stream);
+int sd_adamw_hyper(double lr, double beta1, double beta2, double eps, double weight_decay, long step, float *hyper7_host);
+
+/* Per-step part of the dropout mask key from DEVICE memory: when set (non-NULL), every dropout kernel adds *device_word to
+ * the high half of its Philox key at run time, so a hipGraph replay of a training step draws fresh masks once the host has
+ * changed the word.  Process-wide; NULL switches it off. */
+int sd_set_dropout_epoch(const uint32_t *device_word);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference's surface) ----
  * While enabled, every kernel launch made by this library is bracketed by a hipEvent pair
  * on the launch stream.  sd_profile_collect waits for them, returns the summed device

@@ -96,6 +96,9 @@ SIGNATURES = {
     "sd_op_small_k_matmul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "sd_mse_loss": (C.c_int, [C.c_void_p] * 5 + [C.c_long, C.c_void_p]),
     "sd_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_double] * 5 + [C.c_long, C.c_void_p]),
+    "sd_adamw_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p, C.c_void_p]),
+    "sd_adamw_hyper": (C.c_int, [C.c_double] * 5 + [C.c_long, c_float_p]),
+    "sd_set_dropout_epoch": (C.c_int, [C.c_void_p]),
     "sd_profile_enable": (C.c_int, [C.c_int]),
     "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }

@@ -155,7 +155,9 @@ struct DropoutArgs {
     unsigned thresh;      // keep iff word >= thresh;  0 = no dropout
     float scale;          // 1 / (1 - p)
     unsigned seed_lo, seed_hi, site_lo, site_hi;
+    const unsigned *epoch;   // device word added to seed_hi at run time (sd_set_dropout_epoch), or NULL
 };
+extern const unsigned *g_dropout_epoch;   // sd_kernels.hip
 
 static inline DropoutArgs make_dropout(float p, uint64_t seed, uint64_t site) {
     DropoutArgs a;
@@ -164,6 +166,7 @@ static inline DropoutArgs make_dropout(float p, uint64_t seed, uint64_t site) {
     a.scale = p <= 0.f ? 1.0f : 1.0f / (1.0f - p);
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
     a.site_lo = (unsigned)site; a.site_hi = (unsigned)(site >> 32);
+    a.epoch = g_dropout_epoch;
     return a;
 }
 
@@ -186,7 +189,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 // multipliers (0 or 1/(1-p)) of the 4 elements of quad `quad` (= padded flat index >> 2)
 __device__ __forceinline__ f32x4 dropout_quad(const DropoutArgs &a, unsigned long quad) {
     unsigned w[4];
-    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), a.site_lo, a.site_hi, a.seed_lo, a.seed_hi, w);
+    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), a.site_lo, a.site_hi, a.seed_lo, a.seed_hi + (a.epoch ? *a.epoch : 0u), w);
     f32x4 m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = w[e] >= a.thresh ? a.scale : 0.f;

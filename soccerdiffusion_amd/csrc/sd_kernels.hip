@@ -30,6 +30,15 @@ int fail(int code, const char *msg) {
     return code;
 }
 
+// Device word that every dropout kernel adds to the high half of its Philox key at RUN time (NULL: none).  A training
+// step captured into a hipGraph freezes its kernel arguments, so the per-step part of the mask key must come from
+// memory: the host bumps the word before each replay (soccerdiffusion_amd.training.GraphedTrainStep).
+const unsigned *g_dropout_epoch = nullptr;
+extern "C" int sd_set_dropout_epoch(const uint32_t *device_word) {
+    g_dropout_epoch = device_word;
+    return 0;
+}
+
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;

@@ -717,6 +717,48 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
     }
 }
 
+// The same update with its seven scalars read from DEVICE memory (hyper[0..6] = decay, 1 - beta1, beta2, 1 - beta2,
+// lr / bias_correction1, sqrt(bias_correction2), eps): the form a hipGraph-captured training step needs - the learning rate
+// (OneCycleLR), beta1 (cycled momentum) and the bias corrections change every step, kernel arguments of a graph do not.
+__global__ void adamw_dev_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+                                 const float *__restrict__ hyper) {
+    const float decay = hyper[0], one_minus_b1 = hyper[1], b2 = hyper[2], one_minus_b2 = hyper[3], step_size = hyper[4],
+                bc2_sqrt = hyper[5], eps = hyper[6];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * decay;
+        float mi = m[i];
+        mi = mi + one_minus_b1 * (gi - mi);
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int sd_adamw_step_dev(float *p, const float *g, float *m, float *v, long n, const float *hyper7_dev, void *stream) {
+    if (!p || !g || !m || !v || !hyper7_dev || n <= 0) return fail(SD_E_BADARG, "sd_adamw_step_dev: bad argument");
+    SD_LAUNCH(adamw_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper7_dev);
+    SD_CHECK_LAUNCH("adamw_dev_kernel");
+    return 0;
+}
+
+/* host-side helper shared with the binding: the seven scalars of step `step` exactly as sd_adamw_step derives them */
+extern "C" int sd_adamw_hyper(double lr, double beta1, double beta2, double eps, double weight_decay, long step, float *hyper7_host) {
+    if (!hyper7_host || step <= 0) return fail(SD_E_BADARG, "sd_adamw_hyper: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hyper7_host[0] = (float)(1.0 - lr * weight_decay);
+    hyper7_host[1] = (float)(1.0 - beta1);
+    hyper7_host[2] = (float)beta2;
+    hyper7_host[3] = (float)(1.0 - beta2);
+    hyper7_host[4] = (float)(lr / bc1);
+    hyper7_host[5] = (float)sqrt(bc2);
+    hyper7_host[6] = (float)eps;
+    return 0;
+}
+
 extern "C" int sd_adamw_step(float *p, const float *g, float *m, float *v, long n, double lr, double beta1, double beta2,
                              double eps, double weight_decay, long step, void *stream) {
     if (!p || !g || !m || !v || n <= 0 || step <= 0) return fail(SD_E_BADARG, "sd_adamw_step: bad argument");

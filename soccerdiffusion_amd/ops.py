@@ -689,6 +689,31 @@ def mse_loss(pred: Tensor, target: Tensor, want_grad: bool = True):
     return loss, grad
 
 
+def adamw_step_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper7: Tensor) -> None:
+    """AdamW update with its seven scalars in device memory (graph-capturable; see adamw_hyper)."""
+    lib = _lib.load()
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper7, "hyper7")):
+        _req(t, n)
+    if hyper7.numel() < 7:
+        raise ValueError("hyper7 needs 7 floats")
+    check(lib.sd_adamw_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), hyper7.data_ptr(), _stream()),
+          "sd_adamw_step_dev")
+
+
+def adamw_hyper(lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int, out: Tensor) -> None:
+    """Fills ``out[:7]`` (a CPU float32 tensor, e.g. pinned) with the scalars sd_adamw_step derives for update ``step``."""
+    if out.is_cuda or out.dtype != torch.float32 or out.numel() < 7 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous CPU float32 tensor with >= 7 elements")
+    check(_lib.load().sd_adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, C.cast(out.data_ptr(), _lib.c_float_p)), "sd_adamw_hyper")
+
+
+def set_dropout_epoch(word: Optional[Tensor]) -> None:
+    """Process-wide: the uint32 device word every dropout kernel adds to its Philox key at run time (None = off)."""
+    if word is not None and (not word.is_cuda or word.element_size() != 4 or word.numel() < 1):
+        raise ValueError("the epoch word must be a 4-byte element on the device")
+    check(_lib.load().sd_set_dropout_epoch(None if word is None else word.data_ptr()), "sd_set_dropout_epoch")
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
                weight_decay: float, step: int) -> None:
     lib = _lib.load()

@@ -467,9 +467,24 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step += 1
         ops.adamw_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], self._step)
-        for p in g["params"]:
-            self.state[p]["step"] = torch.tensor(float(self._step))
         self.refresh_transposes()
+
+    @torch.no_grad()
+    def step_from_device_hyper(self, hyper7: Tensor) -> None:
+        """The update with its scalars read from device memory (``hyper_for_step``): what a captured graph replays.
+        Does NOT advance ``_step`` - the caller that fills ``hyper7`` does."""
+        ops.adamw_step_dev(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, hyper7)
+        self.refresh_transposes()
+
+    def hyper_for_step(self, step: int, out) -> None:
+        """The seven scalars of update number ``step`` at the CURRENT lr / betas of the param group -> ``out`` (7 floats)."""
+        g = self.param_groups[0]
+        ops.adamw_hyper(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], step, out)
+
+    def state_dict(self):
+        for p in self.param_groups[0]["params"]:   # torch AdamW's per-parameter step counters, all equal here
+            self.state[p]["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         views = {id(p): (self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in self.param_groups[0]["params"]}
@@ -548,3 +563,115 @@ def train_step(model, optimizer: FusedAdamW, lr_scheduler, scheduler, joint_targ
     if lr_scheduler is not None:
         lr_scheduler.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """``train_step`` captured into a hipGraph and replayed (decoder-pretraining path or full model, static shapes).
+
+    The B = 256 step is ~120 kernel launches issued from Python through autograd; rocprofv3 shows the GPU idle for
+    ~18 % of the step waiting for them.  A replay has no host work beyond one 32-byte upload.  What changes from step to
+    step cannot sit in kernel arguments, which a graph freezes, so it comes from device memory instead:
+      * AdamW's scalars (OneCycleLR's lr and cycled beta1, the bias corrections) - ``sd_adamw_step_dev``;
+      * the per-step part of the dropout key - ``sd_set_dropout_epoch`` (process-wide; reset by ``close()``);
+      * timesteps and noise come from ``generator`` (registered with the graph: torch advances its Philox offset per replay).
+    The first ``eager_steps`` calls run the ordinary ``train_step`` (they are real training steps and warm every lazy
+    initialisation up); the next call captures, and from then on every call replays.
+    With ``world_size`` > 1 the graph ends after the backward; the all-reduce and the update follow eagerly."""
+
+    def __init__(self, model, optimizer: FusedAdamW, lr_scheduler, scheduler, world_size: int = 1,
+                 generator: Optional[torch.Generator] = None, eager_steps: int = 2):
+        self.model, self.opt, self.lr_sched, self.sched = model, optimizer, lr_scheduler, scheduler
+        self.world, self.gen, self.eager_left = world_size, generator, eager_steps
+        self.graph = None
+        dev = optimizer.flat_param.device
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)       # 7 AdamW scalars + the dropout epoch word
+        self._ring = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self._events = [None] * 8
+        self._n = 0
+        self._epoch = 0
+        self._static = None
+
+    # ---- inputs -------------------------------------------------------------------------
+    def _stage(self, targets, context, input_data):
+        if self._static is None:
+            self._static = {"targets": targets.clone(),
+                            "context": None if context is None else [c.clone() for c in context],
+                            "input": None if input_data is None else {k: v.clone() for k, v in input_data.items()}}
+            return
+        st = self._static
+        st["targets"].copy_(targets)
+        if context is not None:
+            for dst, src in zip(st["context"], context):
+                dst.copy_(src)
+        if input_data is not None:
+            for k, v in input_data.items():
+                st["input"][k].copy_(v)
+
+    def _upload_hyper(self):
+        slot = self._n % len(self._ring)
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()     # the upload that last used this pinned buffer has run
+        host = self._ring[slot]
+        self.opt.hyper_for_step(self.opt._step + 1, host)
+        self._epoch = (self._epoch + 1) & 0x7FFFFFFF
+        host[7:8].view(torch.int32)[0] = self._epoch
+        self.hyper.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[slot] = ev
+        self._n += 1
+
+    def _body(self):
+        st = self._static
+        B = st["targets"].shape[0]
+        dev = st["targets"].device
+        self.opt.zero_grad()
+        t = torch.randint(0, self.sched.config["num_train_timesteps"], (B,), device=dev, generator=self.gen).long()
+        noise = torch.randn(st["targets"].shape, device=dev, generator=self.gen)
+        noisy = self.sched.add_noise(st["targets"], noise, t)
+        if st["context"] is not None:
+            pred = self.model.forward_with_context(st["context"], noisy, t)
+        else:
+            pred = self.model(st["input"], noisy, t)
+        loss = mse_loss(pred, noise)
+        loss.backward()
+        if self.world <= 1:
+            self.opt.step_from_device_hyper(self.hyper[:7])
+        return loss.detach()
+
+    def __call__(self, joint_targets: Tensor, context=None, input_data=None) -> Tensor:
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            return train_step(self.model, self.opt, self.lr_sched, self.sched, joint_targets, context=context,
+                              input_data=input_data, world_size=self.world, generator=self.gen)
+        self._stage(joint_targets, context, input_data)
+        if self.graph is None:
+            ops.set_dropout_epoch(self.hyper[7:8])
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            if self.gen is not None:
+                self.graph.register_generator_state(self.gen)
+            with torch.cuda.graph(self.graph):
+                self._loss = self._body()
+        self._upload_hyper()
+        self.graph.replay()
+        if self.world > 1:
+            allreduce_gradients(self.opt, self.world)
+            self.opt.step_from_device_hyper(self.hyper[:7])
+        self.opt._step += 1
+        if self.lr_sched is not None:
+            self.lr_sched.step()
+        return self._loss
+
+    def close(self) -> None:
+        """Detaches the process-wide dropout epoch word (it lives in this object's ``hyper`` buffer)."""
+        if self.graph is not None:
+            torch.cuda.synchronize()
+            ops.set_dropout_epoch(None)
+            self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

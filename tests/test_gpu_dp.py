@@ -67,3 +67,49 @@ def test_broadcast_then_step_world1_is_identity():
     before = opt.flat_param.clone()
     training.broadcast_parameters(opt, m)
     assert torch.equal(before, opt.flat_param)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_graphed_train_step_matches_eager(p):
+    """training.GraphedTrainStep (the step replayed from a hipGraph: AdamW scalars and the dropout epoch from device
+    memory, timesteps / noise from the registered generator): at p = 0 the parameters after 7 steps equal the eager loop's
+    (same generator seed, same OneCycleLR); at p = 0.1 replays draw fresh masks (losses differ from step to step, the
+    run stays finite and trains)."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    B, T, J, d = 8, 100, 20, 256
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.randn(B, T, J, device="cuda", generator=g0)
+    ctx = [torch.randn(B, 10, d, device="cuda", generator=g0)]
+    ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+
+    def run(graphed, steps=7):
+        m = _model(seed=1)
+        m.set_dropout(p, seed=99)
+        opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=20)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        losses = []
+        if graphed:
+            gs = training.GraphedTrainStep(m, opt, sch, ns, generator=gen, eager_steps=2)
+            for _ in range(steps):
+                losses.append(float(gs(x0, context=ctx)))
+            gs.close()
+        else:
+            for _ in range(steps):
+                losses.append(float(training.train_step(m, opt, sch, ns, x0, context=ctx, generator=gen)))
+        return opt.flat_param.clone(), losses, opt._step, sch.get_last_lr()[0], opt.state_dict()
+
+    pg, lg, sg, lrg, sdg = run(True)
+    assert sg == 7 and all(torch.isfinite(torch.tensor(lg)))
+    assert float(sdg["state"][0]["step"]) == 7.0
+    if p == 0.0:
+        pe, le, se, lre, _ = run(False)
+        assert se == sg and abs(lre - lrg) < 1e-12
+        assert max(abs(a - b) for a, b in zip(lg, le)) < 1e-5 * max(le), (lg, le)
+        rel = float((pg - pe).norm() / pe.norm())
+        assert rel < 1e-5, rel   # fp32 atomics of the weight-gradient GEMMs: summation order differs run to run
+    else:
+        assert len({round(v, 6) for v in lg}) == len(lg)      # every replay drew new noise / masks
+        assert lg[-1] < lg[0] * 1.5
