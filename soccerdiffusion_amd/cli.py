@@ -64,7 +64,7 @@ def build_model(params: dict):
     )
 
 
-def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
+def synthetic_dataset(n: int, params: dict, seed: int = 0, image_size: Optional[tuple] = None) -> dict:
     """Sine-wave joints around pi (the reference stores angles in [0, 2pi)), random unit
     quaternions, random game states — shaped like the reference's `Result` fields."""
     g = torch.Generator().manual_seed(seed)
@@ -80,9 +80,10 @@ def synthetic_dataset(n: int, params: dict, seed: int = 0) -> dict:
     feat = 5 if params["imu_orientation_embedding_method"] == "five_dim" else 4
     rot = quat if feat == 4 else torch.cat([quat[..., :3], torch.sin(quat[..., 3:]), torch.cos(quat[..., 3:])], -1)
     extra = {}
-    if params.get("use_images"):  # (n, F, 3, R, R) noise frames
+    if params.get("use_images"):  # (n, F, 3, H, W) noise frames; the reference's dataset delivers square R x R ones
         R = params.get("image_resolution", 480)
-        extra["image_data"] = torch.rand(n, params["image_context_length"], 3, R, R, generator=g)
+        H, W = image_size if image_size is not None else (R, R)
+        extra["image_data"] = torch.rand(n, params["image_context_length"], 3, H, W, generator=g)
     return {
         **extra,
         "joint_command": wave[:, Ha:].contiguous(),
@@ -139,7 +140,17 @@ def load_data(args, params: dict) -> dict:
         if "joint_command" not in data:
             raise SystemExit("--data file must hold a dict with a 'joint_command' (N, T, J) tensor")
         return data
-    return synthetic_dataset(args.synthetic, params, seed=args.seed)
+    size = None
+    if getattr(args, "image_size", None):
+        try:
+            h, w = (int(v) for v in args.image_size.lower().split("x"))
+        except ValueError:
+            raise SystemExit("--image-size expects HxW, e.g. 480x640") from None
+        if h != w and not params.get("image_use_final_avgpool", True):
+            raise SystemExit("non-square frames need image_use_final_avgpool: True (the no-avgpool head assumes a square map, "
+                             "reference encoder/image.py:69-83)")
+        size = (h, w)
+    return synthetic_dataset(args.synthetic, params, seed=args.seed, image_size=size)
 
 
 def shard_plan(n_total: int, batch_size: int, rank: int, world: int):
@@ -411,6 +422,8 @@ def main(argv: Optional[list] = None) -> int:
         p.add_argument("--data", type=str, default=None, help="tensor file with joint_command (+ context keys)")
         p.add_argument("--db", type=str, default=None, help="SQLite database in the reference's schema (SOCCER_DIFFUSION_DB_PATH of the reference)")
         p.add_argument("--synthetic", type=int, default=None, metavar="N", help="train / sample on N synthetic sine-wave samples")
+        p.add_argument("--image-size", type=str, default=None, metavar="HxW", help="--synthetic only: frame size when it is not the "
+                       "square image_resolution of the config (BASELINE's image-conditioned case uses 480x640)")
         p.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():

@@ -217,8 +217,11 @@ class SoccerDiffusionDataset(torch.utils.data.Dataset):
         k = IMAGE_SIZE // R
         if k > 1:
             shp = x.shape[:-3]
-            x = x.reshape(*shp, R, k, R, k, 3).mean(dim=(-4, -2))
-            x = torch.round(x)                      # half to even, as cvRound
+            x = x.reshape(*shp, R, k, R, k, 3)
+            if k == 2:   # cv2's 2x2 INTER_AREA fast path is integer arithmetic: (a + b + c + d + 2) >> 2, i.e. half UP
+                x = torch.floor((x.sum(dim=(-4, -2)) + 2.0) * 0.25)
+            else:        # general area path: float block mean, then saturate_cast = cvRound (half to even)
+                x = torch.round(x.mean(dim=(-4, -2)))
         x = x / 255.0
         mean = torch.tensor((0.485, 0.456, 0.406), device=x.device)
         std = torch.tensor((0.229, 0.224, 0.225), device=x.device)

@@ -373,6 +373,7 @@ def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
     memory = memory.contiguous()
     dc = gen.dropout.for_call(gen.training)
     for li, lp in enumerate(gen.transformer_decoder.layers):
+        _layer_input_hook(h, li)
         h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3, dc=dc, li=li)
     return _FcOut.apply(h, gen.fc_out.weight, gen.fc_out.bias)
 
@@ -539,11 +540,78 @@ def allreduce_gradients(optimizer: FusedAdamW, world_size: int, group=None) -> N
     optimizer.flat_grad.mul_(1.0 / world_size)
 
 
+class BucketedAllReduce:
+    """Gradient exchange overlapped with the backward: the flat gradient buffer is cut into
+    one bucket per decoder layer (fc_out rides with the last layer, whose gradients are complete first) plus one for
+    everything else (embedding, step token, context encoders).  ``ready(l)`` - called from a tensor hook when the
+    gradient with respect to layer l's INPUT exists, i.e. when every gradient kernel of layer l has been enqueued -
+    starts that bucket's asynchronous sum all-reduce (RCCL runs it on its own stream behind the work enqueued so far,
+    while the backward of layers l-1 .. 0 keeps the compute stream busy); ``finish()`` reduces the rest, waits for all
+    of them and applies the 1 / world mean.  The buckets partition the buffer, so the result equals
+    ``allreduce_gradients`` exactly (same sum order per element: one all-reduce each)."""
+
+    def __init__(self, optimizer: FusedAdamW, decoder, world_size: int, group=None):
+        self.opt, self.world, self.group = optimizer, world_size, group
+        base = optimizer.flat_param.data_ptr()
+        layers = list(decoder.transformer_decoder.layers)
+        self.ranges = []
+        for i, lp in enumerate(layers):
+            ps = list(lp.parameters()) + (list(decoder.fc_out.parameters()) if i == len(layers) - 1 else [])
+            offs = sorted(((p.data_ptr() - base) // 4, p.numel()) for p in ps)
+            lo, hi = offs[0][0], offs[-1][0] + offs[-1][1]
+            if hi - lo != sum(n for _, n in offs) or lo < 0 or hi > optimizer.flat_param.numel():
+                raise RuntimeError("layer parameters are not one contiguous range of the flat buffer")
+            self.ranges.append((lo, hi))
+        self.ranges.sort()
+        for (a, b), (c, d) in zip(self.ranges, self.ranges[1:]):
+            if b != c:
+                raise RuntimeError("decoder layers are not adjacent in the flat buffer")
+        self.handles, self.done = [], set()
+
+    def ready(self, layer: int) -> None:
+        import torch.distributed as dist
+
+        if self.world <= 1 or layer in self.done:
+            return
+        self.done.add(layer)
+        lo, hi = self.ranges[layer]
+        self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        import torch.distributed as dist
+
+        if self.world <= 1:
+            return
+        for l in range(len(self.ranges)):
+            self.ready(l)          # a layer whose hook never fired (no gradient path) is reduced here
+        n = self.opt.flat_grad.numel()
+        lo, hi = self.ranges[0][0], self.ranges[-1][1]
+        for a, b in ((0, lo), (hi, n)):
+            if b > a:
+                self.handles.append(dist.all_reduce(self.opt.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles, self.done = [], set()
+        self.opt.flat_grad.mul_(1.0 / self.world)
+
+
+_BUCKETS: Optional[BucketedAllReduce] = None   # the exchange in progress (set by train_step around loss.backward())
+
+
+def _layer_input_hook(h: Tensor, layer: int) -> None:
+    """Fires when the gradient of decoder layer ``layer``'s input exists: its bucket is complete."""
+    if _BUCKETS is not None and h.requires_grad:
+        h.register_hook(lambda g, l=layer: (_BUCKETS.ready(l) if _BUCKETS is not None else None, None)[1])
+
+
 def train_step(model, optimizer: FusedAdamW, lr_scheduler, scheduler, joint_targets: Tensor, context=None,
                input_data=None, noise: Optional[Tensor] = None, timesteps: Optional[Tensor] = None,
-               world_size: int = 1, generator: Optional[torch.Generator] = None) -> Tensor:
+               world_size: int = 1, generator: Optional[torch.Generator] = None, bucketed: bool = True) -> Tensor:
     """One iteration of the reference loop body (train.py:204-240) on already-normalised
-    targets.  ``context`` given = the --decoder-pretraining path (train.py:221-224)."""
+    targets.  ``context`` given = the --decoder-pretraining path (train.py:221-224).
+    Data parallel (``world_size`` > 1): the gradient all-reduce runs per decoder layer, overlapped with the rest of the
+    backward (``BucketedAllReduce``); ``bucketed=False`` = one all-reduce after it."""
+    global _BUCKETS
     B = joint_targets.shape[0]
     dev = joint_targets.device
     optimizer.zero_grad()
@@ -552,13 +620,25 @@ def train_step(model, optimizer: FusedAdamW, lr_scheduler, scheduler, joint_targ
     if noise is None:
         noise = torch.randn(joint_targets.shape, device=dev, generator=generator)
     noisy = scheduler.add_noise(joint_targets, noise, timesteps)
-    if context is not None:
-        pred = model.forward_with_context(context, noisy, timesteps)
-    else:
-        pred = model(input_data, noisy, timesteps)
-    loss = mse_loss(pred, noise)
-    loss.backward()
-    allreduce_gradients(optimizer, world_size)
+    buckets = None
+    if world_size > 1 and bucketed:
+        buckets = getattr(optimizer, "_buckets", None)
+        if buckets is None or buckets.world != world_size:
+            buckets = optimizer._buckets = BucketedAllReduce(optimizer, model.diffusion_action_generator, world_size)
+    _BUCKETS = buckets            # the forward registers one hook per decoder layer while this is set
+    try:
+        if context is not None:
+            pred = model.forward_with_context(context, noisy, timesteps)
+        else:
+            pred = model(input_data, noisy, timesteps)
+        loss = mse_loss(pred, noise)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        else:
+            allreduce_gradients(optimizer, world_size)
+    finally:
+        _BUCKETS = None
     optimizer.step()
     if lr_scheduler is not None:
         lr_scheduler.step()
@@ -579,9 +659,11 @@ class GraphedTrainStep:
     With ``world_size`` > 1 the graph ends after the backward; the all-reduce and the update follow eagerly."""
 
     def __init__(self, model, optimizer: FusedAdamW, lr_scheduler, scheduler, world_size: int = 1,
-                 generator: Optional[torch.Generator] = None, eager_steps: int = 2):
+                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None):
         self.model, self.opt, self.lr_sched, self.sched = model, optimizer, lr_scheduler, scheduler
         self.world, self.gen, self.eager_left = world_size, generator, eager_steps
+        # data parallel: the captured part ends after the backward, the all-reduce and the update follow eagerly
+        self.split = (world_size > 1) if split_update is None else bool(split_update)
         self.graph = None
         dev = optimizer.flat_param.device
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)       # 7 AdamW scalars + the dropout epoch word
@@ -635,7 +717,7 @@ class GraphedTrainStep:
             pred = self.model(st["input"], noisy, t)
         loss = mse_loss(pred, noise)
         loss.backward()
-        if self.world <= 1:
+        if not self.split:
             self.opt.step_from_device_hyper(self.hyper[:7])
         return loss.detach()
 
@@ -655,7 +737,7 @@ class GraphedTrainStep:
                 self._loss = self._body()
         self._upload_hyper()
         self.graph.replay()
-        if self.world > 1:
+        if self.split:
             allreduce_gradients(self.opt, self.world)
             self.opt.step_from_device_hyper(self.hyper[:7])
         self.opt._step += 1

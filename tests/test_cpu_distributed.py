@@ -199,3 +199,48 @@ def test_bench_refuses_a_silent_single_gpu_run():
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
     r = _run_bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from soccerdiffusion_amd import training
+
+        model = _tiny_model()
+        opt = training.FusedAdamW(model.parameters(), lr=1e-3)
+        n = opt.flat_param.numel()
+        br = training.BucketedAllReduce(opt, model.diffusion_action_generator, world)
+        # the buckets are the decoder layers, adjacent, inside the buffer, and leave a head (step token, embedding) before them
+        ok = len(br.ranges) == 2 and br.ranges[0][1] == br.ranges[1][0] and br.ranges[0][0] > 0 and br.ranges[-1][1] == n
+        g = torch.Generator().manual_seed(200 + rank)
+        local = torch.randn(n, generator=g)
+        gathered = [torch.empty(n) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world
+        for order in ((1, 0), (0,), ()):            # backward order; a hook that never fires; none at all
+            opt.flat_grad.copy_(local)
+            for l in order:
+                br.ready(l)
+            br.ready(order[0]) if order else None   # a second call for the same layer is a no-op
+            br.finish()
+            ok = ok and torch.allclose(opt.flat_grad, want, atol=1e-6)
+        # and it equals the single all-reduce bit for bit (one sum per element either way)
+        opt.flat_grad.copy_(local)
+        training.allreduce_gradients(opt, world)
+        single = opt.flat_grad.clone()
+        opt.flat_grad.copy_(local)
+        br.ready(1); br.ready(0); br.finish()
+        ok = ok and torch.equal(single, opt.flat_grad)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bucketed_allreduce_world2():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}

@@ -84,7 +84,7 @@ def test_graphed_train_step_matches_eager(p):
     ctx = [torch.randn(B, 10, d, device="cuda", generator=g0)]
     ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
 
-    def run(graphed, steps=7):
+    def run(graphed, steps=7, split=None):
         m = _model(seed=1)
         m.set_dropout(p, seed=99)
         opt = training.FusedAdamW(m.parameters(), lr=1e-3)
@@ -92,7 +92,7 @@ def test_graphed_train_step_matches_eager(p):
         gen = torch.Generator(device="cuda").manual_seed(11)
         losses = []
         if graphed:
-            gs = training.GraphedTrainStep(m, opt, sch, ns, generator=gen, eager_steps=2)
+            gs = training.GraphedTrainStep(m, opt, sch, ns, generator=gen, eager_steps=2, split_update=split)
             for _ in range(steps):
                 losses.append(float(gs(x0, context=ctx)))
             gs.close()
@@ -110,6 +110,9 @@ def test_graphed_train_step_matches_eager(p):
         assert max(abs(a - b) for a, b in zip(lg, le)) < 1e-5 * max(le), (lg, le)
         rel = float((pg - pe).norm() / pe.norm())
         assert rel < 1e-5, rel   # fp32 atomics of the weight-gradient GEMMs: summation order differs run to run
+        # the data-parallel form (graph ends after the backward, all-reduce and update issued eagerly after each replay)
+        ps, ls, ss, _, _ = run(True, split=True)
+        assert ss == sg and float((ps - pe).norm() / pe.norm()) < 1e-5
     else:
         assert len({round(v, 6) for v in lg}) == len(lg)      # every replay drew new noise / masks
         assert lg[-1] < lg[0] * 1.5

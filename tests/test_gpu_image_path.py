@@ -100,3 +100,28 @@ def test_patch_embed_input_gradient_matches_torch():
     (torch.nn.functional.conv1d(x2.transpose(1, 2), W2, b2).transpose(1, 2) + pe).backward(dy)
     for a, c in ((x.grad, x2.grad), (W.grad, W2.grad), (b.grad, b2.grad)):
         assert (a - c).abs().max() / c.abs().max() < 1e-4
+
+
+def test_backbone_on_gpu_matches_the_same_modules_on_cpu_fp32():
+    """The ResNet-18 restatement has nothing to be pinned against offline (torchvision and its weights are absent: parity
+    UNPINNED vs torchvision).  What can be pinned is that the MI355X run (MIOpen convolutions) of these
+    torch.nn modules computes what their CPU fp32 run computes - forward tokens and the input gradient - on a
+    non-square frame through the avgpool head, and on a square one through the reference's conv head."""
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+    for avgpool, (H, W) in ((True, (96, 128)), (False, (64, 64))):
+        torch.manual_seed(0)
+        enc = image_encoder_factory(ImageEncoderType.RESNET18, 64, avgpool, H).eval()
+        x = torch.rand(2, 3, 3, H, W, generator=torch.Generator().manual_seed(1))
+        xc = x.clone().requires_grad_(True)
+        want = enc(xc)
+        want.square().sum().backward()
+        import copy
+
+        g = copy.deepcopy(enc).cuda()
+        xg = x.cuda().requires_grad_(True)
+        got = g(xg)
+        got.square().sum().backward()
+        assert got.shape == (2, 3, 64)
+        assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
+        assert float((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm()) < 1e-3
