@@ -1410,7 +1410,11 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     if (fa.g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer_f16: empty shape");
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((fa.g.a.R + 63) / 64)), block(256);
-    const size_t lds = PanelCfg<256>::LDS_BYTES;
+    // SD_LAYER_LDS_PAD=<bytes>: occupancy experiment - request more LDS than the panel needs so that only ONE
+    // workgroup fits a CU (pad >= 16 KB) and compare with the normal two
+    static const char *padenv = getenv("SD_LAYER_LDS_PAD");
+    static const size_t pad = padenv ? (size_t)atol(padenv) : 0;
+    const size_t lds = PanelCfg<256>::LDS_BYTES + pad;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -16,7 +16,7 @@ f=glob.glob("$OUT/trace/**/*kernel_stats.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 with open("$OUT/summary.txt","w") as fh:
-    hdr="# rocprofv3 --kernel-trace --stats, bench.py --mode train --steps 10 --warmup 2 $@ (12 steps): name, calls, total ms, avg us, %%; all kernels %.2f ms" % (tot/1e6)
+    hdr="# rocprofv3 --kernel-trace --stats, bench.py --mode train --steps 10 --warmup 2 $@ (the 3 warm-up steps incl. the graph capture + 10 timed): name, calls, total ms, avg us, %%; all kernels %.2f ms" % (tot/1e6)
     print(hdr); fh.write(hdr+"\n")
     for r in rows[:28]:
         line = r["Name"][:100].ljust(100)+r["Calls"].rjust(7)+("%.2f"%(float(r["TotalDurationNs"])/1e6)).rjust(10)+("%.1f"%(float(r["AverageNs"])/1e3)).rjust(10)+r["Percentage"].rjust(8)
