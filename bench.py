@@ -230,7 +230,8 @@ class TrainLeg:
         self.ctx = [torch.randn(batch, MC, D, device=dev, generator=self.g)]
         self.graphed = None
         if graph:   # the step replayed from a hipGraph (training.GraphedTrainStep); the first two calls run eagerly
-            self.graphed = training.GraphedTrainStep(self.model, self.opt, self.lr, self.ns, world_size=world, generator=self.g)
+            self.graphed = training.GraphedTrainStep(self.model, self.opt, self.lr, self.ns, world_size=world, generator=self.g,
+                                                     fork_dw=os.environ.get("SD_TRAIN_FORK_DW", "0") == "1")
 
     def step(self):
         if self.graphed is not None:

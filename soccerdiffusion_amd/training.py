@@ -76,6 +76,41 @@ def _transposed_block(W: Tensor, p: int, d: int) -> Tensor:
     return W[p * d : (p + 1) * d].t().contiguous()
 
 
+# ---- weight gradients off the critical path ---------------------------------------------------------------------
+# dW += dY^T X depends on dY and on a saved activation only; nothing in the rest of the backward depends on it.  While
+# a side stream is armed (GraphedTrainStep arms it during capture, so the graph gets a parallel branch per weight
+# gradient), these GEMMs are enqueued there and joined once after loss.backward().  Both kinds of kernel are latency-
+# bound on their own (one wave of 400 workgroups each, section 5.9 of DESIGN.md) and fit a CU together (45 KB + 66.5 KB of
+# LDS), so the chip overlaps them.  The operands are kept alive until the join: the caching allocator must not hand their
+# blocks to a later main-stream allocation while the side stream still reads them, and autograd must not accumulate
+# into a gradient buffer in place (it only does so when it holds the last reference).
+_SIDE = {"stream": None, "keep": [], "dirty": False}
+
+
+def arm_side_stream(stream) -> None:
+    _SIDE["stream"] = stream
+
+
+def join_side_stream() -> None:
+    """Main stream waits for the weight-gradient branch; the operand references are dropped."""
+    if _SIDE["dirty"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["dirty"] = False
+    _SIDE["keep"].clear()
+
+
+def _dw(dY: Tensor, X: Tensor, dW: Tensor, db: Optional[Tensor]) -> None:
+    side = _SIDE["stream"]
+    if side is None:
+        ops.gemm_tn(dY, X, dW, db)
+        return
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gemm_tn(dY, X, dW, db)
+    _SIDE["keep"].append((dY, X))
+    _SIDE["dirty"] = True
+
+
 def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
     """dX[R,d] = dY[R,N] @ W[N,d]: the forward panel kernel on W^T, one pass per d-wide
     column slice of dY (N = d, 2d or 3d), accumulated through the residual input."""
@@ -149,7 +184,7 @@ class _LNLinear(Function):
         n, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b)  # recomputed, not stored
         (dg, rg), (dbeta, rbeta) = ctx.sink.target(0, ln_w), ctx.sink.target(1, ln_w)
         (dW, rW), (db, rb) = ctx.sink.target(2, W), ctx.sink.target(3, W[:, 0])
-        ops.gemm_tn(dpre, n, dW, db)
+        _dw(dpre, n, dW, db)
         dn = _dx_through_weight(dpre, W)
         dx = ops.layernorm_bwd_into(dn, x2, mean, rstd, ln_w, dg, dbeta)
         return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None, None
@@ -179,7 +214,7 @@ class _LinearRes(Function):
         dy2 = dy.contiguous().view(-1, W.shape[0])
         dym = ops.dropout(dy2, ctx.drop) if ctx.drop is not None else dy2   # gradient of the dropped branch; the residual gets dy
         (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
-        ops.gemm_tn(dym, a2, dW, db)
+        _dw(dym, a2, dW, db)
         da = _dx_through_weight(dym, W)
         return da.view(ctx.shape), rW, rb, dy, None, None
 
@@ -200,7 +235,7 @@ class _Linear(Function):
         a2, W = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
         (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
-        ops.gemm_tn(dy2, a2, dW, db)
+        _dw(dy2, a2, dW, db)
         da = _dx_through_weight(dy2, W) if ctx.needs_input_grad[0] else None
         return (da.view(ctx.shape) if da is not None else None), rW, rb, None
 
@@ -659,8 +694,12 @@ class GraphedTrainStep:
     With ``world_size`` > 1 the graph ends after the backward; the all-reduce and the update follow eagerly."""
 
     def __init__(self, model, optimizer: FusedAdamW, lr_scheduler, scheduler, world_size: int = 1,
-                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None):
+                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None,
+                 fork_dw: bool = False):
         self.model, self.opt, self.lr_sched, self.sched = model, optimizer, lr_scheduler, scheduler
+        # weight-gradient GEMMs on a parallel branch of the graph (see _dw).  Measured at B = 256: the branch does overlap
+        # (rocprofv3: 1.0 of 5.2 ms of kernel time concurrent) but both kernels slow down by as much - 5.85 vs 5.83 ms - so off
+        self.fork_dw = fork_dw
         self.world, self.gen, self.eager_left = world_size, generator, eager_steps
         # data parallel: the captured part ends after the backward, the all-reduce and the update follow eagerly
         self.split = (world_size > 1) if split_update is None else bool(split_update)
@@ -717,6 +756,7 @@ class GraphedTrainStep:
             pred = self.model(st["input"], noisy, t)
         loss = mse_loss(pred, noise)
         loss.backward()
+        join_side_stream()
         if not self.split:
             self.opt.step_from_device_hyper(self.hyper[:7])
         return loss.detach()
@@ -733,8 +773,15 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             if self.gen is not None:
                 self.graph.register_generator_state(self.gen)
-            with torch.cuda.graph(self.graph):
-                self._loss = self._body()
+            if self.fork_dw:
+                arm_side_stream(torch.cuda.Stream(device=self.hyper.device))
+            try:
+                with torch.cuda.graph(self.graph):
+                    self._loss = self._body()
+            finally:
+                arm_side_stream(None)
+                _SIDE["keep"].clear()
+                _SIDE["dirty"] = False
         self._upload_hyper()
         self.graph.replay()
         if self.split:
