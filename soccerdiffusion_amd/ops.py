@@ -631,14 +631,18 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, 
     return dx, dg, db
 
 
-def layernorm_bwd_into(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, dg: Tensor, db: Tensor) -> Tensor:
-    """LayerNorm backward that ACCUMULATES the affine gradients into existing dg / db buffers."""
+def layernorm_bwd_into(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, dg: Tensor, db: Tensor,
+                       dres: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm backward that ACCUMULATES the affine gradients into existing dg / db buffers; ``dres`` (same shape as x)
+    is added to dx inside the kernel (the residual branch's gradient)."""
     lib = _lib.load()
     _req(dy, "dy"); _req(x, "x")
+    if dres is not None:
+        _req(dres, "dres")
     d = x.shape[-1]
     R = x.numel() // d
     dx = torch.empty_like(x)
-    check(lib.sd_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), None,
+    check(lib.sd_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), _ptr(dres),
                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(), R, d, _stream()), "sd_op_layernorm_bwd")
     return dx
 

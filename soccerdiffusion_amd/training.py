@@ -159,7 +159,8 @@ class _LNLinear(Function):
     """y = act(LayerNorm(x) W^T + b) — LN1+QKV, LN2+Q, LN3+FFN1(+GELU [+ dropout])."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None, drop=None):
+    def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None, drop=None, link=None):
+        ctx.link = link
         x2 = x.reshape(-1, x.shape[-1])
         pre = ops.linear(x2, W, b, ln=(ln_w, ln_b))
         if gelu:
@@ -186,8 +187,11 @@ class _LNLinear(Function):
         (dW, rW), (db, rb) = ctx.sink.target(2, W), ctx.sink.target(3, W[:, 0])
         _dw(dpre, n, dW, db)
         dn = _dx_through_weight(dpre, W)
-        dx = ops.layernorm_bwd_into(dn, x2, mean, rstd, ln_w, dg, dbeta)
-        return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None, None
+        # the residual branch's gradient of the same h (left by _LinearRes.backward, which ran first) is added inside the
+        # LayerNorm backward kernel instead of by an autograd accumulation kernel
+        dres = ctx.link.pop("dres", None) if ctx.link is not None else None
+        dx = ops.layernorm_bwd_into(dn, x2, mean, rstd, ln_w, dg, dbeta, dres=dres)
+        return dx.view(ctx.shape), rg, rbeta, rW, rb, None, None, None, None
 
 
 class _LinearRes(Function):
@@ -195,11 +199,12 @@ class _LinearRes(Function):
     (torch: x + dropout1(sa_block(x)), x + dropout3(ff_block(x)))."""
 
     @staticmethod
-    def forward(ctx, a, W, b, res, sink=None, drop=None):
+    def forward(ctx, a, W, b, res, sink=None, drop=None, link=None):
         a2 = a.reshape(-1, a.shape[-1])
         ctx.save_for_backward(a2, W)
         ctx.shape = a.shape
         ctx.drop = drop
+        ctx.link = link
         ctx.sink = sink if sink is not None else _GradSink()
         res2 = res.reshape(-1, W.shape[0]).contiguous()
         if drop is not None:
@@ -216,7 +221,10 @@ class _LinearRes(Function):
         (dW, rW), (db, rb) = ctx.sink.target(0, W), ctx.sink.target(1, W[:, 0])
         _dw(dym, a2, dW, db)
         da = _dx_through_weight(dym, W)
-        return da.view(ctx.shape), rW, rb, dy, None, None
+        if ctx.link is not None:   # h's other consumer is the _LNLinear that shares this link: it adds dy inside its kernel
+            ctx.link["dres"] = dy2
+            return da.view(ctx.shape), rW, rb, None, None, None, None
+        return da.view(ctx.shape), rW, rb, dy, None, None, None
 
 
 class _Linear(Function):
@@ -381,23 +389,32 @@ def _layer(lp, h, heads, memory=None, ffn_norm=None, dc=None, li: int = 0):
     def site(kind):
         return dc.site(li, kind) if dc is not None else None
 
+    # In each of the three sub-blocks h has exactly two consumers, the LayerNorm branch and the residual add, and the
+    # residual's backward runs first: it hands its gradient to the LayerNorm backward through `link` (fused add).  Only
+    # when h itself needs a gradient - otherwise autograd would never run the LayerNorm branch's backward for it.
+    def link():
+        return {} if h.requires_grad else None
+
     sa, n1 = lp.self_attn, lp.norm1
+    lk = link()
     qkv = _LNLinear.apply(h, n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias, False,
-                          _GradSink(n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias))
+                          _GradSink(n1.weight, n1.bias, sa.in_proj_weight, sa.in_proj_bias), None, lk)
     a = _SelfAttention.apply(qkv, heads, site(SITE_SA_PROBS))
-    h = _LinearRes.apply(a, sa.out_proj.weight, sa.out_proj.bias, h, _GradSink(sa.out_proj.weight, sa.out_proj.bias), site(SITE_SA_OUT))
+    h = _LinearRes.apply(a, sa.out_proj.weight, sa.out_proj.bias, h, _GradSink(sa.out_proj.weight, sa.out_proj.bias), site(SITE_SA_OUT), lk)
     if memory is not None:
         d = h.shape[-1]
         ca, n2 = lp.multihead_attn, lp.norm2
         w, b = ca.in_proj_weight, ca.in_proj_bias
+        lk = link()
         q = _LNLinear.apply(h, n2.weight, n2.bias, w[:d], b[:d], False,
-                            _GradSink(n2.weight, n2.bias, (w, slice(0, d)), (b, slice(0, d))))
+                            _GradSink(n2.weight, n2.bias, (w, slice(0, d)), (b, slice(0, d))), None, lk)
         kv = _Linear.apply(memory, w[d:], b[d:], _GradSink((w, slice(d, 3 * d)), (b, slice(d, 3 * d))))  # memory is NOT layer-normed
         a = _CrossAttention.apply(q, kv, heads, site(SITE_CA_PROBS))
-        h = _LinearRes.apply(a, ca.out_proj.weight, ca.out_proj.bias, h, _GradSink(ca.out_proj.weight, ca.out_proj.bias), site(SITE_CA_OUT))
+        h = _LinearRes.apply(a, ca.out_proj.weight, ca.out_proj.bias, h, _GradSink(ca.out_proj.weight, ca.out_proj.bias), site(SITE_CA_OUT), lk)
+    lk = link()
     u = _LNLinear.apply(h, ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias, True,
-                        _GradSink(ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias), site(SITE_FFN_ACT))
-    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias), site(SITE_FFN_OUT))
+                        _GradSink(ffn_norm.weight, ffn_norm.bias, lp.linear1.weight, lp.linear1.bias), site(SITE_FFN_ACT), lk)
+    return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias), site(SITE_FFN_OUT), lk)
 
 
 def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
