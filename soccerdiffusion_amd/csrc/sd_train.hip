@@ -1087,6 +1087,295 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
     }
 }
 
+
+// ======================================================================================
+// Attention backward on the fp16 pipe (head dim 64, Tq <= 128, S <= 128): one workgroup per (sample, head).
+// Every product is three v_mfma_f32_32x32x16_f16 on operands split into fp16 hi + lo; the fp32-MFMA kernel
+// above spends 41 k of its 55 k cycles per wave in 64-cycle fp32 MFMAs and holds one workgroup per CU.
+// Both orientations of the score tile are computed, so that every later product takes its B operand straight from the
+// accumulator (contraction index = accumulator rows) and nothing but the four input images goes through LDS:
+//   A (a wave's 32 queries on the lanes):  S^T = K Q^T, dP^T = V dO^T, dS^T -> dQ^T += K^T dS^T      (K^T by transposing reads)
+//   B (a wave's 32 keys on the lanes):     S = Q K^T,  dP = dO V^T,   P, dS -> dV^T += dO^T P, dK^T += Q^T dS
+// Q, K, V, dO sit in LDS as row-major hi | lo planes (272-byte rows: conflict-free 16-byte row reads); the operands that need
+// "8 consecutive rows of one column" come from ds_read_b64_tr_b16.  Scales: Q, K, V fixed 2^3 (as the forward), dO one power
+// of two per workgroup (abs-max), P 2^10, dS one power of two per lane = per query (A) / per key (B) - constant over the
+// contraction, as a scale must be.  With dropout, pass A leaves its masks in LDS as bits for pass B (one Philox call per
+// 4 consecutive keys of a query; in B those sit on 4 different lanes).
+// Measured at B = 256, T = S = 100 (tools/exp/attbwd_time.py): 160.6 -> 115 us per call; of the 115, staging the five arrays is
+// 34 us (131 MB at 3.9 TB/s; 140 KB of LDS = one workgroup per CU, so nothing overlaps it), pass A 32 us, pass B 51 us - the
+// VALU work around the 336 MFMAs per wave (exponentials, per-element splits) is about as long as the MFMAs themselves.
+// ======================================================================================
+constexpr int AB_P = 136;                 // halfs per image row: hi[64] | lo[64] | 8 pad
+constexpr float AB_QKV = 8.0f, AB_PS = 1024.0f;
+constexpr size_t AB_LDS = (size_t)4 * 128 * AB_P * sizeof(f16) + 3 * 128 * sizeof(float) + 128 * 4 * sizeof(unsigned);
+
+__device__ __forceinline__ f16x8 ab_tr(const f16 *plane, int r16, int col0, int lane) {
+    // 8 rows {r16 + 4 half + 0..3, r16 + 8 + 4 half + 0..3} (the k order of an accumulator used as the B operand) of column
+    // col0 + (lane & 31)
+    const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, gc = ((lane >> 4) & 1) * 16, half = lane >> 5;
+    const f16 *a = plane + (r16 + 4 * half + q) * AB_P + col0 + gc + p4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 8 * AB_P));
+    const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+    return f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+// acc (+)= A B with A = (ah, al), B = (bh, bl): lo.hi, hi.lo, hi.hi
+__device__ __forceinline__ f32x16 ab_mfma3(const f16x8 &ah, const f16x8 &al, const f16x8 &bh, const f16x8 &bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float ab_pow2_scale(float m) { return f16_scale_from_bits(__builtin_bit_cast(unsigned, m)); }
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ k,
+                                                               const float *__restrict__ v, int ldkv, const float *__restrict__ o, int ldo,
+                                                               const float *__restrict__ dO, int lddo, const float *__restrict__ lse2,
+                                                               float *dq, int lddq, float *dk, float *dv, int lddkv, int Tq, int S,
+                                                               int heads, float scale, DropoutArgs da) {
+    constexpr int HD = 64;
+    extern __shared__ __attribute__((aligned(16))) f16 ab_smem[];
+    f16 *sQ = ab_smem, *sK = sQ + 128 * AB_P, *sV = sK + 128 * AB_P, *sdO = sV + 128 * AB_P;
+    float *sLse = reinterpret_cast<float *>(sdO + 128 * AB_P), *sDelta = sLse + 128, *sRed = sDelta + 128;
+    unsigned *sMask = reinterpret_cast<unsigned *>(sRed + 128);   // [128 queries][4 words]: bit = key kept
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const float *qb = q + (long)b * Tq * ldq + h * HD, *ob = o + (long)b * Tq * ldo + h * HD, *dob = dO + (long)b * Tq * lddo + h * HD;
+    const float *kb = k + (long)b * S * ldkv + h * HD, *vb = v + (long)b * S * ldkv + h * HD;
+    const float sl2e = scale * 1.44269504088896340736f;
+
+    // ---- stage: 128 rows x 16 pieces of 4 floats per image; a row's 16 pieces sit in one DPP row of 16 lanes ----
+    // every load of the workgroup is in flight before the first value is used: 40 x 16 bytes per thread, one HBM round trip
+    // (with the delta reduction inside the load loop the compiler waited per iteration: 8 round trips, 92 us per launch even
+    // for the 11-key cross-attention)
+    f32x4 qv[8], kv[8], vv[8], dov[8], ovv[8];
+    float dmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, c4 = (idx & 15) * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        qv[i] = row < Tq ? *reinterpret_cast<const f32x4 *>(qb + (long)row * ldq + c4) : z;
+        dov[i] = row < Tq ? *reinterpret_cast<const f32x4 *>(dob + (long)row * lddo + c4) : z;
+        ovv[i] = row < Tq ? *reinterpret_cast<const f32x4 *>(ob + (long)row * ldo + c4) : z;
+        kv[i] = row < S ? *reinterpret_cast<const f32x4 *>(kb + (long)row * ldkv + c4) : z;
+        vv[i] = row < S ? *reinterpret_cast<const f32x4 *>(vb + (long)row * ldkv + c4) : z;
+    }
+    float lsev[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (tid + 256 * i) >> 4;
+        lsev[i] = ((lane & 15) == 0 && row < Tq) ? lse2[((long)b * heads + h) * Tq + row] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (tid + 256 * i) >> 4;
+        float dl = dov[i][0] * ovv[i][0] + dov[i][1] * ovv[i][1] + dov[i][2] * ovv[i][2] + dov[i][3] * ovv[i][3];
+        dl = row16_sum(dl);                       // delta_q = sum_f dO O
+        if ((lane & 15) == 0) {
+            sDelta[row] = dl;
+            sLse[row] = lsev[i];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dmax = fmaxf(dmax, fabsf(dov[i][e]));
+    }
+    dmax = wave_max(dmax);
+    if (lane == 0) sRed[wave] = dmax;
+    __syncthreads();
+    const float s_do = ab_pow2_scale(fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3])));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, c4 = (idx & 15) * 4;
+        f16x4 hh, ll;
+        f16_split4(qv[i], AB_QKV, hh, ll);
+        *reinterpret_cast<f16x4 *>(sQ + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sQ + row * AB_P + HD + c4) = ll;
+        f16_split4(kv[i], AB_QKV, hh, ll);
+        *reinterpret_cast<f16x4 *>(sK + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sK + row * AB_P + HD + c4) = ll;
+        f16_split4(vv[i], AB_QKV, hh, ll);
+        *reinterpret_cast<f16x4 *>(sV + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sV + row * AB_P + HD + c4) = ll;
+        f16_split4(dov[i], s_do, hh, ll);
+        *reinterpret_cast<f16x4 *>(sdO + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sdO + row * AB_P + HD + c4) = ll;
+    }
+    if (DROP)
+        for (int i = tid; i < 128 * 4; i += 256) sMask[i] = 0u;
+    __syncthreads();
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float c_s = sl2e / (AB_QKV * AB_QKV);          // raw score accumulator -> log2-domain score
+    const float c_dp = 1.0f / (AB_QKV * s_do);           // raw dP accumulator -> dP
+    const int n_kt = (S + 31) / 32, n_qt = (Tq + 31) / 32;
+    const int mine = wave * 32 + l31;                    // this lane's query (pass A) / key (pass B)
+
+    // fragments of this lane's own row of two images: B operands (k = 8 half + j of k-step ks)
+    auto row_frags = [&](const f16 *img, f16x8 (&fh)[4], f16x8 (&fl)[4]) {
+        const f16 *p = img + mine * AB_P + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fh[ks] = *reinterpret_cast<const f16x8 *>(p + ks * 16);
+            fl[ks] = *reinterpret_cast<const f16x8 *>(p + HD + ks * 16);
+        }
+    };
+    // two 32 x 32 tiles at once: rows [t*32, t*32+32) of images A0 / A1 (lanes = their rows) times this lane's own rows of the
+    // B images.  All 16 fragment reads are issued before the first MFMA (one LDS latency per tile pair: with one wave per
+    // SIMD nothing else hides it)
+    auto tile2 = [&](const f16 *imgA0, const f16 *imgA1, int t, const f16x8 (&b0h)[4], const f16x8 (&b0l)[4], const f16x8 (&b1h)[4],
+                     const f16x8 (&b1l)[4], f32x16 &r0, f32x16 &r1) {
+        const f16 *p0 = imgA0 + (t * 32 + l31) * AB_P + 8 * half, *p1 = imgA1 + (t * 32 + l31) * AB_P + 8 * half;
+        f16x8 a0h[4], a0l[4], a1h[4], a1l[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a0h[ks] = *reinterpret_cast<const f16x8 *>(p0 + ks * 16);
+            a0l[ks] = *reinterpret_cast<const f16x8 *>(p0 + HD + ks * 16);
+            a1h[ks] = *reinterpret_cast<const f16x8 *>(p1 + ks * 16);
+            a1l[ks] = *reinterpret_cast<const f16x8 *>(p1 + HD + ks * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        r0 = zero16;
+        r1 = zero16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            r0 = ab_mfma3(a0h[ks], a0l[ks], b0h[ks], b0l[ks], r0);
+            r1 = ab_mfma3(a1h[ks], a1l[ks], b1h[ks], b1l[ks], r1);
+        }
+    };
+    auto split8 = [&](const f32x16 &t, int j2, float sc, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = t[8 * j2 + e] * sc;
+            hi[e] = (f16)x;
+            lo[e] = (f16)(x - (float)hi[e]);
+        }
+    };
+    // out^T (64 features x this wave's 32 columns) += img^T B over the 16-row groups of `tiles` score tiles; the transposing
+    // reads of a whole tile (2 groups x 2 feature tiles x 2 planes) are issued before its MFMAs
+    auto contract = [&](const f16 *img, const f32x16 (&t)[4], int tiles, float sc, f32x16 (&out)[2]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (tt >= tiles) break;
+            f16x8 ah[2][2], al[2][2];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    ah[j2][ft] = ab_tr(img, tt * 32 + j2 * 16, ft * 32, lane);
+                    al[j2][ft] = ab_tr(img + HD, tt * 32 + j2 * 16, ft * 32, lane);
+                }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                f16x8 bh, bl;
+                split8(t[tt], j2, sc, bh, bl);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) out[ft] = ab_mfma3(ah[j2][ft], al[j2][ft], bh, bl, out[ft]);
+            }
+        }
+    };
+    auto store_T = [&](float *dst, int ld, int rows, const f32x16 (&acc)[2], float un) {
+        if (mine < rows) {   // lane = row of the output, registers 4g..4g+3 = 4 consecutive features
+            float *op = dst + (long)mine * ld;
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 t4 = {acc[ft][4 * g] * un, acc[ft][4 * g + 1] * un, acc[ft][4 * g + 2] * un, acc[ft][4 * g + 3] * un};
+                    *reinterpret_cast<f32x4 *>(op + ft * 32 + 8 * g + 4 * half) = t4;
+                }
+        }
+    };
+
+    // ================= pass A: this wave's queries; dQ =================
+    if (wave * 32 < Tq) {
+        f16x8 qh[4], ql[4], doh[4], dol[4];
+        row_frags(sQ, qh, ql);
+        row_frags(sdO, doh, dol);
+        const bool q_ok = mine < Tq;
+        const float lse = sLse[q_ok ? mine : 0], delta = sDelta[q_ok ? mine : 0];
+        f32x16 ds[4];
+        float dsmax = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= n_kt) { ds[kt] = zero16; continue; }
+            f32x16 sT, dpT;
+            tile2(sK, sV, kt, qh, ql, doh, dol, sT, dpT);
+            f32x4 dm[4];
+            if constexpr (DROP) {
+                const unsigned long mrow = ((unsigned long)b * heads + h) * Tq + (q_ok ? mine : 0);
+                const unsigned long wq = (unsigned long)((S + 3) >> 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dm[g] = dropout_quad(da, mrow * wq + (unsigned long)((kt * 32 + 8 * g + 4 * half) >> 2));
+                if (q_ok) {   // leave the mask bits of (query mine, keys kt*32 ..) for pass B
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (dm[r >> 2][r & 3] != 0.f) bits |= 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
+                    atomicOr(&sMask[mine * 4 + kt], bits);   // the two halves of a query own disjoint bits
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float p = (key < S && q_ok) ? exp2f(sT[r] * c_s - lse) : 0.f;
+                float dp = dpT[r] * c_dp;
+                if constexpr (DROP) dp *= dm[r >> 2][r & 3];
+                const float d = p * (dp - delta) * scale;
+                ds[kt][r] = d;
+                dsmax = fmaxf(dsmax, fabsf(d));
+            }
+        }
+        dsmax = fmaxf(dsmax, __shfl_xor(dsmax, 32, 64));
+        const float s_q = ab_pow2_scale(dsmax);       // one scale per query: constant over the keys it is contracted with
+        f32x16 dqT[2] = {zero16, zero16};
+        contract(sK, ds, n_kt, s_q, dqT);
+        store_T(dq + (long)b * Tq * lddq + h * HD, lddq, Tq, dqT, 1.0f / (AB_QKV * s_q));
+    }
+    if (DROP) __syncthreads();   // mask bits complete
+
+    // ================= pass B: this wave's keys; dK, dV =================
+    if (wave * 32 < S) {
+        f16x8 kh[4], kl[4], vh[4], vl[4];
+        row_frags(sK, kh, kl);
+        row_frags(sV, vh, vl);
+        const bool k_ok = mine < S;
+        f32x16 pd[4], ds[4];
+        float dsmax = 0.f;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            if (qt >= n_qt) { pd[qt] = zero16; ds[qt] = zero16; continue; }
+            f32x16 sN, dpN;                              // rows = queries, lane = key
+            tile2(sQ, sdO, qt, kh, kl, vh, vl, sN, dpN);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool ok = k_ok && qi < Tq;
+                const float p = ok ? exp2f(sN[r] * c_s - sLse[qi]) : 0.f;
+                float dp = dpN[r] * c_dp, pm = p;
+                if constexpr (DROP) {
+                    const float m = ((sMask[qi * 4 + (mine >> 5)] >> (mine & 31)) & 1u) ? da.scale : 0.f;
+                    dp *= m;
+                    pm *= m;
+                }
+                const float d = p * (dp - sDelta[qi]) * scale;
+                pd[qt][r] = pm;
+                ds[qt][r] = d;
+                dsmax = fmaxf(dsmax, fabsf(d));
+            }
+        }
+        dsmax = fmaxf(dsmax, __shfl_xor(dsmax, 32, 64));
+        const float s_k = ab_pow2_scale(dsmax);       // one scale per key
+        f32x16 dvT[2] = {zero16, zero16}, dkT[2] = {zero16, zero16};
+        contract(sdO, pd, n_qt, AB_PS, dvT);
+        contract(sQ, ds, n_qt, s_k, dkT);
+        store_T(dv + (long)b * S * lddkv + h * HD, lddkv, S, dvT, 1.0f / (s_do * AB_PS));
+        store_T(dk + (long)b * S * lddkv + h * HD, lddkv, S, dkT, 1.0f / (AB_QKV * s_k));
+    }
+}
+
 extern "C" int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v, int ldkv, const float *o,
                                    int ldo, const float *dO, int lddo, const float *lse2, float *dq, int lddq, float *dk,
                                    float *dv, int lddkv, int B, int Tq, int S, int d, int heads, void *stream) {
@@ -1108,6 +1397,26 @@ extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     dim3 grid(B * heads), block(256);
+    {   // head dim 64, <= 128 queries and keys, 16-byte aligned rows: the fp16-pipe kernel (SD_ATT_BWD=f32: the fp32-MFMA one)
+        static const char *env = getenv("SD_ATT_BWD");
+        auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool lds_ok = ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddkv % 4 == 0;
+        // (up to 32 keys - the cross-attention over 11 memory rows - only one wave would own keys in pass B: the fp32 kernel is
+        // faster there, 60 vs 83 us at B = 256)
+        if (hd == 64 && Tq <= 128 && S > 32 && S <= 128 && lds_ok && al16(q) && al16(k) && al16(v) && al16(o) && al16(dO) && al16(dq) && al16(dk) &&
+            al16(dv) && !(env && strcmp(env, "f32") == 0)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void *)attention_bwd16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS);
+                (void)hipFuncSetAttribute((const void *)attention_bwd16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS);
+                attr_set = true;
+            }
+            if (da.thresh) SD_LAUNCH(attention_bwd16_kernel<true>, grid, block, AB_LDS, s, q, ldq, k, v, ldkv, o, ldo, dO, lddo, lse2, dq, lddq, dk, dv, lddkv, Tq, S, heads, scale, da);
+            else SD_LAUNCH(attention_bwd16_kernel<false>, grid, block, AB_LDS, s, q, ldq, k, v, ldkv, o, ldo, dO, lddo, lse2, dq, lddq, dk, dv, lddkv, Tq, S, heads, scale, da);
+            SD_CHECK_LAUNCH("attention_bwd16_kernel");
+            return 0;
+        }
+    }
 #define SD_ATTNB(HD_)                                                                                            \
     do {                                                                                                         \
         auto kfn = da.thresh ? attention_bwd_kernel<HD_, true> : attention_bwd_kernel<HD_, false>;               \
