@@ -180,6 +180,8 @@ def spawn_ranks(n: int) -> int:
     import torch
 
     have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if os.environ.get("SD_BENCH_SHARE_GPU") == "1":   # rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL
+        have = max(have, n)
     if have < n:
         sys.stderr.write(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)\n")
         return 2
@@ -327,13 +329,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    share = os.environ.get("SD_BENCH_SHARE_GPU") == "1"   # rehearsal of the N-rank code path on one GPU (tests): gloo, all ranks on cuda:0
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
     try:
         if args.mode == "train":
             run_train(args, rank, world, dev, dist)

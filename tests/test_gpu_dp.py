@@ -116,3 +116,33 @@ def test_graphed_train_step_matches_eager(p):
     else:
         assert len({round(v, 6) for v in lg}) == len(lg)      # every replay drew new noise / masks
         assert lg[-1] < lg[0] * 1.5
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(mode):
+    """The N-rank code path of bench.py end to end - the parent starts 2 ranks itself, rendezvous on 127.0.0.1, rank-0
+    broadcast, barrier + MAX-over-ranks timing, the gradient all-reduce behind the graphed step, one JSON line from rank 0 -
+    rehearsed on ONE GPU (SD_BENCH_SHARE_GPU=1: both ranks on cuda:0, gloo instead of RCCL; an 8-GPU node is the driver's to
+    run).  Checks what a scaling record needs: n_gpus = 2, whole-job value = 2 x batch x steps / time, weak scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SD_BENCH_SHARE_GPU"] = "1"
+    args = ["--gpus", "2", "--mode", mode, "--steps", "2", "--warmup", "1", "--batch", "64" if mode == "sample" else "16", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    per_gpu = 64 if mode == "sample" else 16
+    assert abs(d["value"] - 2 * per_gpu * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
+    assert d["cpu_baseline"] is None
+    if mode == "train":
+        assert d["train"]["allreduce_bytes"] > 10_000_000 and d["train"]["allreduce_ms"] > 0
+        assert "all-reduce" in d["config"]["parallelism"]
