@@ -172,7 +172,18 @@ def shard_plan(n_total: int, batch_size: int, rank: int, world: int):
 
 def _dist_env():
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("SD_BENCH_SHARE_GPU") == "1":   # rehearsal of the multi-rank path on a 1-GPU box (tests): all ranks on cuda:0
+        local = 0
     return rank, world, local
+
+
+def _init_dist(device) -> None:
+    import torch.distributed as dist
+
+    if os.environ.get("SD_BENCH_SHARE_GPU") == "1":
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
 
 
 def cmd_train(args) -> int:
@@ -184,9 +195,7 @@ def cmd_train(args) -> int:
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=device)
+        _init_dist(device)
 
     checkpoint = None
     params: dict = {}
@@ -256,6 +265,7 @@ def cmd_train(args) -> int:
                                            world_size=world, generator=dev_gen)
             if i % 20 == 0 and rank == 0:
                 print(f"Epoch {epoch}, it {i}, Loss: {float(loss):.05f}, LR: {lr_scheduler.get_last_lr()[0]:0.7f}", flush=True)
+        training.assert_replicas_equal(optimizer)   # one pair of tiny all-reduces per epoch
         if rank == 0:
             torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
                         "lr_scheduler_state_dict": lr_scheduler.state_dict(), "hyperparams": params,
@@ -279,9 +289,7 @@ def cmd_distill(args) -> int:
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=device)
+        _init_dist(device)
     checkpoint = torch.load(args.checkpoint, map_location="cpu", weights_only=True)
     teacher_params = checkpoint["hyperparams"]
     with open(args.config) as f:
@@ -308,6 +316,8 @@ def cmd_distill(args) -> int:
     # no_grad), so torch's AdamW leaves them untouched; the flat optimizer therefore only owns the rest
     trainable = [p for n, p in student.named_parameters() if n.startswith(("diffusion_action_generator.", "step_encoding."))]
     optimizer = training.FusedAdamW(trainable, lr=params["lr"])
+    if world > 1:
+        training.broadcast_parameters(optimizer, student)
 
     gen = torch.Generator().manual_seed(args.seed + rank)
     source = data_source(args, params, device)
@@ -340,6 +350,7 @@ def cmd_distill(args) -> int:
             mean_loss += float(loss)
             if i % 20 == 0 and rank == 0:
                 print(f"Epoch {epoch}, it {i}, Loss: {mean_loss / (i + 1):.05f}, LR: {lr_scheduler.get_last_lr()[0]:0.7f}", flush=True)
+        training.assert_replicas_equal(optimizer)
         if rank == 0:
             torch.save({"model_state_dict": student.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
                         "lr_scheduler_state_dict": lr_scheduler.state_dict(), "hyperparams": params,

@@ -581,6 +581,23 @@ def broadcast_parameters(optimizer: FusedAdamW, model=None, src: int = 0, group=
     optimizer.refresh_transposes()
 
 
+def assert_replicas_equal(optimizer: FusedAdamW, group=None) -> None:
+    """Data-parallel invariant: every rank holds bit-identical parameters (same start by broadcast, same averaged gradient,
+    same deterministic update).  Two scalars per rank (sum and sum of squares of the flat parameter buffer, in fp64) are
+    MIN- and MAX-reduced; a difference means the replicas have drifted apart - raise instead of training on silently."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return
+    p = optimizer.flat_param.double()
+    sig = torch.stack([p.sum(), (p * p).sum()])
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"data-parallel replicas diverged: parameter checksums differ across ranks ({lo.tolist()} .. {hi.tolist()})")
+
+
 def allreduce_gradients(optimizer: FusedAdamW, world_size: int, group=None) -> None:
     """Data-parallel gradient exchange: ONE sum all-reduce of the flat fp32 gradient buffer
     over RCCL/xGMI (gloo on CPU tests), then the mean.  The reference is single-device."""

@@ -136,3 +136,39 @@ def test_train_with_image_context_from_sqlite_database(tmp_path):
     assert losses and all(math.isfinite(x) for x in losses)
     sd = torch.load(ckpt, weights_only=True)["model_state_dict"]
     assert "image_sequence_encoder.image_encoder.encoder.conv1.weight" in sd
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_train_and_distill_rehearsal_on_one_gpu(tmp_path):
+    """`cli train` / `cli distill` under torchrun with 2 ranks (replicas used to start from different weights and
+    could disagree on the number of steps): rank-0 broadcast, equal shards with a common step count (257 samples, batch 32),
+    the per-layer all-reduce hooked into the backward, dropout with per-rank masks - and the invariant
+    `training.assert_replicas_equal` checked at the end of every epoch (it raises when the parameter checksums differ).
+    Rehearsed on ONE GPU: SD_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 and uses gloo instead of RCCL."""
+    import socket
+
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump(dict(CFG, epochs=2)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=REPO, SD_BENCH_SHARE_GPU="1")
+
+    def torchrun(*argv):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "soccerdiffusion_amd.cli", *argv]
+        return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=420)
+
+    ckpt = tmp_path / "dp.pth"
+    r = torchrun("train", "-c", str(cfg), "-o", str(ckpt), "--synthetic", "257")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "diverged" not in r.stderr
+    back = torch.load(ckpt, weights_only=True)
+    assert back["current_epoch"] == 1
+    # 257 samples / 2 ranks = 128 each -> 4 steps per epoch on BOTH ranks: OneCycleLR was built for 8 steps
+    assert back["lr_scheduler_state_dict"]["total_steps"] == 8
+    assert all(torch.isfinite(v).all() for v in back["model_state_dict"].values() if v.is_floating_point())
+    r = torchrun("distill", str(cfg), str(ckpt), "-o", str(tmp_path / "student.pth"), "--synthetic", "130")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert torch.load(tmp_path / "student.pth", weights_only=True)["hyperparams"]["distilled_decoder"] is True
