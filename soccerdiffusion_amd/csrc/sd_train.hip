@@ -515,32 +515,49 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         pg[j] = 0.f;
         pb[j] = 0.f;
     }
-    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float d[PL], xh[PL], gd[PL], s1 = 0.f, s2 = 0.f;
-        ln_load<PL>(d, dy + row * D + c0);
-        ln_load<PL>(xh, x + row * D + c0);
+    // NU rows of a wave in flight (the row loop is a chain of load -> wave reduction -> store) and FEW workgroups: every
+    // workgroup ends with 2 D atomics on the same 2 D addresses, and same-address float atomics run at ~22 G/s chip-wide
+    // (MI355X_MICROARCH.md) - 1 024 workgroups spent 23 of their 38 us there, 2 048 took 57 us
+    constexpr int NU = 4;
+    const long stride = (long)gridDim.x * 4;
+    for (long row0 = (long)blockIdx.x * 4 + wave; row0 < R; row0 += NU * stride) {
+        float d[NU][PL], xh[NU][PL], r[NU][PL], mu[NU], rs[NU];
+        bool ok[NU];
 #pragma unroll
-        for (int j = 0; j < PL; ++j) {
-            xh[j] = (xh[j] - mu) * rs;
-            gd[j] = d[j] * gw[j];
-            s1 += gd[j];
-            s2 += gd[j] * xh[j];
-            pg[j] += d[j] * xh[j];
-            pb[j] += d[j];
+        for (int u = 0; u < NU; ++u) {
+            const long row = row0 + u * stride;
+            ok[u] = row < R;
+            const long rr = ok[u] ? row : row0;
+            mu[u] = mean[rr];
+            rs[u] = rstd[rr];
+            ln_load<PL>(d[u], dy + rr * D + c0);
+            ln_load<PL>(xh[u], x + rr * D + c0);
+            if (dres) ln_load<PL>(r[u], dres + rr * D + c0);
         }
-        s1 = wave_sum(s1) * (1.0f / D);
-        s2 = wave_sum(s2) * (1.0f / D);
-        float o[PL];
 #pragma unroll
-        for (int j = 0; j < PL; ++j) o[j] = rs * (gd[j] - s1 - xh[j] * s2);
-        if (dres) {
-            float r[PL];
-            ln_load<PL>(r, dres + row * D + c0);
+        for (int u = 0; u < NU; ++u) {
+            if (!ok[u]) continue;   // wave-uniform
+            const long row = row0 + u * stride;
+            float gd[PL], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < PL; ++j) o[j] += r[j];
+            for (int j = 0; j < PL; ++j) {
+                xh[u][j] = (xh[u][j] - mu[u]) * rs[u];
+                gd[j] = d[u][j] * gw[j];
+                s1 += gd[j];
+                s2 += gd[j] * xh[u][j];
+                pg[j] += d[u][j] * xh[u][j];
+                pb[j] += d[u][j];
+            }
+            s1 = wave_sum(s1) * (1.0f / D);
+            s2 = wave_sum(s2) * (1.0f / D);
+            float o[PL];
+#pragma unroll
+            for (int j = 0; j < PL; ++j) {
+                o[j] = rs[u] * (gd[j] - s1 - xh[u][j] * s2);
+                if (dres) o[j] += r[u][j];
+            }
+            ln_store<PL>(dx + row * D + c0, o);
         }
-        ln_store<PL>(dx + row * D + c0, o);
     }
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
@@ -575,7 +592,7 @@ extern "C" int sd_op_layernorm_bwd(const float *dy, const float *x, const float 
     if (!dy || !x || !mean || !rstd || !g || !dx || !dg || !db || R <= 0)
         return fail(SD_E_BADARG, "sd_op_layernorm_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((R + 3) / 4 > 1024 ? 1024 : (R + 3) / 4)), block(256);
+    dim3 grid((unsigned)((R + 3) / 4 > 256 ? 256 : (R + 3) / 4)), block(256);
     switch (d) {
         case 64: SD_LAUNCH(layernorm_bwd_kernel<64>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
         case 128: SD_LAUNCH(layernorm_bwd_kernel<128>, grid, block, 0, s, dy, x, mean, rstd, g, dres, dx, dg, db, R); break;
