@@ -174,8 +174,10 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
                                               unsigned (&w)[4]) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 64-bit product per multiplier (v_mad_u64_u32) instead of a mul_lo / mul_hi pair: integer multiplies are
+        // quarter rate, and they are most of this function
+        const unsigned long p0 = (unsigned long)0xD2511F53u * (unsigned long)c0, p1 = (unsigned long)0xCD9E8D57u * (unsigned long)c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;

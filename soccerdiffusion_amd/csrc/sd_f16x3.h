@@ -1571,7 +1571,7 @@ __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const
 // is applied to the quad-transposed values (4 consecutive columns of one row = one Philox call, sd_common.h) and the
 // residual is then added from a 16-byte load.
 template <int D, bool HAS_LN, int ACT, bool HAS_RES, bool DROP = false>
-__global__ __launch_bounds__(256) void panel_gemm16_kernel(const float *__restrict__ A, const float *__restrict__ W,
+__global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void panel_gemm16_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, const float *__restrict__ ln_w,
                                                             const float *__restrict__ ln_b, const float *res, float *out, int R,
                                                             int N, int lda, DropoutArgs da = DropoutArgs{}) {
