@@ -133,13 +133,13 @@ __device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h
     }
 }
 
-// power of two s with max * s in [8192, 16384) from the bits of an abs-max
+// power of two s with max * s in [8192, 16384) from the bits of an abs-max (m = f 2^e, f in [0.5, 1): s = 2^(14 - e)).
+// Exponent arithmetic on the bits: frexpf / ldexpf cost ~25 instructions each with their special cases, and this sits in
+// per-row / per-slab paths.  Zero, non-finite and < 2^-113 maxima (the scale would not be a normal float) give 1.
 __device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
-    const float m = __builtin_bit_cast(float, maxbits);
-    if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
-    int e;
-    (void)frexpf(m, &e);   // m = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, 14 - e);
+    const unsigned eb = (maxbits >> 23) & 0xffu;           // biased exponent: frexp's e = eb - 126
+    const unsigned sbits = (267u - eb) << 23;              // 2^(14 - e) = 2^(140 - eb)
+    return (eb >= 14u && eb != 255u) ? __builtin_bit_cast(float, sbits) : 1.0f;
 }
 
 // --------------------------------------------------------------------------------------

@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
 // reduction), two power-of-two scales, split into fp16 hi + lo, 24 fp16 MFMAs into a zero-initialised sub-accumulator,
 // which is then added - un-scaled - to the fp32 accumulator of the whole chunk (block floating point per 32 rows).
 // --------------------------------------------------------------------------------------
+// max inside each group of 16 consecutive lanes (one DPP row): 4 VALU-rate steps, no LDS round trips
+__device__ __forceinline__ float row16_maxf(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)));
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -277,6 +286,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(const float *__restri
 // workgroup from an abs-max sweep over its row chunk (no per-slab exchange, no sub-accumulator, two slabs of loads in
 // flight) took 53.6 us: the second sweep's reads cost more than the synchronisation they remove - the kernel moves
 // 105 MB per launch (each operand is read by two column tiles) and sits at 2.4 TB/s with one workgroup wave on the chip.
+// A second variant - 512-row chunks, one workgroup per CU, four slabs of loads in flight, two LDS buffers and one barrier per
+// slab - took 58.6 us: with three slabs prefetched a slab still cost 6.9 k cycles, so the slab is bound by its own ~700 vector
+// instructions around 24 MFMAs (abs-max, split, transposing-read addresses, un-scale; one wave per SIMD issues them at 5 - 7
+// cycles each), not by memory latency.  Hence the running row pointers below instead of 64-bit row * stride products.
 // Requires N % 128 == 0, K % 128 == 0, 16-byte aligned rows (the d x d / 3d x d / 2d x d weight gradients).
 // --------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -291,7 +304,7 @@ __device__ __forceinline__ f16x8 tns_frag(const f16 *plane, int row0, int col0, 
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * TNS_PITCH));
     const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
-    return f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn16s_kernel(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
@@ -309,16 +322,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16s_kernel(const float *__restr
     if (rend > R) rend = R;
     // staging map: thread -> rows (tid >> 5) + 8 v, columns 4 (tid & 31) .. +3
     const int srow = tid >> 5, scol = (tid & 31) * 4;
-    const float *yb = dY + n0 + scol, *xb = X + k0 + scol;
+    // running pointers of this thread's first row of the next slab (64-bit row * stride products are quarter-rate multiplies:
+    // 64 of them per slab before)
+    const float *yp = dY + (rbeg + srow) * (long)ldy + n0 + scol, *xp = X + (rbeg + srow) * (long)ldx + k0 + scol;
+    const long ystep = 8L * ldy, xstep = 8L * ldx;
     f32x4 yv[4], xv[4];
     auto load = [&](long r) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int left = (int)(rend - r) - srow;    // rows of this slab from this thread's first one to the chunk's end
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const long row = r + srow + 8 * v;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            yv[v] = row < rend ? *reinterpret_cast<const f32x4 *>(yb + row * ldy) : z;
-            xv[v] = row < rend ? *reinterpret_cast<const f32x4 *>(xb + row * ldx) : z;
+            yv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(yp + v * ystep) : z;
+            xv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(xp + v * xstep) : z;
         }
+        yp += 4 * ystep;
+        xp += 4 * xstep;
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -414,6 +432,179 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16s_kernel(const float *__restr
     }
 }
 
+
+// --------------------------------------------------------------------------------------
+// gemm_tn16d_kernel: two wave quartets per workgroup, half the atomics.
+// What bounds the staged kernel is its epilogue: all 400 workgroups of a d x d gradient finish together and add 26 MB with
+// float atomics, which run at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md): ~20 of its 45 us (512-row chunks halve the atomics
+// but double every workgroup's serial slab loop: 45.5 us).  Here quartet g = threadIdx.x >> 8 runs the same slab loop on its own
+// TN_RC rows with its own LDS planes - the chip holds the same eight waves per CU as before - and the two partial 128 x 128
+// tiles are added through LDS before ONE set of atomics per workgroup.  44.8 -> 41.6 us in the training step.
+// Ablation, back to back at R = 25 600, N = K = 256 (tools/exp/tn_time.py with diagnostic switches): 36.9 us; without the
+// atomics 28.2, without the MFMAs and transposing reads 31.1, without the slab loads 34.1, without all three 18.2 - the bare
+// skeleton (abs-max, split into planes, two barriers per slab, the quartet exchange) is half the kernel.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn16d_kernel(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                                             float *dW, int ldw, float *db, long R, int N, int K) {
+    __shared__ __attribute__((aligned(16))) f16 sT2[2][4 * TNS_PLANE];   // per quartet: dY hi, dY lo, X hi, X lo
+    __shared__ __attribute__((aligned(16))) float sMax2[2][2][16];   // per quartet and operand: 4 waves x 4 DPP-row maxima
+    __shared__ float sB[2][8][128];
+    const int grp = threadIdx.x >> 8;
+    f16 *sT = sT2[grp];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = K / 128;
+    const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+    const long wbeg = (long)blockIdx.y * (2 * TN_RC);
+    long rbeg = wbeg + (long)grp * TN_RC;
+    if (rbeg > R) rbeg = R;
+    long rend = rbeg + TN_RC;
+    if (rend > R) rend = R;
+    // both quartets run the SAME number of slabs (the barriers are workgroup-wide): that of the first, fuller one; rows past a
+    // quartet's end read as zero
+    const long rows0 = (R - wbeg) < TN_RC ? (R - wbeg) : TN_RC;
+    const int n_it = (int)((rows0 + 31) / 32);
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const float *yp = dY + (rbeg + srow) * (long)ldy + n0 + scol, *xp = X + (rbeg + srow) * (long)ldx + k0 + scol;
+    const long ystep = 8L * ldy, xstep = 8L * ldx;
+    f32x4 yv[4], xv[4];
+    auto load = [&](long r) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int left = (int)(rend - r) - srow;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            yv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(yp + v * ystep) : z;
+            xv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(xp + v * xstep) : z;
+        }
+        yp += 4 * ystep;
+        xp += 4 * xstep;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    load(rbeg);
+    for (int it = 0; it < n_it; ++it) {
+        const long r = rbeg + 32L * it;
+        float my = 0.f, mx = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            bsum = bsum + yv[v];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                my = fmaxf(my, fabsf(yv[v][e]));
+                mx = fmaxf(mx, fabsf(xv[v][e]));
+            }
+        }
+        // 16 partial maxima per operand (4 waves x 4 DPP rows) go to LDS; everyone reduces them after the barrier: no
+        // cross-row shuffles (12 dependent ds_bpermute round trips per slab before)
+        my = row16_maxf(my);
+        mx = row16_maxf(mx);
+        if ((lane & 15) == 0) {
+            sMax2[grp][0][wave * 4 + (lane >> 4)] = my;
+            sMax2[grp][1][wave * 4 + (lane >> 4)] = mx;
+        }
+        __syncthreads();   // maxima visible; every wave is done reading the previous slab's planes
+        float sy, sx;
+        {
+            const f32x4 *py = reinterpret_cast<const f32x4 *>(sMax2[grp][0]), *px = reinterpret_cast<const f32x4 *>(sMax2[grp][1]);
+            f32x4 ay = py[0], ax = px[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                const f32x4 ty = py[i], tx = px[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ay[e] = fmaxf(ay[e], ty[e]);
+                    ax[e] = fmaxf(ax[e], tx[e]);
+                }
+            }
+            sy = f16_scale_from_bits(__builtin_bit_cast(unsigned, fmaxf(fmaxf(ay[0], ay[1]), fmaxf(ay[2], ay[3]))));
+            sx = f16_scale_from_bits(__builtin_bit_cast(unsigned, fmaxf(fmaxf(ax[0], ax[1]), fmaxf(ax[2], ax[3]))));
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            f16x4 h, l;
+            f16 *o = sT + (srow + 8 * v) * TNS_PITCH + scol;
+            f16_split4(yv[v], sy, h, l);
+            *reinterpret_cast<f16x4 *>(o) = h;
+            *reinterpret_cast<f16x4 *>(o + TNS_PLANE) = l;
+            f16_split4(xv[v], sx, h, l);
+            *reinterpret_cast<f16x4 *>(o + 2 * TNS_PLANE) = h;
+            *reinterpret_cast<f16x4 *>(o + 3 * TNS_PLANE) = l;
+        }
+        if (it + 1 < n_it) load(r + 32);
+        __syncthreads();
+        f32x16 sub[2][2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+            const int row0 = 16 * st + 8 * half;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = tns_frag(sT, row0, wm * 64 + t * 32, lane);
+                al[t] = tns_frag(sT + TNS_PLANE, row0, wm * 64 + t * 32, lane);
+                bh[t] = tns_frag(sT + 2 * TNS_PLANE, row0, wn * 64 + t * 32, lane);
+                bl[t] = tns_frag(sT + 3 * TNS_PLANE, row0, wn * 64 + t * 32, lane);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    if (st == 0) sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], zero16, 0, 0, 0);
+                    else sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], sub[tm][tn], 0, 0, 0);
+                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], sub[tm][tn], 0, 0, 0);
+                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], sub[tm][tn], 0, 0, 0);
+                }
+        }
+        // 1 / (sy sx) of two powers of two: exponent arithmetic instead of a division
+        const float un = __builtin_bit_cast(float, (254u << 23) - __builtin_bit_cast(unsigned, sy * sx));
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = acc[tm][tn] + sub[tm][tn] * un;
+    }
+    // ---- quartet 1 hands its tile to quartet 0 through the (now free) plane memory: [wave][tile][register][lane] floats ----
+    __syncthreads();
+    float *xch = reinterpret_cast<float *>(&sT2[0][0]);   // 2 x 40 KB >= 64 KB
+    if (grp == 1) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((wave * 4 + tm * 2 + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+        *reinterpret_cast<f32x4 *>(&sB[1][srow][scol]) = bsum;
+    } else {
+        *reinterpret_cast<f32x4 *>(&sB[0][srow][scol]) = bsum;
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int k = k0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r] + xch[((wave * 4 + tm * 2 + tn) * 16 + r) * 64 + lane]);
+                }
+            }
+        if (db && (blockIdx.x % tiles_k) == 0 && tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += sB[0][g][tid] + sB[1][g][tid];
+            atomicAdd(db + n0 + tid, v);
+        }
+    }
+}
+
 extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,
                              int N, int K, void *stream) {
     if (!dY || !X || !dW || R <= 0 || N <= 0 || K <= 0 || ldy < N || ldx < K || ldw < K)
@@ -425,6 +616,10 @@ extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, 
     const bool staged = N % 128 == 0 && K % 128 == 0 && ldy % 4 == 0 && ldx % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (env && strcmp(env, "f32") == 0) SD_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    else if (staged && !(env && (strcmp(env, "regs") == 0 || strcmp(env, "quartet") == 0))) {   // "quartet": the 4-wave staged kernel (A/B runs)
+        dim3 gridd(((N + 127) / 128) * ((K + 127) / 128), (unsigned)((R + 2 * TN_RC - 1) / (2 * TN_RC)));
+        SD_LAUNCH(gemm_tn16d_kernel, gridd, dim3(512), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    }
     else if (staged && !(env && strcmp(env, "regs") == 0)) SD_LAUNCH(gemm_tn16s_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
     else SD_LAUNCH(gemm_tn16_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
     SD_CHECK_LAUNCH("gemm_tn_kernel");
@@ -1134,7 +1329,7 @@ __device__ __forceinline__ f16x8 ab_tr(const f16 *plane, int r16, int col0, int 
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 8 * AB_P));
     const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
-    return f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // acc (+)= A B with A = (ah, al), B = (bh, bl): lo.hi, hi.lo, hi.hi
