@@ -83,6 +83,33 @@ __global__ void f16_pack_weight_kernel(const float *__restrict__ W, int N, const
     }
 }
 
+// Training: every D x D weight block of a step in ONE launch, fixed scale F16_W_SCALE (the value panel_gemm16_kernel applies
+// when it splits in registers).  src_off[b] = float offset of block b (D rows of D floats, row-major) in `src`; block b's planes
+// go to dst + b * 2 * D * D halfs in the pass layout of f16_pack_weight_kernel.  grid = (chunks, n_blocks).
+template <int D>
+__global__ void f16_pack_blocks_kernel(const float *__restrict__ src, const long *__restrict__ src_off, f16 *__restrict__ dst, float scale) {
+    using C = PanelCfg<D>;
+    constexpr int NK = D / 16;
+    const float *W = src + src_off[blockIdx.y];
+    f16 *out = dst + (long)blockIdx.y * 2 * D * D;
+    constexpr int total = D * (D / 8);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / (D / 8), k8 = i % (D / 8);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(W + (long)n * D + k8 * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(W + (long)n * D + k8 * 8 + 4);
+        f16x4 h0, l0, h1, l1;
+        f16_split4(a, scale, h0, l0);
+        f16_split4(b, scale, h1, l1);
+        const int wn = n / C::WN, tn = (n % C::WN) / 32, l31 = n & 31;
+        const int ks = k8 >> 1, lane = (k8 & 1) * 32 + l31;
+        f16 *o = out + ((((long)wn * NK + ks) * C::TN + tn) * 2) * 512 + lane * 8;
+        *reinterpret_cast<f16x4 *>(o) = h0;
+        *reinterpret_cast<f16x4 *>(o + 4) = h1;
+        *reinterpret_cast<f16x4 *>(o + 512) = l0;
+        *reinterpret_cast<f16x4 *>(o + 516) = l1;
+    }
+}
+
 // G rows -> per (item, head) blocks [ks][plane][half][16 slots][8]: the A operand of S^T = G LN2(h)^T.
 // src row (item*4 + h)*src_slots + s holds slot slot0 + s; slots without a source row are written as zeros.
 template <int D>
@@ -1570,7 +1597,9 @@ __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const
 // DROP (training): out = res + dropout(A W^T + bias) - torch's x + dropout1(sa_block(x)) / x + dropout2(ff_block(x)); the mask
 // is applied to the quad-transposed values (4 consecutive columns of one row = one Philox call, sd_common.h) and the
 // residual is then added from a 16-byte load.
-template <int D, bool HAS_LN, int ACT, bool HAS_RES, bool DROP = false>
+// PRE (training): W is not the fp32 matrix but its split fragment-major planes (f16_pack_blocks_kernel, scale 2^8, one block
+// of D rows per pass) - the sampler's K loop: one contiguous 1-KiB wave load per fragment and no split in registers.
+template <int D, bool HAS_LN, int ACT, bool HAS_RES, bool DROP = false, bool PRE = false>
 __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void panel_gemm16_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, const float *__restrict__ ln_w,
                                                             const float *__restrict__ ln_b, const float *res, float *out, int R,
@@ -1620,63 +1649,71 @@ __global__ __launch_bounds__(256, (D <= 256 ? 2 : 1)) void panel_gemm16_kernel(c
 
     for (int n0 = 0; n0 < N; n0 += D) {
         f32x16 acc[C::TM][C::TN];
-        const float *wBase = W + (long)(n0 + wn * C::WN + l31) * D + 8 * half;
-        f32x4 braw[2][C::TN][2];
-        f16x8 af[2][C::TM][2];
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            braw[0][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
-            braw[0][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + 4);
-        }
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D);
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < NK) {
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) {
-                    braw[nxt][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16);
-                    braw[nxt][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16 + 4);
-                }
-#pragma unroll
-                for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        af[nxt][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
-            }
-            f16x8 bh[C::TN], bl[C::TN];
-#pragma unroll
+        if constexpr (PRE) {
+            constexpr long WSTREAM = (long)NK * C::TN * 2 * 512;   // halfs per (pass, wave) fragment stream
+            const f16 *wf = reinterpret_cast<const f16 *>(W) + ((long)(n0 / D) * C::WAVES_N + __builtin_amdgcn_readfirstlane(wn)) * WSTREAM;
+            F16Ring<D> ring;
+            f16_prime<D>(ring, wf, (unsigned)lane * 8);
+            f16_gemm<D, true>(acc, aH, wf, (unsigned)lane * 8, ring);
+        } else {
+            const float *wBase = W + (long)(n0 + wn * C::WN + l31) * D + 8 * half;
+            f32x4 braw[2][C::TN][2];
+            f16x8 af[2][C::TM][2];
+    #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn) {
-                f16x4 h0, l0, h1, l1;
-                f16_split4(braw[cur][tn][0], F16_W_SCALE, h0, l0);
-                f16_split4(braw[cur][tn][1], F16_W_SCALE, h1, l1);
-                bh[tn] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                bl[tn] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                braw[0][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D);
+                braw[0][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + 4);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+    #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) {
-                    if (ks == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][tm][1], bh[tn], z, 0, 0, 0);
-                    } else {
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][1], bh[tn], acc[tm][tn], 0, 0, 0);
+    #pragma unroll
+                for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D);
+    #pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < NK) {
+    #pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) {
+                        braw[nxt][tn][0] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16);
+                        braw[nxt][tn][1] = *reinterpret_cast<const f32x4 *>(wBase + (long)tn * 32 * D + (ks + 1) * 16 + 4);
                     }
+    #pragma unroll
+                    for (int tm = 0; tm < C::TM; ++tm)
+    #pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            af[nxt][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
                 }
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bl[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bh[tn], acc[tm][tn], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                f16x8 bh[C::TN], bl[C::TN];
+    #pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    f16x4 h0, l0, h1, l1;
+                    f16_split4(braw[cur][tn][0], F16_W_SCALE, h0, l0);
+                    f16_split4(braw[cur][tn][1], F16_W_SCALE, h1, l1);
+                    bh[tn] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    bl[tn] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) {
+                        if (ks == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][tm][1], bh[tn], z, 0, 0, 0);
+                        } else {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][1], bh[tn], acc[tm][tn], 0, 0, 0);
+                        }
+                    }
+    #pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bl[tn], acc[tm][tn], 0, 0, 0);
+    #pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+    #pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][tm][0], bh[tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // epilogue: un-scale (per row), bias, residual, activation; quad transpose -> 16-byte stores

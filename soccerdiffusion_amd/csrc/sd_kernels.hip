@@ -1388,6 +1388,74 @@ int linear16(const float *A, const float *W, const float *bias, const float *ln_
     return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
 }
 
+// training: the row GEMM on pre-split weight planes (sd_pack_weight_blocks); same variants as launch_panel16
+template <int D>
+static int launch_panel16_packed(const float *A, int lda, const void *wpk, const float *bias, const float *ln_w, const float *ln_b,
+                                 const float *res, float *out, int R, int N, int act, hipStream_t s, const DropoutArgs &da) {
+    using C = PanelCfg<D>;
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    dim3 grid((R + C::BM - 1) / C::BM), block(256);
+    const size_t lds = C::LDS_BYTES + C::BM * sizeof(float);
+    const float *W = reinterpret_cast<const float *>(wpk);
+#define SD_PANEL16P(LN_, ACT_, RES_, DROP_)                                                                    \
+    do {                                                                                                       \
+        auto kfn = panel_gemm16_kernel<D, LN_, ACT_, RES_, DROP_, true>;                                       \
+        static bool attr_set = false;                                                                          \
+        if (lds > 64 * 1024 && !attr_set) {                                                                    \
+            (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        SD_LAUNCH(kfn, grid, block, lds, s, A, W, bias, ln_w, ln_b, res, out, R, N, lda, da);                  \
+    } while (0)
+    const bool ln = ln_w != nullptr, rs = res != nullptr;
+    if (da.thresh) {
+        if (ln || act != 0 || !rs || N % 4 != 0) return fail(SD_E_BADARG, "sd_op_linear_packed: dropout needs res, no LayerNorm, no activation");
+        SD_PANEL16P(false, 0, true, true);
+    } else if (ln && act == 0 && !rs) SD_PANEL16P(true, 0, false, false);
+    else if (!ln && act == 0 && !rs) SD_PANEL16P(false, 0, false, false);
+    else if (!ln && act == 0 && rs) SD_PANEL16P(false, 0, true, false);
+    else return fail(SD_E_BADARG, "sd_op_linear_packed: unsupported LN/act/res combination");
+#undef SD_PANEL16P
+    SD_CHECK_LAUNCH("panel_gemm16_kernel");
+    return 0;
+}
+
+extern "C" int sd_op_linear_packed(const float *A, int lda, const void *wpk, const float *bias, const float *ln_w, const float *ln_b,
+                                   const float *res, float *out, int R, int N, int d, float p, uint64_t seed, uint64_t site,
+                                   void *stream) {
+    if (!A || !wpk || !out || R <= 0 || N <= 0 || N % d != 0) return fail(SD_E_BADARG, "sd_op_linear_packed: bad argument");
+    if ((ln_w == nullptr) != (ln_b == nullptr)) return fail(SD_E_BADARG, "sd_op_linear_packed: ln_w/ln_b mismatch");
+    if (!(p >= 0.f) || !(p < 1.f)) return fail(SD_E_BADARG, "sd_op_linear_packed: p must be in [0, 1)");
+    if (lda == 0) lda = d;
+    if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "sd_op_linear_packed: row stride must be >= d and a multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const DropoutArgs da = p > 0.f ? make_dropout(p, seed, site) : DropoutArgs{};
+    switch (d) {
+        case 64: return launch_panel16_packed<64>(A, lda, wpk, bias, ln_w, ln_b, res, out, R, N, 0, s, da);
+        case 128: return launch_panel16_packed<128>(A, lda, wpk, bias, ln_w, ln_b, res, out, R, N, 0, s, da);
+        case 256: return launch_panel16_packed<256>(A, lda, wpk, bias, ln_w, ln_b, res, out, R, N, 0, s, da);
+        case 512: return launch_panel16_packed<512>(A, lda, wpk, bias, ln_w, ln_b, res, out, R, N, 0, s, da);
+    }
+    return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+}
+
+extern "C" int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_blocks, void *dst, int d, void *stream) {
+    if (!src || !src_off_dev || !dst || n_blocks <= 0) return fail(SD_E_BADARG, "sd_pack_weight_blocks: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long *off = reinterpret_cast<const long *>(src_off_dev);
+    f16 *out = reinterpret_cast<f16 *>(dst);
+    const int chunks = d * (d / 8) / 256 > 0 ? d * (d / 8) / 256 : 1;
+    switch (d) {
+        case 64: SD_LAUNCH((f16_pack_blocks_kernel<64>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
+        case 128: SD_LAUNCH((f16_pack_blocks_kernel<128>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
+        case 256: SD_LAUNCH((f16_pack_blocks_kernel<256>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
+        case 512: SD_LAUNCH((f16_pack_blocks_kernel<512>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
+        default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
+    }
+    SD_CHECK_LAUNCH("f16_pack_blocks_kernel");
+    return 0;
+}
+
 extern "C" int sd_op_linear_dropout(const float *A, int lda, const float *W, const float *bias, const float *res, float *out, int R,
                                     int N, int d, float p, uint64_t seed, uint64_t site, void *stream) {
     if (!A || !W || !out || !res || R <= 0 || N <= 0 || N % d != 0) return fail(SD_E_BADARG, "sd_op_linear_dropout: bad argument");

@@ -495,6 +495,33 @@ def linear_strided(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, res: Opt
     return out
 
 
+def pack_weight_blocks(src: Tensor, src_off: Tensor, n_blocks: int, d: int, dst: Tensor) -> None:
+    """Split ``n_blocks`` d x d fp32 blocks (block b at ``src`` + ``src_off[b]`` floats; device int64 offsets) into the fp16
+    hi | lo fragment planes of ``linear_packed`` (2 d^2 halfs per block, consecutive in ``dst``), one launch."""
+    lib = _lib.load()
+    _req(src, "src")
+    if src_off.dtype != torch.int64 or not src_off.is_cuda or dst.dtype != torch.float16 or dst.numel() < 2 * d * d * n_blocks:
+        raise ValueError("pack_weight_blocks: src_off must be a device int64 tensor and dst a float16 tensor of 2 d^2 n_blocks")
+    check(lib.sd_pack_weight_blocks(src.data_ptr(), src_off.data_ptr(), n_blocks, dst.data_ptr(), d, _stream()),
+          "sd_pack_weight_blocks")
+
+
+def linear_packed(A: Tensor, wpk: int, N: int, bias: Optional[Tensor] = None, ln: Optional[tuple] = None,
+                  res: Optional[Tensor] = None, drop=None, out: Optional[Tensor] = None) -> Tensor:
+    """out[R,N] = [res +] [dropout](LN?(A) W^T + bias) with ``wpk`` = the ADDRESS of the split planes of W's N / d blocks
+    (pack_weight_blocks); A may be a column slice."""
+    lib = _lib.load()
+    ap, lda = _rows(A, "A")
+    d = A.shape[-1]
+    R = A.numel() // d
+    if out is None:
+        out = torch.empty(R, N, dtype=torch.float32, device=A.device)
+    p, seed, site = _drop(drop)
+    check(lib.sd_op_linear_packed(ap, lda, wpk, _ptr(bias), _ptr(ln[0]) if ln else None, _ptr(ln[1]) if ln else None, _ptr(res),
+                                  out.data_ptr(), R, N, d, p, seed, site, _stream()), "sd_op_linear_packed")
+    return out
+
+
 # ---- dropout (training; one Philox mask function shared by every kernel, include/soccerdiffusion_hip.h) ----------------
 def _drop(drop) -> tuple:
     """(p, seed, site) -> ctypes-ready triple; None = no dropout."""

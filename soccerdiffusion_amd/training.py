@@ -16,6 +16,7 @@ block, its forward and backward are calls into libsoccerdiffusion_hip.so.
 
 from __future__ import annotations
 
+import os
 from typing import Iterable, Optional
 
 import torch
@@ -66,14 +67,48 @@ class _GradSink:
 _WT_BLOCKS: dict = {}
 
 
-def _transposed_block(W: Tensor, p: int, d: int) -> Tensor:
+def _wt_entry(W: Tensor, p: int, d: int):
+    """(optimizer, float offset of block p's transpose in flat_wt) while the gather is current, else None."""
     ent = _WT_BLOCKS.get(W.data_ptr() + 4 * p * d * d)
     if ent is not None:
         owner, off, bd, pi = ent
         opt = owner()
         if opt is not None and bd == d and W.shape[1] == d and opt._wt_params[pi]._version == opt._wt_versions[pi]:
-            return opt.flat_wt[off : off + d * d].view(d, d)
+            return opt, off
+    return None
+
+
+def _transposed_block(W: Tensor, p: int, d: int) -> Tensor:
+    ent = _wt_entry(W, p, d)
+    if ent is not None:
+        return ent[0].flat_wt[ent[1] : ent[1] + d * d].view(d, d)
     return W[p * d : (p + 1) * d].t().contiguous()
+
+
+# The same registry serves the split planes of the row GEMMs: after every step FusedAdamW also splits each block and each
+# transposed block into the fp16 hi | lo fragment planes the panel kernel multiplies with (ops.pack_weight_blocks, two
+# launches), so the ~45 GEMMs of a step stream 1-KiB fragments instead of splitting fp32 weights in registers in every
+# workgroup.  flat_wpk holds [planes of the blocks | planes of the transposed blocks], 2 d^2 halfs each, in flat_wt's order.
+def _packed_weight(W: Tensor, p: int = 0, transposed: bool = False):
+    """Address of the planes of block p of W (and of the blocks behind it), or None when W has no current planes."""
+    d = W.shape[1]
+    if W.stride() != (d, 1):
+        return None
+    ent = _wt_entry(W, p, d)
+    if ent is None or ent[0].flat_wpk is None:
+        return None
+    opt, off = ent
+    return opt.flat_wpk.data_ptr() + 2 * (2 * off + (2 * opt.flat_wt.numel() if transposed else 0))
+
+
+def _linear(A: Tensor, W: Tensor, b, ln=None, res=None, drop=None) -> Tensor:
+    """out = [res +] [dropout](LN?(A) W^T + b) on W's split planes when its optimizer keeps them, else on W itself."""
+    wpk = _packed_weight(W)
+    if wpk is not None:
+        return ops.linear_packed(A, wpk, W.shape[0], b, ln=ln, res=res, drop=drop)
+    if drop is not None:
+        return ops.linear_dropout(A.contiguous(), W, b, res, drop)
+    return ops.linear(A, W, b, ln=ln, res=res)
 
 
 # ---- weight gradients off the critical path ---------------------------------------------------------------------
@@ -117,7 +152,11 @@ def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
     N, d = W.shape
     out = None
     for p in range(N // d):
-        out = ops.linear_strided(dy2d[:, p * d : (p + 1) * d], _transposed_block(W, p, d), res=out, out=out)
+        wpk = _packed_weight(W, p, transposed=True)
+        if wpk is not None:
+            out = ops.linear_packed(dy2d[:, p * d : (p + 1) * d], wpk, d, None, res=out, out=out)
+        else:
+            out = ops.linear_strided(dy2d[:, p * d : (p + 1) * d], _transposed_block(W, p, d), res=out, out=out)
     return out
 
 
@@ -162,7 +201,7 @@ class _LNLinear(Function):
     def forward(ctx, x, ln_w, ln_b, W, b, gelu: bool, sink=None, drop=None, link=None):
         ctx.link = link
         x2 = x.reshape(-1, x.shape[-1])
-        pre = ops.linear(x2, W, b, ln=(ln_w, ln_b))
+        pre = _linear(x2, W, b, ln=(ln_w, ln_b))
         if gelu:
             y = ops.gelu_dropout_fwd(pre, drop) if drop is not None else ops.gelu_fwd(pre)
         else:
@@ -207,10 +246,7 @@ class _LinearRes(Function):
         ctx.link = link
         ctx.sink = sink if sink is not None else _GradSink()
         res2 = res.reshape(-1, W.shape[0]).contiguous()
-        if drop is not None:
-            y = ops.linear_dropout(a2.contiguous(), W, b, res2, drop)
-        else:
-            y = ops.linear(a2, W, b, res=res2)
+        y = _linear(a2, W, b, res=res2, drop=drop)
         return y.view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
@@ -236,7 +272,7 @@ class _Linear(Function):
         ctx.save_for_backward(a2, W)
         ctx.shape = a.shape
         ctx.sink = sink if sink is not None else _GradSink()
-        return ops.linear(a2, W, b).view(*a.shape[:-1], W.shape[0])
+        return _linear(a2, W, b).view(*a.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -478,7 +514,7 @@ class FusedAdamW(torch.optim.Optimizer):
         idx, self._wt_blocks, self._wt_params, at, out_at = [], [], [], 0, 0
         for p in params:
             k = p.numel()
-            if p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % p.shape[1] == 0:
+            if p.dim() == 2 and p.shape[1] in (64, 128, 256, 512) and p.shape[0] % p.shape[1] == 0:
                 N, d = p.shape
                 idx.append(at + torch.arange(k, dtype=torch.int64).view(N // d, d, d).transpose(1, 2).reshape(-1))
                 for blk in range(N // d):
@@ -489,6 +525,25 @@ class FusedAdamW(torch.optim.Optimizer):
             at += k
         self._wt_index = torch.cat(idx).to(dev) if idx else None
         self.flat_wt = torch.empty(out_at, dtype=torch.float32, device=dev) if idx else None
+        # split planes of the same blocks (see _packed_weight): per block width, (source offsets, first block) of the launch
+        self.flat_wpk, self._pk_launches = None, []
+        if idx and dev.type == "cuda" and os.environ.get("SD_TRAIN_PACKED", "1") != "0":
+            self.flat_wpk = torch.empty(4 * out_at, dtype=torch.float16, device=dev)
+            base = self.flat_param.data_ptr()
+            for d in sorted({b[2] for b in self._wt_blocks}):
+                run = [b for b in self._wt_blocks if b[2] == d]
+                # blocks of one width are contiguous in flat_wt only if no other width interleaves: pack run by run
+                runs, cur = [], [run[0]]
+                for b in run[1:]:
+                    if b[1] == cur[-1][1] + d * d:
+                        cur.append(b)
+                    else:
+                        runs.append(cur); cur = [b]
+                runs.append(cur)
+                for r in runs:
+                    fwd = torch.tensor([(b[0] - base) // 4 for b in r], dtype=torch.int64, device=dev)
+                    wt = torch.tensor([b[1] for b in r], dtype=torch.int64, device=dev)
+                    self._pk_launches.append((d, len(r), fwd, wt, 2 * r[0][1]))
         self._wt_versions = []
         self.refresh_transposes()
 
@@ -498,6 +553,9 @@ class FusedAdamW(torch.optim.Optimizer):
             return
         import weakref
         torch.index_select(self.flat_param, 0, self._wt_index, out=self.flat_wt)
+        for d, n, fwd, wt, half_off in self._pk_launches:
+            ops.pack_weight_blocks(self.flat_param, fwd, n, d, self.flat_wpk[half_off:])
+            ops.pack_weight_blocks(self.flat_wt, wt, n, d, self.flat_wpk[2 * self.flat_wt.numel() + half_off:])
         self._wt_versions = [p._version for p in self._wt_params]
         if not getattr(self, "_wt_registered", False):
             owner = weakref.ref(self)

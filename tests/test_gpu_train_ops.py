@@ -139,6 +139,68 @@ def test_linear_strided_accumulates_slices(ops):
     assert rel_err(out, want) < TOL
 
 
+@pytest.mark.parametrize("d", [64, 128, 256, 512])
+def test_linear_packed_matches_fp64_and_the_unpacked_kernel(ops, d):
+    """Row GEMM on pre-split weight planes (what FusedAdamW keeps per step): LN, residual, residual + dropout, column-slice
+    input, several blocks per call, block offsets out of order."""
+    R, nb = 203, 3
+    W = _rand(nb * d, d, seed=3, scale=1 / math.sqrt(d))
+    bias = _rand(nb * d, seed=4, scale=0.1)
+    A = _rand(R, 2 * d, seed=5)
+    res = _rand(R, nb * d, seed=6)
+    g, b = 1 + 0.1 * _rand(d, seed=7), 0.1 * _rand(d, seed=8)
+    Wc, Ac = W.cuda(), A.cuda()
+    # blocks stored in reverse order in the source buffer: the offsets array, not the layout, defines block b
+    src = torch.cat([Wc[(nb - 1 - i) * d : (nb - i) * d].reshape(-1) for i in range(nb)])
+    off = torch.tensor([(nb - 1 - i) * d * d for i in range(nb)], dtype=torch.int64, device="cuda")
+    planes = torch.empty(2 * d * d * nb, dtype=torch.float16, device="cuda")
+    ops.pack_weight_blocks(src, off, nb, d, planes)
+    a = Ac[:, d:]   # row stride 2d
+    a64 = A[:, d:].double()
+    for ln, rs in ((None, None), ((g, b), None), (None, res)):
+        want = (torch.nn.functional.layer_norm(a64, (d,), g.double(), b.double(), 1e-5) if ln else a64) @ W.double().t() + bias.double()
+        if rs is not None:
+            want = want + rs.double()
+        got = ops.linear_packed(a, planes.data_ptr(), nb * d, bias.cuda(), ln=tuple(t.cuda() for t in ln) if ln else None,
+                                res=rs.cuda() if rs is not None else None)
+        assert rel_err(got, want.float()) < 1e-5
+        plain = ops.linear(a.contiguous(), Wc, bias.cuda(), ln=tuple(t.cuda() for t in ln) if ln else None,
+                           res=rs.cuda() if rs is not None else None)
+        assert rel_err(got, plain) < 1e-5
+    drop = (0.1, 1234, 77)
+    got = ops.linear_packed(a, planes.data_ptr(), nb * d, bias.cuda(), res=res.cuda(), drop=drop)
+    mask = ops.dropout_mask(R, nb * d, drop, "cuda").cpu().double()
+    want = res.double() + mask * (a64 @ W.double().t() + bias.double())
+    assert rel_err(got, want.float()) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.linear_packed(a, planes.data_ptr(), nb * d, bias.cuda(), ln=(g.cuda(), b.cuda()), res=res.cuda())
+
+
+def test_optimizer_keeps_split_planes_current(ops):
+    """FusedAdamW repacks the planes after every step; the autograd linear uses them and falls back when they are stale."""
+    from soccerdiffusion_amd import training as tr
+
+    d = 128
+    W = torch.nn.Parameter(_rand(3 * d, d, seed=1, scale=0.1).cuda())
+    bvec = torch.nn.Parameter(_rand(3 * d, seed=2, scale=0.1).cuda())
+    opt = tr.FusedAdamW([W, bvec], lr=1e-2)
+    assert opt.flat_wpk is not None and tr._packed_weight(W) is not None and tr._packed_weight(W[d:]) is not None
+    x = _rand(70, d, seed=3).cuda()
+    for _ in range(2):
+        y = tr._linear(x, W, bvec)
+        assert rel_err(y, x.double().cpu() @ W.detach().double().cpu().t() + bvec.detach().double().cpu()) < 1e-5
+        dx = tr._dx_through_weight(y, W)
+        assert rel_err(dx, y.double().cpu() @ W.detach().double().cpu()) < 1e-5
+        W.grad.copy_(_rand(3 * d, d, seed=9).cuda())
+        opt.step()
+    with torch.no_grad():
+        W.mul_(2.0)   # bumps the version: the planes are stale until the next refresh
+    assert tr._packed_weight(W) is None
+    assert rel_err(tr._linear(x, W, bvec), x.double().cpu() @ W.detach().double().cpu().t() + bvec.detach().double().cpu()) < 1e-5
+    opt.refresh_transposes()
+    assert tr._packed_weight(W) is not None
+
+
 def test_small_k_matmul_and_colsum(ops):
     A, Bm = _rand(1000, 20, seed=1), _rand(20, 256, seed=2)
     assert rel_err(ops.small_k_matmul(A.cuda(), Bm.cuda()), A @ Bm) < 1e-5
