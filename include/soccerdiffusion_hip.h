@@ -252,6 +252,47 @@ int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_bl
 int sd_op_linear_packed(const float *A, int lda, const void *wpk, const float *bias, const float *ln_w, const float *ln_b,
                         const float *res, float *out, int R, int N, int d, float p, uint64_t seed, uint64_t site, void *stream);
 
+/* ---- Fused row chains of one transformer layer for TRAINING (reference: the nn.TransformerDecoderLayer / EncoderLayer
+ * blocks built by soccer_diffusion/ml/model/decoder.py:26-33 and encoder/base.py:29-40, norm_first = True, as autograd runs
+ * them in ml/training/train.py:204-240).  One 64-row panel per workgroup goes through every row-local operation between
+ * two attention cores in ONE launch; the forward writes exactly the tensors the backward and the weight-gradient GEMMs read.
+ * All weights are split planes (sd_pack_weight_blocks); all row tensors are [R, d] fp32, contiguous, unless noted.
+ * d in {64, 128, 256}; p = 0 turns every mask off; mask rows = R, width = d (sites as in sd_op_linear_dropout /
+ * sd_op_gelu_dropout_fwd).  Stages with a NULL first pointer are skipped.
+ *
+ * sd_train_fwd_chain:
+ *   [a]    h1 = h_in + dropout_{site_out}(a Wo^T + bo)                 -> h_out            (a == NULL: h1 = h_in)
+ *   [w1]   n = LN(h1; ln_w, ln_b) -> n_out;  pre = n W1^T + b1 -> pre;  u = dropout_{site_act}(gelu(pre)) -> u
+ *          h2 = h1 + dropout_{site_ffn}(u W2^T + b2)                   -> h2_out           (w1 == NULL: h2 = h1)
+ *   [wn]   nn = LN(h2; nln_w, nln_b) -> nn_out;  y = nn Wn^T + bn      -> y_out [R, n_next d]   (n_next = 0: stop)
+ * sd_train_bwd_chain (dY [R, passes d] with row stride ldy; wt = planes of the `passes` TRANSPOSED blocks):
+ *   g = dropout_{site_in}(dy) -> dym (p > 0, passes == 1, not for the x-without-pre form);   t = g Wt   (dX of a linear layer)
+ *   [pre]  t = t o gelu'(pre) o mask_{site_act} -> dpre;  t = t Wt1                    (back through FFN1)
+ *   [x]    dx = LayerNorm-backward(t; x, ln_w) + dres -> dx;  dg += sum_rows t o xhat;  db += sum_rows t   (fp32 atomics)
+ *          (x == NULL: dx = t) */
+typedef struct sd_train_fwd_chain_args {
+    int64_t R;
+    int32_t d, n_next;
+    const float *a; const void *wo; const float *bo; const float *h_in; float *h_out;
+    const float *ln_w, *ln_b; float *n_out; const void *w1; const float *b1; float *pre; float *u;
+    const void *w2; const float *b2; float *h2_out;
+    const float *nln_w, *nln_b; float *nn_out; const void *wn; const float *bn; float *y_out;
+    float p;
+    uint64_t seed, site_out, site_act, site_ffn;
+} sd_train_fwd_chain_args;
+typedef struct sd_train_bwd_chain_args {
+    int64_t R;
+    int32_t d, passes, ldy;
+    const float *dy; float *dym; const void *wt;
+    const float *pre; float *dpre; const void *wt1;
+    const float *x; const float *ln_w; const float *dres; float *dg; float *db;
+    float *dx;
+    float p;
+    uint64_t seed, site_in, site_act;
+} sd_train_bwd_chain_args;
+int sd_train_fwd_chain(const sd_train_fwd_chain_args *args, void *stream);
+int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
+
 /* sd_op_attention_lse / sd_op_attention_bwd with dropout on the probabilities: O = (softmax(S) o mask) V, the softmax
  * normaliser and lse2 are those of the un-dropped probabilities; mask rows = (b * heads + h) * Tq + q, width = S. */
 int sd_op_attention_lse_dropout(const float *q, int ldq, const float *k, const float *v, int ldkv, float *out,

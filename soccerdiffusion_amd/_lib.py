@@ -53,6 +53,23 @@ class EncoderWeights(C.Structure):
     ]
 
 
+class TrainFwdChainArgs(C.Structure):
+    """sd_train_fwd_chain_args (field order = header order)."""
+
+    _fields_ = ([("R", C.c_int64), ("d", C.c_int32), ("n_next", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("a", "wo", "bo", "h_in", "h_out", "ln_w", "ln_b", "n_out", "w1", "b1", "pre", "u", "w2", "b2",
+                                             "h2_out", "nln_w", "nln_b", "nn_out", "wn", "bn", "y_out")]
+                + [("p", C.c_float), ("seed", C.c_uint64), ("site_out", C.c_uint64), ("site_act", C.c_uint64), ("site_ffn", C.c_uint64)])
+
+
+class TrainBwdChainArgs(C.Structure):
+    """sd_train_bwd_chain_args (field order = header order)."""
+
+    _fields_ = ([("R", C.c_int64), ("d", C.c_int32), ("passes", C.c_int32), ("ldy", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("dy", "dym", "wt", "pre", "dpre", "wt1", "x", "ln_w", "dres", "dg", "db", "dx")]
+                + [("p", C.c_float), ("seed", C.c_uint64), ("site_in", C.c_uint64), ("site_act", C.c_uint64)])
+
+
 # name -> (restype, argtypes); mirrors the header one to one (tests check the export list)
 SIGNATURES = {
     "sd_abi_version": (C.c_int, []),
@@ -82,6 +99,8 @@ SIGNATURES = {
     "sd_op_gelu_dropout_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sd_op_linear_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sd_train_fwd_chain": (C.c_int, [C.POINTER(TrainFwdChainArgs), C.c_void_p]),
+    "sd_train_bwd_chain": (C.c_int, [C.POINTER(TrainBwdChainArgs), C.c_void_p]),
     "sd_pack_weight_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "sd_op_linear_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -96,6 +96,25 @@ __device__ __forceinline__ float gelu_erf_fast(float u) {
     return 0.5f * u * (z >= 0.f ? 2.0f - e : e);
 }
 
+// d/du gelu(u) = Phi(u) + u phi(u) with the same erfc fit (Phi(u) = 1 - erfc(u / sqrt 2) / 2, mirrored for u < 0)
+__device__ __forceinline__ float gelu_grad_fast(float u) {
+    const float z = u * 0.70710678118654752440f, a = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.5f, a, 1.0f));
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f);
+    p = fmaf(p, t, 1.48851587f);
+    p = fmaf(p, t, -1.13520398f);
+    p = fmaf(p, t, 0.27886807f);
+    p = fmaf(p, t, -0.18628806f);
+    p = fmaf(p, t, 0.09678418f);
+    p = fmaf(p, t, 0.37409196f);
+    p = fmaf(p, t, 1.00002368f);
+    p = fmaf(p, t, -1.26551223f);
+    const float g = __builtin_amdgcn_exp2f(-a * a * 1.44269504088896340736f);     // exp(-u^2 / 2)
+    const float e = 0.5f * t * g * __builtin_amdgcn_exp2f(p * 1.44269504088896340736f);   // erfc(a) / 2
+    return (z >= 0.f ? 1.0f - e : e) + u * 0.39894228040143267794f * g;
+}
+
 typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

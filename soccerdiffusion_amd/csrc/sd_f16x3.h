@@ -192,82 +192,6 @@ __global__ void f16_pack_vstep_kernel(const float *__restrict__ gvstep, long ite
 // ---------------------------------------------------------------------------------------------------
 // device pieces of the fused kernels
 // ---------------------------------------------------------------------------------------------------
-#ifndef SD_F16_WRING
-#define SD_F16_WRING 2   // slots of the run-ahead weight ring (2: +0.2 % over 3, 4: -1.7 %)
-#endif
-template <int D>
-struct F16Ring {
-    f16x8 b[SD_F16_WRING][PanelCfg<D>::TN][2];   // [slot][column tile][plane]
-};
-
-// wf: this wave's fragment stream of one pass (wave-uniform pointer: scalar base); loff = lane*8 halfs
-template <int D>
-__device__ __forceinline__ void f16_prime(F16Ring<D> &ring, const f16 *wf, unsigned loff) {
-    using C = PanelCfg<D>;
-#pragma unroll
-    for (int s = 0; s < SD_F16_WRING - 1; ++s)
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) ring.b[s][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + loff + (unsigned)(((s * C::TN + tn) * 2 + pl) * 512));
-}
-
-// acc (+)= A(panel planes) W^T over K = D;  aH: (f16*)panel + row*(2*LDA) + 8*half of this lane's first row.
-// ZERO: the accumulator starts at 0 (passed to the first MFMA as the inline constant, no register clearing)
-template <int D, bool ZERO>
-__device__ __forceinline__ void f16_gemm(f32x16 (&acc)[PanelCfg<D>::TM][PanelCfg<D>::TN], const f16 *aH, const f16 *wf, unsigned loff,
-                                         F16Ring<D> &ring) {
-    using C = PanelCfg<D>;
-    constexpr int NK = D / 16, ROWP = 2 * C::LDA;
-    f16x8 af[2][C::TM][2];
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) af[0][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D);
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        constexpr int RS = SD_F16_WRING;
-        const int cur = ks % RS, fill = (ks + RS - 1) % RS;
-#ifndef SD_ABL_NO_WLOAD   // ablation builds (tools/ab_build.sh): results are wrong, timings tell what bounds the kernel
-        if (ks + RS - 1 < NK) {
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    ring.b[fill][tn][pl] = *reinterpret_cast<const f16x8 *>(wf + loff + (unsigned)((((ks + RS - 1) * C::TN + tn) * 2 + pl) * 512));
-        }
-#endif
-#ifndef SD_ABL_NO_ALOAD
-        if (ks + 1 < NK) {
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    af[(ks + 1) & 1][tm][pl] = *reinterpret_cast<const f16x8 *>(aH + tm * 32 * ROWP + pl * D + (ks + 1) * 16);
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};   // small terms first: lo.hi, hi.lo, hi.hi
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) {
-                    if (ZERO && ks == 0 && t == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][tm][TA[0]], ring.b[cur][tn][TB[0]], z, 0, 0, 0);
-                    } else {
-#ifdef SD_ABL_ONE_MFMA
-                        if (t == 2)
-#endif
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][tm][TA[t]], ring.b[cur][tn][TB[t]], acc[tm][tn], 0, 0, 0);
-                    }
-                }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // H += U*c + bias   /   U = U*c + bias.  Written on whole accumulator vectors so that the backend emits packed
 // v_pk_fma_f32 (two fp32 FMAs per instruction)
 template <int D, bool INTO_H>
@@ -1532,68 +1456,6 @@ __global__ __launch_bounds__(256, SD_ATT_LV_OCC) void attention_f16_head_lv_kern
 // Per 16-deep k-step and wave: 12 fp16 MFMAs (384 cycles) + ~80 VALU instructions for the two splits, against
 // 32 fp32 MFMAs (2048 cycles).
 // ---------------------------------------------------------------------------------------------------
-constexpr float F16_W_SCALE = 256.0f;
-
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false)));
-    return v;
-}
-
-// fp32 panel rows (optionally LayerNorm-ed on the way) -> split planes in place + 1/scale per row
-template <int D, bool HAS_LN>
-__device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const float *ln_w, const float *ln_b, int lane, int wave) {
-    using C = PanelCfg<D>;
-    constexpr int V4 = D / 64;
-    const int sub = lane & 15, grp = lane >> 4;
-    for (int row = wave * 4 + grp; row < C::BM; row += 16) {
-        f32x4 v[V4];
-#pragma unroll
-        for (int j = 0; j < V4; ++j) v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + 4 * (sub + 16 * j));
-        if constexpr (HAS_LN) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < V4; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-            const float mean = row16_sum(s) * (1.0f / D);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < V4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[j][e] -= mean;
-                    q += v[j][e] * v[j][e];
-                }
-            const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / D) + SD_LN_EPS);
-#pragma unroll
-            for (int j = 0; j < V4; ++j) {
-                const int c = 4 * (sub + 16 * j);
-                const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + c);
-                const f32x4 gb = *reinterpret_cast<const f32x4 *>(ln_b + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] * rstd * gw[e] + gb[e];
-            }
-        }
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < V4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
-        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, row16_max(m)));
-        if (sub == 0) sInv[row] = 1.0f / scale;
-        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
-#pragma unroll
-        for (int j = 0; j < V4; ++j) {
-            const int c = 4 * (sub + 16 * j);
-            f16x4 h, l;
-            f16_split4(v[j], scale, h, l);
-            *reinterpret_cast<f16x4 *>(rowp + c) = h;
-            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
-        }
-    }
-}
-
 // DROP (training): out = res + dropout(A W^T + bias) - torch's x + dropout1(sa_block(x)) / x + dropout2(ff_block(x)); the mask
 // is applied to the quad-transposed values (4 consecutive columns of one row = one Philox call, sd_common.h) and the
 // residual is then added from a 16-byte load.

@@ -23,6 +23,7 @@
 #include "../../include/soccerdiffusion_hip.h"
 
 #include "sd_common.h"
+#include "sd_panel.h"
 
 static thread_local const char *g_last_error = "ok";
 int fail(int code, const char *msg) {
@@ -78,18 +79,6 @@ ProfScope::~ProfScope() {
 // has no barrier at all.  LDS rows are padded by 4 floats: 16 consecutive rows then hit
 // 16 distinct 4-bank groups for ds_read_b128.
 // ======================================================================================
-template <int D>
-struct PanelCfg {
-    static constexpr int BM = 64;
-    static constexpr int WAVES_N = (D / 32 >= 4) ? 4 : D / 32;
-    static constexpr int WAVES_M = 4 / WAVES_N;
-    static constexpr int WM = BM / WAVES_M;  // rows per wave
-    static constexpr int WN = D / WAVES_N;   // output columns per wave per pass
-    static constexpr int TM = WM / 32;
-    static constexpr int TN = WN / 32;
-    static constexpr int LDA = D + 4;
-    static constexpr size_t LDS_BYTES = (size_t)BM * LDA * sizeof(float);
-};
 
 template <int D>
 __device__ __forceinline__ void panel_layer_norm(float *sA, int lda, const float *ln_w, const float *ln_b, int lane, int wave,
@@ -388,31 +377,6 @@ __device__ __forceinline__ void chain_gemm_primed(f32x16 (&acc)[PanelCfg<D>::TM]
     }
 }
 
-// per-thread geometry of the accumulator tile map
-template <int D>
-struct ChainPos {
-    using C = PanelCfg<D>;
-    int lane, wave, l31, half, wm, wn;
-    long r0;
-    int R_left;  // valid rows in this panel (<= 64)
-    __device__ ChainPos(long R) {
-        lane = threadIdx.x & 63;
-        wave = threadIdx.x >> 6;
-        l31 = lane & 31;
-        half = lane >> 5;
-        wm = wave / C::WAVES_N;
-        wn = wave % C::WAVES_N;
-        // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8): relabel them so that consecutive panels -
-        // which share a trajectory's folded cross-attention blocks - run on the same XCD and meet in its L2.
-        const unsigned nb = gridDim.x, q8 = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
-        const unsigned panel = xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-        r0 = (long)panel * C::BM;
-        const long left = R - r0;
-        R_left = left < C::BM ? (int)left : C::BM;
-    }
-    __device__ __forceinline__ int row(int tm, int r) const { return wm * C::WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
-    __device__ __forceinline__ int col(int tn) const { return wn * C::WN + tn * 32 + l31; }
-};
 
 template <int D>
 __device__ __forceinline__ void chain_load_panel(float *sA, const float *src, const ChainPos<D> &p) {

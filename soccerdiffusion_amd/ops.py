@@ -522,6 +522,45 @@ def linear_packed(A: Tensor, wpk: int, N: int, bias: Optional[Tensor] = None, ln
     return out
 
 
+def _addr(t) -> Optional[int]:
+    """Address of a tensor / an int address / None, for the pointer fields of the chain argument structs."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("chain operands must be contiguous float32 tensors on the MI355X; soccerdiffusion_amd has no CPU path")
+    return t.data_ptr()
+
+
+def train_fwd_chain(R: int, d: int, h_in: Tensor, *, a=None, wo=None, bo=None, h_out=None, ln=None, n_out=None, w1=None, b1=None,
+                    pre=None, u=None, w2=None, b2=None, h2_out=None, nln=None, nn_out=None, wn=None, bn=None, y_out=None,
+                    n_next: int = 0, p: float = 0.0, seed: int = 0, sites=(0, 0, 0)) -> None:
+    """One launch of sd_train_fwd_chain (include/soccerdiffusion_hip.h).  Weights (wo, w1, w2, wn) are ADDRESSES of split
+    planes; ``ln`` / ``nln`` are (weight, bias) pairs; ``sites`` = (out-projection, GELU, FFN output) dropout sites."""
+    lib = _lib.load()
+    args = _lib.TrainFwdChainArgs(
+        R=R, d=d, n_next=n_next, a=_addr(a), wo=wo, bo=_addr(bo), h_in=_addr(h_in), h_out=_addr(h_out),
+        ln_w=_addr(ln[0]) if ln else None, ln_b=_addr(ln[1]) if ln else None, n_out=_addr(n_out), w1=w1, b1=_addr(b1), pre=_addr(pre),
+        u=_addr(u), w2=w2, b2=_addr(b2), h2_out=_addr(h2_out), nln_w=_addr(nln[0]) if nln else None,
+        nln_b=_addr(nln[1]) if nln else None, nn_out=_addr(nn_out), wn=wn, bn=_addr(bn), y_out=_addr(y_out), p=float(p),
+        seed=int(seed) & 0xFFFFFFFFFFFFFFFF, site_out=int(sites[0]), site_act=int(sites[1]), site_ffn=int(sites[2]))
+    check(lib.sd_train_fwd_chain(C.byref(args), _stream()), "sd_train_fwd_chain")
+
+
+def train_bwd_chain(R: int, d: int, dy: Tensor, wt: int, dx: Tensor, *, passes: int = 1, dym=None, pre=None, dpre=None, wt1=None,
+                    x=None, ln_w=None, dres=None, dg=None, db=None, p: float = 0.0, seed: int = 0, sites=(0, 0)) -> None:
+    """One launch of sd_train_bwd_chain.  ``dy`` (R, passes * d) may be a row-strided view; ``wt`` / ``wt1`` are ADDRESSES of
+    the split planes of the transposed blocks; ``sites`` = (mask of dy, mask after the GELU)."""
+    lib = _lib.load()
+    dyp, ldy = _rows(dy, "dy")
+    args = _lib.TrainBwdChainArgs(
+        R=R, d=d, passes=passes, ldy=ldy, dy=dyp, dym=_addr(dym), wt=wt, pre=_addr(pre), dpre=_addr(dpre), wt1=wt1, x=_addr(x),
+        ln_w=_addr(ln_w), dres=_addr(dres), dg=_addr(dg), db=_addr(db), dx=_addr(dx), p=float(p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+        site_in=int(sites[0]), site_act=int(sites[1]))
+    check(lib.sd_train_bwd_chain(C.byref(args), _stream()), "sd_train_bwd_chain")
+
+
 # ---- dropout (training; one Philox mask function shared by every kernel, include/soccerdiffusion_hip.h) ----------------
 def _drop(drop) -> tuple:
     """(p, seed, site) -> ctypes-ready triple; None = no dropout."""

@@ -453,6 +453,207 @@ def _layer(lp, h, heads, memory=None, ffn_norm=None, dc=None, li: int = 0):
     return _LinearRes.apply(u, lp.linear2.weight, lp.linear2.bias, h, _GradSink(lp.linear2.weight, lp.linear2.bias), site(SITE_FFN_OUT), lk)
 
 
+# ---- fused layers: the row chains of a layer in one launch each (csrc/sd_train_chain.hip) ---------------------------
+# Per decoder layer the forward is  attention, chain A (out-projection + residual, LN2 + Q), K/V of the memory, attention,
+# chain B (out-projection + residual, LN3 + FFN1 + GELU + FFN2 + residual, the NEXT layer's LN1 + QKV); the backward is
+# five chain launches, two attention backward kernels and seven weight-gradient GEMMs.  A layer therefore hands its
+# successor (h, LN1(h), qkv); the successor's backward differentiates LN1 / in_proj (they are its parameters).
+# Conditions (else the per-operation nodes above run): hidden_dim 64 / 128 / 256, dim_feedforward == hidden_dim, every
+# weight owned by a FusedAdamW that keeps its split planes current.  SD_TRAIN_FUSED=0 turns the path off (A/B runs).
+_DEC_PARAMS = ("norm1.weight", "norm1.bias", "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+               "self_attn.out_proj.bias", "norm2.weight", "norm2.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
+               "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "norm3.weight", "norm3.bias", "linear1.weight",
+               "linear1.bias", "linear2.weight", "linear2.bias")
+_ENC_PARAMS = ("norm1.weight", "norm1.bias", "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+               "self_attn.out_proj.bias", "norm2.weight", "norm2.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias")
+
+
+def _layer_params(lp, decoder: bool) -> list:
+    out = []
+    for name in (_DEC_PARAMS if decoder else _ENC_PARAMS):
+        t = lp
+        for part in name.split("."):
+            t = getattr(t, part)
+        out.append(t)
+    return out
+
+
+def _fused_ok(layers, d: int, decoder: bool) -> bool:
+    if os.environ.get("SD_TRAIN_FUSED", "1") == "0" or d not in (64, 128, 256) or not layers:
+        return False
+    for lp in layers:
+        P = _layer_params(lp, decoder)
+        if any((not t.is_cuda) or t.dtype != torch.float32 for t in P):
+            return False
+        mats = [t for t in P if t.dim() == 2]
+        if any(t.shape[1] != d or t.shape[0] % d != 0 for t in mats) or lp.linear1.weight.shape[0] != d:
+            return False
+        if any(_packed_weight(t) is None or _packed_weight(t, 0, transposed=True) is None for t in mats):
+            return False
+    return True
+
+
+class _FusedCfg:
+    __slots__ = ("heads", "dc", "li", "decoder", "next_ln", "next_w", "next_b")
+
+    def __init__(self, heads, dc, li, decoder, nxt):
+        self.heads, self.dc, self.li, self.decoder = heads, dc, li, decoder
+        if nxt is not None:
+            self.next_ln = (nxt.norm1.weight.detach(), nxt.norm1.bias.detach())
+            self.next_w, self.next_b = nxt.self_attn.in_proj_weight.detach(), nxt.self_attn.in_proj_bias.detach()
+        else:
+            self.next_ln = self.next_w = self.next_b = None
+
+    def site(self, kind: int) -> int:
+        return self.dc.site(self.li, kind)[2] if self.dc is not None else 0
+
+    def drop(self, kind: int):
+        return self.dc.site(self.li, kind) if self.dc is not None else None
+
+    @property
+    def p(self) -> float:
+        return self.dc.p if self.dc is not None else 0.0
+
+    @property
+    def seed(self) -> int:
+        return self.dc.seed if self.dc is not None else 0
+
+
+def _new(*shape, like: Tensor) -> Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+class _FusedLayer(Function):
+    """One pre-norm transformer layer (nn.TransformerDecoderLayer with memory, nn.TransformerEncoderLayer without) given
+    (h, LN1(h), qkv = LN1(h) Wqkv^T + b); returns (h', LN1'(h'), qkv') for the next layer (empty tensors after the last)."""
+
+    @staticmethod
+    def forward(ctx, h, n1, qkv, memory, cfg: _FusedCfg, *P):
+        B, T, d = h.shape
+        R = B * T
+        dec = cfg.decoder
+        heads, p, seed = cfg.heads, cfg.p, cfg.seed
+        if dec:
+            (n1w, n1b, Wqkv, bqkv, Wo, bo, n2w, n2b, Wc, bc, Woc, boc, nfw, nfb, W1, b1, W2, b2) = P
+        else:
+            (n1w, n1b, Wqkv, bqkv, Wo, bo, nfw, nfb, W1, b1, W2, b2) = P
+        h = h.contiguous()
+        a_sa, lse_sa = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
+        saved_c = ()
+        if dec:
+            h1, n2, q = _new(B, T, d, like=h), _new(R, d, like=h), _new(B, T, d, like=h)
+            ops.train_fwd_chain(R, d, h, a=a_sa, wo=_packed_weight(Wo), bo=bo, h_out=h1, nln=(n2w, n2b), nn_out=n2,
+                                wn=_packed_weight(Wc), bn=bc, y_out=q, n_next=1, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0, 0))
+            M = memory.shape[1]
+            mem2 = memory.reshape(B * M, d)
+            kv = ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:]).view(B, M, 2 * d)
+            a_ca, lse_ca = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
+            a_in, w_in, b_in, h_res, site_out = a_ca, Woc, boc, h1, cfg.site(SITE_CA_OUT)
+            saved_c = (h1, n2, q, kv, a_ca, lse_ca)
+        else:
+            a_in, w_in, b_in, h_res, site_out = a_sa, Wo, bo, h, cfg.site(SITE_SA_OUT)
+        h2, nf, pre, u, h3 = _new(B, T, d, like=h), _new(R, d, like=h), _new(R, d, like=h), _new(R, d, like=h), _new(B, T, d, like=h)
+        if cfg.next_w is not None:
+            nn1, qkv2 = _new(R, d, like=h), _new(B, T, 3 * d, like=h)
+            nxt = dict(nln=cfg.next_ln, nn_out=nn1, wn=_packed_weight(cfg.next_w), bn=cfg.next_b, y_out=qkv2, n_next=3)
+        else:
+            nn1, qkv2 = _new(0, like=h), _new(0, like=h)
+            nxt = {}
+        ops.train_fwd_chain(R, d, h_res, a=a_in, wo=_packed_weight(w_in), bo=b_in, h_out=h2, ln=(nfw, nfb), n_out=nf,
+                            w1=_packed_weight(W1), b1=b1, pre=pre, u=u, w2=_packed_weight(W2), b2=b2, h2_out=h3, p=p, seed=seed,
+                            sites=(site_out, cfg.site(SITE_FFN_ACT), cfg.site(SITE_FFN_OUT)), **nxt)
+        ctx.cfg = cfg
+        ctx.n_c = len(saved_c)
+        ctx.save_for_backward(h, n1, qkv, memory if dec else None, a_sa, lse_sa, h2, nf, pre, u, *saved_c, *P)
+        ctx.mark_non_differentiable(nn1, qkv2)
+        return h3, nn1, qkv2
+
+    @staticmethod
+    def backward(ctx, dh3, _dn, _dqkv):
+        cfg = ctx.cfg
+        dec, heads, p, seed = cfg.decoder, cfg.heads, cfg.p, cfg.seed
+        sv = ctx.saved_tensors
+        h, n1, qkv, memory, a_sa, lse_sa, h2, nf, pre, u = sv[:10]
+        saved_c, P = sv[10 : 10 + ctx.n_c], sv[10 + ctx.n_c :]
+        B, T, d = h.shape
+        R = B * T
+        if dec:
+            (n1w, n1b, Wqkv, bqkv, Wo, bo, n2w, n2b, Wc, bc, Woc, boc, nfw, nfb, W1, b1, W2, b2) = P
+            h1, n2, q, kv, a_ca, lse_ca = saved_c
+        else:
+            (n1w, n1b, Wqkv, bqkv, Wo, bo, nfw, nfb, W1, b1, W2, b2) = P
+        # where the parameter gradients go: straight into the preallocated .grad buffers (FusedAdamW's flat buffer), else
+        # fresh tensors handed back to autograd
+        direct = all(t.grad is not None and t.grad.is_cuda for t in P)
+        G = [t.grad if direct else torch.zeros_like(t) for t in P]
+        g = dict(zip(_DEC_PARAMS if dec else _ENC_PARAMS, G))
+        nf_name = "norm3" if dec else "norm2"
+        wT = lambda W, blk=0: _packed_weight(W, blk, transposed=True)   # noqa: E731
+        dh3 = dh3.contiguous()
+        dh3_2 = dh3.view(R, d)
+
+        # feed-forward block: dy -> mask -> W2^T -> gelu' o mask -> W1^T -> LayerNorm backward (+ dy)
+        dym, dpre, dh2 = (_new(R, d, like=h) if p > 0 else dh3_2), _new(R, d, like=h), _new(B, T, d, like=h)
+        ops.train_bwd_chain(R, d, dh3_2, wT(W2), dh2, dym=dym if p > 0 else None, pre=pre, dpre=dpre, wt1=wT(W1), x=h2, ln_w=nfw,
+                            dres=dh3, dg=g[nf_name + ".weight"], db=g[nf_name + ".bias"], p=p, seed=seed,
+                            sites=(cfg.site(SITE_FFN_OUT), cfg.site(SITE_FFN_ACT)))
+        _dw(dym, u, g["linear2.weight"], g["linear2.bias"])
+        _dw(dpre, nf, g["linear1.weight"], g["linear1.bias"])
+
+        dmem = None
+        if dec:
+            # cross-attention block
+            dym, da = (_new(R, d, like=h) if p > 0 else dh2.view(R, d)), _new(B, T, d, like=h)
+            ops.train_bwd_chain(R, d, dh2.view(R, d), wT(Woc), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_CA_OUT), 0))
+            _dw(dym, a_ca.view(R, d), g["multihead_attn.out_proj.weight"], g["multihead_attn.out_proj.bias"])
+            dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+            ops.attention_bwd(q, kv[..., :d], kv[..., d:], a_ca, da, lse_ca, dq, dkv[..., :d], dkv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
+            M = memory.shape[1]
+            gWc, gbc = g["multihead_attn.in_proj_weight"], g["multihead_attn.in_proj_bias"]
+            _dw(dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:])
+            if ctx.needs_input_grad[3]:
+                dmem = _dx_through_weight(dkv.view(B * M, 2 * d), Wc[d:]).view(memory.shape)
+            dh1 = _new(B, T, d, like=h)
+            ops.train_bwd_chain(R, d, dq.view(R, d), wT(Wc), dh1, x=h1, ln_w=n2w, dres=dh2, dg=g["norm2.weight"], db=g["norm2.bias"])
+            _dw(dq.view(R, d), n2, gWc[:d], gbc[:d])
+            dres = dh1
+        else:
+            dres = dh2
+
+        # self-attention block
+        dym, da = (_new(R, d, like=h) if p > 0 else dres.view(R, d)), _new(B, T, d, like=h)
+        ops.train_bwd_chain(R, d, dres.view(R, d), wT(Wo), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0))
+        _dw(dym, a_sa.view(R, d), g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"])
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], a_sa, da, lse_sa, dqkv[..., :d], dqkv[..., d : 2 * d],
+                          dqkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
+        dh = _new(B, T, d, like=h)
+        ops.train_bwd_chain(R, d, dqkv.view(R, 3 * d), wT(Wqkv), dh, passes=3, x=h, ln_w=n1w, dres=dres, dg=g["norm1.weight"],
+                            db=g["norm1.bias"])
+        _dw(dqkv.view(R, 3 * d), n1, g["self_attn.in_proj_weight"], g["self_attn.in_proj_bias"])
+        return (dh, None, None, dmem, None) + tuple(None if direct else t for t in G)
+
+
+FUSED_STACKS = [0]   # how many layer stacks went through the fused path (tests assert that it is the path that ran)
+
+
+def _fused_stack(layers, h: Tensor, heads: int, memory, dc, decoder: bool, hooks: bool) -> Tensor:
+    FUSED_STACKS[0] += 1
+    B, T, d = h.shape
+    h = h.contiguous()
+    lp0 = layers[0]
+    with torch.no_grad():
+        n1, qkv = _new(B * T, d, like=h), _new(B, T, 3 * d, like=h)
+        ops.train_fwd_chain(B * T, d, h.detach(), nln=(lp0.norm1.weight, lp0.norm1.bias), nn_out=n1,
+                            wn=_packed_weight(lp0.self_attn.in_proj_weight), bn=lp0.self_attn.in_proj_bias, y_out=qkv, n_next=3)
+    for li, lp in enumerate(layers):
+        if hooks:
+            _layer_input_hook(h, li)
+        cfg = _FusedCfg(heads, dc, li, decoder, layers[li + 1] if li + 1 < len(layers) else None)
+        h, n1, qkv = _FusedLayer.apply(h, n1, qkv, memory, cfg, *_layer_params(lp, decoder))
+    return h
+
+
 def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
     """Differentiable DiffusionActionGenerator.forward (reference ml/model/decoder.py:38-54)."""
     T = x.shape[1]
@@ -460,9 +661,13 @@ def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
     h = _PatchEmbed.apply(x, gen.embedding.weight, gen.embedding.bias, pe)
     memory = memory.contiguous()
     dc = gen.dropout.for_call(gen.training)
-    for li, lp in enumerate(gen.transformer_decoder.layers):
-        _layer_input_hook(h, li)
-        h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3, dc=dc, li=li)
+    layers = list(gen.transformer_decoder.layers)
+    if _fused_ok(layers, h.shape[-1], decoder=True):
+        h = _fused_stack(layers, h, gen.num_heads, memory, dc, decoder=True, hooks=True)
+    else:
+        for li, lp in enumerate(layers):
+            _layer_input_hook(h, li)
+            h = _layer(lp, h, gen.num_heads, memory=memory, ffn_norm=lp.norm3, dc=dc, li=li)
     return _FcOut.apply(h, gen.fc_out.weight, gen.fc_out.bias)
 
 
@@ -472,7 +677,10 @@ def encoder_forward_autograd(enc, x: Tensor) -> Tensor:
     pe = enc.positional_encoding.pe[0, :n].contiguous()
     h = _PatchEmbed.apply(x, enc.embedding.weight, enc.embedding.bias, pe)
     dc = enc.dropout.for_call(enc.training)
-    for li, lp in enumerate(enc.transformer_encoder.layers):
+    layers = list(enc.transformer_encoder.layers)
+    if _fused_ok(layers, h.shape[-1], decoder=False):
+        return _fused_stack(layers, h, enc.num_heads, None, dc, decoder=False, hooks=False)
+    for li, lp in enumerate(layers):
         h = _layer(lp, h, enc.num_heads, memory=None, ffn_norm=lp.norm2, dc=dc, li=li)
     return h
 

@@ -129,8 +129,9 @@ def _decoder_masks(ops, gen, call, B, T, M, d, heads):
     return masks
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("d,L,T,B", [(256, 2, 100, 3), (64, 2, 16, 2)])
-def test_training_step_with_dropout_matches_oracle_with_the_same_masks(ops, d, L, T, B):
+def test_training_step_with_dropout_matches_oracle_with_the_same_masks(ops, d, L, T, B, fused):
     """One decoder-pretraining step in train() mode at p = 0.1: prediction, loss and every parameter gradient equal the
     oracle's autograd when it applies the same masks at torch's six sites per layer."""
     from soccerdiffusion_amd import training
@@ -143,6 +144,9 @@ def test_training_step_with_dropout_matches_oracle_with_the_same_masks(ops, d, L
     m.load_state_dict(sd)
     m.train()
     m.set_dropout(0.1, seed=4242)
+    if fused:   # split weight planes of a FusedAdamW switch the stack to the fused row chains
+        m._opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    stacks_before = training.FUSED_STACKS[0]
     g = torch.Generator().manual_seed(3)
     x0, eps = torch.randn(B, T, J, generator=g), torch.randn(B, T, J, generator=g)
     ctx = torch.randn(B, Mc, d, generator=g)
@@ -152,6 +156,7 @@ def test_training_step_with_dropout_matches_oracle_with_the_same_masks(ops, d, L
     calls_before = gen.dropout.calls
     pred = m.forward_with_context([ctx.cuda()], x_t.cuda(), t.cuda())
     assert gen.dropout.calls == calls_before + 1
+    assert training.FUSED_STACKS[0] - stacks_before == (1 if fused else 0)
     loss = training.mse_loss(pred, eps.cuda())
     loss.backward()
     masks = _decoder_masks(ops, gen, gen.dropout.calls, B, T, Mc + 1, d, 4)

@@ -37,12 +37,30 @@ def _check_grads(model, golden_grads):
     return worst
 
 
-def test_decoder_pretraining_step_gradients_golden(g1):
+def _arm_fused(m, fused):
+    """fused: give the model a FusedAdamW - its split weight planes switch the layer stacks to the fused row chains
+    (training._fused_stack); without one the per-operation autograd nodes run.  Returns the check to call afterwards."""
+    from soccerdiffusion_amd import training
+
+    if not fused:
+        return lambda n: None
+    m._opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    before = training.FUSED_STACKS[0]
+
+    def check(n):
+        assert training.FUSED_STACKS[0] - before == n, "the fused chains did not run"
+
+    return check
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_decoder_pretraining_step_gradients_golden(g1, fused):
     from soccerdiffusion_amd import training
 
     m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
+    ran = _arm_fused(m, fused)
     tr = g1["train"]
     pred = m.forward_with_context([g1["ctx"].cuda()], g1["x"].cuda(), g1["steps_int"].cuda())
     loss = training.mse_loss(pred, tr["noise"].cuda())
@@ -50,14 +68,17 @@ def test_decoder_pretraining_step_gradients_golden(g1):
     assert abs(float(loss) - float(tr["loss"])) / float(tr["loss"]) < 1e-5
     loss.backward()
     _check_grads(m, tr["grads"])
+    ran(1)
 
 
-def test_full_model_step_gradients_golden(g2):
+@pytest.mark.parametrize("fused", [False, True])
+def test_full_model_step_gradients_golden(g2, fused):
     from soccerdiffusion_amd import training
 
     m = _build0(g2["config"], full=True).cuda()
     m.load_state_dict(g2["state_dict"])
     m.train()
+    ran = _arm_fused(m, fused)
     tr = g2["train"]
     inp = {k: v.cuda() for k, v in g2["input_data"].items()}
     pred = m(inp, g2["x"].cuda(), g2["steps"].cuda())
@@ -65,9 +86,11 @@ def test_full_model_step_gradients_golden(g2):
     assert rel_err(pred, tr["pred"]) < TOL
     loss.backward()
     _check_grads(m, tr["grads"])
+    ran(4)   # the decoder and the three sequence encoders (joint commands, IMU, joint states)
 
 
-def test_c2_shape_gradients_vs_oracle():
+@pytest.mark.parametrize("fused", [False, True])
+def test_c2_shape_gradients_vs_oracle(fused):
     """BASELINE config 2 shape (d=256, L=4, T=100, M=11), small batch, vs CPU autograd of the oracle."""
     from soccerdiffusion_amd import training
     from soccerdiffusion_amd.synthetic import synthetic_state_dict
@@ -76,6 +99,7 @@ def test_c2_shape_gradients_vs_oracle():
     sd = synthetic_state_dict(256, 20, 4, seed=5)
     m = _build0(c, full=False).cuda()
     m.load_state_dict(sd)
+    ran = _arm_fused(m, fused)
     g = torch.Generator().manual_seed(3)
     B = 3
     x0, eps = torch.randn(B, 100, 20, generator=g), torch.randn(B, 100, 20, generator=g)
@@ -89,6 +113,7 @@ def test_c2_shape_gradients_vs_oracle():
     loss.backward()
     assert abs(float(loss) - float(want_loss)) / float(want_loss) < 1e-5
     _check_grads(m, want)
+    ran(1)
 
 
 def test_fused_adamw_onecycle_matches_torch(g1):

@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
-for src in ("soccerdiffusion_amd/csrc/sd_kernels.hip", "soccerdiffusion_amd/csrc/sd_train.hip"):
+for src in ("soccerdiffusion_amd/csrc/sd_kernels.hip", "soccerdiffusion_amd/csrc/sd_train.hip", "soccerdiffusion_amd/csrc/sd_train_chain.hip"):
     out = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Iinclude", "-c", src, "-o", "/dev/null",
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     cur = None
