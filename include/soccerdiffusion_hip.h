@@ -270,6 +270,7 @@ int sd_op_linear_packed(const float *A, int lda, const void *wpk, const float *b
  *   [pre]  t = t o gelu'(pre) o mask_{site_act} -> dpre;  t = t Wt1                    (back through FFN1)
  *   [x]    dx = LayerNorm-backward(t; x, ln_w) + dres -> dx;  dg += sum_rows t o xhat;  db += sum_rows t   (fp32 atomics)
  *          (x == NULL: dx = t) */
+#define SD_AMAX_WORDS 64
 typedef struct sd_train_fwd_chain_args {
     int64_t R;
     int32_t d, n_next;
@@ -279,6 +280,10 @@ typedef struct sd_train_fwd_chain_args {
     const float *nln_w, *nln_b; float *nn_out; const void *wn; const float *bn; float *y_out;
     float p;
     uint64_t seed, site_out, site_act, site_ffn;
+    /* optional: bits of max |x| over a, n_out, u, nn_out are atomically max-ed into these arrays of SD_AMAX_WORDS words
+     * (zero them first; a workgroup uses word blockIdx % SD_AMAX_WORDS) - the per-tensor scales of sd_gemm_tn_grouped, a
+     * by-product of the row passes */
+    uint32_t *amax_a, *amax_n, *amax_u, *amax_nn;
 } sd_train_fwd_chain_args;
 typedef struct sd_train_bwd_chain_args {
     int64_t R;
@@ -289,9 +294,22 @@ typedef struct sd_train_bwd_chain_args {
     float *dx;
     float p;
     uint64_t seed, site_in, site_act;
+    uint32_t *amax_dy, *amax_dpre;   /* optional, as above: max |.| of the (masked) dy over all passes, and of dpre */
 } sd_train_bwd_chain_args;
 int sd_train_fwd_chain(const sd_train_fwd_chain_args *args, void *stream);
 int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
+
+/* Several weight gradients dW += dY^T X (and db += column sums of dY, db may be NULL) in one launch, on the fp16 matrix
+ * pipe with ONE power-of-two scale per operand tensor: amax_dy / amax_x point at SD_AMAX_WORDS device words whose maximum is
+ * the bits of (an upper bound of) max |dY| / max |X| - what sd_train_*_chain leave behind.  dY [R, N] and X [R, K] with row strides ldy / ldx
+ * (multiples of 4, 16-byte aligned), N and K multiples of 128; dW [N, K] with row stride ldw.  Accumulates with fp32 atomics. */
+typedef struct sd_gemm_tn_problem {
+    const float *dY; const float *X; float *dW; float *db;
+    const uint32_t *amax_dy; const uint32_t *amax_x;
+    int64_t R;
+    int32_t N, K, ldy, ldx, ldw;
+} sd_gemm_tn_problem;
+int sd_gemm_tn_grouped(const sd_gemm_tn_problem *problems, int n_problems, void *stream);
 
 /* sd_op_attention_lse / sd_op_attention_bwd with dropout on the probabilities: O = (softmax(S) o mask) V, the softmax
  * normaliser and lse2 are those of the un-dropped probabilities; mask rows = (b * heads + h) * Tq + q, width = S. */

@@ -152,6 +152,20 @@ __device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h
     }
 }
 
+// The same split from packed instructions (v_pk_mul_f32, v_cvt_pkrtz_f16_f32, v_pk_add_f32: ~3 VALU per element instead of
+// ~7 with the two halves packed afterwards): hi is rounded toward zero, which costs nothing - lo holds the remainder
+// (< 1 ulp of hi, 11 bits) - and lo's own truncation leaves 2^-21 relative instead of 2^-22.
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f16_split4_pk(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
+    const f32x2 a = f32x2{x[0], x[1]} * scale, b = f32x2{x[2], x[3]} * scale;
+    const fp16x2_t ha = __builtin_amdgcn_cvt_pkrtz(a[0], a[1]), hb = __builtin_amdgcn_cvt_pkrtz(b[0], b[1]);
+    const f32x2 ra = a - f32x2{(float)ha[0], (float)ha[1]}, rb = b - f32x2{(float)hb[0], (float)hb[1]};
+    const fp16x2_t la = __builtin_amdgcn_cvt_pkrtz(ra[0], ra[1]), lb = __builtin_amdgcn_cvt_pkrtz(rb[0], rb[1]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    h = __builtin_bit_cast(f16x4, u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)});
+    l = __builtin_bit_cast(f16x4, u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)});
+}
+
 // power of two s with max * s in [8192, 16384) from the bits of an abs-max (m = f 2^e, f in [0.5, 1): s = 2^(14 - e)).
 // Exponent arithmetic on the bits: frexpf / ldexpf cost ~25 instructions each with their special cases, and this sits in
 // per-row / per-slab paths.  Zero, non-finite and < 2^-113 maxima (the scale would not be a normal float) give 1.

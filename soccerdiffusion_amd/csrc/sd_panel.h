@@ -130,14 +130,24 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// amax (training): the bits of the largest |value| of the panel are atomically max-ed into one of the SD_AMAX_WORDS words at
+// amax (sd_gemm_tn_grouped's scale = the maximum over the words).  One word for all of a launch's 1 600 waves serialises
+// them in one L2 atomic unit: +6 us per row pass measured; spread by workgroup, a word sees ~25.
+__device__ __forceinline__ void f16_emit_amax(unsigned *amax, float wmax, int lane) {
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 16, 64));
+    wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+    if (lane == 0) atomicMax(amax + (blockIdx.x & (SD_AMAX_WORDS - 1)), __builtin_bit_cast(unsigned, wmax));
+}
+
 // fp32 panel rows (optionally LayerNorm-ed on the way) -> split planes in place + 1/scale per row.
 // n_out (training): the first n_rows LayerNorm-ed rows are also written to n_out (row pitch D; the X operand of dW).
 template <int D, bool HAS_LN>
 __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const float *ln_w, const float *ln_b, int lane, int wave,
-                                                   float *n_out = nullptr, int n_rows = 0) {
+                                                   float *n_out = nullptr, int n_rows = 0, unsigned *amax = nullptr) {
     using C = PanelCfg<D>;
     constexpr int V4 = D / 64;
     const int sub = lane & 15, grp = lane >> 4;
+    float wmax = 0.f;
     for (int row = wave * 4 + grp; row < C::BM; row += 16) {
         f32x4 v[V4];
 #pragma unroll
@@ -171,7 +181,9 @@ __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const
         for (int j = 0; j < V4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
-        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, row16_max(m)));
+        m = row16_max(m);
+        wmax = fmaxf(wmax, m);
+        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, m));
         if (sub == 0) sInv[row] = 1.0f / scale;
         f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
 #pragma unroll
@@ -183,6 +195,7 @@ __device__ __forceinline__ void f16_rows_to_planes(float *sA, float *sInv, const
             *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
         }
     }
+    if (amax) f16_emit_amax(amax, wmax, lane);
 }
 
 #endif

@@ -605,6 +605,234 @@ __global__ __launch_bounds__(512, 2) void gemm_tn16d_kernel(const float *__restr
     }
 }
 
+// --------------------------------------------------------------------------------------
+// gemm_tn16g_kernel: several weight gradients in ONE launch, ONE power-of-two scale per operand TENSOR.
+// What the block-floating-point kernels above pay per 32-row slab - abs-max over the slab, the exchange of the maxima through
+// LDS, a sub-accumulator un-scaled into the fp32 accumulator - is half of their time, and a launch per d x d gradient leaves
+// each workgroup 8 - 16 slabs between its prologue and 64 KB of atomics.  The fused training chains (sd_train_chain.hip) know
+// the abs-max of every operand they produce or consume (their row passes compute it for the per-row scales anyway) and
+// leave it in a device word; with it the whole K loop accumulates in the MFMA accumulators and the slab loop is load ->
+// split -> LDS -> transposing reads -> 24 MFMAs.  hi + lo keep 22 bits of every element within 2^17 of the tensor's maximum
+// and an absolute error of 2^-38 max below that: rows with small gradients lose relative precision only where they cannot
+// matter to a sum that contains the large ones.  Grouping (up to 8 problems, e.g. the six d x d gradients of a layer) makes the
+// row chunks long (~60 slabs for a decoder layer at B = 256) with ~2 workgroups per CU and a quarter of the atomics.
+// Requires N % 128 == 0, K % 128 == 0, 16-byte aligned rows.
+// --------------------------------------------------------------------------------------
+constexpr int TNG_MAX = 8;
+struct TnProblem {
+    const float *dY, *X;
+    float *dW, *db;
+    const unsigned *amax_y, *amax_x;
+    long R;
+    int ldy, ldx, ldw, tiles_k, tiles, chunks, chunk_rows, wg_begin;
+};
+struct TnGroup {
+    TnProblem p[TNG_MAX];
+    int n;
+};
+
+#ifndef SD_TNG_OCC
+#define SD_TNG_OCC 2
+#endif
+#ifndef SD_TNG_WGS
+#define SD_TNG_WGS 512
+#endif
+// Software pipeline over 16-row slabs (one MFMA k-step): two LDS buffers, ONE barrier per slab, global loads two slabs ahead,
+// and the split of slab s + 1 into the other buffer in the same basic block as the transposing reads and the 12 MFMAs of
+// slab s, so that one wave's VALU work runs in the shadow of its own MFMAs.  The two-barrier form (load -> split -> barrier ->
+// reads + MFMAs -> barrier) measured 147 us for a decoder layer's six gradients and its parts simply added up: without the
+// MFMAs and reads 60, without the loads 94, without both 24 - nothing overlapped.
+constexpr int TNP_ROWS = 16;
+constexpr int TNP_PLANE = TNP_ROWS * TNS_PITCH;     // halfs per plane
+__global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) {
+    __shared__ __attribute__((aligned(16))) f16 sT[2][4 * TNP_PLANE];   // per buffer: dY hi, dY lo, X hi, X lo
+    __shared__ float sB[8][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroups go round-robin over the 8 XCDs (blockIdx % 8).  All tiles of one row chunk read the same rows of dY / X (a d x d
+    // gradient has 2 x 2 tiles, in_proj 6 x 2): relabel so that they are consecutive on ONE XCD and meet in its L2.
+    const unsigned nb = gridDim.x, q8 = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    const int vid = (int)(xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3));
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TNG_MAX; ++i)
+        if (i < g.n && vid >= g.p[i].wg_begin) pi = i;
+    const TnProblem &P = g.p[pi];
+    const int local = vid - P.wg_begin, chunk = local / P.tiles, tile = local - chunk * P.tiles;
+    const int n0 = (tile / P.tiles_k) * 128, k0 = (tile % P.tiles_k) * 128;
+    const long rbeg = (long)chunk * P.chunk_rows;
+    long rend = rbeg + P.chunk_rows;
+    if (rend > P.R) rend = P.R;
+    const int n_slabs = (int)((rend - rbeg + TNP_ROWS - 1) / TNP_ROWS);
+    static_assert(SD_AMAX_WORDS == 64, "one abs-max word per lane");
+    const float sy = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(__builtin_bit_cast(float, P.amax_y[lane]))));
+    const float sx = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(__builtin_bit_cast(float, P.amax_x[lane]))));
+    // staging map: thread -> rows (tid >> 5) + 8 v, columns 4 (tid & 31) .. +3 of both operands
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const float *yp = P.dY + (rbeg + srow) * (long)P.ldy + n0 + scol, *xp = P.X + (rbeg + srow) * (long)P.ldx + k0 + scol;
+    const long ystep = 8L * P.ldy, xstep = 8L * P.ldx;
+    int left = (int)(rend - rbeg) - srow;    // rows from this thread's first row of the NEXT slab to load to the chunk's end
+    f32x4 y0[2], x0[2], y1[2], x1[2], y2[2], x2[2], y3[2], x3[2];   // four slabs of loads: three in flight behind the one being split
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    // Straight-line loads: rows past the chunk's end (the ragged last slab, the prefetches behind it) read the chunk's first
+    // row instead and are zeroed when they are split.  Any control flow around the loads - per-lane predicates, or a
+    // wave-uniform "is there another slab" - made the compiler keep the loaded registers in different places on the two paths
+    // and copy them right behind the loads, with an s_waitcnt vmcnt(0) in front: the prefetch distance was zero.
+    const float *ysafe = P.dY + rbeg * (long)P.ldy + n0 + scol, *xsafe = P.X + rbeg * (long)P.ldx + k0 + scol;
+    int left_s = left;   // the same counter for the split
+    auto load = [&](f32x4 (&yv)[2], f32x4 (&xv)[2]) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const bool ok = 8 * v < left;
+#ifdef SD_TNG_ABL_NOLOAD
+            yv[v] = f32x4{(float)left, 1.f, 2.f, 3.f}; xv[v] = f32x4{(float)v, 1.f, 2.f, (float)left};
+#else
+            yv[v] = *reinterpret_cast<const f32x4 *>(ok ? yp + v * ystep : ysafe);
+            xv[v] = *reinterpret_cast<const f32x4 *>(ok ? xp + v * xstep : xsafe);
+#endif
+        }
+        yp += 2 * ystep;
+        xp += 2 * xstep;
+        left -= TNP_ROWS;
+    };
+    auto split = [&](const f32x4 (&yv)[2], const f32x4 (&xv)[2], f16 *buf) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const float keep = 8 * v < left_s ? 1.0f : 0.0f;   // folded into the scale: no extra instruction per element
+            bsum = bsum + yv[v] * keep;
+            f16x4 h, l;
+            f16 *o = buf + (srow + 8 * v) * TNS_PITCH + scol;
+            f16_split4_pk(yv[v], sy * keep, h, l);
+            *reinterpret_cast<f16x4 *>(o) = h;
+            *reinterpret_cast<f16x4 *>(o + TNP_PLANE) = l;
+            f16_split4_pk(xv[v], sx * keep, h, l);
+            *reinterpret_cast<f16x4 *>(o + 2 * TNP_PLANE) = h;
+            *reinterpret_cast<f16x4 *>(o + 3 * TNP_PLANE) = l;
+        }
+        left_s -= TNP_ROWS;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma = [&](const f16 *buf) {
+        f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#ifdef SD_TNG_ABL_NOTR   // ablation builds (tools/ab_build.sh): wrong results, timings tell what bounds the kernel
+            ah[t] = al[t] = bh[t] = bl[t] = f16x8{(f16)(float)lane, 1, 2, 3, 4, 5, 6, (f16)(float)t};
+            asm volatile("" : "+v"(ah[t]), "+v"(al[t]), "+v"(bh[t]), "+v"(bl[t]));
+#else
+            ah[t] = tns_frag(buf, 8 * half, wm * 64 + t * 32, lane);
+            al[t] = tns_frag(buf + TNP_PLANE, 8 * half, wm * 64 + t * 32, lane);
+            bh[t] = tns_frag(buf + 2 * TNP_PLANE, 8 * half, wn * 64 + t * 32, lane);
+            bl[t] = tns_frag(buf + 3 * TNP_PLANE, 8 * half, wn * 64 + t * 32, lane);
+#endif
+        }
+        // product-major: four independent accumulators between two MFMAs on the same one
+#ifndef SD_TNG_ABL_NOMFMA
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t == 0 ? al[tm] : ah[tm], t == 1 ? bl[tn] : bh[tn], acc[tm][tn], 0, 0, 0);
+#else
+        acc[0][0][0] += (float)ah[0][0] + (float)al[1][1] + (float)bh[0][2] + (float)bl[1][3] + (float)ah[1][4] + (float)al[0][5] + (float)bh[1][6] + (float)bl[0][7];
+#endif
+    };
+    load(y0, x0);
+    load(y1, x1);
+    load(y2, x2);
+    split(y0, x0, sT[0]);
+    for (int s = 0; s < n_slabs; s += 4) {   // slabs past the end are zeros: the loop body is branch-free
+        __syncthreads();   // buffer 0 holds slab s; every wave is done reading buffer 1
+        load(y3, x3);
+        mfma(sT[0]);
+        split(y1, x1, sT[1]);
+        __syncthreads();   // buffer 1 holds slab s + 1; every wave is done reading buffer 0
+        load(y0, x0);
+        mfma(sT[1]);
+        split(y2, x2, sT[0]);
+        __syncthreads();
+        load(y1, x1);
+        mfma(sT[0]);
+        split(y3, x3, sT[1]);
+        __syncthreads();
+        load(y2, x2);
+        mfma(sT[1]);
+        split(y0, x0, sT[0]);
+    }
+    const float un = 1.0f / (sy * sx);
+    float *dW = P.dW;
+    const int ldw = P.ldw;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int k = k0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r] * un);
+            }
+        }
+    if (P.db && (tile % P.tiles_k) == 0) {   // column sums of dY: 8 row groups x 128 columns through LDS
+        *reinterpret_cast<f32x4 *>(&sB[srow][scol]) = bsum;
+        __syncthreads();
+        if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int gI = 0; gI < 8; ++gI) v += sB[gI][tid];
+            atomicAdd(P.db + n0 + tid, v);
+        }
+    }
+}
+
+extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *stream) {
+    if (!pr || n <= 0) return fail(SD_E_BADARG, "sd_gemm_tn_grouped: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
+    for (int first = 0; first < n; first += TNG_MAX) {
+        const int cnt = n - first < TNG_MAX ? n - first : TNG_MAX;
+        TnGroup g;
+        g.n = cnt;
+        long slab_tiles = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const sd_gemm_tn_problem &q = pr[first + i];
+            if (!q.dY || !q.X || !q.dW || !q.amax_dy || !q.amax_x || q.R <= 0 || q.N <= 0 || q.K <= 0 || q.N % 128 || q.K % 128 || q.ldy < q.N ||
+                q.ldx < q.K || q.ldw < q.K || q.ldy % 4 || q.ldx % 4 || (reinterpret_cast<uintptr_t>(q.dY) & 15) || (reinterpret_cast<uintptr_t>(q.X) & 15))
+                return fail(SD_E_BADARG, "sd_gemm_tn_grouped: operands must be 16-byte aligned with N and K multiples of 128, and carry their abs-max words");
+            slab_tiles += (long)(q.N / 128) * (q.K / 128) * ((q.R + 31) / 32);
+        }
+        // ~2 workgroups per CU (256 CUs), each with the same number of 32-row slabs
+        long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
+        if (per_wg < 8) per_wg = 8;
+        int wgs = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const sd_gemm_tn_problem &q = pr[first + i];
+            TnProblem &P = g.p[i];
+            P.dY = q.dY; P.X = q.X; P.dW = q.dW; P.db = q.db; P.amax_y = q.amax_dy; P.amax_x = q.amax_x; P.R = q.R;
+            P.ldy = q.ldy; P.ldx = q.ldx; P.ldw = q.ldw; P.tiles_k = q.K / 128; P.tiles = (q.N / 128) * (q.K / 128);
+            const long slabs = (q.R + 31) / 32;
+            long chunk_slabs = per_wg < slabs ? per_wg : slabs;
+            chunk_slabs += chunk_slabs & 1;   // chunks of a multiple of 64 rows: the kernel's loop takes four 16-row slabs per turn
+            P.chunk_rows = (int)(chunk_slabs * 32);
+            P.chunks = (int)((slabs + chunk_slabs - 1) / chunk_slabs);
+            P.wg_begin = wgs;
+            wgs += (q.N / 128) * (q.K / 128) * P.chunks;
+        }
+        SD_LAUNCH(gemm_tn16g_kernel, dim3((unsigned)wgs), dim3(256), 0, s, g);
+        SD_CHECK_LAUNCH("gemm_tn16g_kernel");
+    }
+    return 0;
+}
+
 extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, float *dW, int ldw, float *db, long R,
                              int N, int K, void *stream) {
     if (!dY || !X || !dW || R <= 0 || N <= 0 || K <= 0 || ldy < N || ldx < K || ldw < K)

@@ -31,6 +31,7 @@ struct FwdArgs {
     const f16 *w2; const float *b2; float *h2_out;
     const float *nln_w, *nln_b; float *nn_out; const f16 *wn; const float *bn; float *y_out;
     DropoutArgs d_out, d_act, d_ffn;
+    unsigned *amax_a, *amax_n, *amax_u, *amax_nn;
 };
 
 struct BwdArgs {
@@ -41,13 +42,12 @@ struct BwdArgs {
     const float *x; const float *ln_w; const float *dres; float *dg; float *db;
     float *dx;
     DropoutArgs d_in, d_act;
+    unsigned *amax_dy, *amax_dpre;
 };
 
-// 64 rows of `src` (row pitch ld) -> fp32 LDS panel, rows past the end as zeros; MASK: x o dropout mask of width D, the
-// masked rows also go to masked_out (pitch D) when it is not NULL
-template <int D, bool MASK>
-__device__ __forceinline__ void tc_load_rows(float *sA, const float *src, int ld, const ChainPos<D> &p, const DropoutArgs &da,
-                                             float *masked_out) {
+// 64 rows of `src` (row pitch ld) -> fp32 LDS panel, rows past the end as zeros
+template <int D>
+__device__ __forceinline__ void tc_load_rows(float *sA, const float *src, int ld, const ChainPos<D> &p) {
     using C = PanelCfg<D>;
     constexpr int VEC_PER_ROW = D / 4, ITERS = C::BM * VEC_PER_ROW / 256, BATCH = ITERS < 16 ? ITERS : 16;
     const float *base = src + p.r0 * ld;
@@ -63,15 +63,46 @@ __device__ __forceinline__ void tc_load_rows(float *sA, const float *src, int ld
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
             const int i = threadIdx.x + (b0 + b) * 256, row = i / VEC_PER_ROW, c4 = i - row * VEC_PER_ROW;
-            if constexpr (MASK) {
-                if (row < p.R_left) {
-                    v[b] = v[b] * dropout_quad(da, (unsigned long)(p.r0 + row) * (unsigned long)VEC_PER_ROW + (unsigned long)c4);
-                    if (masked_out) *reinterpret_cast<f32x4 *>(masked_out + (p.r0 + row) * D + c4 * 4) = v[b];
-                }
-            }
             *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c4 * 4) = v[b];
         }
     }
+}
+
+// fp32 panel rows -> f(row, first column, quad) -> split planes in place + 1/scale per row.  The row loop is a run-time
+// loop (4 rows per wave and iteration): a Philox call per quad inside f stays at D / 64 independent chains per lane - applied
+// in the unrolled global-load loop instead, 16 of them were interleaved and spilled.
+template <int D, class F>
+__device__ __forceinline__ void tc_rows_to_planes(float *sA, float *sInv, const ChainPos<D> &p, unsigned *amax, F &&f) {
+    using C = PanelCfg<D>;
+    constexpr int V4 = D / 64;
+    const int sub = p.lane & 15, grp = p.lane >> 4;
+    float wmax = 0.f;
+    for (int row = p.wave * 4 + grp; row < C::BM; row += 16) {
+        f32x4 v[V4];
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + c);
+            f(row, c, v[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
+        }
+        m = row16_max(m);
+        wmax = fmaxf(wmax, m);
+        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, m));
+        if (sub == 0) sInv[row] = 1.0f / scale;
+        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            f16x4 h, l;
+            f16_split4(v[j], scale, h, l);
+            *reinterpret_cast<f16x4 *>(rowp + c) = h;
+            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
+        }
+    }
+    if (amax) f16_emit_amax(amax, wmax, p.lane);
 }
 
 // un-scale of this lane's accumulator rows (1 / (row scale * weight scale)), registers 4g .. 4g+3 <-> inv[tm][g]
@@ -135,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
 
     if constexpr (HAS_OUT) {
         f16_prime<D>(ring, fa.wo + wOff, loff);
-        tc_load_rows<D, false>(sA, fa.a, D, p, fa.d_out, nullptr);
+        tc_load_rows<D>(sA, fa.a, D, p);
         __syncthreads();
-        f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave);
+        f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave, nullptr, 0, fa.amax_a);
         __syncthreads();
         f16_gemm<D, true>(U, aH, fa.wo + wOff, loff, ring);
         if (HAS_FFN) f16_prime<D>(ring, fa.w1 + wOff, loff);
@@ -159,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
         __syncthreads();
     } else {
         if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
-        tc_load_rows<D, false>(sA, fa.h_in, D, p, fa.d_out, nullptr);
+        tc_load_rows<D>(sA, fa.h_in, D, p);
         __syncthreads();
     }
 
     if constexpr (HAS_FFN) {
-        f16_rows_to_planes<D, true>(sA, sInv, fa.ln_w, fa.ln_b, p.lane, p.wave, fa.n_out + p.r0 * D, p.R_left);
+        f16_rows_to_planes<D, true>(sA, sInv, fa.ln_w, fa.ln_b, p.lane, p.wave, fa.n_out + p.r0 * D, p.R_left, fa.amax_n);
         __syncthreads();
         f16_gemm<D, true>(U, aH, fa.w1 + wOff, loff, ring);
         f16_prime<D>(ring, fa.w2 + wOff, loff);
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
             *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c0) = v;
         });
         __syncthreads();
-        f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave);
+        f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave, nullptr, 0, fa.amax_u);
         __syncthreads();
         f16_gemm<D, true>(U, aH, fa.w2 + wOff, loff, ring);
         if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
     }
 
     if (fa.n_next == 0) return;   // workgroup-uniform
-    f16_rows_to_planes<D, true>(sA, sInv, fa.nln_w, fa.nln_b, p.lane, p.wave, fa.nn_out + p.r0 * D, p.R_left);
+    f16_rows_to_planes<D, true>(sA, sInv, fa.nln_w, fa.nln_b, p.lane, p.wave, fa.nn_out + p.r0 * D, p.R_left, fa.amax_nn);
     __syncthreads();
     tc_load_inv<D>(inv, sInv, p);
     const int ldo = fa.n_next * D;
@@ -237,45 +268,6 @@ __device__ __forceinline__ void tc_acc_to_lds(float *sA, const f32x16 (&acc)[Pan
                 const int c0 = p.wn * C::WN + tn * 32 + (p.l31 & ~3);
                 *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c0) = f32x4{x0, x1, x2, x3};
             }
-}
-
-// panel rows t -> dpre = t o gelu'(pre) [o mask] (stored) -> split planes in place + 1/scale per row
-template <int D, bool DROP>
-__device__ __forceinline__ void tc_gelu_bwd_rows(float *sA, float *sInv, const BwdArgs &fa, const ChainPos<D> &p) {
-    using C = PanelCfg<D>;
-    constexpr int V4 = D / 64, QPR = D / 4;
-    const int sub = p.lane & 15, grp = p.lane >> 4;
-    for (int row = p.wave * 4 + grp; row < C::BM; row += 16) {
-        const bool valid = row < p.R_left;
-        f32x4 v[V4];
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < V4; ++j) {
-            const int c = 4 * (sub + 16 * j);
-            v[j] = *reinterpret_cast<const f32x4 *>(sA + row * C::LDA + c);
-            if (valid) {
-                const long at = (p.r0 + row) * D + c;
-                const f32x4 u = *reinterpret_cast<const f32x4 *>(fa.pre + at);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[j][e] *= gelu_grad_fast(u[e]);
-                if constexpr (DROP) v[j] = v[j] * dropout_quad(fa.d_act, (unsigned long)(p.r0 + row) * QPR + (unsigned long)(c >> 2));
-                *reinterpret_cast<f32x4 *>(fa.dpre + at) = v[j];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
-        }
-        const float scale = f16_scale_from_bits(__builtin_bit_cast(unsigned, row16_max(m)));
-        if (sub == 0) sInv[row] = 1.0f / scale;
-        f16 *rowp = reinterpret_cast<f16 *>(sA + row * C::LDA);
-#pragma unroll
-        for (int j = 0; j < V4; ++j) {
-            const int c = 4 * (sub + 16 * j);
-            f16x4 h, l;
-            f16_split4(v[j], scale, h, l);
-            *reinterpret_cast<f16x4 *>(rowp + c) = h;
-            *reinterpret_cast<f16x4 *>(rowp + D + c) = l;
-        }
-    }
 }
 
 // panel rows dn (gradient of the LayerNorm output) -> dx = LN-backward(dn; x, gamma) + dres (stored); dgamma / dbeta of the
@@ -382,9 +374,18 @@ __global__ __launch_bounds__(256, 2) void train_bwd_chain_kernel(BwdArgs fa) {
         const f16 *w = fa.wt + (long)pass * C::WAVES_N * WSTREAM + wOff;
         f16_prime<D>(ring, w, loff);
         if (pass) __syncthreads();   // the previous pass's planes are no longer read
-        tc_load_rows<D, DROP>(sA, fa.dy + pass * D, fa.ldy, p, fa.d_in, fa.dym);
+        tc_load_rows<D>(sA, fa.dy + pass * D, fa.ldy, p);
         __syncthreads();
-        f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave);
+        if constexpr (DROP) {   // g = dy o mask (one pass, row pitch D: checked on the host), kept for the weight gradient
+            tc_rows_to_planes<D>(sA, sInv, p, fa.amax_dy, [&](int row, int c, f32x4 &v) {
+                if (row < p.R_left) {
+                    v = v * dropout_quad(fa.d_in, (unsigned long)(p.r0 + row) * (D / 4) + (unsigned long)(c >> 2));
+                    if (fa.dym) *reinterpret_cast<f32x4 *>(fa.dym + (p.r0 + row) * D + c) = v;
+                }
+            });
+        } else {
+            f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave, nullptr, 0, fa.amax_dy);
+        }
         __syncthreads();
         f16_gemm<D, true>(U, aH, w, loff, ring);
         tc_load_inv<D>(inv, sInv, p);
@@ -404,7 +405,16 @@ __global__ __launch_bounds__(256, 2) void train_bwd_chain_kernel(BwdArgs fa) {
         __syncthreads();
         tc_acc_to_lds<D>(sA, ACC, p);
         __syncthreads();
-        tc_gelu_bwd_rows<D, DROP>(sA, sInv, fa, p);
+        tc_rows_to_planes<D>(sA, sInv, p, fa.amax_dpre, [&](int row, int c, f32x4 &v) {   // dpre = t o gelu'(pre) [o mask], kept for dW1
+            if (row < p.R_left) {
+                const long at = (p.r0 + row) * D + c;
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(fa.pre + at);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u[e]);
+                if constexpr (DROP) v = v * dropout_quad(fa.d_act, (unsigned long)(p.r0 + row) * (D / 4) + (unsigned long)(c >> 2));
+                *reinterpret_cast<f32x4 *>(fa.dpre + at) = v;
+            }
+        });
         __syncthreads();
         f16_gemm<D, true>(U, aH, fa.wt1 + wOff, loff, ring);
         tc_load_inv<D>(inv, sInv, p);
@@ -512,6 +522,7 @@ extern "C" int sd_train_fwd_chain(const sd_train_fwd_chain_args *a, void *stream
     fa.d_out = make_dropout(a->p, a->seed, a->site_out);
     fa.d_act = make_dropout(a->p, a->seed, a->site_act);
     fa.d_ffn = make_dropout(a->p, a->seed, a->site_ffn);
+    fa.amax_a = a->amax_a; fa.amax_n = a->amax_n; fa.amax_u = a->amax_u; fa.amax_nn = a->amax_nn;
     const bool drop = a->p > 0.f && has_out;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
@@ -539,6 +550,7 @@ extern "C" int sd_train_bwd_chain(const sd_train_bwd_chain_args *a, void *stream
     fa.x = a->x; fa.ln_w = a->ln_w; fa.dres = a->dres; fa.dg = a->dg; fa.db = a->db; fa.dx = a->dx;
     fa.d_in = make_dropout(a->p, a->seed, a->site_in);
     fa.d_act = make_dropout(a->p, a->seed, a->site_act);
+    fa.amax_dy = a->amax_dy; fa.amax_dpre = a->amax_dpre;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     switch (a->d) {

@@ -535,30 +535,48 @@ def _addr(t) -> Optional[int]:
 
 def train_fwd_chain(R: int, d: int, h_in: Tensor, *, a=None, wo=None, bo=None, h_out=None, ln=None, n_out=None, w1=None, b1=None,
                     pre=None, u=None, w2=None, b2=None, h2_out=None, nln=None, nn_out=None, wn=None, bn=None, y_out=None,
-                    n_next: int = 0, p: float = 0.0, seed: int = 0, sites=(0, 0, 0)) -> None:
+                    n_next: int = 0, p: float = 0.0, seed: int = 0, sites=(0, 0, 0), amax=(None, None, None, None)) -> None:
     """One launch of sd_train_fwd_chain (include/soccerdiffusion_hip.h).  Weights (wo, w1, w2, wn) are ADDRESSES of split
-    planes; ``ln`` / ``nln`` are (weight, bias) pairs; ``sites`` = (out-projection, GELU, FFN output) dropout sites."""
+    planes; ``ln`` / ``nln`` are (weight, bias) pairs; ``sites`` = (out-projection, GELU, FFN output) dropout sites;
+    ``amax`` = addresses of the abs-max words of (a, n_out, u, nn_out) or None."""
     lib = _lib.load()
     args = _lib.TrainFwdChainArgs(
         R=R, d=d, n_next=n_next, a=_addr(a), wo=wo, bo=_addr(bo), h_in=_addr(h_in), h_out=_addr(h_out),
         ln_w=_addr(ln[0]) if ln else None, ln_b=_addr(ln[1]) if ln else None, n_out=_addr(n_out), w1=w1, b1=_addr(b1), pre=_addr(pre),
         u=_addr(u), w2=w2, b2=_addr(b2), h2_out=_addr(h2_out), nln_w=_addr(nln[0]) if nln else None,
         nln_b=_addr(nln[1]) if nln else None, nn_out=_addr(nn_out), wn=wn, bn=_addr(bn), y_out=_addr(y_out), p=float(p),
-        seed=int(seed) & 0xFFFFFFFFFFFFFFFF, site_out=int(sites[0]), site_act=int(sites[1]), site_ffn=int(sites[2]))
+        seed=int(seed) & 0xFFFFFFFFFFFFFFFF, site_out=int(sites[0]), site_act=int(sites[1]), site_ffn=int(sites[2]),
+        amax_a=amax[0], amax_n=amax[1], amax_u=amax[2], amax_nn=amax[3])
     check(lib.sd_train_fwd_chain(C.byref(args), _stream()), "sd_train_fwd_chain")
 
 
 def train_bwd_chain(R: int, d: int, dy: Tensor, wt: int, dx: Tensor, *, passes: int = 1, dym=None, pre=None, dpre=None, wt1=None,
-                    x=None, ln_w=None, dres=None, dg=None, db=None, p: float = 0.0, seed: int = 0, sites=(0, 0)) -> None:
+                    x=None, ln_w=None, dres=None, dg=None, db=None, p: float = 0.0, seed: int = 0, sites=(0, 0),
+                    amax=(None, None)) -> None:
     """One launch of sd_train_bwd_chain.  ``dy`` (R, passes * d) may be a row-strided view; ``wt`` / ``wt1`` are ADDRESSES of
-    the split planes of the transposed blocks; ``sites`` = (mask of dy, mask after the GELU)."""
+    the split planes of the transposed blocks; ``sites`` = (mask of dy, mask after the GELU); ``amax`` = addresses of the
+    abs-max words of (masked dy, dpre) or None."""
     lib = _lib.load()
     dyp, ldy = _rows(dy, "dy")
     args = _lib.TrainBwdChainArgs(
         R=R, d=d, passes=passes, ldy=ldy, dy=dyp, dym=_addr(dym), wt=wt, pre=_addr(pre), dpre=_addr(dpre), wt1=wt1, x=_addr(x),
         ln_w=_addr(ln_w), dres=_addr(dres), dg=_addr(dg), db=_addr(db), dx=_addr(dx), p=float(p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
-        site_in=int(sites[0]), site_act=int(sites[1]))
+        site_in=int(sites[0]), site_act=int(sites[1]), amax_dy=amax[0], amax_dpre=amax[1])
     check(lib.sd_train_bwd_chain(C.byref(args), _stream()), "sd_train_bwd_chain")
+
+
+def gemm_tn_grouped(problems) -> None:
+    """dW += dY^T X (db += column sums of dY) for every (dY, X, dW, db, amax_dy, amax_x) in ``problems`` in one launch per 8.
+    dY / X may be row-strided views; ``amax_*`` are ADDRESSES of device words with the bits of max |dY| / max |X|."""
+    lib = _lib.load()
+    arr = (_lib.GemmTnProblem * len(problems))()
+    for q, (dY, X, dW, db, ay, ax) in zip(arr, problems):
+        yp, ldy = _rows(dY, "dY"); xp, ldx = _rows(X, "X")
+        _req(dW, "dW")
+        q.dY, q.X, q.dW, q.db, q.amax_dy, q.amax_x = yp, xp, dW.data_ptr(), _ptr(db), ay, ax
+        q.R, q.N, q.K = dY.numel() // dY.shape[-1], dY.shape[-1], X.shape[-1]
+        q.ldy, q.ldx, q.ldw = ldy, ldx, dW.stride(0)
+    check(lib.sd_gemm_tn_grouped(arr, len(problems), _stream()), "sd_gemm_tn_grouped")
 
 
 # ---- dropout (training; one Philox mask function shared by every kernel, include/soccerdiffusion_hip.h) ----------------

@@ -493,11 +493,17 @@ def _fused_ok(layers, d: int, decoder: bool) -> bool:
     return True
 
 
-class _FusedCfg:
-    __slots__ = ("heads", "dc", "li", "decoder", "next_ln", "next_w", "next_b")
+# abs-max words of a layer (row li of the stack's int32 table; bits of max |x|, atomically max-ed by the chains' row passes):
+# the per-tensor scales of the grouped weight-gradient GEMM
+AMAX_WORDS = 64   # SD_AMAX_WORDS: the producers spread their atomics over this many words per tensor
+(_AX_N1, _AX_ASA, _AX_N2, _AX_ACA, _AX_NF, _AX_U, _AX_DY2, _AX_DPRE, _AX_DYC, _AX_DQ, _AX_DYS, _AX_DQKV) = range(12)
 
-    def __init__(self, heads, dc, li, decoder, nxt):
-        self.heads, self.dc, self.li, self.decoder = heads, dc, li, decoder
+
+class _FusedCfg:
+    __slots__ = ("heads", "dc", "li", "decoder", "next_ln", "next_w", "next_b", "amax")
+
+    def __init__(self, heads, dc, li, decoder, nxt, amax):
+        self.heads, self.dc, self.li, self.decoder, self.amax = heads, dc, li, decoder, amax
         if nxt is not None:
             self.next_ln = (nxt.norm1.weight.detach(), nxt.norm1.bias.detach())
             self.next_w, self.next_b = nxt.self_attn.in_proj_weight.detach(), nxt.self_attn.in_proj_bias.detach()
@@ -506,6 +512,10 @@ class _FusedCfg:
 
     def site(self, kind: int) -> int:
         return self.dc.site(self.li, kind)[2] if self.dc is not None else 0
+
+    def ax(self, idx: int, layer_offset: int = 0) -> int:
+        """Address of abs-max word ``idx`` of this layer (or of the next one)."""
+        return self.amax.data_ptr() + 4 * AMAX_WORDS * ((self.li + layer_offset) * 16 + idx)
 
     def drop(self, kind: int):
         return self.dc.site(self.li, kind) if self.dc is not None else None
@@ -543,15 +553,16 @@ class _FusedLayer(Function):
         if dec:
             h1, n2, q = _new(B, T, d, like=h), _new(R, d, like=h), _new(B, T, d, like=h)
             ops.train_fwd_chain(R, d, h, a=a_sa, wo=_packed_weight(Wo), bo=bo, h_out=h1, nln=(n2w, n2b), nn_out=n2,
-                                wn=_packed_weight(Wc), bn=bc, y_out=q, n_next=1, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0, 0))
+                                wn=_packed_weight(Wc), bn=bc, y_out=q, n_next=1, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0, 0),
+                                amax=(cfg.ax(_AX_ASA), None, None, cfg.ax(_AX_N2)))
             M = memory.shape[1]
             mem2 = memory.reshape(B * M, d)
             kv = ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:]).view(B, M, 2 * d)
             a_ca, lse_ca = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
-            a_in, w_in, b_in, h_res, site_out = a_ca, Woc, boc, h1, cfg.site(SITE_CA_OUT)
+            a_in, w_in, b_in, h_res, site_out, ax_a = a_ca, Woc, boc, h1, cfg.site(SITE_CA_OUT), _AX_ACA
             saved_c = (h1, n2, q, kv, a_ca, lse_ca)
         else:
-            a_in, w_in, b_in, h_res, site_out = a_sa, Wo, bo, h, cfg.site(SITE_SA_OUT)
+            a_in, w_in, b_in, h_res, site_out, ax_a = a_sa, Wo, bo, h, cfg.site(SITE_SA_OUT), _AX_ASA
         h2, nf, pre, u, h3 = _new(B, T, d, like=h), _new(R, d, like=h), _new(R, d, like=h), _new(R, d, like=h), _new(B, T, d, like=h)
         if cfg.next_w is not None:
             nn1, qkv2 = _new(R, d, like=h), _new(B, T, 3 * d, like=h)
@@ -561,7 +572,8 @@ class _FusedLayer(Function):
             nxt = {}
         ops.train_fwd_chain(R, d, h_res, a=a_in, wo=_packed_weight(w_in), bo=b_in, h_out=h2, ln=(nfw, nfb), n_out=nf,
                             w1=_packed_weight(W1), b1=b1, pre=pre, u=u, w2=_packed_weight(W2), b2=b2, h2_out=h3, p=p, seed=seed,
-                            sites=(site_out, cfg.site(SITE_FFN_ACT), cfg.site(SITE_FFN_OUT)), **nxt)
+                            sites=(site_out, cfg.site(SITE_FFN_ACT), cfg.site(SITE_FFN_OUT)),
+                            amax=(cfg.ax(ax_a), cfg.ax(_AX_NF), cfg.ax(_AX_U), cfg.ax(_AX_N1, 1)), **nxt)
         ctx.cfg = cfg
         ctx.n_c = len(saved_c)
         ctx.save_for_backward(h, n1, qkv, memory if dec else None, a_sa, lse_sa, h2, nf, pre, u, *saved_c, *P)
@@ -596,16 +608,20 @@ class _FusedLayer(Function):
         dym, dpre, dh2 = (_new(R, d, like=h) if p > 0 else dh3_2), _new(R, d, like=h), _new(B, T, d, like=h)
         ops.train_bwd_chain(R, d, dh3_2, wT(W2), dh2, dym=dym if p > 0 else None, pre=pre, dpre=dpre, wt1=wT(W1), x=h2, ln_w=nfw,
                             dres=dh3, dg=g[nf_name + ".weight"], db=g[nf_name + ".bias"], p=p, seed=seed,
-                            sites=(cfg.site(SITE_FFN_OUT), cfg.site(SITE_FFN_ACT)))
-        _dw(dym, u, g["linear2.weight"], g["linear2.bias"])
-        _dw(dpre, nf, g["linear1.weight"], g["linear1.bias"])
+                            sites=(cfg.site(SITE_FFN_OUT), cfg.site(SITE_FFN_ACT)), amax=(cfg.ax(_AX_DY2), cfg.ax(_AX_DPRE)))
+        # the weight gradients of the layer: one grouped launch at the end (hidden_dim a multiple of 128), else one each
+        grouped = d % 128 == 0 and os.environ.get("SD_TRAIN_GROUPED_DW", "1") != "0"
+        dws = [(dym, u, g["linear2.weight"], g["linear2.bias"], cfg.ax(_AX_DY2), cfg.ax(_AX_U)),
+               (dpre, nf, g["linear1.weight"], g["linear1.bias"], cfg.ax(_AX_DPRE), cfg.ax(_AX_NF))]
 
         dmem = None
         if dec:
             # cross-attention block
             dym, da = (_new(R, d, like=h) if p > 0 else dh2.view(R, d)), _new(B, T, d, like=h)
-            ops.train_bwd_chain(R, d, dh2.view(R, d), wT(Woc), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_CA_OUT), 0))
-            _dw(dym, a_ca.view(R, d), g["multihead_attn.out_proj.weight"], g["multihead_attn.out_proj.bias"])
+            ops.train_bwd_chain(R, d, dh2.view(R, d), wT(Woc), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_CA_OUT), 0),
+                                amax=(cfg.ax(_AX_DYC), None))
+            dws.append((dym, a_ca.view(R, d), g["multihead_attn.out_proj.weight"], g["multihead_attn.out_proj.bias"], cfg.ax(_AX_DYC),
+                        cfg.ax(_AX_ACA)))
             dq, dkv = torch.empty_like(q), torch.empty_like(kv)
             ops.attention_bwd(q, kv[..., :d], kv[..., d:], a_ca, da, lse_ca, dq, dkv[..., :d], dkv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
             M = memory.shape[1]
@@ -614,23 +630,38 @@ class _FusedLayer(Function):
             if ctx.needs_input_grad[3]:
                 dmem = _dx_through_weight(dkv.view(B * M, 2 * d), Wc[d:]).view(memory.shape)
             dh1 = _new(B, T, d, like=h)
-            ops.train_bwd_chain(R, d, dq.view(R, d), wT(Wc), dh1, x=h1, ln_w=n2w, dres=dh2, dg=g["norm2.weight"], db=g["norm2.bias"])
-            _dw(dq.view(R, d), n2, gWc[:d], gbc[:d])
+            ops.train_bwd_chain(R, d, dq.view(R, d), wT(Wc), dh1, x=h1, ln_w=n2w, dres=dh2, dg=g["norm2.weight"], db=g["norm2.bias"],
+                                amax=(cfg.ax(_AX_DQ), None))
+            dws.append((dq.view(R, d), n2, gWc[:d], gbc[:d], cfg.ax(_AX_DQ), cfg.ax(_AX_N2)))
             dres = dh1
         else:
             dres = dh2
 
         # self-attention block
         dym, da = (_new(R, d, like=h) if p > 0 else dres.view(R, d)), _new(B, T, d, like=h)
-        ops.train_bwd_chain(R, d, dres.view(R, d), wT(Wo), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0))
-        _dw(dym, a_sa.view(R, d), g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"])
+        ops.train_bwd_chain(R, d, dres.view(R, d), wT(Wo), da, dym=dym if p > 0 else None, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0),
+                            amax=(cfg.ax(_AX_DYS), None))
+        dws.append((dym, a_sa.view(R, d), g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"], cfg.ax(_AX_DYS), cfg.ax(_AX_ASA)))
         dqkv = torch.empty_like(qkv)
         ops.attention_bwd(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], a_sa, da, lse_sa, dqkv[..., :d], dqkv[..., d : 2 * d],
                           dqkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
         dh = _new(B, T, d, like=h)
         ops.train_bwd_chain(R, d, dqkv.view(R, 3 * d), wT(Wqkv), dh, passes=3, x=h, ln_w=n1w, dres=dres, dg=g["norm1.weight"],
-                            db=g["norm1.bias"])
-        _dw(dqkv.view(R, 3 * d), n1, g["self_attn.in_proj_weight"], g["self_attn.in_proj_bias"])
+                            db=g["norm1.bias"], amax=(cfg.ax(_AX_DQKV), None))
+        dws.append((dqkv.view(R, 3 * d), n1, g["self_attn.in_proj_weight"], g["self_attn.in_proj_bias"], cfg.ax(_AX_DQKV), cfg.ax(_AX_N1)))
+        if grouped:
+            side = _SIDE["stream"]
+            if side is None:
+                ops.gemm_tn_grouped(dws)
+            else:   # a parallel branch of the captured graph (GraphedTrainStep(fork_dw=True)); operands kept alive until the join
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ops.gemm_tn_grouped(dws)
+                _SIDE["keep"].append(dws)
+                _SIDE["dirty"] = True
+        else:
+            for dY, X, dW, db, _, _ in dws:
+                _dw(dY, X, dW, db)
         return (dh, None, None, dmem, None) + tuple(None if direct else t for t in G)
 
 
@@ -642,14 +673,16 @@ def _fused_stack(layers, h: Tensor, heads: int, memory, dc, decoder: bool, hooks
     B, T, d = h.shape
     h = h.contiguous()
     lp0 = layers[0]
+    amax = torch.zeros(len(layers) + 1, 16, AMAX_WORDS, dtype=torch.int32, device=h.device)
     with torch.no_grad():
         n1, qkv = _new(B * T, d, like=h), _new(B, T, 3 * d, like=h)
         ops.train_fwd_chain(B * T, d, h.detach(), nln=(lp0.norm1.weight, lp0.norm1.bias), nn_out=n1,
-                            wn=_packed_weight(lp0.self_attn.in_proj_weight), bn=lp0.self_attn.in_proj_bias, y_out=qkv, n_next=3)
+                            wn=_packed_weight(lp0.self_attn.in_proj_weight), bn=lp0.self_attn.in_proj_bias, y_out=qkv, n_next=3,
+                            amax=(None, None, None, amax.data_ptr() + 4 * AMAX_WORDS * _AX_N1))
     for li, lp in enumerate(layers):
         if hooks:
             _layer_input_hook(h, li)
-        cfg = _FusedCfg(heads, dc, li, decoder, layers[li + 1] if li + 1 < len(layers) else None)
+        cfg = _FusedCfg(heads, dc, li, decoder, layers[li + 1] if li + 1 < len(layers) else None, amax)
         h, n1, qkv = _FusedLayer.apply(h, n1, qkv, memory, cfg, *_layer_params(lp, decoder))
     return h
 

@@ -82,6 +82,18 @@ def test_forward_chain_feed_forward_block(ops, d, R, p):
                         p=p, seed=seed, sites=sites, **out)
     for name, want in (("h_out", h1), ("n_out", n), ("pre", pre), ("u", u), ("h2_out", h2), ("nn_out", nn), ("y_out", y)):
         assert rel_err(out[name], want.float()) < TOL, name
+    # the abs-max words (the grouped weight-gradient GEMM's scales): exactly max |x| of a, LN3 output, u, LN1' output
+    ax = torch.zeros(4, 64, dtype=torch.int32, device="cuda")    # SD_AMAX_WORDS words per tensor, the maximum counts
+    ops.train_fwd_chain(R, d, c(h), a=c(a), wo=pk["wo"].fwd.data_ptr(), bo=c(bo), ln=(c(g3), c(be3)), w1=pk["w1"].fwd.data_ptr(), b1=c(b1),
+                        w2=pk["w2"].fwd.data_ptr(), b2=c(b2), nln=(c(g1), c(be1)), wn=pk["wn"].fwd.data_ptr(), bn=c(bn), n_next=3,
+                        p=p, seed=seed, sites=sites, amax=tuple(ax.data_ptr() + 256 * i for i in range(4)), **out)
+    got = ax.view(torch.float32).max(dim=1).values.cpu()
+    for i, t in enumerate((a, out["n_out"], out["u"], out["nn_out"])):
+        m = float(t.abs().max())
+        if R % 64 == 0 or i in (0, 2):     # rows past the end of a ragged panel are LayerNorm(0) = beta: an upper bound only
+            assert got[i] == m, i
+        else:
+            assert m <= got[i] <= max(m, float(max(be3.abs().max(), be1.abs().max()))), i
 
     # the same chain without a next projection (last layer), and the out-projection + next projection form (chain A)
     out2 = dict(h_out=new(R, d), n_out=new(R, d), pre=new(R, d), u=new(R, d), h2_out=new(R, d))
@@ -137,6 +149,12 @@ def test_backward_chains(ops, d, R, p):
         assert rel_err(o["dym"], dym.float()) < TOL
     assert rel_err(o["dpre"], dpre.float()) < TOL
     assert rel_err(odx, dx.float()) < TOL
+    ax = torch.zeros(2, 64, dtype=torch.int32, device="cuda")
+    ops.train_bwd_chain(R, d, c(dy), p2.t.data_ptr(), odx, pre=c(pre), wt1=p1.t.data_ptr(), x=c(x), ln_w=c(gam), dres=c(dy),
+                        p=p, seed=seed, sites=sites, amax=(ax.data_ptr(), ax.data_ptr() + 256),
+                        **dict(o, dg=torch.zeros(d, device="cuda"), db=torch.zeros(d, device="cuda")))
+    got = ax.view(torch.float32).max(dim=1).values.cpu()
+    assert got[0] == float((o["dym"] if p > 0 else dy).abs().max()) and got[1] == float(o["dpre"].abs().max())
     assert rel_err(o["dg"] - 1, dg.float()) < 2e-5      # accumulated onto the buffer's contents (fp32 atomics)
     assert rel_err(o["db"] - 1, db.float()) < 2e-5
 

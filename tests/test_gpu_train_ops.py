@@ -201,6 +201,51 @@ def test_optimizer_keeps_split_planes_current(ops):
     assert tr._packed_weight(W) is not None
 
 
+def _amax_word(t):
+    """Device int32 word with the bits of max |t| (what the fused chains leave behind for the grouped GEMM)."""
+    w = torch.zeros(64, dtype=torch.int32, device=t.device)    # SD_AMAX_WORDS words, the maximum counts
+    w[int(t.numel()) % 64] = t.abs().max().reshape(1).view(torch.int32)[0]
+    return w
+
+
+def test_gemm_tn_grouped_matches_fp64(ops):
+    """Several weight gradients in one launch with one scale per operand tensor: column-slice operands, ragged row counts,
+    rows whose magnitudes differ by 10^4, accumulation onto existing contents, optional bias gradient."""
+    g = torch.Generator().manual_seed(0)
+    cases = [(1000, 256, 256, True), (77, 384, 128, False), (2816, 512, 256, True), (25, 128, 128, True)]
+    probs, wants, keep = [], [], []
+    for i, (R, N, K, bias) in enumerate(cases):
+        rowscale = torch.exp(torch.randn(R, 1, generator=g) * 2.3)            # e^(+-2.3 sigma): four decades between rows
+        dY = (torch.randn(R, N + 8, generator=g) * rowscale * 1e-3).cuda()
+        X = torch.randn(R, K + 4, generator=g).cuda()
+        dW0 = torch.randn(N, K, generator=g).cuda()
+        db0 = torch.randn(N, generator=g).cuda()
+        dW, db = dW0.clone(), db0.clone()
+        ay, ax = _amax_word(dY[:, :N]), _amax_word(X[:, :K])
+        keep += [dY, X, ay, ax]
+        probs.append((dY[:, :N], X[:, :K], dW, db if bias else None, ay.data_ptr(), ax.data_ptr()))
+        wants.append((dW0.double().cpu() + dY[:, :N].double().cpu().t() @ X[:, :K].double().cpu(), db0.double().cpu() + dY[:, :N].double().cpu().sum(0), dW, db, bias, dW0, db0))
+    ops.gemm_tn_grouped(probs)
+    for wW, wb, dW, db, bias, dW0, db0 in wants:
+        # error relative to the update, not to the random contents it is added to
+        assert rel_err(dW - dW0, (wW - dW0.double().cpu()).float()) < 1e-5
+        if bias:
+            assert rel_err(db - db0, (wb - db0.double().cpu()).float()) < 1e-5
+        else:
+            assert torch.equal(db, db0)
+    # more than 8 problems -> several launches; an abs-max word that is an upper bound (not the exact maximum) is fine
+    R, N, K = 300, 128, 128
+    dY, X = torch.randn(R, N, generator=g).cuda(), torch.randn(R, K, generator=g).cuda()
+    ay, ax = _amax_word(dY * 3), _amax_word(X * 1.5)
+    outs = [torch.zeros(N, K, device="cuda") for _ in range(11)]
+    ops.gemm_tn_grouped([(dY, X, o, None, ay.data_ptr(), ax.data_ptr()) for o in outs])
+    want = (dY.double().cpu().t() @ X.double().cpu()).float()
+    for o in outs:
+        assert rel_err(o, want) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.gemm_tn_grouped([(dY[:, :100], X, outs[0], None, ay.data_ptr(), ax.data_ptr())])   # N not a multiple of 128
+
+
 def test_small_k_matmul_and_colsum(ops):
     A, Bm = _rand(1000, 20, seed=1), _rand(20, 256, seed=2)
     assert rel_err(ops.small_k_matmul(A.cuda(), Bm.cuda()), A @ Bm) < 1e-5
