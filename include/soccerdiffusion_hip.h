@@ -227,7 +227,7 @@ int sd_op_attention_bwd(const float *q, int ldq, const float *k, const float *v,
  * encoder/base.py:29-40 never set it; train.py never calls .eval()): on the attention probabilities
  * (nn.MultiheadAttention), after each attention out-projection (dropout1 / dropout2), after the GELU and after linear2
  * (dropout / dropout3).  ONE counter-based mask for every kernel, nothing stored: element (row, col) of the logical
- * (rows x width) tensor of site `site` is kept iff word (col & 3) of Philox4x32-10(counter = {quad lo, quad hi, site lo,
+ * (rows x width) tensor of site `site` is kept iff word (col & 3) of Philox4x32-7(counter = {quad lo, quad hi, site lo,
  * site hi}, key = seed) >= p * 2^32, quad = (row * ceil4(width) + col) >> 2; kept values are scaled by 1 / (1 - p).
  * The backward entry points regenerate the mask from the same (p, seed, site).  p = 0 is the parity path. */
 

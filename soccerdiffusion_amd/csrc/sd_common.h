@@ -179,7 +179,7 @@ __device__ __forceinline__ float f16_scale_from_bits(unsigned maxbits) {
 // Dropout (training only; reference: torch's default p = 0.1 inside nn.TransformerDecoderLayer / EncoderLayer and
 // nn.MultiheadAttention, soccer_diffusion/ml/model/decoder.py:26-33 never overrides it).  ONE mask function for every
 // kernel: element (row, col) of the logical (rows x width) tensor of dropout site `site` is kept iff word
-// (col & 3) of Philox4x32-10(counter = {quad lo, quad hi, site lo, site hi}, key = seed) is >= thresh, with
+// (col & 3) of Philox4x32-7(counter = {quad lo, quad hi, site lo, site hi}, key = seed) is >= thresh, with
 // quad = (row * ceil4(width) + col) >> 2 - rows are padded to a multiple of 4 columns so that 4 consecutive columns of
 // a row always come from one Philox call, whatever the width (attention rows have S = 11 keys).  Nothing is stored: the
 // backward kernels regenerate the mask from (seed, site).  Kept values are scaled by 1 / (1 - p).
@@ -203,10 +203,13 @@ static inline DropoutArgs make_dropout(float p, uint64_t seed, uint64_t site) {
     return a;
 }
 
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+__device__ __forceinline__ void philox4x32_7(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned (&w)[4]) {
+    // 7 rounds: the smallest round count Random123 (Salmon et al., SC'11) reports as passing BigCrush; cuRAND / torch run
+    // 10.  A round is two quarter-rate 64-bit multiplies (~56 cycles per wave): with 10 rounds the masks were 19 % of the
+    // fused forward chain of training (tools/exp/chain_stamps.py).
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 7; ++i) {
         // one 64-bit product per multiplier (v_mad_u64_u32) instead of a mul_lo / mul_hi pair: integer multiplies are
         // quarter rate, and they are most of this function
         const unsigned long p0 = (unsigned long)0xD2511F53u * (unsigned long)c0, p1 = (unsigned long)0xCD9E8D57u * (unsigned long)c2;
@@ -223,8 +226,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 
 // multipliers (0 or 1/(1-p)) of the 4 elements of quad `quad` (= padded flat index >> 2)
 __device__ __forceinline__ f32x4 dropout_quad(const DropoutArgs &a, unsigned long quad) {
+#ifdef SD_ABL_NOPHILOX   // ablation builds: every element kept
+    return f32x4{a.scale, a.scale, a.scale, a.scale} + (float)(quad == 0x123456789ul);
+#endif
     unsigned w[4];
-    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), a.site_lo, a.site_hi, a.seed_lo, a.seed_hi + (a.epoch ? *a.epoch : 0u), w);
+    philox4x32_7((unsigned)quad, (unsigned)(quad >> 32), a.site_lo, a.site_hi, a.seed_lo, a.seed_hi + (a.epoch ? *a.epoch : 0u), w);
     f32x4 m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) m[e] = w[e] >= a.thresh ? a.scale : 0.f;

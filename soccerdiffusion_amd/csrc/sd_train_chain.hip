@@ -21,6 +21,21 @@
 #include "sd_common.h"
 #include "sd_panel.h"
 
+// Phase stamps of workgroup 0, wave 0 (developer builds: AB_TU=sd_train_chain tools/ab_build.sh stamps -DSD_TC_STAMPS; read with
+// tools/exp/chain_stamps.py)
+#ifdef SD_TC_STAMPS
+__device__ unsigned long long tc_stamps[64];
+#define TC_STAMP(i)                                                                                \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0) tc_stamps[i] = __builtin_readcyclecounter();      \
+    } while (0)
+extern "C" int sd_tc_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_stamps), sizeof(unsigned long long) * 64);
+}
+#else
+#define TC_STAMP(i)
+#endif
+
 namespace {
 
 struct FwdArgs {
@@ -164,13 +179,17 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
     f32x4 inv[C::TM][4];
     F16Ring<D> ring;
 
+    TC_STAMP(0);
     if constexpr (HAS_OUT) {
         f16_prime<D>(ring, fa.wo + wOff, loff);
         tc_load_rows<D>(sA, fa.a, D, p);
         __syncthreads();
+        TC_STAMP(1);
         f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave, nullptr, 0, fa.amax_a);
         __syncthreads();
+        TC_STAMP(2);
         f16_gemm<D, true>(U, aH, fa.wo + wOff, loff, ring);
+        TC_STAMP(3);
         if (HAS_FFN) f16_prime<D>(ring, fa.w1 + wOff, loff);
         else if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
         tc_load_inv<D>(inv, sInv, p);
@@ -180,7 +199,9 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
                 const long at = (p.r0 + row) * D + c0;
                 if constexpr (DROP) v = v * dropout_quad(fa.d_out, (unsigned long)(p.r0 + row) * QPR + (unsigned long)(c0 >> 2));
                 v = v + *reinterpret_cast<const f32x4 *>(fa.h_in + at);
+#ifndef SD_TC_ABL_NOSTORE   // ablation builds (tools/ab_build.sh): wrong results, timings tell what bounds the kernel
                 *reinterpret_cast<f32x4 *>(fa.h_out + at) = v;
+#endif
             } else {
                 v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -188,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
             *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c0) = v;
         });
         __syncthreads();
+        TC_STAMP(4);
     } else {
         if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
         tc_load_rows<D>(sA, fa.h_in, D, p);
@@ -197,26 +219,35 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
     if constexpr (HAS_FFN) {
         f16_rows_to_planes<D, true>(sA, sInv, fa.ln_w, fa.ln_b, p.lane, p.wave, fa.n_out + p.r0 * D, p.R_left, fa.amax_n);
         __syncthreads();
+        TC_STAMP(5);
         f16_gemm<D, true>(U, aH, fa.w1 + wOff, loff, ring);
+        TC_STAMP(6);
         f16_prime<D>(ring, fa.w2 + wOff, loff);
         tc_load_inv<D>(inv, sInv, p);
         __syncthreads();
         tc_for_quads<D>(U, inv, fa.b1, p, [&](int, int, int, int row, int c0, f32x4 v) {
             if (row < p.R_left) {
                 const long at = (p.r0 + row) * D + c0;
+#ifndef SD_TC_ABL_NOSTORE
                 *reinterpret_cast<f32x4 *>(fa.pre + at) = v;
+#endif
                 v = gelu4(v);
                 if constexpr (DROP) v = v * dropout_quad(fa.d_act, (unsigned long)(p.r0 + row) * QPR + (unsigned long)(c0 >> 2));
+#ifndef SD_TC_ABL_NOSTORE
                 *reinterpret_cast<f32x4 *>(fa.u + at) = v;
+#endif
             } else {
                 v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c0) = v;
         });
         __syncthreads();
+        TC_STAMP(7);
         f16_rows_to_planes<D, false>(sA, sInv, nullptr, nullptr, p.lane, p.wave, nullptr, 0, fa.amax_u);
         __syncthreads();
+        TC_STAMP(8);
         f16_gemm<D, true>(U, aH, fa.w2 + wOff, loff, ring);
+        TC_STAMP(9);
         if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
         tc_load_inv<D>(inv, sInv, p);
         __syncthreads();
@@ -225,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
                 const long at = (p.r0 + row) * D + c0;
                 if constexpr (DROP) v = v * dropout_quad(fa.d_ffn, (unsigned long)(p.r0 + row) * QPR + (unsigned long)(c0 >> 2));
                 v = v + Hq[tm][tn][g];
+#ifndef SD_TC_ABL_NOSTORE
                 *reinterpret_cast<f32x4 *>(fa.h2_out + at) = v;
+#endif
             } else {
                 v = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -234,18 +267,26 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
         __syncthreads();
     }
 
+    TC_STAMP(10);
     if (fa.n_next == 0) return;   // workgroup-uniform
     f16_rows_to_planes<D, true>(sA, sInv, fa.nln_w, fa.nln_b, p.lane, p.wave, fa.nn_out + p.r0 * D, p.R_left, fa.amax_nn);
     __syncthreads();
+    TC_STAMP(11);
     tc_load_inv<D>(inv, sInv, p);
     const int ldo = fa.n_next * D;
     for (int pass = 0; pass < fa.n_next; ++pass) {
         const f16 *w = fa.wn + (long)pass * C::WAVES_N * WSTREAM + wOff;
         f16_gemm<D, true>(U, aH, w, loff, ring);
         if (pass + 1 < fa.n_next) f16_prime<D>(ring, w + C::WAVES_N * WSTREAM, loff);
+        TC_STAMP(12 + 2 * pass);
         tc_for_quads<D>(U, inv, fa.bn + pass * D, p, [&](int, int, int, int row, int c0, f32x4 v) {
+#ifndef SD_TC_ABL_NOSTORE
             if (row < p.R_left) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(fa.y_out + (p.r0 + row) * ldo + pass * D + c0));
+#else
+            if (v[0] == 1234.5f) fa.y_out[0] = v[1];
+#endif
         });
+        TC_STAMP(13 + 2 * pass);
     }
 }
 
