@@ -2101,6 +2101,31 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float *__restric
             sW[kk * DC + cc] = (c0 + cc < d) ? w[(long)(c0 + cc) * K + kk] : 0.f;
         }
         __syncthreads();
+        if (RB == 64 && DC % 256 == 0) {
+            // a thread owns one output column for all 64 rows: the weight goes through a register and the patch value is ONE
+            // address for the whole workgroup (a broadcast read) - half the LDS reads of the generic loop below, none of
+            // them conflicting (80 -> 25 us for the decoder's Linear(20 -> 256) at 25 600 rows, a training step's embedding)
+            for (int cc = tid; cc < DC; cc += 256) {
+                float acc[64];
+#pragma unroll
+                for (int row = 0; row < 64; ++row) acc[row] = 0.f;
+                for (int kk = 0; kk < K; ++kk) {
+                    const float wv = sW[kk * DC + cc];
+#pragma unroll
+                    for (int row = 0; row < 64; ++row) acc[row] = fmaf(sX[row * (K + 1) + kk], wv, acc[row]);
+                }
+                const int c = c0 + cc;
+                if (c < d) {
+                    const float bv = bias[c];
+#pragma unroll
+                    for (int row = 0; row < 64; ++row) {
+                        const long r = r0 + row;
+                        if (r < rows) out[r * d + c] = acc[row] + bv + pe[(long)(r % n_per_sample) * d + c];
+                    }
+                }
+            }
+            continue;
+        }
         for (int i = tid; i < RB * DC; i += 256) {
             const int row = i / DC, cc = i - row * DC;
             const long r = r0 + row;
