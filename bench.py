@@ -368,7 +368,7 @@ def run_train(args, rank, world, dev, dist):
         "metric": "training trajectories/s (fwd + bwd + AdamW per trajectory; denoiser d=256 L=4, H=100, J=20)",
         "value": rec["value"], "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; attention backward on the fp32 MFMA)",
+        "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; the 11-key cross-attention backward on the fp32 MFMA)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{1 if world == 1 else 3}]: one training step (add_noise, forward, MSE, backward, "
                                f"{'RCCL all-reduce of the flat fp32 gradient, ' if world > 1 else ''}AdamW, OneCycleLR) of the transformer "
@@ -377,7 +377,7 @@ def run_train(args, rank, world, dev, dist):
                                f"{'the step replayed from a hipGraph' if leg.graphed is not None else 'launches issued eagerly'}",
                    "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "joints": J, "hidden_dim": D, "decoder_layers": L,
                    "memory_tokens": M, "parallelism": f"dp{world}" + (" (one flat-gradient all-reduce per step)" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": "whole training step (no single dominant kernel: profiles/)",
+        "roofline": {"bound": "mfma", "kernel": "whole training step (no single dominant kernel: profiles/r02_train_step_kernel_stats.txt)",
                      "achieved": rec["algorithmic_tflops_per_gpu"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": rec["frac_of_f16_mfma_peak"], "traffic": None,
                      "definition": "3 x F_step (SURVEY 8(d)) x trajectories / wall time, per GPU"},
