@@ -364,7 +364,7 @@ __device__ __forceinline__ void f16_store_h(float *h, const f32x16 (&H)[PanelCfg
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {H[tm][tn][4 * g], H[tm][tn][4 * g + 1], H[tm][tn][4 * g + 2], H[tm][tn][4 * g + 3]};
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + (unsigned)(((tn * C::TM + tm) * 4 + g) * 256)));
+                SD_NT_STORE(v, reinterpret_cast<f32x4 *>(base + (unsigned)(((tn * C::TM + tm) * 4 + g) * 256)));
             }
 }
 
@@ -395,7 +395,7 @@ __device__ __forceinline__ void f16_store_qkv(float *qkv, int which, int T, cons
                     unsigned off = 0;
                     if (t >= T) { t -= T; off = next_sample; }      // T >= 64: at most one sample boundary inside a panel
                     const f32x4 v = {x0, x1, x2, x3};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + off + (unsigned)(t * 64 + tn * 32 + (p.l31 & ~3))));
+                    SD_NT_STORE(v, reinterpret_cast<f32x4 *>(base + off + (unsigned)(t * 64 + tn * 32 + (p.l31 & ~3))));
                 }
             }
 }

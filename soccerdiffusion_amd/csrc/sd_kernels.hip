@@ -504,7 +504,7 @@ __device__ __forceinline__ void chain_store_acc(float *dst, int ld, int col0,
                 const int row = p.wm * C::WM + tm * 32 + 8 * g + 4 * p.half + i4;
                 if (row < p.R_left) {
                     const f32x4 v = {x0, x1, x2, x3};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(base + lane_off + (unsigned)((tm * 32 + 8 * g) * ld + tn * 32)));
+                    SD_NT_STORE(v, reinterpret_cast<f32x4 *>(base + lane_off + (unsigned)((tm * 32 + 8 * g) * ld + tn * 32)));
                 }
             }
 }

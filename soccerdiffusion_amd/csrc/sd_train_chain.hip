@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
         TC_STAMP(12 + 2 * pass);
         tc_for_quads<D>(U, inv, fa.bn + pass * D, p, [&](int, int, int, int row, int c0, f32x4 v) {
 #ifndef SD_TC_ABL_NOSTORE
-            if (row < p.R_left) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(fa.y_out + (p.r0 + row) * ldo + pass * D + c0));
+            if (row < p.R_left) SD_NT_STORE(v, reinterpret_cast<f32x4 *>(fa.y_out + (p.r0 + row) * ldo + pass * D + c0));
 #else
             if (v[0] == 1234.5f) fa.y_out[0] = v[1];
 #endif
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void train_bwd_chain_kernel(BwdArgs fa) {
                     quad_transpose(x0, x1, x2, x3, p.lane);
                     const int row = p.wm * C::WM + tm * 32 + 8 * g + 4 * p.half + i4;
                     const int c0 = p.wn * C::WN + tn * 32 + (p.l31 & ~3);
-                    if (row < p.R_left) __builtin_nontemporal_store(f32x4{x0, x1, x2, x3}, reinterpret_cast<f32x4 *>(fa.dx + (p.r0 + row) * D + c0));
+                    if (row < p.R_left) SD_NT_STORE((f32x4{x0, x1, x2, x3}), reinterpret_cast<f32x4 *>(fa.dx + (p.r0 + row) * D + c0));
                 }
     }
 }
