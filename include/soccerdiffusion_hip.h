@@ -246,9 +246,9 @@ int sd_op_linear_dropout(const float *A, int lda, const float *W, const float *b
 /* Training GEMMs on pre-split weights.  sd_pack_weight_blocks splits n_blocks d x d fp32 blocks (block b = d rows of d
  * floats at src + src_off_dev[b]; offsets in a DEVICE int64 array) into the fp16 hi | lo fragment planes the kernels read
  * (2 d^2 halfs per block, consecutive in dst; scale 2^8: |w| < 256) in ONE launch - once per optimizer step for every weight
- * and every transposed block of the dX GEMMs.  sd_op_linear_packed is sd_op_linear_strided / sd_op_linear_dropout with `wpk` =
+ * and, with transposed != 0 (planes of the block's TRANSPOSE), for the B operands of the dX GEMMs.  sd_op_linear_packed is sd_op_linear_strided / sd_op_linear_dropout with `wpk` =
  * the planes of the N / d consecutive blocks of W instead of W itself (LayerNorm or residual [+ dropout], no activation). */
-int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_blocks, void *dst, int d, void *stream);
+int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_blocks, void *dst, int d, int transposed, void *stream);
 int sd_op_linear_packed(const float *A, int lda, const void *wpk, const float *bias, const float *ln_w, const float *ln_b,
                         const float *res, float *out, int R, int N, int d, float p, uint64_t seed, uint64_t site, void *stream);
 

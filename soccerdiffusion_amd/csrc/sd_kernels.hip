@@ -1403,19 +1403,26 @@ extern "C" int sd_op_linear_packed(const float *A, int lda, const void *wpk, con
     return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
 }
 
-extern "C" int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_blocks, void *dst, int d, void *stream) {
+extern "C" int sd_pack_weight_blocks(const float *src, const int64_t *src_off_dev, int n_blocks, void *dst, int d, int transposed,
+                                     void *stream) {
     if (!src || !src_off_dev || !dst || n_blocks <= 0) return fail(SD_E_BADARG, "sd_pack_weight_blocks: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const long *off = reinterpret_cast<const long *>(src_off_dev);
     f16 *out = reinterpret_cast<f16 *>(dst);
-    const int chunks = d * (d / 8) / 256 > 0 ? d * (d / 8) / 256 : 1;
+    const int chunks = d * (d / 8) / 256 > 0 ? d * (d / 8) / 256 : 1, tiles = (d / 64) * (d / 64);
+#define SD_PACK(D_)                                                                                                              \
+    do {                                                                                                                         \
+        if (transposed) SD_LAUNCH((f16_pack_blocks_t_kernel<D_>), dim3(tiles, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); \
+        else SD_LAUNCH((f16_pack_blocks_kernel<D_>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE);         \
+    } while (0)
     switch (d) {
-        case 64: SD_LAUNCH((f16_pack_blocks_kernel<64>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
-        case 128: SD_LAUNCH((f16_pack_blocks_kernel<128>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
-        case 256: SD_LAUNCH((f16_pack_blocks_kernel<256>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
-        case 512: SD_LAUNCH((f16_pack_blocks_kernel<512>), dim3(chunks, n_blocks), dim3(256), 0, s, src, off, out, F16_W_SCALE); break;
+        case 64: SD_PACK(64); break;
+        case 128: SD_PACK(128); break;
+        case 256: SD_PACK(256); break;
+        case 512: SD_PACK(512); break;
         default: return fail(SD_E_BADDIM, "hidden_dim must be one of 64, 128, 256, 512");
     }
+#undef SD_PACK
     SD_CHECK_LAUNCH("f16_pack_blocks_kernel");
     return 0;
 }

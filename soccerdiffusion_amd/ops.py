@@ -495,14 +495,15 @@ def linear_strided(A: Tensor, W: Tensor, bias: Optional[Tensor] = None, res: Opt
     return out
 
 
-def pack_weight_blocks(src: Tensor, src_off: Tensor, n_blocks: int, d: int, dst: Tensor) -> None:
-    """Split ``n_blocks`` d x d fp32 blocks (block b at ``src`` + ``src_off[b]`` floats; device int64 offsets) into the fp16
-    hi | lo fragment planes of ``linear_packed`` (2 d^2 halfs per block, consecutive in ``dst``), one launch."""
+def pack_weight_blocks(src: Tensor, src_off: Tensor, n_blocks: int, d: int, dst: Tensor, transposed: bool = False) -> None:
+    """Split ``n_blocks`` d x d fp32 blocks (block b at ``src`` + ``src_off[b]`` floats; device int64 offsets) - or their
+    transposes - into the fp16 hi | lo fragment planes of ``linear_packed`` (2 d^2 halfs per block, consecutive in ``dst``),
+    one launch."""
     lib = _lib.load()
     _req(src, "src")
     if src_off.dtype != torch.int64 or not src_off.is_cuda or dst.dtype != torch.float16 or dst.numel() < 2 * d * d * n_blocks:
         raise ValueError("pack_weight_blocks: src_off must be a device int64 tensor and dst a float16 tensor of 2 d^2 n_blocks")
-    check(lib.sd_pack_weight_blocks(src.data_ptr(), src_off.data_ptr(), n_blocks, dst.data_ptr(), d, _stream()),
+    check(lib.sd_pack_weight_blocks(src.data_ptr(), src_off.data_ptr(), n_blocks, dst.data_ptr(), d, int(bool(transposed)), _stream()),
           "sd_pack_weight_blocks")
 
 

@@ -80,7 +80,7 @@ def _wt_entry(W: Tensor, p: int, d: int):
 
 def _transposed_block(W: Tensor, p: int, d: int) -> Tensor:
     ent = _wt_entry(W, p, d)
-    if ent is not None:
+    if ent is not None and ent[0].flat_wt is not None:
         return ent[0].flat_wt[ent[1] : ent[1] + d * d].view(d, d)
     return W[p * d : (p + 1) * d].t().contiguous()
 
@@ -98,7 +98,7 @@ def _packed_weight(W: Tensor, p: int = 0, transposed: bool = False):
     if ent is None or ent[0].flat_wpk is None:
         return None
     opt, off = ent
-    return opt.flat_wpk.data_ptr() + 2 * (2 * off + (2 * opt.flat_wt.numel() if transposed else 0))
+    return opt.flat_wpk.data_ptr() + 2 * (2 * off + (2 * opt._wt_total if transposed else 0))
 
 
 def _linear(A: Tensor, W: Tensor, b, ln=None, res=None, drop=None) -> Tensor:
@@ -327,18 +327,27 @@ class _CrossAttention(Function):
         return dq, dkv, None, None
 
 
+def _grad_targets(*params):
+    """(tensors to accumulate into, values to hand back to autograd): straight into the preallocated ``.grad`` buffers
+    (FusedAdamW's flat buffer, zeroed per step: no zero-fill, no accumulation kernel) when every parameter has one."""
+    if all(p.grad is not None and p.grad.is_cuda for p in params):
+        return [p.grad for p in params], [None] * len(params)
+    z = [torch.zeros_like(p) for p in params]
+    return z, z
+
+
 class _PatchEmbed(Function):
     """Conv1d(kernel = stride = p) (+ bias + positional table); p = 1 is nn.Linear(J -> d).
     The input is data (noisy trajectory / sensor history): no input gradient."""
 
     @staticmethod
     def forward(ctx, x, W, b, pe):
-        ctx.save_for_backward(x, W)
+        ctx.save_for_backward(x, W, b)
         return ops.patch_embed(x.contiguous(), W, b, pe)
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, W, b = ctx.saved_tensors
         d = W.shape[0]
         if W.dim() == 2:
             patches = x.reshape(-1, x.shape[-1])
@@ -347,10 +356,9 @@ class _PatchEmbed(Function):
             B, S, _ = x.shape
             n = S // p
             patches = x[:, : n * p].reshape(B, n, p, C).permute(0, 1, 3, 2).reshape(B * n, C * p).contiguous()
-        dW = torch.zeros(d, patches.shape[1], dtype=torch.float32, device=W.device)
-        db = torch.zeros(d, dtype=torch.float32, device=W.device)
+        (dW, db), (rW, rb) = _grad_targets(W, b)
         dy2 = dy.contiguous().view(-1, d)
-        ops.gemm_tn(dy2, patches, dW, db)
+        ops.gemm_tn(dy2, patches, dW.view(d, patches.shape[1]), db)
         dx = None
         if ctx.needs_input_grad[0]:
             # only the image tokens are a differentiable input (they come from the ResNet): kernel size 1, C = d
@@ -358,7 +366,7 @@ class _PatchEmbed(Function):
                 dx = _dx_through_weight(dy2, W.view(d, d)).view(x.shape)
             else:
                 raise NotImplementedError("input gradient of a patch embedding is only implemented for kernel size 1 with C = hidden_dim")
-        return dx, dW.view(W.shape), db, None
+        return dx, rW, rb, None
 
 
 class _FcOut(Function):
@@ -367,31 +375,33 @@ class _FcOut(Function):
     @staticmethod
     def forward(ctx, h, W, b):
         h2 = h.reshape(-1, h.shape[-1])
-        ctx.save_for_backward(h2, W)
+        ctx.save_for_backward(h2, W, b)
         ctx.shape = h.shape
         return ops.fc_out(h2, W, b).view(*h.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        h2, W = ctx.saved_tensors
+        h2, W, b = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
-        dW, db = _zeros_like_param(W), torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+        (dW, db), (rW, rb) = _grad_targets(W, b)
         ops.gemm_tn(dy2, h2, dW, db)
         dh = ops.small_k_matmul(dy2, W)
-        return dh.view(ctx.shape), dW, db
+        return dh.view(ctx.shape), rW, rb
 
 
 class _StepTokenFn(Function):
     @staticmethod
     def forward(ctx, steps, freq, token):
         ctx.half = token.shape[-1]
+        ctx.save_for_backward(token)
         return ops.step_token(steps, freq, token)
 
     @staticmethod
     def backward(ctx, dtok):
-        dtoken = torch.zeros(1, ctx.half, dtype=torch.float32, device=dtok.device)
+        (token,) = ctx.saved_tensors
+        (dtoken,), (rtoken,) = _grad_targets(token)
         ops.colsum(dtok.contiguous()[:, 0, ctx.half :], dtoken.view(-1))  # the learned half is expanded over the batch
-        return None, None, dtoken
+        return None, None, rtoken
 
 
 class _MSELoss(Function):
@@ -764,8 +774,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._wt_params.append(p)
                 out_at += k
             at += k
-        self._wt_index = torch.cat(idx).to(dev) if idx else None
-        self.flat_wt = torch.empty(out_at, dtype=torch.float32, device=dev) if idx else None
+        self._wt_total = out_at
         # split planes of the same blocks (see _packed_weight): per block width, (source offsets, first block) of the launch
         self.flat_wpk, self._pk_launches = None, []
         if idx and dev.type == "cuda" and os.environ.get("SD_TRAIN_PACKED", "1") != "0":
@@ -785,18 +794,24 @@ class FusedAdamW(torch.optim.Optimizer):
                     fwd = torch.tensor([(b[0] - base) // 4 for b in r], dtype=torch.int64, device=dev)
                     wt = torch.tensor([b[1] for b in r], dtype=torch.int64, device=dev)
                     self._pk_launches.append((d, len(r), fwd, wt, 2 * r[0][1]))
+        # without planes (no GPU, SD_TRAIN_PACKED=0): an fp32 copy of every W^T block from one gather per step
+        self._wt_index = torch.cat(idx).to(dev) if idx and self.flat_wpk is None else None
+        self.flat_wt = torch.empty(out_at, dtype=torch.float32, device=dev) if idx and self.flat_wpk is None else None
         self._wt_versions = []
         self.refresh_transposes()
 
     def refresh_transposes(self) -> None:
-        """Gather W^T of every d x d weight block from the flat parameter buffer (one kernel; see _WT_BLOCKS)."""
-        if self._wt_index is None or not self.flat_param.is_cuda:
+        """The per-step derived copies of the weights: the split planes of every d x d block and of its transpose (two
+        launches per block width; the transposition happens inside the pack kernel), or - without planes - an fp32 gather
+        of the transposed blocks (one kernel; see _WT_BLOCKS)."""
+        if not self._wt_blocks or not self.flat_param.is_cuda:
             return
         import weakref
-        torch.index_select(self.flat_param, 0, self._wt_index, out=self.flat_wt)
+        if self.flat_wt is not None:
+            torch.index_select(self.flat_param, 0, self._wt_index, out=self.flat_wt)
         for d, n, fwd, wt, half_off in self._pk_launches:
             ops.pack_weight_blocks(self.flat_param, fwd, n, d, self.flat_wpk[half_off:])
-            ops.pack_weight_blocks(self.flat_wt, wt, n, d, self.flat_wpk[2 * self.flat_wt.numel() + half_off:])
+            ops.pack_weight_blocks(self.flat_param, fwd, n, d, self.flat_wpk[2 * self._wt_total + half_off:], transposed=True)
         self._wt_versions = [p._version for p in self._wt_params]
         if not getattr(self, "_wt_registered", False):
             owner = weakref.ref(self)

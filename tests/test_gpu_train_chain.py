@@ -38,7 +38,7 @@ class _Planes:
         self.fwd = torch.empty(2 * d * d * nb, dtype=torch.float16, device="cuda")
         self.t = torch.empty(2 * d * d * nb, dtype=torch.float16, device="cuda")
         ops.pack_weight_blocks(Wc.reshape(-1), off, nb, d, self.fwd)
-        ops.pack_weight_blocks(Wt, off, nb, d, self.t)
+        ops.pack_weight_blocks(Wc.reshape(-1), off, nb, d, self.t, transposed=True)
 
 
 def _ln(x, w, b):

@@ -204,28 +204,43 @@ def test_checkpoint_dict_interchange(g1, tmp_path):
     assert rel_err(opt3.flat_param, opt.flat_param) < 1e-6
 
 
-def test_transposed_weight_blocks_follow_the_optimizer(g1):
-    """The dX GEMMs read W^T blocks that FusedAdamW gathers once per step: they must equal the current weights after
-    every step, and a torch in-place write to a parameter must retire them until the next step."""
+@pytest.mark.parametrize("packed", [True, False])
+def test_transposed_weight_blocks_follow_the_optimizer(g1, packed, monkeypatch):
+    """The dX GEMMs read per-step copies of W^T that FusedAdamW refreshes after every update - split fp16 planes (packed) or,
+    with SD_TRAIN_PACKED=0, an fp32 gather: they must equal the current weights after every step, and a torch in-place write
+    to a parameter must retire them until the next step."""
     from soccerdiffusion_amd import training
     from soccerdiffusion_amd.scheduler import DDIMScheduler
 
+    if not packed:
+        monkeypatch.setenv("SD_TRAIN_PACKED", "0")
     m = _build0(g1["config"], full=False).cuda()
     m.load_state_dict(g1["state_dict"])
     m.train()
     opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    assert (opt.flat_wpk is not None) == packed and (opt.flat_wt is None) == packed
     noise_sched = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
     mats = [p for p in m.parameters() if p.dim() == 2 and p.shape[1] % 64 == 0 and p.shape[0] % p.shape[1] == 0]
     assert mats
+    probe = torch.randn(5, 64, generator=torch.Generator().manual_seed(7)).cuda()
 
     def check_all(expect_cached, only=None):
         for W in (mats if only is None else only):
             d = W.shape[1]
             for blk in range(W.shape[0] // d):
-                wt = training._transposed_block(W, blk, d)
-                assert torch.equal(wt, W.detach()[blk * d : (blk + 1) * d].t())
-                cached = wt.data_ptr() >= opt.flat_wt.data_ptr() and wt.data_ptr() < opt.flat_wt.data_ptr() + 4 * opt.flat_wt.numel()
-                assert cached == expect_cached
+                want = W.detach()[blk * d : (blk + 1) * d].t()
+                if packed:
+                    wpk = training._packed_weight(W, blk, transposed=True)
+                    assert (wpk is not None) == expect_cached
+                    if wpk is not None:   # probe (W^T)^T = probe W_blk through the planes of the transposed block
+                        from soccerdiffusion_amd import ops
+                        got = ops.linear_packed(probe, wpk, d, None)
+                        assert rel_err(got, probe.double().cpu() @ want.double().cpu().t()) < 1e-5
+                else:
+                    wt = training._transposed_block(W, blk, d)
+                    assert torch.equal(wt, want)
+                    cached = wt.data_ptr() >= opt.flat_wt.data_ptr() and wt.data_ptr() < opt.flat_wt.data_ptr() + 4 * opt.flat_wt.numel()
+                    assert cached == expect_cached
 
     check_all(True)
     g = torch.Generator().manual_seed(1)

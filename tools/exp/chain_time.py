@@ -11,7 +11,7 @@ def planes(W):
     Wt = torch.cat([W[b * d:(b + 1) * d].t().contiguous().reshape(-1) for b in range(nb)])
     off = torch.arange(nb, dtype=torch.int64, device="cuda") * d * d
     f = torch.empty(2 * d * d * nb, dtype=torch.float16, device="cuda"); t = torch.empty_like(f)
-    ops.pack_weight_blocks(W.reshape(-1).contiguous(), off, nb, d, f); ops.pack_weight_blocks(Wt, off, nb, d, t)
+    ops.pack_weight_blocks(W.reshape(-1).contiguous(), off, nb, d, f); ops.pack_weight_blocks(W.reshape(-1).contiguous(), off, nb, d, t, transposed=True)
     return f, t
 s = 1 / math.sqrt(d)
 Wo, W1, W2, Wn = (planes(rnd(n, d, scale=s)) for n in (d, d, d, 3 * d))
