@@ -143,3 +143,48 @@ def test_range_guard_flags_overflow_and_falls_back_to_fp32(ops):
         warnings.simplefilter("ignore")
         with pytest.raises(FloatingPointError):
             ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, bad.cuda())
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_c2_training_step_at_full_batch_fused_equals_per_operation_path(ops, monkeypatch, p):
+    """BASELINE configs[1] at its size (B = 256: 400 panels on 256 CUs, ~500 workgroups in the grouped weight-gradient launch,
+    the XCD relabelling, abs-max words spread over 64 slots): every parameter gradient of the fused row chains equals the
+    per-operation autograd nodes' (the path the reference's golden gradients pin at small sizes) - same weights, same batch,
+    same dropout masks - and a few trajectories equal the oracle's forward."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.synthetic import synthetic_state_dict
+    from test_gpu_model import _build
+
+    B, Mc = 256, 10
+    sd = synthetic_state_dict(D, J, L, seed=5)
+    m = _build(dict(d=D, J=J, L=L, T=T), full=False).cuda()
+    m.load_state_dict(sd)
+    m.train()
+    m.set_dropout(p, seed=99)
+    opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(11)
+    x_t, eps = torch.randn(B, T, J, generator=g).cuda(), torch.randn(B, T, J, generator=g).cuda()
+    ctx = torch.randn(B, Mc, D, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    gen = m.diffusion_action_generator
+    grads, preds = {}, {}
+    for mode in ("fused", "nodes"):
+        monkeypatch.setenv("SD_TRAIN_FUSED", "1" if mode == "fused" else "0")
+        gen.dropout.calls = 7          # the same call index: the same masks
+        opt.zero_grad()
+        before = training.FUSED_STACKS[0]
+        pred = m.forward_with_context([ctx], x_t, t)
+        assert training.FUSED_STACKS[0] - before == (1 if mode == "fused" else 0)
+        training.mse_loss(pred, eps).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+        preds[mode] = pred.detach()
+    assert rel_err(preds["fused"], preds["nodes"]) < 2e-6
+    scale = max(float(v.norm()) for v in grads["nodes"].values())
+    for k, gn in grads["nodes"].items():
+        rel = float((grads["fused"][k].double() - gn.double()).norm()) / max(float(gn.norm()), 1e-3 * scale)
+        assert rel < 2e-5, (k, rel)
+    if p == 0.0:
+        picks = [0, 100, 255]
+        want = ref.forward_with_context(sd, [ctx[picks].cpu()], x_t[picks].cpu(), t[picks].cpu())
+        assert rel_err(preds["fused"][picks], want) < 1e-4
