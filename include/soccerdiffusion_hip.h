@@ -284,6 +284,7 @@ typedef struct sd_train_fwd_chain_args {
      * (zero them first; a workgroup uses word blockIdx % SD_AMAX_WORDS) - the per-tensor scales of sd_gemm_tn_grouped, a
      * by-product of the row passes */
     uint32_t *amax_a, *amax_n, *amax_u, *amax_nn;
+    uint32_t *amax_h2;   /* optional: max |h2_out| (the input of fc_out after the last layer) */
 } sd_train_fwd_chain_args;
 typedef struct sd_train_bwd_chain_args {
     int64_t R;
@@ -295,6 +296,7 @@ typedef struct sd_train_bwd_chain_args {
     float p;
     uint64_t seed, site_in, site_act;
     uint32_t *amax_dy, *amax_dpre;   /* optional, as above: max |.| of the (masked) dy over all passes, and of dpre */
+    uint32_t *amax_dx;               /* optional: max |dx| of the LayerNorm-backward form (the embedding's dY under layer 0) */
 } sd_train_bwd_chain_args;
 int sd_train_fwd_chain(const sd_train_fwd_chain_args *args, void *stream);
 int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
@@ -302,7 +304,8 @@ int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
 /* Several weight gradients dW += dY^T X (and db += column sums of dY, db may be NULL) in one launch, on the fp16 matrix
  * pipe with ONE power-of-two scale per operand tensor: amax_dy / amax_x point at SD_AMAX_WORDS device words whose maximum is
  * the bits of (an upper bound of) max |dY| / max |X| - what sd_train_*_chain leave behind.  dY [R, N] and X [R, K] with row strides ldy / ldx
- * (multiples of 4, 16-byte aligned), N and K multiples of 128; dW [N, K] with row stride ldw.  Accumulates with fp32 atomics. */
+ * (multiples of 4, 16-byte aligned), N and K multiples of 4 (tiles of 128 x 128, ragged ones masked); dW [N, K] with row
+ * stride ldw.  Accumulates with fp32 atomics.  sd_op_absmax fills the words of an operand no chain produced (zero them first). */
 typedef struct sd_gemm_tn_problem {
     const float *dY; const float *X; float *dW; float *db;
     const uint32_t *amax_dy; const uint32_t *amax_x;
@@ -310,6 +313,7 @@ typedef struct sd_gemm_tn_problem {
     int32_t N, K, ldy, ldx, ldw;
 } sd_gemm_tn_problem;
 int sd_gemm_tn_grouped(const sd_gemm_tn_problem *problems, int n_problems, void *stream);
+int sd_op_absmax(const float *x, int64_t rows, int width, int ld, uint32_t *amax, void *stream);
 
 /* sd_op_attention_lse / sd_op_attention_bwd with dropout on the probabilities: O = (softmax(S) o mask) V, the softmax
  * normaliser and lse2 are those of the un-dropped probabilities; mask rows = (b * heads + h) * Tq + q, width = S. */

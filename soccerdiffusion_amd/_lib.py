@@ -60,7 +60,7 @@ class TrainFwdChainArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("a", "wo", "bo", "h_in", "h_out", "ln_w", "ln_b", "n_out", "w1", "b1", "pre", "u", "w2", "b2",
                                              "h2_out", "nln_w", "nln_b", "nn_out", "wn", "bn", "y_out")]
                 + [("p", C.c_float), ("seed", C.c_uint64), ("site_out", C.c_uint64), ("site_act", C.c_uint64), ("site_ffn", C.c_uint64)]
-                + [(n, C.c_void_p) for n in ("amax_a", "amax_n", "amax_u", "amax_nn")])
+                + [(n, C.c_void_p) for n in ("amax_a", "amax_n", "amax_u", "amax_nn", "amax_h2")])
 
 
 class TrainBwdChainArgs(C.Structure):
@@ -69,7 +69,7 @@ class TrainBwdChainArgs(C.Structure):
     _fields_ = ([("R", C.c_int64), ("d", C.c_int32), ("passes", C.c_int32), ("ldy", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("dy", "dym", "wt", "pre", "dpre", "wt1", "x", "ln_w", "dres", "dg", "db", "dx")]
                 + [("p", C.c_float), ("seed", C.c_uint64), ("site_in", C.c_uint64), ("site_act", C.c_uint64)]
-                + [(n, C.c_void_p) for n in ("amax_dy", "amax_dpre")])
+                + [(n, C.c_void_p) for n in ("amax_dy", "amax_dpre", "amax_dx")])
 
 
 class GemmTnProblem(C.Structure):
@@ -111,6 +111,7 @@ SIGNATURES = {
     "sd_train_fwd_chain": (C.c_int, [C.POINTER(TrainFwdChainArgs), C.c_void_p]),
     "sd_train_bwd_chain": (C.c_int, [C.POINTER(TrainBwdChainArgs), C.c_void_p]),
     "sd_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTnProblem), C.c_int, C.c_void_p]),
+    "sd_op_absmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sd_pack_weight_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_linear_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn16d_kernel(const float *__restr
 // and an absolute error of 2^-38 max below that: rows with small gradients lose relative precision only where they cannot
 // matter to a sum that contains the large ones.  Grouping (up to 8 problems, e.g. the six d x d gradients of a layer) makes the
 // row chunks long (~60 slabs for a decoder layer at B = 256) with ~2 workgroups per CU and a quarter of the atomics.
-// Requires N % 128 == 0, K % 128 == 0, 16-byte aligned rows.
+// Requires N % 4 == 0, K % 4 == 0, 16-byte aligned rows; ragged tiles (N or K not a multiple of 128) are masked.
 // --------------------------------------------------------------------------------------
 constexpr int TNG_MAX = 8;
 struct TnProblem {
@@ -624,7 +624,7 @@ struct TnProblem {
     float *dW, *db;
     const unsigned *amax_y, *amax_x;
     long R;
-    int ldy, ldx, ldw, tiles_k, tiles, chunks, chunk_rows, wg_begin;
+    int N, K, ldy, ldx, ldw, tiles_k, tiles, chunks, chunk_rows, wg_begin;
 };
 struct TnGroup {
     TnProblem p[TNG_MAX];
@@ -679,7 +679,11 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
     // row instead and are zeroed when they are split.  Any control flow around the loads - per-lane predicates, or a
     // wave-uniform "is there another slab" - made the compiler keep the loaded registers in different places on the two paths
     // and copy them right behind the loads, with an s_waitcnt vmcnt(0) in front: the prefetch distance was zero.
-    const float *ysafe = P.dY + rbeg * (long)P.ldy + n0 + scol, *xsafe = P.X + rbeg * (long)P.ldx + k0 + scol;
+    // Ragged N / K (the J = 20 sides of the embedding and fc_out gradients): a thread whose four columns lie past the operand's
+    // width reads the tile's first columns instead and splits them with scale 0.
+    const bool ycol_ok = n0 + scol < P.N, xcol_ok = k0 + scol < P.K;
+    const float ycolf = ycol_ok ? 1.0f : 0.0f, xcolf = xcol_ok ? 1.0f : 0.0f;
+    const float *ysafe = P.dY + rbeg * (long)P.ldy + n0 + (ycol_ok ? scol : 0), *xsafe = P.X + rbeg * (long)P.ldx + k0 + (xcol_ok ? scol : 0);
     int left_s = left;   // the same counter for the split
     auto load = [&](f32x4 (&yv)[2], f32x4 (&xv)[2]) {
 #pragma unroll
@@ -688,8 +692,8 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
 #ifdef SD_TNG_ABL_NOLOAD
             yv[v] = f32x4{(float)left, 1.f, 2.f, 3.f}; xv[v] = f32x4{(float)v, 1.f, 2.f, (float)left};
 #else
-            yv[v] = *reinterpret_cast<const f32x4 *>(ok ? yp + v * ystep : ysafe);
-            xv[v] = *reinterpret_cast<const f32x4 *>(ok ? xp + v * xstep : xsafe);
+            yv[v] = *reinterpret_cast<const f32x4 *>(ok && ycol_ok ? yp + v * ystep : ysafe);
+            xv[v] = *reinterpret_cast<const f32x4 *>(ok && xcol_ok ? xp + v * xstep : xsafe);
 #endif
         }
         yp += 2 * ystep;
@@ -700,13 +704,13 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const float keep = 8 * v < left_s ? 1.0f : 0.0f;   // folded into the scale: no extra instruction per element
-            bsum = bsum + yv[v] * keep;
+            bsum = bsum + yv[v] * (keep * ycolf);
             f16x4 h, l;
             f16 *o = buf + (srow + 8 * v) * TNS_PITCH + scol;
-            f16_split4_pk(yv[v], sy * keep, h, l);
+            f16_split4_pk(yv[v], sy * (keep * ycolf), h, l);
             *reinterpret_cast<f16x4 *>(o) = h;
             *reinterpret_cast<f16x4 *>(o + TNP_PLANE) = l;
-            f16_split4_pk(xv[v], sx * keep, h, l);
+            f16_split4_pk(xv[v], sx * (keep * xcolf), h, l);
             *reinterpret_cast<f16x4 *>(o + 2 * TNP_PLANE) = h;
             *reinterpret_cast<f16x4 *>(o + 3 * TNP_PLANE) = l;
         }
@@ -779,19 +783,60 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r] * un);
+                if (n < P.N && k < P.K) atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r] * un);
             }
         }
     if (P.db && (tile % P.tiles_k) == 0) {   // column sums of dY: 8 row groups x 128 columns through LDS
         *reinterpret_cast<f32x4 *>(&sB[srow][scol]) = bsum;
         __syncthreads();
-        if (tid < 128) {
+        if (tid < 128 && n0 + tid < P.N) {
             float v = 0.f;
 #pragma unroll
             for (int gI = 0; gI < 8; ++gI) v += sB[gI][tid];
             atomicAdd(P.db + n0 + tid, v);
         }
     }
+}
+
+// bits of max |x| over a (rows x width) fp32 tensor with row stride ld -> the SD_AMAX_WORDS words at amax (atomic max: zero them first):
+// the scale of an operand of sd_gemm_tn_grouped that no fused chain produced
+__global__ __launch_bounds__(256) void absmax_words_kernel(const float *__restrict__ x, long rows, int width, int ld, unsigned *amax) {
+    const int w4 = width >> 2;
+    const long n4 = rows * w4;
+    float m = 0.f;
+    if (ld == width) {   // contiguous: a flat 16-byte stream, four loads in flight per thread
+        const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+        const long stride = (long)gridDim.x * blockDim.x;
+        long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(fmaxf(m, fmaxf(fabsf(a[e]), fabsf(b[e]))), fmaxf(fabsf(c[e]), fabsf(d[e])));
+        }
+        for (; i < n4; i += stride) {
+            const f32x4 a = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(a[0]), fabsf(a[1]))), fmaxf(fabsf(a[2]), fabsf(a[3])));
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / w4;
+            const int c = (int)(i - r * w4) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * ld + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax + (blockIdx.x & (SD_AMAX_WORDS - 1)), __builtin_bit_cast(unsigned, m));
+}
+
+extern "C" int sd_op_absmax(const float *x, int64_t rows, int width, int ld, uint32_t *amax, void *stream) {
+    if (!x || !amax || rows <= 0 || width <= 0 || width % 4 || ld < width || ld % 4 || (reinterpret_cast<uintptr_t>(x) & 15))
+        return fail(SD_E_BADARG, "sd_op_absmax: x must be 16-byte aligned with width and row stride multiples of 4");
+    long blocks = (rows * (width / 4) + 1023) / 1024;   // ~4 x 16 bytes per thread
+    if (blocks > 1024) blocks = 1024;
+    SD_LAUNCH(absmax_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)rows, width, ld, amax);
+    SD_CHECK_LAUNCH("absmax_words_kernel");
+    return 0;
 }
 
 extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *stream) {
@@ -805,27 +850,41 @@ extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *str
         long slab_tiles = 0;
         for (int i = 0; i < cnt; ++i) {
             const sd_gemm_tn_problem &q = pr[first + i];
-            if (!q.dY || !q.X || !q.dW || !q.amax_dy || !q.amax_x || q.R <= 0 || q.N <= 0 || q.K <= 0 || q.N % 128 || q.K % 128 || q.ldy < q.N ||
+            if (!q.dY || !q.X || !q.dW || !q.amax_dy || !q.amax_x || q.R <= 0 || q.N <= 0 || q.K <= 0 || q.N % 4 || q.K % 4 || q.ldy < q.N ||
                 q.ldx < q.K || q.ldw < q.K || q.ldy % 4 || q.ldx % 4 || (reinterpret_cast<uintptr_t>(q.dY) & 15) || (reinterpret_cast<uintptr_t>(q.X) & 15))
-                return fail(SD_E_BADARG, "sd_gemm_tn_grouped: operands must be 16-byte aligned with N and K multiples of 128, and carry their abs-max words");
-            slab_tiles += (long)(q.N / 128) * (q.K / 128) * ((q.R + 31) / 32);
+                return fail(SD_E_BADARG, "sd_gemm_tn_grouped: operands must be 16-byte aligned with N, K and the row strides multiples of 4, and carry their abs-max words");
+            slab_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((q.R + 31) / 32);
         }
         // ~2 workgroups per CU (256 CUs), each with the same number of 32-row slabs
+        // ... and no more workgroups than fit at once (chunks are rounded up per problem: nine extra workgroups behind a full
+        // chip made a second round, +30 % on the launch)
         long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
         if (per_wg < 8) per_wg = 8;
+        for (;; ++per_wg) {
+            long total = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const sd_gemm_tn_problem &q = pr[first + i];
+                const long slabs = (q.R + 31) / 32;
+                long cs = per_wg < slabs ? per_wg : slabs;
+                cs += cs & 1;
+                total += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((slabs + cs - 1) / cs);
+            }
+            if (total <= SD_TNG_WGS) break;
+        }
         int wgs = 0;
         for (int i = 0; i < cnt; ++i) {
             const sd_gemm_tn_problem &q = pr[first + i];
             TnProblem &P = g.p[i];
             P.dY = q.dY; P.X = q.X; P.dW = q.dW; P.db = q.db; P.amax_y = q.amax_dy; P.amax_x = q.amax_x; P.R = q.R;
-            P.ldy = q.ldy; P.ldx = q.ldx; P.ldw = q.ldw; P.tiles_k = q.K / 128; P.tiles = (q.N / 128) * (q.K / 128);
+            P.N = q.N; P.K = q.K;
+            P.ldy = q.ldy; P.ldx = q.ldx; P.ldw = q.ldw; P.tiles_k = (q.K + 127) / 128; P.tiles = ((q.N + 127) / 128) * P.tiles_k;
             const long slabs = (q.R + 31) / 32;
             long chunk_slabs = per_wg < slabs ? per_wg : slabs;
             chunk_slabs += chunk_slabs & 1;   // chunks of a multiple of 64 rows: the kernel's loop takes four 16-row slabs per turn
             P.chunk_rows = (int)(chunk_slabs * 32);
             P.chunks = (int)((slabs + chunk_slabs - 1) / chunk_slabs);
             P.wg_begin = wgs;
-            wgs += (q.N / 128) * (q.K / 128) * P.chunks;
+            wgs += P.tiles * P.chunks;
         }
         SD_LAUNCH(gemm_tn16g_kernel, dim3((unsigned)wgs), dim3(256), 0, s, g);
         SD_CHECK_LAUNCH("gemm_tn16g_kernel");

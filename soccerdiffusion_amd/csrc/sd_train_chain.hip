@@ -46,7 +46,7 @@ struct FwdArgs {
     const f16 *w2; const float *b2; float *h2_out;
     const float *nln_w, *nln_b; float *nn_out; const f16 *wn; const float *bn; float *y_out;
     DropoutArgs d_out, d_act, d_ffn;
-    unsigned *amax_a, *amax_n, *amax_u, *amax_nn;
+    unsigned *amax_a, *amax_n, *amax_u, *amax_nn, *amax_h2;
 };
 
 struct BwdArgs {
@@ -57,7 +57,7 @@ struct BwdArgs {
     const float *x; const float *ln_w; const float *dres; float *dg; float *db;
     float *dx;
     DropoutArgs d_in, d_act;
-    unsigned *amax_dy, *amax_dpre;
+    unsigned *amax_dy, *amax_dpre, *amax_dx;
 };
 
 // 64 rows of `src` (row pitch ld) -> fp32 LDS panel, rows past the end as zeros
@@ -251,11 +251,13 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
         if (fa.n_next) f16_prime<D>(ring, fa.wn + wOff, loff);
         tc_load_inv<D>(inv, sInv, p);
         __syncthreads();
+        float h2max = 0.f;
         tc_for_quads<D>(U, inv, fa.b2, p, [&](int tm, int tn, int g, int row, int c0, f32x4 v) {
             if (row < p.R_left) {
                 const long at = (p.r0 + row) * D + c0;
                 if constexpr (DROP) v = v * dropout_quad(fa.d_ffn, (unsigned long)(p.r0 + row) * QPR + (unsigned long)(c0 >> 2));
                 v = v + Hq[tm][tn][g];
+                h2max = fmaxf(fmaxf(h2max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #ifndef SD_TC_ABL_NOSTORE
                 *reinterpret_cast<f32x4 *>(fa.h2_out + at) = v;
 #endif
@@ -264,6 +266,11 @@ __global__ __launch_bounds__(256, 2) void train_fwd_chain_kernel(FwdArgs fa) {
             }
             *reinterpret_cast<f32x4 *>(sA + row * C::LDA + c0) = v;
         });
+        if (fa.amax_h2) {   // workgroup-uniform; only the last layer asks for it
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) h2max = fmaxf(h2max, __shfl_xor(h2max, o, 64));
+            f16_emit_amax(fa.amax_h2, h2max, p.lane);
+        }
         __syncthreads();
     }
 
@@ -319,6 +326,7 @@ __device__ __forceinline__ void tc_ln_bwd_rows(float *sA, const BwdArgs &fa, con
     constexpr int V4 = D / 64;
     const int sub = p.lane & 15, grp = p.lane >> 4;
     f32x4 gam[V4], dgam[V4], dbet[V4];
+    float dxmax = 0.f;
 #pragma unroll
     for (int j = 0; j < V4; ++j) {
         gam[j] = *reinterpret_cast<const f32x4 *>(fa.ln_w + 4 * (sub + 16 * j));
@@ -366,8 +374,14 @@ __device__ __forceinline__ void tc_ln_bwd_rows(float *sA, const BwdArgs &fa, con
                 f32x4 dx = (dn[j] - c1 - xv[j] * c2) * rstd;
                 if (fa.dres) dx = dx + *reinterpret_cast<const f32x4 *>(fa.dres + at0 + c);
                 *reinterpret_cast<f32x4 *>(fa.dx + at0 + c) = dx;
+                dxmax = fmaxf(fmaxf(dxmax, fmaxf(fabsf(dx[0]), fabsf(dx[1]))), fmaxf(fabsf(dx[2]), fabsf(dx[3])));
             }
         }
+    }
+    if (fa.amax_dx) {   // workgroup-uniform
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o, 64));
+        f16_emit_amax(fa.amax_dx, dxmax, p.lane);
     }
     // the 4 row groups of a wave hold the same columns: fold them, then the 4 waves through LDS
 #pragma unroll
@@ -563,7 +577,7 @@ extern "C" int sd_train_fwd_chain(const sd_train_fwd_chain_args *a, void *stream
     fa.d_out = make_dropout(a->p, a->seed, a->site_out);
     fa.d_act = make_dropout(a->p, a->seed, a->site_act);
     fa.d_ffn = make_dropout(a->p, a->seed, a->site_ffn);
-    fa.amax_a = a->amax_a; fa.amax_n = a->amax_n; fa.amax_u = a->amax_u; fa.amax_nn = a->amax_nn;
+    fa.amax_a = a->amax_a; fa.amax_n = a->amax_n; fa.amax_u = a->amax_u; fa.amax_nn = a->amax_nn; fa.amax_h2 = a->amax_h2;
     const bool drop = a->p > 0.f && has_out;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
@@ -591,7 +605,7 @@ extern "C" int sd_train_bwd_chain(const sd_train_bwd_chain_args *a, void *stream
     fa.x = a->x; fa.ln_w = a->ln_w; fa.dres = a->dres; fa.dg = a->dg; fa.db = a->db; fa.dx = a->dx;
     fa.d_in = make_dropout(a->p, a->seed, a->site_in);
     fa.d_act = make_dropout(a->p, a->seed, a->site_act);
-    fa.amax_dy = a->amax_dy; fa.amax_dpre = a->amax_dpre;
+    fa.amax_dy = a->amax_dy; fa.amax_dpre = a->amax_dpre; fa.amax_dx = a->amax_dx;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     switch (a->d) {

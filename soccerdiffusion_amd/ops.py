@@ -547,7 +547,7 @@ def train_fwd_chain(R: int, d: int, h_in: Tensor, *, a=None, wo=None, bo=None, h
         u=_addr(u), w2=w2, b2=_addr(b2), h2_out=_addr(h2_out), nln_w=_addr(nln[0]) if nln else None,
         nln_b=_addr(nln[1]) if nln else None, nn_out=_addr(nn_out), wn=wn, bn=_addr(bn), y_out=_addr(y_out), p=float(p),
         seed=int(seed) & 0xFFFFFFFFFFFFFFFF, site_out=int(sites[0]), site_act=int(sites[1]), site_ffn=int(sites[2]),
-        amax_a=amax[0], amax_n=amax[1], amax_u=amax[2], amax_nn=amax[3])
+        amax_a=amax[0], amax_n=amax[1], amax_u=amax[2], amax_nn=amax[3], amax_h2=amax[4] if len(amax) > 4 else None)
     check(lib.sd_train_fwd_chain(C.byref(args), _stream()), "sd_train_fwd_chain")
 
 
@@ -562,8 +562,16 @@ def train_bwd_chain(R: int, d: int, dy: Tensor, wt: int, dx: Tensor, *, passes: 
     args = _lib.TrainBwdChainArgs(
         R=R, d=d, passes=passes, ldy=ldy, dy=dyp, dym=_addr(dym), wt=wt, pre=_addr(pre), dpre=_addr(dpre), wt1=wt1, x=_addr(x),
         ln_w=_addr(ln_w), dres=_addr(dres), dg=_addr(dg), db=_addr(db), dx=_addr(dx), p=float(p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
-        site_in=int(sites[0]), site_act=int(sites[1]), amax_dy=amax[0], amax_dpre=amax[1])
+        site_in=int(sites[0]), site_act=int(sites[1]), amax_dy=amax[0], amax_dpre=amax[1], amax_dx=amax[2] if len(amax) > 2 else None)
     check(lib.sd_train_bwd_chain(C.byref(args), _stream()), "sd_train_bwd_chain")
+
+
+def absmax(x: Tensor, amax: int) -> None:
+    """Max the bits of max |x| into the SD_AMAX_WORDS words at address ``amax`` (zeroed by the caller); x may be row-strided."""
+    lib = _lib.load()
+    xp, ld = _rows(x, "x")
+    width = x.shape[-1]
+    check(lib.sd_op_absmax(xp, x.numel() // width, width, ld, amax, _stream()), "sd_op_absmax")
 
 
 def gemm_tn_grouped(problems) -> None:

@@ -212,7 +212,8 @@ def test_gemm_tn_grouped_matches_fp64(ops):
     """Several weight gradients in one launch with one scale per operand tensor: column-slice operands, ragged row counts,
     rows whose magnitudes differ by 10^4, accumulation onto existing contents, optional bias gradient."""
     g = torch.Generator().manual_seed(0)
-    cases = [(1000, 256, 256, True), (77, 384, 128, False), (2816, 512, 256, True), (25, 128, 128, True)]
+    cases = [(1000, 256, 256, True), (77, 384, 128, False), (2816, 512, 256, True), (25, 128, 128, True),
+             (1500, 20, 256, True), (1500, 256, 20, True), (333, 132, 68, False)]   # ragged tiles: the J = 20 gradients
     probs, wants, keep = [], [], []
     for i, (R, N, K, bias) in enumerate(cases):
         rowscale = torch.exp(torch.randn(R, 1, generator=g) * 2.3)            # e^(+-2.3 sigma): four decades between rows
@@ -243,7 +244,12 @@ def test_gemm_tn_grouped_matches_fp64(ops):
     for o in outs:
         assert rel_err(o, want) < 1e-5
     with pytest.raises(RuntimeError):
-        ops.gemm_tn_grouped([(dY[:, :100], X, outs[0], None, ay.data_ptr(), ax.data_ptr())])   # N not a multiple of 128
+        ops.gemm_tn_grouped([(dY[:, :102], X, outs[0], None, ay.data_ptr(), ax.data_ptr())])   # N not a multiple of 4
+    # sd_op_absmax: the words of an operand that no chain produced
+    words = torch.zeros(64, dtype=torch.int32, device="cuda")
+    big = torch.randn(700, 260, generator=g).cuda()
+    ops.absmax(big[:, 4:24], words.data_ptr())
+    assert float(words.view(torch.float32).max()) == float(big[:, 4:24].abs().max())
 
 
 def test_small_k_matmul_and_colsum(ops):
