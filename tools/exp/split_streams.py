@@ -12,10 +12,11 @@ packed = ops.pack_denoiser(sd, dev, max_len=T)
 ts = ops.ddim_timesteps(N); coef = ops.ddim_coefficients(ts, ops.alphas_cumprod(), N)
 toks = ops.step_token(torch.tensor(ts, device=dev), ops.step_frequencies(D).to(dev), sd["step_encoding.token"].to(dev)).reshape(N, D).contiguous()
 lib = _lib.load()
-for B in (256, 512):
+REPS = int(os.environ.get("SPLIT_REPS", "10"))
+for B in tuple(int(b) for b in os.environ.get("SPLIT_B", "256,512").split(",")):
     x_T = torch.randn(B, T, J, device=dev); ctx = torch.randn(B, MC, D, device=dev)
     ref = ops.ddim_sample(packed, ctx, toks, coef, x_T)
-    for k in (1, 2, 4):
+    for k in tuple(int(v) for v in os.environ.get("SPLIT_K", "1,2,4").split(",")):
         bs = B // k
         xs = [torch.zeros(bs, T, J, device=dev) for _ in range(k)]
         cs = [ctx[i * bs:(i + 1) * bs].contiguous() for i in range(k)]
@@ -42,8 +43,8 @@ for B in (256, 512):
         g.replay(); torch.cuda.synchronize()
         same = torch.equal(torch.cat(xs), ref)
         t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(REPS):
             g.replay()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
+        dt = (time.perf_counter() - t0) / REPS
         print(f"B={B} streams={k}: {dt * 1e3:.2f} ms per rollout -> {B / dt:.0f} traj/s   (close to unsplit: {float((torch.cat(xs) - ref).abs().max()):.2e}, identical {same})", flush=True)
