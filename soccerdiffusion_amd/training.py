@@ -27,10 +27,6 @@ from . import ops
 Tensor = torch.Tensor
 
 
-def _zeros_like_param(p: Tensor) -> Tensor:
-    return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
-
-
 class _GradSink:
     """Where a block's parameter gradients go.  When the parameters' ``.grad`` buffers are
     preallocated (FusedAdamW aliases them to one flat buffer and zeroes it per step), the
