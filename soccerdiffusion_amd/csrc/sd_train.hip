@@ -1600,13 +1600,17 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
 // of two per workgroup (abs-max), P 2^10, dS one power of two per lane = per query (A) / per key (B) - constant over the
 // contraction, as a scale must be.  With dropout, pass A leaves its masks in LDS as bits for pass B (one Philox call per
 // 4 consecutive keys of a query; in B those sit on 4 different lanes).
-// Measured at B = 256, T = S = 100 (tools/exp/attbwd_time.py): 160.6 -> 115 us per call; of the 115, staging the five arrays is
-// 34 us (131 MB at 3.9 TB/s; 140 KB of LDS = one workgroup per CU, so nothing overlaps it), pass A 32 us, pass B 51 us - the
-// VALU work around the 336 MFMAs per wave (exponentials, per-element splits) is about as long as the MFMAs themselves.
+// Measured at B = 256, T = S = 100 (tools/exp/attbwd_time.py): 160.6 -> 115 us per call with all four images resident (140 KB
+// of LDS = ONE workgroup per CU: of the 115, staging the five arrays was 34 us with nothing to overlap it, pass A 32 us, pass B
+// 51 us - the VALU work around the 336 MFMAs per wave is about as long as the MFMAs themselves).
+// Only TWO images are resident at a time now (72 KB, two workgroups per CU, 256 registers): a pass needs the other two images
+// only as "this lane's own row" fragments, which live in registers.  Q, dO are staged first and every lane takes its row
+// fragments; K, V replace them for pass A; before pass B every lane takes its own K, V row fragments and the waves write Q, dO
+// back from the fragments they kept.  An aliasing ablation had promised 116 -> 70 us; measured: see DESIGN.md 5.10.
 // ======================================================================================
 constexpr int AB_P = 136;                 // halfs per image row: hi[64] | lo[64] | 8 pad
 constexpr float AB_QKV = 8.0f, AB_PS = 1024.0f;
-constexpr size_t AB_LDS = (size_t)4 * 128 * AB_P * sizeof(f16) + 3 * 128 * sizeof(float) + 128 * 4 * sizeof(unsigned);
+constexpr size_t AB_LDS = (size_t)2 * 128 * AB_P * sizeof(f16) + 3 * 128 * sizeof(float) + 128 * 4 * sizeof(unsigned);
 
 __device__ __forceinline__ f16x8 ab_tr(const f16 *plane, int r16, int col0, int lane) {
     // 8 rows {r16 + 4 half + 0..3, r16 + 8 + 4 half + 0..3} (the k order of an accumulator used as the B operand) of column
@@ -1629,15 +1633,16 @@ __device__ __forceinline__ f32x16 ab_mfma3(const f16x8 &ah, const f16x8 &al, con
 __device__ __forceinline__ float ab_pow2_scale(float m) { return f16_scale_from_bits(__builtin_bit_cast(unsigned, m)); }
 
 template <bool DROP>
-__global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ k,
+__global__ __launch_bounds__(256, 2) void attention_bwd16_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ k,
                                                                const float *__restrict__ v, int ldkv, const float *__restrict__ o, int ldo,
                                                                const float *__restrict__ dO, int lddo, const float *__restrict__ lse2,
                                                                float *dq, int lddq, float *dk, float *dv, int lddkv, int Tq, int S,
                                                                int heads, float scale, DropoutArgs da) {
     constexpr int HD = 64;
     extern __shared__ __attribute__((aligned(16))) f16 ab_smem[];
-    f16 *sQ = ab_smem, *sK = sQ + 128 * AB_P, *sV = sK + 128 * AB_P, *sdO = sV + 128 * AB_P;
-    float *sLse = reinterpret_cast<float *>(sdO + 128 * AB_P), *sDelta = sLse + 128, *sRed = sDelta + 128;
+    f16 *img0 = ab_smem, *img1 = img0 + 128 * AB_P;   // {Q, dO} -> {K, V} (pass A) -> {Q, dO} (pass B)
+    f16 *sQ = img0, *sdO = img1, *sK = img0, *sV = img1;
+    float *sLse = reinterpret_cast<float *>(img1 + 128 * AB_P), *sDelta = sLse + 128, *sRed = sDelta + 128;
     unsigned *sMask = reinterpret_cast<unsigned *>(sRed + 128);   // [128 queries][4 words]: bit = key kept
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -1686,18 +1691,12 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__res
     __syncthreads();
     const float s_do = ab_pow2_scale(fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3])));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i) {   // Q, dO first: every lane takes its own row out of them below
         const int idx = tid + 256 * i, row = idx >> 4, c4 = (idx & 15) * 4;
         f16x4 hh, ll;
         f16_split4(qv[i], AB_QKV, hh, ll);
         *reinterpret_cast<f16x4 *>(sQ + row * AB_P + c4) = hh;
         *reinterpret_cast<f16x4 *>(sQ + row * AB_P + HD + c4) = ll;
-        f16_split4(kv[i], AB_QKV, hh, ll);
-        *reinterpret_cast<f16x4 *>(sK + row * AB_P + c4) = hh;
-        *reinterpret_cast<f16x4 *>(sK + row * AB_P + HD + c4) = ll;
-        f16_split4(vv[i], AB_QKV, hh, ll);
-        *reinterpret_cast<f16x4 *>(sV + row * AB_P + c4) = hh;
-        *reinterpret_cast<f16x4 *>(sV + row * AB_P + HD + c4) = ll;
         f16_split4(dov[i], s_do, hh, ll);
         *reinterpret_cast<f16x4 *>(sdO + row * AB_P + c4) = hh;
         *reinterpret_cast<f16x4 *>(sdO + row * AB_P + HD + c4) = ll;
@@ -1705,12 +1704,36 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__res
     if (DROP)
         for (int i = tid; i < 128 * 4; i += 256) sMask[i] = 0u;
     __syncthreads();
+    const int mine = wave * 32 + (lane & 31);            // this lane's query (pass A) / key (pass B)
+    f16x8 qh[4], ql[4], doh[4], dol[4];                  // this lane's own Q / dO row: B operands of pass A, and what pass B's images
+    {                                                    // are rebuilt from
+        const f16 *pq = sQ + mine * AB_P + 8 * (lane >> 5), *pd = sdO + mine * AB_P + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qh[ks] = *reinterpret_cast<const f16x8 *>(pq + ks * 16);
+            ql[ks] = *reinterpret_cast<const f16x8 *>(pq + HD + ks * 16);
+            doh[ks] = *reinterpret_cast<const f16x8 *>(pd + ks * 16);
+            dol[ks] = *reinterpret_cast<const f16x8 *>(pd + HD + ks * 16);
+        }
+    }
+    __syncthreads();   // every lane has its row: K, V take the two images over
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, c4 = (idx & 15) * 4;
+        f16x4 hh, ll;
+        f16_split4(kv[i], AB_QKV, hh, ll);
+        *reinterpret_cast<f16x4 *>(sK + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sK + row * AB_P + HD + c4) = ll;
+        f16_split4(vv[i], AB_QKV, hh, ll);
+        *reinterpret_cast<f16x4 *>(sV + row * AB_P + c4) = hh;
+        *reinterpret_cast<f16x4 *>(sV + row * AB_P + HD + c4) = ll;
+    }
+    __syncthreads();
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c_s = sl2e / (AB_QKV * AB_QKV);          // raw score accumulator -> log2-domain score
     const float c_dp = 1.0f / (AB_QKV * s_do);           // raw dP accumulator -> dP
     const int n_kt = (S + 31) / 32, n_qt = (Tq + 31) / 32;
-    const int mine = wave * 32 + l31;                    // this lane's query (pass A) / key (pass B)
 
     // fragments of this lane's own row of two images: B operands (k = 8 half + j of k-step ks)
     auto row_frags = [&](const f16 *img, f16x8 (&fh)[4], f16x8 (&fl)[4]) {
@@ -1790,9 +1813,6 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__res
 
     // ================= pass A: this wave's queries; dQ =================
     if (wave * 32 < Tq) {
-        f16x8 qh[4], ql[4], doh[4], dol[4];
-        row_frags(sQ, qh, ql);
-        row_frags(sdO, doh, dol);
         const bool q_ok = mine < Tq;
         const float lse = sLse[q_ok ? mine : 0], delta = sDelta[q_ok ? mine : 0];
         f32x16 ds[4];
@@ -1833,13 +1853,25 @@ __global__ __launch_bounds__(256) void attention_bwd16_kernel(const float *__res
         contract(sK, ds, n_kt, s_q, dqT);
         store_T(dq + (long)b * Tq * lddq + h * HD, lddq, Tq, dqT, 1.0f / (AB_QKV * s_q));
     }
-    if (DROP) __syncthreads();   // mask bits complete
+    // ---- the images change hands: every lane takes its own K / V row, then Q / dO come back from the kept fragments ----
+    f16x8 kh[4], kl[4], vh[4], vl[4];
+    row_frags(sK, kh, kl);
+    row_frags(sV, vh, vl);
+    __syncthreads();   // pass A is done with K, V everywhere (and its mask bits are complete)
+    {
+        f16 *pq = sQ + mine * AB_P + 8 * half, *pd = sdO + mine * AB_P + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            *reinterpret_cast<f16x8 *>(pq + ks * 16) = qh[ks];
+            *reinterpret_cast<f16x8 *>(pq + HD + ks * 16) = ql[ks];
+            *reinterpret_cast<f16x8 *>(pd + ks * 16) = doh[ks];
+            *reinterpret_cast<f16x8 *>(pd + HD + ks * 16) = dol[ks];
+        }
+    }
+    __syncthreads();
 
     // ================= pass B: this wave's keys; dK, dV =================
     if (wave * 32 < S) {
-        f16x8 kh[4], kl[4], vh[4], vl[4];
-        row_frags(sK, kh, kl);
-        row_frags(sV, vh, vl);
         const bool k_ok = mine < S;
         f32x16 pd[4], ds[4];
         float dsmax = 0.f;
