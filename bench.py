@@ -368,7 +368,7 @@ def run_train(args, rank, world, dev, dist):
         "metric": "training trajectories/s (fwd + bwd + AdamW per trajectory; denoiser d=256 L=4, H=100, J=20)",
         "value": rec["value"], "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; the 11-key cross-attention backward on the fp32 MFMA)",
+        "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{1 if world == 1 else 3}]: one training step (add_noise, forward, MSE, backward, "
                                f"{'RCCL all-reduce of the flat fp32 gradient, ' if world > 1 else ''}AdamW, OneCycleLR) of the transformer "

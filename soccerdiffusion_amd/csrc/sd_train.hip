@@ -1932,9 +1932,9 @@ extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float 
         static const char *env = getenv("SD_ATT_BWD");
         auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         const bool lds_ok = ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddkv % 4 == 0;
-        // (up to 32 keys - the cross-attention over 11 memory rows - only one wave would own keys in pass B: the fp32 kernel is
-        // faster there, 60 vs 83 us at B = 256)
-        if (hd == 64 && Tq <= 128 && S > 32 && S <= 128 && lds_ok && al16(q) && al16(k) && al16(v) && al16(o) && al16(dO) && al16(dq) && al16(dk) &&
+        // (up to 32 keys - the cross-attention over 11 memory rows - only one wave owns keys in pass B; with one workgroup per CU
+        // the fp32 kernel was faster there, 60 vs 83 us at B = 256; with two it is 54 vs 62)
+        if (hd == 64 && Tq <= 128 && S <= 128 && lds_ok && al16(q) && al16(k) && al16(v) && al16(o) && al16(dO) && al16(dq) && al16(dk) &&
             al16(dv) && !(env && strcmp(env, "f32") == 0)) {
             static bool attr_set = false;
             if (!attr_set) {
