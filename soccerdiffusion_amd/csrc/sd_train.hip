@@ -634,6 +634,9 @@ struct TnGroup {
 #ifndef SD_TNG_OCC
 #define SD_TNG_OCC 2
 #endif
+#ifndef SD_TNG_SETS
+#define SD_TNG_SETS 4
+#endif
 #ifndef SD_TNG_WGS
 #define SD_TNG_WGS 512
 #endif
@@ -673,7 +676,11 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
     const float *yp = P.dY + (rbeg + srow) * (long)P.ldy + n0 + scol, *xp = P.X + (rbeg + srow) * (long)P.ldx + k0 + scol;
     const long ystep = 8L * P.ldy, xstep = 8L * P.ldx;
     int left = (int)(rend - rbeg) - srow;    // rows from this thread's first row of the NEXT slab to load to the chunk's end
+#if SD_TNG_SETS == 2
+    f32x4 y0[2], x0[2], y1[2], x1[2];
+#else
     f32x4 y0[2], x0[2], y1[2], x1[2], y2[2], x2[2], y3[2], x3[2];   // four slabs of loads: three in flight behind the one being split
+#endif
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     // Straight-line loads: rows past the chunk's end (the ragged last slab, the prefetches behind it) read the chunk's first
     // row instead and are zeroed when they are split.  Any control flow around the loads - per-lane predicates, or a
@@ -750,6 +757,21 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
         acc[0][0][0] += (float)ah[0][0] + (float)al[1][1] + (float)bh[0][2] + (float)bl[1][3] + (float)ah[1][4] + (float)al[0][5] + (float)bh[1][6] + (float)bl[0][7];
 #endif
     };
+#if SD_TNG_SETS == 2   // one slab of loads in flight behind the one being split: 56 registers fewer, three workgroups per CU
+    load(y0, x0);
+    load(y1, x1);
+    split(y0, x0, sT[0]);
+    for (int s = 0; s < n_slabs; s += 2) {   // slabs past the end are zeros: the loop body is branch-free
+        __syncthreads();   // buffer 0 holds slab s; every wave is done reading buffer 1
+        load(y0, x0);
+        mfma(sT[0]);
+        split(y1, x1, sT[1]);
+        __syncthreads();   // buffer 1 holds slab s + 1; every wave is done reading buffer 0
+        load(y1, x1);
+        mfma(sT[1]);
+        split(y0, x0, sT[0]);
+    }
+#else
     load(y0, x0);
     load(y1, x1);
     load(y2, x2);
@@ -772,6 +794,7 @@ __global__ __launch_bounds__(256, SD_TNG_OCC) void gemm_tn16g_kernel(TnGroup g) 
         mfma(sT[1]);
         split(y0, x0, sT[0]);
     }
+#endif
     const float un = 1.0f / (sy * sx);
     float *dW = P.dW;
     const int ldw = P.ldw;
