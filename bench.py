@@ -174,6 +174,38 @@ def cpu_baseline(sd, seconds_budget=25.0):
     }
 
 
+def cpu_baseline_train(sd, seconds_budget=15.0):
+    """The same contract for --mode train: the oracle's training step (forward, MSE, torch CPU autograd backward; no optimizer:
+    AdamW on 2.6 M parameters is noise next to it) at p = 0 on a bounded sample - B = 32 trajectories per step, as many steps as
+    the budget allows after one warm-up step, at the thread count the box's CPU share allows."""
+    import torch
+    from oracle import ddim_ref
+    from oracle import denoiser_ref as ref
+
+    quota = cpu_quota()
+    threads = max(1, min(int(quota), physical_cores()))
+    torch.set_num_threads(threads)
+    Bc = 32
+    g = torch.Generator().manual_seed(4321)
+    x0, eps = torch.randn(Bc, T, J, generator=g), torch.randn(Bc, T, J, generator=g)
+    ctx = torch.randn(Bc, MC, D, generator=g)
+    t = torch.randint(0, 1000, (Bc,), generator=g)
+    x_t = ddim_ref.add_noise(x0, eps, t, ddim_ref.alphas_cumprod())
+    ref.train_loss_and_grads(sd, x_t, t, eps, context=[ctx])   # warm-up
+    t0, done = time.perf_counter(), 0
+    while True:
+        ref.train_loss_and_grads(sd, x_t, t, eps, context=[ctx])
+        done += 1
+        if time.perf_counter() - t0 > seconds_budget or done >= 400:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * done / dt, 3), "unit": "trajectories/s", "cores": threads, "kind": "port",
+            "seconds_per_step": round(dt / done, 4),
+            "sample": f"{done} training steps of B={Bc} trajectories after warm-up (forward + MSE + backward of the d={D}, L={L}, T={T}, "
+                      f"J={J}, M={M} denoiser at p = 0, oracle/denoiser_ref.py under torch CPU autograd, fp32, {threads} torch threads; "
+                      f"cgroup CPU quota {quota:g})"}
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, rendezvous on
     127.0.0.1) before this process makes any GPU call, and hand their exit code back."""
@@ -384,6 +416,10 @@ def run_train(args, rank, world, dev, dist):
         "train": rec,
         "cpu_baseline": None,
     }
+    if not args.no_cpu_baseline and world == 1:
+        from soccerdiffusion_amd.synthetic import synthetic_state_dict
+
+        line["cpu_baseline"] = cpu_baseline_train(synthetic_state_dict(D, J, L, seed=7))
     print(json.dumps(line), flush=True)
 
 
