@@ -331,6 +331,9 @@ _AMAX_REG: dict = {}
 
 def _amax_register(t: Tensor, table: Tensor, slot_addr: int, scratch_addr: int) -> None:
     import weakref
+    if len(_AMAX_REG) > 256:   # entries of finished steps
+        for k in [k for k, v in _AMAX_REG.items() if v[0]() is None]:
+            del _AMAX_REG[k]
     _AMAX_REG[t.data_ptr()] = (weakref.ref(table), slot_addr, scratch_addr)
 
 
