@@ -55,7 +55,7 @@ def _mask(ops, R, d, p, seed, site):
     return ops.dropout_mask(R, d, (p, seed, site), "cuda").cpu().double()
 
 
-@pytest.mark.parametrize("d,R,p", [(256, 200, 0.0), (256, 130, 0.1), (128, 64, 0.1), (64, 77, 0.0), (64, 1, 0.25)])
+@pytest.mark.parametrize("d,R,p", [(256, 200, 0.0), (256, 130, 0.1), (128, 64, 0.1), (64, 77, 0.0), (64, 1, 0.25), (128, 1003, 0.1), (256, 4100, 0.0)])
 def test_forward_chain_feed_forward_block(ops, d, R, p):
     s = 1 / math.sqrt(d)
     a, h = _rand(R, d, seed=1), _rand(R, d, seed=2)
@@ -114,7 +114,7 @@ def test_forward_chain_feed_forward_block(ops, d, R, p):
     assert rel_err(outH["y_out"], (nh @ D(Wn).t() + D(bn)).float()) < TOL
 
 
-@pytest.mark.parametrize("d,R,p", [(256, 200, 0.0), (256, 130, 0.1), (128, 65, 0.1), (64, 77, 0.0)])
+@pytest.mark.parametrize("d,R,p", [(256, 200, 0.0), (256, 130, 0.1), (128, 65, 0.1), (64, 77, 0.0), (64, 999, 0.1), (256, 4100, 0.1)])
 def test_backward_chains(ops, d, R, p):
     s = 1 / math.sqrt(d)
     seed, sites = 5, (2001, 2002)
