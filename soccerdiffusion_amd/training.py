@@ -680,8 +680,9 @@ class _FusedLayer(Function):
                 dws.append((dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:], cfg.ax(_AX_DKV), cfg.ax_mem))
             else:
                 _dw(dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:])
-            if ctx.needs_input_grad[3]:
-                dmem = _dx_through_weight(dkv.view(B * M, 2 * d), Wc[d:]).view(memory.shape)
+            if ctx.needs_input_grad[3]:   # (the learned half of the step token sits in the memory): both column passes in one launch
+                dmem = _new(*memory.shape, like=h)
+                ops.train_bwd_chain(B * M, d, dkv.view(B * M, 2 * d), wT(Wc, 1), dmem.view(B * M, d), passes=2)
             dh1 = _new(B, T, d, like=h)
             ops.train_bwd_chain(R, d, dq.view(R, d), wT(Wc), dh1, x=h1, ln_w=n2w, dres=dh2, dg=g["norm2.weight"], db=g["norm2.bias"],
                                 amax=(cfg.ax(_AX_DQ), None))
