@@ -579,6 +579,22 @@ def _new(*shape, like: Tensor) -> Tensor:
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
 
+# The memory side of a decoder layer - K/V projection of 11 rows per trajectory, its dX, the abs-max of dkv - is 44 panels per
+# launch: 12 launches of ~17 us per step that leave five CUs in six idle.  They run on a second stream (a parallel branch of the
+# captured graph) beside the 400-panel chains of the trajectory rows and are joined where their results are needed.
+# SD_TRAIN_MEM_SIDE=0 keeps them in line.
+_MEM_SIDE: dict = {}
+
+
+def _mem_side(device):
+    if os.environ.get("SD_TRAIN_MEM_SIDE", "1") == "0":
+        return None
+    s = _MEM_SIDE.get(device)
+    if s is None:
+        s = _MEM_SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class _FusedLayer(Function):
     """One pre-norm transformer layer (nn.TransformerDecoderLayer with memory, nn.TransformerEncoderLayer without) given
     (h, LN1(h), qkv = LN1(h) Wqkv^T + b); returns (h', LN1'(h'), qkv') for the next layer (empty tensors after the last)."""
@@ -594,6 +610,18 @@ class _FusedLayer(Function):
         else:
             (n1w, n1b, Wqkv, bqkv, Wo, bo, nfw, nfb, W1, b1, W2, b2) = P
         h = h.contiguous()
+        side = None
+        if dec:   # the memory's K/V projection beside the self-attention and chain A
+            M = memory.shape[1]
+            mem2 = memory.reshape(B * M, d)
+            kv = _new(B, M, 2 * d, like=h)
+            side = _mem_side(h.device)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:], out=kv.view(B * M, 2 * d))
+            else:
+                ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:], out=kv.view(B * M, 2 * d))
         a_sa, lse_sa = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
         saved_c = ()
         if dec:
@@ -601,9 +629,8 @@ class _FusedLayer(Function):
             ops.train_fwd_chain(R, d, h, a=a_sa, wo=_packed_weight(Wo), bo=bo, h_out=h1, nln=(n2w, n2b), nn_out=n2,
                                 wn=_packed_weight(Wc), bn=bc, y_out=q, n_next=1, p=p, seed=seed, sites=(cfg.site(SITE_SA_OUT), 0, 0),
                                 amax=(cfg.ax(_AX_ASA), None, None, cfg.ax(_AX_N2)))
-            M = memory.shape[1]
-            mem2 = memory.reshape(B * M, d)
-            kv = ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:]).view(B, M, 2 * d)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             a_ca, lse_ca = ops.attention_lse(q, kv[..., :d], kv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
             a_in, w_in, b_in, h_res, site_out, ax_a = a_ca, Woc, boc, h1, cfg.site(SITE_CA_OUT), _AX_ACA
             saved_c = (h1, n2, q, kv, a_ca, lse_ca)
@@ -675,14 +702,19 @@ class _FusedLayer(Function):
             ops.attention_bwd(q, kv[..., :d], kv[..., d:], a_ca, da, lse_ca, dq, dkv[..., :d], dkv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
             M = memory.shape[1]
             gWc, gbc = g["multihead_attn.in_proj_weight"], g["multihead_attn.in_proj_bias"]
-            if grouped:
-                ops.absmax(dkv.view(B * M, 2 * d), cfg.ax(_AX_DKV))
-                dws.append((dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:], cfg.ax(_AX_DKV), cfg.ax_mem))
-            else:
-                _dw(dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:])
-            if ctx.needs_input_grad[3]:   # (the learned half of the step token sits in the memory): both column passes in one launch
+            if ctx.needs_input_grad[3]:   # (the learned half of the step token sits in the memory)
                 dmem = _new(*memory.shape, like=h)
-                ops.train_bwd_chain(B * M, d, dkv.view(B * M, 2 * d), wT(Wc, 1), dmem.view(B * M, d), passes=2)
+            mside = _mem_side(h.device)
+            if mside is not None:
+                mside.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(mside if mside is not None else torch.cuda.current_stream()):
+                if grouped:
+                    ops.absmax(dkv.view(B * M, 2 * d), cfg.ax(_AX_DKV))
+                    dws.append((dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:], cfg.ax(_AX_DKV), cfg.ax_mem))
+                else:
+                    _dw(dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:])
+                if dmem is not None:   # both column passes in one launch
+                    ops.train_bwd_chain(B * M, d, dkv.view(B * M, 2 * d), wT(Wc, 1), dmem.view(B * M, d), passes=2)
             dh1 = _new(B, T, d, like=h)
             ops.train_bwd_chain(R, d, dq.view(R, d), wT(Wc), dh1, x=h1, ln_w=n2w, dres=dh2, dg=g["norm2.weight"], db=g["norm2.bias"],
                                 amax=(cfg.ax(_AX_DQ), None))
@@ -705,6 +737,8 @@ class _FusedLayer(Function):
         if cfg.li == 0:   # the gradient of the stack's input feeds the embedding's weight gradient
             _amax_register(dh, cfg.amax, cfg.ax(_AX_DX), cfg.ax(_AX_SCR2))
         dws.append((dqkv.view(R, 3 * d), n1, g["self_attn.in_proj_weight"], g["self_attn.in_proj_bias"], cfg.ax(_AX_DQKV), cfg.ax(_AX_N1)))
+        if dec and _mem_side(h.device) is not None:
+            torch.cuda.current_stream().wait_stream(_mem_side(h.device))   # dmem and the abs-max of dkv
         if grouped:
             side = _SIDE["stream"]
             if side is None:
