@@ -652,6 +652,7 @@ class _FusedLayer(Function):
             _amax_register(h3, cfg.amax, cfg.ax(_AX_OUT), cfg.ax(_AX_SCR))
         ctx.cfg = cfg
         ctx.n_c = len(saved_c)
+        ctx.set_materialize_grads(False)   # LN1'(h') and qkv' carry no gradient: autograd would hand zeros of their size to backward
         ctx.save_for_backward(h, n1, qkv, memory if dec else None, a_sa, lse_sa, h2, nf, pre, u, *saved_c, *P)
         ctx.mark_non_differentiable(nn1, qkv2)
         return h3, nn1, qkv2
@@ -677,6 +678,8 @@ class _FusedLayer(Function):
         g = dict(zip(_DEC_PARAMS if dec else _ENC_PARAMS, G))
         nf_name = "norm3" if dec else "norm2"
         wT = lambda W, blk=0: _packed_weight(W, blk, transposed=True)   # noqa: E731
+        if dh3 is None:   # (gradients are not materialised: an unused layer output)
+            dh3 = torch.zeros_like(h)
         dh3 = dh3.contiguous()
         dh3_2 = dh3.view(R, d)
 
