@@ -64,6 +64,16 @@ def executed_flops_per_traj():
             "rollout": N_DDIM * (layer_chain + head + attn) + once}
 
 
+def traj_step_flops_per_traj_step():
+    """Sampler mode 3 (csrc/sd_traj.h): one launch per DDIM step owns everything of SURVEY 8(d)'s F_step except the memory K/V
+    projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product, on 7 token tiles of
+    16 (T = 100 padded to 112), the cross-attention in its folded form."""
+    f = flops_per_traj_step()
+    per_layer = 4 * (84 * 8 + 49 * 2 + 28 * 4 + 112 * 2) + 28 * 8 + 112 * 3 + 2 * 112 * 8   # products of 16x16x32 tiles
+    mfma = 3 * (L * per_layer + 16 * 7 + 14 * 8)                                                # + embedding + fc_out
+    return {"algorithmic": f["total"] - f["kv"], "executed": mfma * 16384.0, "mfma_instructions": mfma}
+
+
 def layer_kernel_algorithmic_flops_per_traj_step(merged: bool):
     """SURVEY §8(d) FLOPs owned by the L launches of the layer kernel in one DDIM step, per trajectory: all row GEMMs
     of the reference algorithm (16 T d^2 per layer, the two cross-attention projections the fold removes INCLUDED -
@@ -501,7 +511,7 @@ def run_sample(args, rank, world, dev, dist):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if mode != 2 else
+        "dtype": "f32" if mode < 2 else
                  "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate: 22-bit operands; "
                  "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
         "data": "synthetic",
@@ -525,6 +535,8 @@ def sample_roofline(ms, cnt, steps, B, elapsed, mode):
     from soccerdiffusion_amd import _lib
 
     names = _lib.KERNEL_CLASSES
+    if mode == 3:
+        return traj_roofline(ms, cnt, steps, B, elapsed)
     dl = names.index("decoder_layer_kernel")
     at = names.index("attention_kernel")
     f = flops_per_traj_step()
@@ -597,6 +609,66 @@ def sample_roofline(ms, cnt, steps, B, elapsed, mode):
     }
 
 
+def traj_roofline(ms, cnt, steps, B, elapsed):
+    """Roofline record of sampler mode 3: ONE kernel (traj_step_kernel) per DDIM step carries a trajectory through the
+    whole denoiser step, so the dominant kernel IS the path."""
+    from soccerdiffusion_amd import _lib
+
+    names = _lib.KERNEL_CLASSES
+    k = names.index("traj_step_kernel")
+    f = flops_per_traj_step()
+    tf = traj_step_flops_per_traj_step()
+    launches = max(int(cnt[k]), 1)
+    k_s = ms[k] / 1e3
+    avg_s = k_s / launches
+    alg_flops = steps * B * N_DDIM * tf["algorithmic"]
+    achieved = alg_flops / k_s / 1e12
+    executed = steps * B * N_DDIM * tf["executed"] / k_s / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS
+    # this design's own bytes per launch: x in + out, the folded cross-attention planes and score biases of every layer
+    # (per trajectory), the split weights once
+    design_bytes = B * (2 * T * J * 4 + L * (2 * 4 * 16 * D * 2 * 2 + 64 * 4)) + L * 6 * D * D * 4 + 2 * 32 * D * 4
+    fused_alg_bytes_per_step = B * FUSED_BYTES_PER_TRAJ_STEP + 10.59e6
+    prof = profiles_record()
+    traffic = prof.get("traj_step_kernel_bytes_per_launch") if prof else None
+    hbm = {"algorithmic_bytes_per_launch_this_design": design_bytes, "achieved": round(design_bytes / avg_s / 1e9, 1), "peak": PEAK_HBM_GBS,
+           "unit": "GB/s", "frac": round(design_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+           "fused_algorithmic_bytes_per_ddim_step": fused_alg_bytes_per_step,
+           "design_bytes_per_trajectory_step": round(design_bytes / B, 1)}
+    if traffic:
+        hbm["traffic_over_this_design"] = round(traffic / design_bytes, 3)
+        hbm["traffic_over_algorithmic"] = round(traffic / fused_alg_bytes_per_step, 1)
+        hbm["traffic_bytes_per_trajectory_step"] = round(traffic / B, 1)
+    return {
+        "bound": "mfma",
+        "kernel": "traj_step_kernel",
+        "achieved": round(achieved, 2),
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4),
+        "traffic": traffic,
+        "definition": "algorithmic FLOPs (SURVEY 8(d) F_step minus the memory K/V projection, which runs once per rollout) of the one "
+                      "launch per DDIM step / summed HIP-event durations of those launches",
+        "algorithmic_flops_per_launch_avg": alg_flops / launches,
+        "launches": launches,
+        "avg_launch_ms": round(avg_s * 1e3, 5),
+        "sampler_mode": "3: trajectory-owning step kernel (one workgroup per trajectory, self-attention inside; fp16x3 split-operand "
+                        "MFMA, fp32 accumulate, folded cross-attention)",
+        "mfma_pipe_occupancy": round(executed / peak, 4),
+        "executed_mfma_tflops": round(executed, 2),
+        "executed_mfma_flops_per_algorithmic_flop": round(tf["executed"] / tf["algorithmic"], 3),
+        "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
+        "hbm": hbm,
+        "kernel_time_share": {n: round(ms[i] / 1e3 / elapsed, 4) for i, n in enumerate(names)},
+        "whole_path": {
+            "achieved": round(steps * B * N_DDIM * f["total"] / elapsed / 1e12, 2),
+            "frac": round(steps * B * N_DDIM * f["total"] / elapsed / 1e12 / peak, 4),
+            "flops_per_trajectory": N_DDIM * f["total"],
+        },
+        "from_profiles": prof,
+    }
+
+
 def profiles_record():
     """Counter-derived figures read from the committed profile summaries (profiles/*.json): measured by rocprofv3 on
     ANOTHER box and run than this line, so they are evidence with provenance, not live measurements."""
@@ -606,6 +678,7 @@ def profiles_record():
         with open(p) as fh:
             t = json.load(fh)
         out["decoder_layer_kernel_bytes_per_launch"] = t.get("decoder_layer_kernel_bytes_per_launch")
+        out["traj_step_kernel_bytes_per_launch"] = t.get("traj_step_kernel_bytes_per_launch")
         out["attention_kernel_bytes_per_launch"] = t.get("attention_kernel_bytes_per_launch")
         if out["attention_kernel_bytes_per_launch"] is None:
             for k, v in t.get("per_kernel", {}).items():
@@ -617,8 +690,12 @@ def profiles_record():
     if os.path.exists(p):
         with open(p) as fh:
             s = json.load(fh)
-        out["mfma_busy_pmc"] = round(s["decoder_layer_kernel_mfma_busy"], 4)
-        out["effective_clock_ghz_pmc"] = round(s["decoder_layer_kernel_effective_clock_ghz"], 3)
+        if "traj_step_kernel_mfma_busy" in s:
+            out["mfma_busy_pmc"] = round(s["traj_step_kernel_mfma_busy"], 4)
+            out["effective_clock_ghz_pmc"] = round(s["traj_step_kernel_effective_clock_ghz"], 3)
+        else:
+            out["mfma_busy_pmc"] = round(s["decoder_layer_kernel_mfma_busy"], 4)
+            out["effective_clock_ghz_pmc"] = round(s["decoder_layer_kernel_effective_clock_ghz"], 3)
         out["sq_source"] = s.get("source")
         out["sq_round"] = s.get("round", "r01")
     if out:

@@ -104,7 +104,10 @@ size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
  *   0 = fp32 MFMA, per-step cross-attention projections;
  *   1 = fp32 MFMA with the cross-attention Q/out projections folded into the cached memory (heads 4, Mc + 1 <= 16, T >= 64);
  *   2 = mode 1 with every row GEMM and the self-attention as 3 fp16 MFMAs on split (hi + lo) operands, fp32
- *       accumulate (hidden_dim 256; SD_SAMPLER_GEMM=f32 in the environment selects mode 1 instead). */
+ *       accumulate (hidden_dim 256; SD_SAMPLER_GEMM=f32 in the environment selects mode 1 instead);
+ *   3 = mode 2's arithmetic in ONE launch per step: a workgroup owns a trajectory (embedding, every layer with its
+ *       self-attention, fc_out, DDIM update; q | k | v and the residual stream never leave the CU; soccerdiffusion_amd/csrc/
+ *       sd_traj.h).  hidden_dim 256, 4 heads, 96 < T <= 100, Mc + 1 <= 16, J <= 32, <= 8 layers; SD_SAMPLER_TRAJ=0 selects mode 2. */
 int sd_sampler_mode(int d, int heads, int T, int Mc, int J);
 
 /* StepToken.forward — soccer_diffusion/ml/model/misc.py:25-35.
@@ -167,7 +170,7 @@ int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *
  *     fp16 infinity, its products NaN, and the NaN stays in its trajectory down to x - so a set bit means "operand
  *     range of mode 2 exceeded (e.g. a LayerNorm weight in the thousands) or non-finite input", never silently wrong
  *     finite numbers.  No synchronisation: read the word after the stream has drained.
- *   max_mode: -1 = automatic (sd_sampler_mode); 0 / 1 / 2 = never use a mode above this one.  max_mode <= 1 also keeps
+ *   max_mode: -1 = automatic (sd_sampler_mode); 0 / 1 / 2 / 3 = never use a mode above this one.  max_mode <= 1 also keeps
  *     the memory K/V projections on the exact-fp32 MFMA: the rerun path after a set status bit
  *     (soccerdiffusion_amd.ops.ddim_sample_guarded does exactly that). */
 #define SD_STATUS_NONFINITE 1
@@ -376,7 +379,8 @@ int sd_set_dropout_epoch(const uint32_t *device_word);
 #define SD_KCLASS_FC_OUT 3       /* fc_out_kernel (+ fused DDIM update)                 */
 #define SD_KCLASS_LAYER_CHAIN 4  /* decoder_layer_kernel / chain_a_kernel / chain_b_kernel */
 #define SD_KCLASS_HEAD 5         /* decoder_head_kernel (embed + LN1 + QKV of layer 0)   */
-#define SD_KCLASS_COUNT 6
+#define SD_KCLASS_TRAJ_STEP 6    /* traj_step_kernel: one whole denoiser step per launch (sampler mode 3) */
+#define SD_KCLASS_COUNT 7
 int sd_profile_enable(int on);
 int sd_profile_collect(double *ms_by_class, long *launches_by_class, int n_classes);
 

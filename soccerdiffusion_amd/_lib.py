@@ -136,7 +136,8 @@ SIGNATURES = {
     "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }
 
-KERNEL_CLASSES = ("panel_gemm_kernel", "attention_kernel", "patch_embed_kernel", "fc_out_kernel", "decoder_layer_kernel", "decoder_head_kernel")
+KERNEL_CLASSES = ("panel_gemm_kernel", "attention_kernel", "patch_embed_kernel", "fc_out_kernel", "decoder_layer_kernel", "decoder_head_kernel",
+                  "traj_step_kernel")
 
 _lib = None
 

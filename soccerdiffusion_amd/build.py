@@ -17,7 +17,7 @@ REPO = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "sd_kernels.hip"), os.path.join(PKG, "csrc", "sd_train.hip"),
        os.path.join(PKG, "csrc", "sd_train_chain.hip")]
 HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG, "csrc", "sd_common.h"),
-       os.path.join(PKG, "csrc", "sd_panel.h"), os.path.join(PKG, "csrc", "sd_f16x3.h")]
+       os.path.join(PKG, "csrc", "sd_panel.h"), os.path.join(PKG, "csrc", "sd_f16x3.h"), os.path.join(PKG, "csrc", "sd_traj.h")]
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsoccerdiffusion_hip.so")
 ARCH = "gfx950"
@@ -35,8 +35,8 @@ def _obj(src: str) -> str:
 
 
 def _deps(src: str) -> list:
-    """sd_f16x3.h is included by sd_kernels.hip only, sd_panel.h not by sd_train.hip."""
-    hdr = [h for h in HDR if not (h.endswith("sd_f16x3.h") and not src.endswith("sd_kernels.hip"))
+    """sd_f16x3.h and sd_traj.h are included by sd_kernels.hip only, sd_panel.h not by sd_train.hip."""
+    hdr = [h for h in HDR if not ((h.endswith("sd_f16x3.h") or h.endswith("sd_traj.h")) and not src.endswith("sd_kernels.hip"))
            and not (h.endswith("sd_panel.h") and src.endswith("sd_train.hip"))]
     return [src] + hdr
 

@@ -1297,6 +1297,7 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
 }
 
 #include "sd_f16x3.h"
+#include "sd_traj.h"
 
 template <int D>
 static int launch_panel16(const float *A, int lda, const float *W, const float *bias, const float *ln_w, const float *ln_b,
@@ -2519,6 +2520,7 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
     float *gv, *cb, *gvstep, *cstep;   // folded cross-attention (sampler only)
     // fp16x3 operands of the sampler (sd_f16x3.h): split weights, folded blocks, scales
     f16 *wf, *g16, *v16, *gstep16, *vstep16;
+    f16 *wio;   // sampler mode 3 (sd_traj.h): embedding (256 x 32) and fc_out (32 x 256) planes
     float *scales;
     unsigned *maxbits;
     // split weights of the unfused row chains (chain_f16_kernel, hidden_dim 128 / 256 / 512): per layer
@@ -2558,7 +2560,7 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.gvstep = ws + off; off += align64((size_t)L * n_steps * 4 * 2 * d);
         s.cstep = ws + off; off += align64((size_t)L * n_steps * 4);
     }
-    s.wf = s.g16 = s.v16 = s.gstep16 = s.vstep16 = nullptr;
+    s.wf = s.g16 = s.v16 = s.gstep16 = s.vstep16 = s.wio = nullptr;
     s.scales = nullptr;
     s.maxbits = nullptr;
     if (n_steps > 0 && d == 256) {   // sizes in floats (2 halfs each)
@@ -2569,6 +2571,7 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.vstep16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * n_steps * 16 * d);
         s.scales = ws + off; off += align64((size_t)(L + 1) * 8);
         s.maxbits = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)(L + 1) * 8);
+        s.wio = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)2 * 32 * d);
     }
     s.wfc = nullptr;
     s.scc = nullptr;
@@ -2591,7 +2594,7 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
              align64((size_t)L * n_steps * 4);
     if (n_steps > 0 && d == 256)   // fp16x3 operands (sd_f16x3.h)
         n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
-             align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8);
+             align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8) + align64((size_t)2 * 32 * d);
     if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
     return n;
 }
@@ -2839,6 +2842,115 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
     return 0;
 }
 
+
+// ---- sampler mode 3: the trajectory-owning step kernel (sd_traj.h) ---------------------------------------
+// One launch per DDIM step: embedding, all layers (self-attention inside), fc_out and the DDIM update for one trajectory per
+// workgroup.  Same folded cross-attention blocks (gv, cb) and abs-max words as mode 2; the split planes are written in the
+// 16x16x32 fragment order of sd_traj.h into the same workspace regions.  SD_SAMPLER_TRAJ=0 in the environment keeps mode 2.
+static bool traj_ok(int d, int heads, int T, int Mk, int J, int L) {
+    static const char *env = getenv("SD_SAMPLER_TRAJ");
+    if (env && strcmp(env, "0") == 0) return false;
+    return d == 256 && heads == 4 && T > 96 && T <= tj::TMAX && Mk >= 1 && Mk <= 16 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+}
+
+static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
+    const int d = w->d, L = w->L;
+    const size_t gvstride = (size_t)B * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
+    // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' in words 4 and 5 of every layer
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
+        const int rows[4] = {d, d, d, 3 * d};
+        for (int m = 0; m < 4; ++m) {
+            SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)rows[m] * d)), dim3(256), 0, st, mats[m], (long)rows[m] * d, s.maxbits + l * 8 + m);
+            SD_CHECK_LAUNCH("f16_absmax_kernel");
+        }
+    }
+    SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)d * w->J)), dim3(256), 0, st, w->emb_w, (long)d * w->J, s.maxbits + L * 8 + 6);
+    SD_CHECK_LAUNCH("f16_absmax_kernel");
+    SD_LAUNCH(f16_absmax_kernel, dim3(grid_for((long)d * w->J)), dim3(256), 0, st, w->out_w, (long)d * w->J, s.maxbits + L * 8 + 7);
+    SD_CHECK_LAUNCH("f16_absmax_kernel");
+    SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)d * 4)), dim3(256), 0, st, w->emb_w, d, w->J, d, 32, s.maxbits + L * 8 + 6, 0.f, s.wio,
+              s.scales + L * 8 + 6);
+    SD_CHECK_LAUNCH("pack_w16_kernel");
+    SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)32 * d / 8)), dim3(256), 0, st, w->out_w, w->J, d, 32, d, s.maxbits + L * 8 + 7, 0.f,
+              s.wio + (size_t)2 * 32 * d, s.scales + L * 8 + 7);
+    SD_CHECK_LAUNCH("pack_w16_kernel");
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
+        const int rows[4] = {d, d, d, 3 * d};
+        unsigned *mb = s.maxbits + l * 8;
+        float *sc = s.scales + l * 8;
+        for (int m = 0; m < 4; ++m) {
+            SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)rows[m] * d / 8)), dim3(256), 0, st, mats[m], rows[m], d, rows[m], d, mb + m, 0.f,
+                      f16_wf(s, l, d, m), sc + m);
+            SD_CHECK_LAUNCH("pack_w16_kernel");
+        }
+        const size_t blk = (size_t)32 * d;   // halfs per (trajectory, head)
+        SD_LAUNCH(tj::pack_g16_kernel, dim3(grid_for((long)B * 4 * 16 * d / 8)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, Mc, mb + 4,
+                  s.g16 + (size_t)l * B * 4 * blk, sc + 4);
+        SD_CHECK_LAUNCH("pack_g16_kernel");
+        SD_LAUNCH(tj::pack_v16_kernel, dim3(grid_for((long)B * 16 * 2 * 64)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, Mc, mb + 5,
+                  s.v16 + (size_t)l * B * 4 * blk, sc + 5);
+        SD_CHECK_LAUNCH("pack_v16_kernel");
+        SD_LAUNCH(tj::pack_gstep16_kernel, dim3(grid_for((long)n_steps * 4 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_steps,
+                  mb + 4, s.gstep16 + (size_t)l * n_steps * 4 * blk, (float *)nullptr);
+        SD_CHECK_LAUNCH("pack_gstep16_kernel");
+        SD_LAUNCH(tj::pack_vstep16_kernel, dim3(grid_for((long)n_steps * 4 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_steps, mb + 5,
+                  s.vstep16 + (size_t)l * n_steps * blk);
+        SD_CHECK_LAUNCH("pack_vstep16_kernel");
+    }
+    return 0;
+}
+
+// one denoiser step + DDIM update in ONE launch (step index i selects the step-token blocks)
+static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
+                             const float *coef, hipStream_t st) {
+    const int d = w->d, L = w->L;
+    const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
+    tj::StepArgs a{};
+    a.x = x;
+    a.eps_out = nullptr;
+    a.w_emb = s.wio;
+    a.b_emb = w->emb_b;
+    a.pe = w->pe;
+    a.n1_w = w->layers[0].n1_w;
+    a.n1_b = w->layers[0].n1_b;
+    a.w_out = s.wio + (size_t)2 * 32 * d;
+    a.b_out = w->out_b;
+    a.sc_io = s.scales + L * 8 + 6;
+    a.c0 = coef[0]; a.c1 = coef[1]; a.c2 = coef[2]; a.c3 = coef[3];
+    a.scale_log2e = (1.0f / sqrtf((float)(d / w->heads))) * 1.44269504088896340736f;
+    a.T = T; a.B = B; a.J = w->J; a.L = L; a.Mk = Mc + 1; a.update_x = 1;
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        tj::LayerW &q = a.layer[l];
+        q.n2_w = lw.n2_w; q.n2_b = lw.n2_b; q.n3_w = lw.n3_w; q.n3_b = lw.n3_b;
+        q.w_o = f16_wf(s, l, d, 0); q.w_1 = f16_wf(s, l, d, 1); q.w_2 = f16_wf(s, l, d, 2); q.w_in = f16_wf(s, l, d, 3);
+        q.b_in = lw.sa_in_b; q.b_o = lw.sa_out_b; q.b_1 = lw.lin1_b; q.b_2 = lw.lin2_b; q.b_oc = lw.ca_out_b;
+        q.sc = s.scales + l * 8;
+        q.g16 = s.g16 + (size_t)l * B * 4 * blk;
+        q.v16 = s.v16 + (size_t)l * B * 4 * blk;
+        q.cb = s.cb + l * cbstride;
+        // per-layer regions as carved for mode 2 (n_steps * 4 * blk / n_steps * blk halfs), the step blocks packed densely inside
+        q.gstep = s.gstep16 + (size_t)l * n_steps * 4 * blk + (size_t)i * (4 * 8 * 2 * 32);
+        q.vstep = s.vstep16 + (size_t)l * n_steps * blk + (size_t)i * (2 * 4 * d);
+        q.cstep = s.cstep + ((size_t)l * n_steps + i) * 4;
+        q.nln_w = l + 1 < L ? w->layers[l + 1].n1_w : nullptr;
+        q.nln_b = l + 1 < L ? w->layers[l + 1].n1_b : nullptr;
+    }
+    ProfScope prof(SD_KCLASS_TRAJ_STEP, st);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)tj::traj_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
+        attr_set = true;
+    }
+    SD_LAUNCH(tj::traj_step_kernel, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, st, a);
+    SD_CHECK_LAUNCH("traj_step_kernel");
+    return 0;
+}
+
 // Encoder stack (self-attention + FFN layers): chain B with norm2 as the FFN norm.
 static int encoder_stack(const sd_layer_weights *layers, int L, const Scratch &s, int B, int n, int d, int heads,
                          hipStream_t st) {
@@ -2914,7 +3026,8 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
 extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
     const int Mk = Mc + 1;
     if (!(fold_ok(d, heads, T, Mk) && fused_layer_ok(d, heads, T, Mk))) return 0;
-    return f16_ok(d, J) ? 2 : 1;
+    if (!f16_ok(d, J)) return 1;
+    return traj_ok(d, heads, T, Mk, J, 1) ? 3 : 2;   // (the layer count is checked at the call: <= 8)
 }
 
 extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
@@ -2930,8 +3043,8 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
     if (rc) return rc;
     if (!step_tokens || !coef || !x || !workspace || B <= 0 || T <= 0 || Mc < 0 || n_steps <= 0 || (Mc > 0 && !ctx))
         return fail(SD_E_BADARG, "sd_ddim_sample: null pointer or empty shape");
-    if (max_mode < -1 || max_mode > 2) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode must be -1, 0, 1 or 2");
-    if (max_mode < 0) max_mode = 2;
+    if (max_mode < -1 || max_mode > 3) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode must be -1, 0, 1, 2 or 3");
+    if (max_mode < 0) max_mode = 3;
     if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T, L = w->L;
@@ -2944,6 +3057,7 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
     const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
     const bool f16 = max_mode >= 2 && fold && f16_ok(d, w->J) && s.wf != nullptr;
+    const bool traj = max_mode >= 3 && f16 && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wio != nullptr;
     const bool chain16 = max_mode >= 2 && !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
     if (status) {
         if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
@@ -2984,7 +3098,9 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
                       f16 ? s.maxbits + l * 8 + 5 : (unsigned *)nullptr);
             SD_CHECK_LAUNCH("xattn_fold_kernel");
         }
-        if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
+        if (traj) {
+            if ((rc = traj_prepare(w, s, B, Mc, n_steps, st))) return rc;
+        } else if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
     } else if (Mc > 0) {
         SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * Mc * 2 * d), L), dim3(256), 0, st, s.kvtmp, (long)B * Mc * 2 * d, s.kv,
                   (long)kvstride, B, Mc, Mk, 2 * d, 0);
@@ -2992,7 +3108,9 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
     }
     for (int i = 0; i < n_steps; ++i) {
         // this step's token row -> row Mc of every trajectory, all layers in one launch
-        if (f16) {
+        if (traj) {
+            if ((rc = decoder_step_traj(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st))) return rc;
+        } else if (f16) {
             if ((rc = decoder_stack_f16(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st))) return rc;
         } else if (fold) {
             SD_LAUNCH(fold_place_kernel, dim3(grid_for((long)B * 4 * 2 * d), L), dim3(256), 0, st, s.gvstep + (size_t)i * 4 * 2 * d,

@@ -1,0 +1,972 @@
+// Trajectory-owning decoder kernels of the sampler (hidden_dim 256, 4 heads, 96 < horizon <= 100, <= 16 memory rows): ONE
+// workgroup of 8 waves carries ONE trajectory through a whole denoiser step - embedding, every decoder layer with its
+// self-attention (reference: nn.TransformerDecoderLayer as built by soccer_diffusion/ml/model/decoder.py:26-35, norm_first;
+// forward of decoder.py:38-54), fc_out and the DDIM update - so the residual stream, q | k | v and the attention output
+// never leave the CU.  Same numerics as sd_f16x3.h: every product is three fp16 MFMAs on hi / lo operand pairs with fp32
+// accumulation; the cross-attention is the folded form of sd_kernels.hip (xattn_fold_kernel).
+//
+// Geometry.  Every row GEMM is computed TRANSPOSED, out^T[n][token] = W[n][:] . X[token][:], on v_mfma_f32_16x16x32_f16:
+// T = 100 pads to 7 token tiles of 16 (12 %; 32-row tiles would pad 28 %).  A = a 16-feature tile of W (fragment-major planes in
+// HBM / L2, 1 KiB per wave load), B = X^T from the LDS panel.  Wave w owns output features 32w .. 32w+31 (two n-tiles) of
+// all 7 token tiles: a weight fragment is read by exactly one wave and reused 7 times from registers.  The accumulator
+// has the token on the lane and 4 consecutive features in its registers, so
+//   * LayerNorm statistics come from the accumulators (mean and centred sum of squares of a wave's 32 features, combined
+//     over the 8 waves by Chan's formula through 6.4 KB of LDS) - no fp32 round trip of the panel;
+//   * the residual stream lives in registers for the whole step, pre-multiplied by the (power of two) scale of the
+//     GEMM that accumulates into it.
+// Self-attention, per head: [Q_h | K_h | V_h]^T = 12 n-tiles; wave w computes Q tile w (w < 4) or K tile w-4 for all tokens
+// and a half (by tokens) of V tile w>>1.  Q, K go to LDS as split planes; S^T = K Q^T (keys x queries) per query tile on
+// waves 0..6, softmax in registers (a query is a lane column), V replaces K in LDS, O^T = V^T P^T with P^T straight
+// from the score accumulators (B operand) and V^T through ds_read_b64_tr_b16, O -> LDS (over Q), then the out-projection
+// of this head (K = 64) accumulates into the residual registers.
+// Folded cross-attention: S^T_h = G_h LN2(h)^T is ONE 16 x 16 tile per (head, token tile) (16 key slots); softmax over the
+// accumulator rows; P -> LDS [token][head*16 + slot | step columns]; H += V'^T P^T as a column-split GEMM with K = 96.
+//
+// LDS (163 200 B of 163 840): X panel 100 x 1 KiB (hi | lo, 16-byte chunks XOR-swizzled by token & 15: every ds_read_b128 of
+// a fragment is conflict-free), Q / O 100 x 256 B, K / V 100 x 288 B (together: the 100 x 512 B probabilities of the
+// cross-attention), LayerNorm partials.  Rows >= T are never stored; reads of padded tokens clamp to row T-1 (finite values;
+// padded keys are masked, padded queries never leave the workgroup).
+#pragma once
+#include "sd_common.h"
+
+namespace tj {
+
+constexpr int D = 256, HD = 64, NH = 4, NTT = 7, TMAX = 100;
+constexpr int NTHREADS = 512;
+constexpr int MAX_L = 8;
+constexpr float ACT = 8.0f;                 // scale of LayerNorm outputs, q, k, v, attention / GELU outputs (as sd_f16x3.h)
+constexpr float PSC = 1024.0f;              // scale of the cross-attention probabilities
+constexpr float XSC = 1.0f;                 // scale of the trajectory values x at the embedding: x has no a-priori bound (an untrained
+                                            // denoiser drives |x| into the hundreds); |x| < 65 504, and below 0.125 the lo part's
+                                            // absolute error is 3e-8 - under fp32's own rounding of an O(1) sum
+constexpr int XROW = 1024, QROW = 256, VROW = 288, PROW = 512;
+constexpr int LDS_X = 0;
+constexpr int LDS_Q = LDS_X + TMAX * XROW;  // Q of the current head, later its O; x rows at the embedding
+constexpr int LDS_K = LDS_Q + TMAX * QROW;  // K of the current head, later its V
+constexpr int LDS_P = LDS_Q;                // cross-attention probabilities: 100 x 512 B over Q and K
+constexpr int LDS_STAT = LDS_K + TMAX * VROW;
+constexpr int LDS_BYTES = LDS_STAT + TMAX * 8 * 8;
+static_assert(LDS_BYTES <= 163840 && LDS_P + TMAX * PROW <= LDS_STAT, "LDS budget");
+constexpr long HFRAG_FLOATS = 8L * 2 * NTT * 256;   // residual stream of one trajectory in fragment order (Stage-A kernel)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// diagnostic build (-DTJ_STAMPS): every wave of the first TJ_STAMP_WGS workgroups records the shader clock at phase boundaries
+#ifdef TJ_STAMPS
+constexpr int TJ_NSTAMP = 64, TJ_STAMP_WGS = 512;
+__device__ unsigned long long *g_tj_stamps;
+#define TJ_STAMP(i)                                                                                                            \
+    do {                                                                                                                       \
+        if (blockIdx.x < TJ_STAMP_WGS && (threadIdx.x & 63) == 0)                                                              \
+            g_tj_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * TJ_NSTAMP + (i)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define TJ_STAMP(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// c += (ah + al) (bh + bl) without lo.lo, small terms first
+__device__ __forceinline__ void mma3(f32x4 &c, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+    c = mfma16(al, bh, c);
+    c = mfma16(ah, bl, c);
+    c = mfma16(ah, bh, c);
+}
+
+// all-reduce over the four 16-lane rows of a wave (lanes t, t+16, t+32, t+48): two v_permlane*_swap, no LDS round trip.
+// (__builtin_amdgcn_permlane32_swap(v, v) folds its two results into one on ROCm 7.2: inline assembly, checked on gfx950
+// by tools/exp/perm_test.hip.)
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = a + b;
+    a = v;
+    b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = fmaxf(a, b);
+    a = v;
+    b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// x (already scaled) as hi = fp16(x), lo = fp16(x - hi): v_cvt_pk_f16_f32 both ways, 3 VALU instructions per element
+__device__ __forceinline__ void split4(const f32x4 &x, f16x4 &h, f16x4 &l) {
+    h = __builtin_convertvector(x, f16x4);
+    l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), f16x4);
+}
+__device__ __forceinline__ void split_store(char *hi_at, char *lo_at, const f32x4 &v) {
+    f16x4 h, l;
+    split4(v, h, l);
+    *reinterpret_cast<f16x4 *>(hi_at) = h;
+    *reinterpret_cast<f16x4 *>(lo_at) = l;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// once-per-call packing (host side: sd_kernels.hip, sampler mode 3)
+// ---------------------------------------------------------------------------------------------------
+// W (N x K row-major fp32, zero-padded to Np x Kp with Np % 16 == 0, Kp % 32 == 0) -> [n-tile][k-step][plane][lane][8]:
+// lane = 16 g + i holds W[16 nt + i][32 ks + 8 g + 0..7] * scale as hi / lo.  maxbits: abs-max word (scale derived on the
+// device) or NULL with a fixed scale.
+__global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int Np, int Kp, const unsigned *maxbits, float fixed_scale,
+                                f16 *__restrict__ dst, float *scale_out) {
+    const float scale = maxbits ? f16_scale_from_bits(*maxbits) : fixed_scale;
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const int nks = Kp / 32;
+    const long total = (long)Np * (Kp / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (Kp / 8)), k8 = (int)(i % (Kp / 8));
+        f16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k8 * 8 + e;
+            const float v = (n < N && k < K) ? W[(long)n * K + k] * scale : 0.f;
+            hh[e] = (f16)v;
+            ll[e] = (f16)(v - (float)hh[e]);
+        }
+        const int nt = n >> 4, ks = k8 >> 2, lane = (k8 & 3) * 16 + (n & 15);
+        f16 *o = dst + (((long)nt * nks + ks) * 2) * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = hh[e];
+            o[512 + e] = ll[e];
+        }
+    }
+}
+
+// Folded keys of the context rows: gv rows [(item * 4 + head) * 16 + slot][2 D] (G in the first D columns) ->
+// per (item, head) blocks [ks 8][plane][lane = 16 g + slot][8], k = 32 ks + 8 g + e.  Slots >= n_slots are zero.
+__global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
+                                float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const long total = items * 4 * 16 * (D / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(i % (D / 8)), slot = (int)((i / (D / 8)) % 16);
+        const long ih = i / (D / 8) / 16;
+        f16x4 h0 = {0, 0, 0, 0}, l0 = h0, h1 = h0, l1 = h0;
+        if (slot < n_slots) {
+            const float *row = gv + (ih * 16 + slot) * 2 * D + k8 * 8;
+            f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
+            f16_split4(*reinterpret_cast<const f32x4 *>(row + 4), scale, h1, l1);
+        }
+        f16 *o = dst + ih * (8 * 2 * 512) + ((k8 >> 2) * 2) * 512 + ((k8 & 3) * 16 + slot) * 8;
+        *reinterpret_cast<f16x4 *>(o) = h0;
+        *reinterpret_cast<f16x4 *>(o + 4) = h1;
+        *reinterpret_cast<f16x4 *>(o + 512) = l0;
+        *reinterpret_cast<f16x4 *>(o + 516) = l1;
+    }
+}
+// Folded keys of the step tokens: gvstep rows [item * 4 + head][2 D] -> [item][head][ks][plane][g][8]
+__global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst,
+                                    float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const long total = items * 4 * (D / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(i % (D / 8));
+        const long ih = i / (D / 8);
+        f16x4 h0, l0, h1, l1;
+        const float *row = gvstep + ih * 2 * D + k8 * 8;
+        f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
+        f16_split4(*reinterpret_cast<const f32x4 *>(row + 4), scale, h1, l1);
+        f16 *o = dst + ih * (8 * 2 * 32) + ((k8 >> 2) * 2) * 32 + (k8 & 3) * 8;
+        *reinterpret_cast<f16x4 *>(o) = h0;
+        *reinterpret_cast<f16x4 *>(o + 4) = h1;
+        *reinterpret_cast<f16x4 *>(o + 32) = l0;
+        *reinterpret_cast<f16x4 *>(o + 36) = l1;
+    }
+}
+// Folded values of the context rows -> per item [n-tile 16][kk 2][plane][lane = 16 g + i][8]: V'^T[n = 16 nt + i][k = 32 kk + 8 g + e],
+// k = head * 16 + slot
+__global__ void pack_v16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
+                                float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const long total = items * 16 * 2 * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), kk = (int)((i >> 6) & 1), nt = (int)((i >> 7) & 15);
+        const long item = i >> 11;
+        const int n = 16 * nt + (lane & 15), g = lane >> 4;
+        f16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * kk + 8 * g + e, head = k >> 4, slot = k & 15;
+            const float v = slot < n_slots ? gv[((item * 4 + head) * 16 + slot) * 2 * D + D + n] * scale : 0.f;
+            hh[e] = (f16)v;
+            ll[e] = (f16)(v - (float)hh[e]);
+        }
+        f16 *o = dst + (((item * 16 + nt) * 2 + kk) * 2) * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = hh[e];
+            o[512 + e] = ll[e];
+        }
+    }
+}
+// Folded values of the step tokens -> [item][plane][head][n]
+__global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    const long total = items * 4 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % D), head = (int)((i / D) & 3);
+        const long item = i / D / 4;
+        const float v = gvstep[(item * 4 + head) * 2 * D + D + n] * scale;
+        const f16 h = (f16)v;
+        dst[(item * 2 + 0) * 4 * D + head * D + n] = h;
+        dst[(item * 2 + 1) * 4 * D + head * D + n] = (f16)(v - (float)h);
+    }
+}
+
+// row-major [B][T][256] <-> fragment order [B][wave][a][tt][lane][4] (Stage-A kernel and tests): element r of lane 16 g + t
+// is feature 32 w + 16 a + 4 g + r of token 16 tt + t (tokens >= T: zero)
+__global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restrict__ frag, int B, int T) {
+    const long total = (long)B * 8 * 2 * NTT * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long j = i >> 6;
+        const int tt = (int)(j % NTT); j /= NTT;
+        const int a = (int)(j & 1); j >>= 1;
+        const int w = (int)(j & 7);
+        const long b = j >> 3;
+        const int tok = 16 * tt + (lane & 15), n = 32 * w + 16 * a + 4 * (lane >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tok < T) v = *reinterpret_cast<const f32x4 *>(rows + ((long)b * T + tok) * D + n);
+        *reinterpret_cast<f32x4 *>(frag + i * 4) = v;
+    }
+}
+__global__ void from_hfrag_kernel(const float *__restrict__ frag, float *__restrict__ rows, int B, int T) {
+    const long total = (long)B * 8 * 2 * NTT * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long j = i >> 6;
+        const int tt = (int)(j % NTT); j /= NTT;
+        const int a = (int)(j & 1); j >>= 1;
+        const int w = (int)(j & 7);
+        const long b = j >> 3;
+        const int tok = 16 * tt + (lane & 15), n = 32 * w + 16 * a + 4 * (lane >> 4);
+        if (tok < T) *reinterpret_cast<f32x4 *>(rows + ((long)b * T + tok) * D + n) = *reinterpret_cast<const f32x4 *>(frag + i * 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device pieces
+// ---------------------------------------------------------------------------------------------------
+// Requires 96 < T <= 100: token tiles 0..5 are full, tile 6 holds tokens 96 .. T-1 and its other lanes clamp to T-1.
+// A 16-byte chunk of a row is addressed as  row base + ((g ^ key[1:0]) << 4) + ((m2 ^ key[3:2]) << 6) + constant,  key =
+// token & 15, m2 = two compile-time chunk bits: four address registers per row pitch cover every fragment of tiles 0..5
+// (plus a multiple of 16 rows as an immediate), four more the clamped tile.
+struct Ctx {
+    char *smem;
+    int lane, w, g, t, T;
+    int tok6;            // this lane's token of tile 6, clamped to T - 1
+    bool ok6;            // ... and whether it exists
+    unsigned xa[4], xa6[4];   // X panel: m2 = plane | (ks & 1) << 1   (+ (ks >> 1) * 256 + tt * 16 KiB)
+    // Q-layout rows (256 B; m2 = plane | kk << 1) and P rows (512 B; m2 = plane | (kk & 1) << 1, + (kk >> 1) * 256) hold the same
+    // in-row part as the X panel at a smaller row pitch: derived from xa where they are used (one VALU instruction per address)
+};
+
+__device__ __forceinline__ void ctx_init(Ctx &c, char *smem, int T) {
+    c.smem = smem;
+    c.lane = threadIdx.x & 63;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.g = c.lane >> 4;
+    c.t = c.lane & 15;
+    c.T = T;
+    c.ok6 = 96 + c.t < T;
+    c.tok6 = c.ok6 ? 96 + c.t : T - 1;
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const unsigned in_row = (unsigned)(((c.g ^ (c.t & 3)) << 4) + ((m2 ^ (c.t >> 2)) << 6));
+        const unsigned in_row6 = (unsigned)(((c.g ^ (c.tok6 & 3)) << 4) + ((m2 ^ ((c.tok6 >> 2) & 3)) << 6));
+        c.xa[m2] = (unsigned)(c.t * XROW) + in_row;
+        c.xa6[m2] = (unsigned)(c.tok6 * XROW) + in_row6;
+    }
+}
+
+// A copy of the context whose per-lane values the compiler must treat as new: every address derived from them is then
+// computed inside the loop iteration / phase that uses it.  Without this hipcc hoists ~100 loop-invariant LDS addresses out
+// of the head and layer loops, keeps them live across everything and spills as many registers.
+__device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
+    Ctx d = c;
+    asm volatile("" : "+v"(d.t), "+v"(d.g), "+v"(d.tok6), "+v"(d.lane));
+    asm volatile("" : "+v"(d.xa[0]), "+v"(d.xa[1]), "+v"(d.xa[2]), "+v"(d.xa[3]));
+    asm volatile("" : "+v"(d.xa6[0]), "+v"(d.xa6[1]), "+v"(d.xa6[2]), "+v"(d.xa6[3]));
+    return d;
+}
+
+__device__ __forceinline__ bool tok_ok(const Ctx &c, int tt) { return tt < NTT - 1 || c.ok6; }
+__device__ __forceinline__ int tok_of(const Ctx &c, int tt) { return tt < NTT - 1 ? 16 * tt + c.t : c.tok6; }
+// reader addresses: chunk (g, plane, k-step) of this lane's token in tile tt
+__device__ __forceinline__ unsigned x_at(const Ctx &c, int tt, int pl, int ks) {
+    const int m2 = pl | ((ks & 1) << 1);
+    return (tt < NTT - 1 ? c.xa[m2] + (unsigned)(tt * 16 * XROW) : c.xa6[m2]) + (unsigned)((ks >> 1) * 256);
+}
+__device__ __forceinline__ unsigned q_at(const Ctx &c, int tt, int pl, int kk) {
+    const int m2 = pl | (kk << 1);   // xa = row * 1024 + in_row: the row part shrinks to row * 256
+    return tt < NTT - 1 ? c.xa[m2] - (unsigned)(c.t * (XROW - QROW)) + (unsigned)(tt * 16 * QROW) : c.xa6[m2] - (unsigned)(c.tok6 * (XROW - QROW));
+}
+__device__ __forceinline__ unsigned p_at(const Ctx &c, int tt, int pl, int kk) {
+    const int m2 = pl | ((kk & 1) << 1);
+    return (tt < NTT - 1 ? c.xa[m2] - (unsigned)(c.t * (XROW - PROW)) + (unsigned)(tt * 16 * PROW) : c.xa6[m2] - (unsigned)(c.tok6 * (XROW - PROW))) +
+           (unsigned)((kk >> 1) * 256);
+}
+// generic forms (writers: the chunk's low two bits are not the lane's g).  chunk = gk | plane << 2 | kstep << 3
+__device__ __forceinline__ unsigned x_off(int tok, int chunk) { return (unsigned)(tok * XROW + ((chunk ^ (tok & 15)) << 4)); }
+__device__ __forceinline__ unsigned q_off(int tok, int chunk) { return (unsigned)(tok * QROW + ((chunk ^ (tok & 15)) << 4)); }
+__device__ __forceinline__ unsigned p_off(int tok, int chunk) { return (unsigned)(tok * PROW + ((chunk ^ (tok & 15)) << 4)); }
+
+__device__ __forceinline__ f16x8 lds16(const char *p) { return *reinterpret_cast<const f16x8 *>(p); }
+
+// H[a][tt] (features 32 w + 16 a + 4 g + r of this lane's token in tile tt) -> X panel, as split planes of value * ACT.
+// k = feature: k-step w, 8-group 2 a + g / 2, position 4 (g & 1) + r
+__device__ __forceinline__ void store_x(const Ctx &c, int a, int tt, const f32x4 &v) {
+    if (!tok_ok(c, tt)) return;
+    const int chunk = (2 * a + (c.g >> 1)) | (c.w << 3), tok = tok_of(c, tt);
+    char *X = c.smem + LDS_X;
+    split_store(X + x_off(tok, chunk) + 8 * (c.g & 1), X + x_off(tok, chunk | 4) + 8 * (c.g & 1), v);
+}
+
+// LayerNorm over the 256 features of H -> split planes of the X panel (scaled by ACT).  Per wave: mean and centred sum of
+// squares of its 32 features (two-pass, in registers + two row all-reduces), then Chan's combination of the 8 waves' pairs:
+// one exchange, two barriers (the first also fences the X panel's previous readers).
+__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
+    const Ctx c = ctx_local(c0);
+    float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
+    float mw[NTT], qw[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const f32x4 s4 = H[0][tt] + H[1][tt];
+        mw[tt] = rows4_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / 32);
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const f32x4 d0 = H[0][tt] - mw[tt], d1 = H[1][tt] - mw[tt];
+        const f32x4 q4 = d0 * d0 + d1 * d1;
+        qw[tt] = rows4_sum((q4[0] + q4[1]) + (q4[2] + q4[3]));
+    }
+    if (c.g == 0) {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+            if (tok_ok(c, tt)) *reinterpret_cast<f32x2 *>(stat + (tok_of(c, tt) * 8 + c.w) * 2) = f32x2{mw[tt], qw[tt]};
+    }
+    __syncthreads();
+    float mean[NTT], rstd[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const float *sp = stat + tok_of(c, tt) * 16;
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(sp + 8), p3 = *reinterpret_cast<const f32x4 *>(sp + 12);
+        const float m = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
+        const f32x4 e0 = f32x4{p0[0], p0[2], p1[0], p1[2]} - m, e1 = f32x4{p2[0], p2[2], p3[0], p3[2]} - m;
+        const f32x4 ee = e0 * e0 + e1 * e1;
+        const float m2 = (((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]))) + 32.0f * ((ee[0] + ee[1]) + (ee[2] + ee[3]));
+        mean[tt] = m;
+        rstd[tt] = __builtin_amdgcn_rsqf(m2 * (1.0f / D) + SD_LN_EPS);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int n0 = 32 * c.w + 16 * a + 4 * c.g;
+        const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + n0) * ACT, gb = *reinterpret_cast<const f32x4 *>(ln_b + n0) * ACT;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            store_x(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
+            __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 14 and spills
+        }
+    }
+    __syncthreads();   // X complete
+}
+
+// acc0[tt] += A0 . X^T for all token tiles, acc1[i] += A1 . X^T for token tiles tt1 + i (tt1 = ODD ? 4 : 0), K = 256.
+// pa0 / pa1: fragment streams [ks][plane][lane][8] of the two n-tiles (wave-uniform pointers)
+template <bool ODD>
+__device__ __forceinline__ void gemm_head(const Ctx &c, f32x4 (&acc0)[NTT], f32x4 (&acc1)[4], const f16 *pa0, const f16 *pa1) {
+    const char *X = c.smem + LDS_X;
+    const unsigned lo = (unsigned)c.lane * 8;
+    f16x8 a0[2][2], a1[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        a0[0][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + pl * 512);
+        a1[0][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + pl * 512);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < 8) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a0[nxt][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + ((ks + 1) * 2 + pl) * 512);
+                a1[nxt][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + ((ks + 1) * 2 + pl) * 512);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const f16x8 bh = lds16(X + x_at(c, tt, 0, ks));
+            const f16x8 bl = lds16(X + x_at(c, tt, 1, ks));
+            mma3(acc0[tt], a0[cur][0], a0[cur][1], bh, bl);
+            if (ODD ? tt >= 4 : tt < 4) mma3(acc1[ODD ? tt - 4 : tt], a1[cur][0], a1[cur][1], bh, bl);
+            if (tt & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[a][tt] += A_a . X^T, n-tiles 2 w + a of a 256 x 256 matrix in fragment-major planes
+__device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *wmat) {
+    const char *X = c.smem + LDS_X;
+    const f16 *pa = wmat + (long)(2 * c.w) * (8 * 2 * 512) + (unsigned)c.lane * 8;
+    f16x8 a[2][2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a[0][n][pl] = *reinterpret_cast<const f16x8 *>(pa + n * (8 * 2 * 512) + pl * 512);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < 8) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[nxt][n][pl] = *reinterpret_cast<const f16x8 *>(pa + n * (8 * 2 * 512) + ((ks + 1) * 2 + pl) * 512);
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const f16x8 bh = lds16(X + x_at(c, tt, 0, ks));
+            const f16x8 bl = lds16(X + x_at(c, tt, 1, ks));
+            mma3(acc[0][tt], a[cur][0][0], a[cur][0][1], bh, bl);
+            mma3(acc[1][tt], a[cur][1][0], a[cur][1][1], bh, bl);
+            if (tt & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[a][tt] += A_a . B^T with B rows of 64 features in a Q-layout buffer (K = 64); pa0 / pa1: streams at the first k-step
+__device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *pa0, const f16 *pa1, const char *Bbuf) {
+    const unsigned lo = (unsigned)c.lane * 8;
+    f16x8 a[2][2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            a[0][kk][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + (kk * 2 + pl) * 512);
+            a[1][kk][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + (kk * 2 + pl) * 512);
+        }
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const f16x8 bh = lds16(Bbuf + q_at(c, tt, 0, kk));
+            const f16x8 bl = lds16(Bbuf + q_at(c, tt, 1, kk));
+            mma3(acc[0][tt], a[0][kk][0], a[0][kk][1], bh, bl);
+            mma3(acc[1][tt], a[1][kk][0], a[1][kk][1], bh, bl);
+        }
+}
+
+struct SaW {
+    const f16 *w_in;      // in_proj (768 x 256) planes
+    const float *b_in;    // 768
+    const f16 *w_o;       // out_proj (256 x 256) planes
+    float s_in;           // power-of-two scale of w_in
+    float scale_log2e;    // log2(e) / sqrt(head dim)
+};
+
+// One head of self-attention: H (residual accumulators, pre-scaled by ACT * s_o) += Wo[:, head] . O_head^T
+__device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x4 (&H)[2][NTT], int st0) {
+    const Ctx c = ctx_local(c0);
+    char *Qb = c.smem + LDS_Q, *Kb = c.smem + LDS_K;
+    const int w = c.w, g = c.g, t = c.t;
+    f32x4 acc0[NTT], acc1[4];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
+    const int nt1 = 32 + 4 * h + (w >> 1);                   // V tile, token half w & 1
+    const f16 *pa0 = a.w_in + (long)nt0 * (8 * 2 * 512), *pa1 = a.w_in + (long)nt1 * (8 * 2 * 512);
+    const bool odd = w & 1;
+    TJ_STAMP(st0);
+    if (odd) gemm_head<true>(c, acc0, acc1, pa0, pa1);
+    else gemm_head<false>(c, acc0, acc1, pa0, pa1);
+    TJ_STAMP(st0 + 1);
+    const float c_in = 1.0f / a.s_in;   // accumulator -> ACT * value
+    {   // Q or K tile -> LDS planes (features 16 (w & 3) + 4 g + r of the head)
+        const int w3 = w & 3;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + (w < 4 ? 0 : D) + HD * h + 16 * w3 + 4 * g) * ACT;
+        char *dst = w < 4 ? Qb : Kb;
+        const int chunk = (2 * (w3 & 1) + (g >> 1)) | ((w3 >> 1) << 3);
+        __syncthreads();   // B1: the previous head's readers of Q / O and K / V are done
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            if (!tok_ok(c, tt)) continue;
+            const int tok = tok_of(c, tt);
+            split_store(dst + q_off(tok, chunk) + 8 * (g & 1), dst + q_off(tok, chunk | 4) + 8 * (g & 1), acc0[tt] * c_in + bv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();       // B2: Q, K complete
+    TJ_STAMP(st0 + 2);
+    // ---- scores of query tile w (waves 0..6): S^T[key][query] = K Q^T
+    f32x4 S[NTT];
+    float psum = 0.f;
+    if (w < NTT) {
+        f16x8 qf[2][2];
+        const int qtok = min(16 * w + t, c.T - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) qf[kk][pl] = lds16(Qb + q_off(qtok, g | (pl << 2) | (kk << 3)));
+#pragma unroll
+        for (int kt = 0; kt < NTT; ++kt) {
+            S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f16x8 kh = lds16(Kb + q_at(c, kt, 0, kk));
+                const f16x8 kl = lds16(Kb + q_at(c, kt, 1, kk));
+                mma3(S[kt], kh, kl, qf[kk][0], qf[kk][1]);
+            }
+        }
+        // softmax over the keys of this lane's query: registers r of tile kt are keys 16 kt + 4 g + r (only tile 6 has masked keys)
+        const float c_s = a.scale_log2e / (ACT * ACT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (96 + 4 * g + r >= c.T) S[NTT - 1][r] = -INFINITY;
+        f32x4 m4 = S[0];
+#pragma unroll
+        for (int kt = 1; kt < NTT; ++kt) m4 = f32x4{fmaxf(m4[0], S[kt][0]), fmaxf(m4[1], S[kt][1]), fmaxf(m4[2], S[kt][2]), fmaxf(m4[3], S[kt][3])};
+        const float m = rows4_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+        const float mb = m * c_s - 10.0f;   // probabilities carry 2^10 (fp16 lo parts stay normal)
+        f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NTT; ++kt) {
+            const f32x4 e = S[kt] * c_s - mb;
+            S[kt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+            ps = ps + S[kt];
+        }
+        psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
+    }
+    TJ_STAMP(st0 + 3);
+    __syncthreads();       // B3: K is dead
+    {   // V piece -> LDS rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r)
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
+        const int tt1 = odd ? 4 : 0, n1 = odd ? 3 : 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n1) continue;
+            const int tok = 16 * (tt1 + i) + t;
+            if (tok >= c.T) continue;
+            char *at = Kb + tok * VROW + 2 * (16 * (w >> 1) + 4 * g);
+            split_store(at, at + 128, acc1[i] * c_in + bv);
+        }
+    }
+    __syncthreads();       // B4: V complete
+    TJ_STAMP(st0 + 4);
+    if (w < NTT) {
+        f32x4 O[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) O[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int q4 = t >> 2, p4 = t & 3;
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            // P fragment of keys 32 kp ..: elements 0..3 = tile 2 kp, 4..7 = tile 2 kp + 1 (beyond the last tile: zero)
+            const f32x4 pa4 = S[2 * kp], pb4 = 2 * kp + 1 < NTT ? S[2 * kp + 1 < NTT ? 2 * kp + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x4 pah, pal, pbh, pbl;
+            split4(pa4, pah, pal);
+            split4(pb4, pbh, pbl);
+            const f16x8 ph = __builtin_shufflevector(pah, pbh, 0, 1, 2, 3, 4, 5, 6, 7), pl = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
+            const char *v0 = Kb + r0 * VROW + 8 * p4, *v1 = Kb + r1 * VROW + 8 * p4;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                f16x8 vf[2];
+#pragma unroll
+                for (int pn = 0; pn < 2; ++pn) {
+                    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v0 + pn * 128 + ft * 32));
+                    const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v1 + pn * 128 + ft * 32));
+                    vf[pn] = __builtin_shufflevector(__builtin_bit_cast(f16x4, x0), __builtin_bit_cast(f16x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                mma3(O[ft], vf[0], vf[1], ph, pl);
+            }
+        }
+        // O^T tile ft: features 16 ft + 4 g + r of query 16 w + t, times ACT / sum -> LDS planes (over Q)
+        const float inv = 1.0f / psum;
+        const int tok = 16 * w + t;
+        if (tok < c.T) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const int chunk = (2 * (ft & 1) + (g >> 1)) | ((ft >> 1) << 3);
+                split_store(Qb + q_off(tok, chunk) + 8 * (g & 1), Qb + q_off(tok, chunk | 4) + 8 * (g & 1), O[ft] * inv);
+            }
+        }
+    }
+    TJ_STAMP(st0 + 5);
+    __syncthreads();       // B5: O complete
+    TJ_STAMP(st0 + 6);
+    const f16 *po0 = a.w_o + ((long)(2 * w) * 8 + 2 * h) * (2 * 512), *po1 = a.w_o + ((long)(2 * w + 1) * 8 + 2 * h) * (2 * 512);
+    gemm_k64(c, H, po0, po1, Qb);
+}
+
+__device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f;
+}
+// H = H * f + bias[feature]
+__device__ __forceinline__ void unscale_h(const Ctx &c, f32x4 (&H)[2][NTT], float f, const float *bias) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 32 * c.w + 16 * a + 4 * c.g);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + bv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one decoder layer on the residual registers (X holds LN1(h) on entry; on exit LN1 of the next layer if nln_w)
+// ---------------------------------------------------------------------------------------------------
+struct LayerW {
+    const float *n2_w, *n2_b, *n3_w, *n3_b;
+    const f16 *w_in, *w_o, *w_1, *w_2;            // fragment-major planes
+    const float *b_in, *b_o, *b_1, *b_2, *b_oc;
+    const float *sc;                              // [0] Wo, [1] W1, [2] W2, [3] in_proj, [4] G, [5] V'
+    const f16 *g16, *v16;                         // folded context blocks of this layer, all trajectories
+    const float *cb;                              // [B][64] score biases
+    const f16 *gstep, *vstep;                     // this layer and step
+    const float *cstep;                           // 4 score biases of the step token
+    const float *nln_w, *nln_b;                   // LayerNorm that follows (next layer's norm1), or NULL
+};
+
+__device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e) {
+    // ---- self-attention block: h += Wo . SA(LN1(h)) + bo
+    {
+        const Ctx &c = c0;
+        const float s_o = L.sc[0], up = ACT * s_o;
+        scale_h(H, up);
+        const SaW sw{L.w_in, L.b_in, L.w_o, L.sc[3], scale_log2e};
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) sa_head(c, sw, h, H, 3 + 7 * h);
+        unscale_h(c, H, 1.0f / up, L.b_o);
+    }
+    TJ_STAMP(31);
+    layer_norm_to_x(c0, H, L.n2_w, L.n2_b);
+    TJ_STAMP(32);
+    // ---- folded cross-attention: wave w scores head w >> 1 for token tiles tt1 .. (half w & 1)
+    {
+        const Ctx c = ctx_local(c0);
+        const int hh = c.w >> 1, Mc = Mk - 1;
+        const bool odd = c.w & 1;
+        const int tt1 = odd ? 4 : 0, n1 = odd ? 3 : 4;
+        char *Pb = c.smem + LDS_P;
+        const char *X = c.smem + LDS_X;
+        f32x4 S[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // lanes of slot Mc read the step token's shared row instead of their trajectory's block
+        const f16 *gp = c.t == Mc ? L.gstep + (long)hh * (8 * 2 * 32) + c.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c.lane * 8;
+        const int gstride = c.t == Mc ? 32 : 512;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f16x8 gh = *reinterpret_cast<const f16x8 *>(gp + (ks * 2) * gstride);
+            const f16x8 gl = *reinterpret_cast<const f16x8 *>(gp + (ks * 2 + 1) * gstride);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i >= n1) continue;
+                // token tile tt1 + i: compile-time for each parity
+                const f16x8 bh = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 0, ks)) : lds16(X + x_at(c, i, 0, ks));
+                const f16x8 bl = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 1, ks)) : lds16(X + x_at(c, i, 1, ks));
+                mma3(S[i], gh, gl, bh, bl);
+            }
+        }
+        // softmax over the Mk key slots (accumulator rows 4 g + r) of each token (lane column)
+        const float c_g = 1.0f / (ACT * L.sc[4]);
+        f32x4 cbv = *reinterpret_cast<const f32x4 *>(L.cb + traj * 64 + hh * 16 + 4 * c.g);
+        const float cs = L.cstep[hh];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * c.g + r == Mc) cbv[r] = cs;
+        __syncthreads();   // the previous readers of Q / K (out-projection, PV) are done: P may be written
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n1) continue;
+            f32x4 v = S[i] * c_g + cbv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * c.g + r >= Mk) v[r] = -INFINITY;
+            const float m = rows4_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            const f32x4 e = (v - m) * scale_log2e;
+            f32x4 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+            const float sum = rows4_sum((p[0] + p[1]) + (p[2] + p[3]));
+            p = p * (PSC / sum);
+            const int tt = tt1 + i, tok = tt < NTT - 1 ? 16 * tt + c.t : c.tok6;
+            if (tt == NTT - 1 && !c.ok6) continue;
+            // k = 16 hh + 4 g + r: k-step hh >> 1, 8-group 2 (hh & 1) + g / 2
+            const int chunk = (2 * (hh & 1) + (c.g >> 1)) | ((hh >> 1) << 3);
+            split_store(Pb + p_off(tok, chunk) + 8 * (c.g & 1), Pb + p_off(tok, chunk | 4) + 8 * (c.g & 1), p);
+            // the step token's probability again at k = 64 + 8 hh (its V' comes from the shared step block): a whole chunk
+            if (c.g == (Mc >> 2)) {
+                const float pv = p[Mc & 3];
+                const f16 ph = (f16)pv, pl = (f16)(pv - (float)ph);
+                const f16x8 z8h = {ph, 0, 0, 0, 0, 0, 0, 0}, z8l = {pl, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | (2 << 3))) = z8h;
+                *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | 4 | (2 << 3))) = z8l;
+            }
+        }
+        __syncthreads();   // P complete
+        TJ_STAMP(33);
+        // h += V'^T P^T + boc: K = 64 (context slots of 4 heads) + 32 (step columns)
+        const float up = PSC * L.sc[5];
+        scale_h(H, up);
+        f16x8 av[2][3][2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *vp = L.v16 + ((traj * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
+                av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const f16x8 bh = lds16(Pb + p_at(c, tt, 0, kk));
+                const f16x8 bl = lds16(Pb + p_at(c, tt, 1, kk));
+                mma3(H[0][tt], av[0][kk][0], av[0][kk][1], bh, bl);
+                mma3(H[1][tt], av[1][kk][0], av[1][kk][1], bh, bl);
+            }
+        unscale_h(c, H, 1.0f / up, L.b_oc);
+    }
+    TJ_STAMP(34);
+    layer_norm_to_x(c0, H, L.n3_w, L.n3_b);
+    TJ_STAMP(35);
+    // ---- feed-forward: h += W2 gelu(W1 LN3(h) + b1) + b2
+    {
+        const Ctx c = ctx_local(c0);
+        f32x4 U[2][NTT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) U[a][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_x2(c, U, L.w_1);
+        TJ_STAMP(36);
+        const float c1 = 1.0f / (ACT * L.sc[1]);
+        __syncthreads();   // every wave has read LN3(h): the panel receives gelu(u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_1 + 32 * c.w + 16 * a + 4 * c.g);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const f32x4 pre = U[a][tt] * c1 + bv;
+                const f32x2 g0 = gelu_erf_fast2(f32x2{pre[0], pre[1]}) * ACT, g1 = gelu_erf_fast2(f32x2{pre[2], pre[3]}) * ACT;
+                store_x(c, a, tt, f32x4{g0[0], g0[1], g1[0], g1[1]});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        TJ_STAMP(37);
+        const float up = ACT * L.sc[2];
+        scale_h(H, up);
+        gemm_x2(c, H, L.w_2);
+        unscale_h(c, H, 1.0f / up, L.b_2);
+    }
+    TJ_STAMP(38);
+    if (L.nln_w) layer_norm_to_x(c0, H, L.nln_w, L.nln_b);
+    TJ_STAMP(39);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stage-A experiment kernel (tools/exp/traj_layer.hip): h' = h + SelfAttention(LN1(h)), h in fragment order
+// ---------------------------------------------------------------------------------------------------
+struct SaArgs {
+    const float *h_in;
+    float *h_out;
+    const float *ln_w, *ln_b;
+    const f16 *w_in;
+    const float *b_in;
+    const f16 *w_o;
+    const float *b_o;
+    float s_in, s_o;
+    float scale_log2e;
+    int T, B;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx c;
+    ctx_init(c, smem, a.T);
+    const long traj = blockIdx.x;
+    TJ_STAMP(0);
+    const float *hin = a.h_in + traj * HFRAG_FLOATS + (long)c.w * (2 * NTT * 256) + c.lane * 4;
+    f32x4 H[2][NTT];
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) H[aa][tt] = *reinterpret_cast<const f32x4 *>(hin + (aa * NTT + tt) * 256);
+    TJ_STAMP(1);
+    layer_norm_to_x(c, H, a.ln_w, a.ln_b);
+    const float up = ACT * a.s_o;
+    scale_h(H, up);
+    TJ_STAMP(2);
+    const SaW sw{a.w_in, a.b_in, a.w_o, a.s_in, a.scale_log2e};
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) sa_head(c, sw, h, H, 3 + 7 * h);
+    TJ_STAMP(31);
+    unscale_h(c, H, 1.0f / up, a.b_o);
+    float *hout = a.h_out + traj * HFRAG_FLOATS + (long)c.w * (2 * NTT * 256) + c.lane * 4;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) __builtin_nontemporal_store(H[aa][tt], reinterpret_cast<f32x4 *>(hout + (aa * NTT + tt) * 256));
+    TJ_STAMP(32);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One whole denoiser step of the sampler per launch: x -> embedding + positional rows -> L decoder layers -> fc_out -> DDIM update
+// of x in place (reference loop: soccer_diffusion/ml/inference/plot.py:122-131 around model.py:159-179)
+// ---------------------------------------------------------------------------------------------------
+struct StepArgs {
+    float *x;                      // [B][T][J] in / out
+    float *eps_out;                // [B][T][J] or NULL (noise prediction, for tests)
+    const f16 *w_emb;              // [16 n-tiles][1][2][64][8] (K = J padded to 32), scale s_emb
+    const float *b_emb, *pe;       // bias [256], positional table [>= T][256]
+    const float *n1_w, *n1_b;      // layer 0's norm1
+    const f16 *w_out;              // [2 n-tiles][8][2][64][8] (rows >= J zero), scale s_out
+    const float *b_out;            // [J]
+    const float *sc_io;            // [0] s_emb, [1] s_out
+    float c0, c1, c2, c3;          // DDIM coefficients of this step (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev))
+    float scale_log2e;
+    int T, B, J, L, Mk, update_x;
+    LayerW layer[MAX_L];
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx c;
+    ctx_init(c, smem, a.T);
+    const long traj = blockIdx.x;
+    const int J = a.J;
+    TJ_STAMP(0);
+    f32x4 H[2][NTT];
+    // ---- embedding: h^T = Wemb . x^T + b + pe^T.  x rows -> Q region as split planes (k = joint, zero-padded to 32)
+    {
+        char *Qb = c.smem + LDS_Q;
+        const float *xr = a.x + traj * (long)a.T * J;
+        const int nvec = a.T * J / 4;            // J % 4 == 0
+        for (int i = threadIdx.x; i < nvec; i += NTHREADS) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * i) * XSC;
+            const int tok = (4 * i) / J, j0 = 4 * i - tok * J;     // 4 consecutive joints of one token
+            const int chunk = j0 >> 3;
+            split_store(Qb + q_off(tok, chunk) + 2 * (j0 & 7), Qb + q_off(tok, chunk | 4) + 2 * (j0 & 7), v);
+            if (j0 + 4 >= J) {   // this thread also zeroes k = J .. 31 of its token (the weights there are zero; LDS garbage might be NaN)
+                const f16x4 z4 = {0, 0, 0, 0};
+                for (int k = J; k < 32; k += 4) {
+                    *reinterpret_cast<f16x4 *>(Qb + q_off(tok, k >> 3) + 2 * (k & 7)) = z4;
+                    *reinterpret_cast<f16x4 *>(Qb + q_off(tok, (k >> 3) | 4) + 2 * (k & 7)) = z4;
+                }
+            }
+        }
+        __syncthreads();
+        const float c_e = 1.0f / (XSC * a.sc_io[0]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *wp = a.w_emb + (long)(2 * c.w + n) * (2 * 512) + c.lane * 8;
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(wp), al = *reinterpret_cast<const f16x8 *>(wp + 512);
+            const int n0 = 32 * c.w + 16 * n + 4 * c.g;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_emb + n0);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                mma3(acc, ah, al, lds16(Qb + q_at(c, tt, 0, 0)), lds16(Qb + q_at(c, tt, 1, 0)));
+                const f32x4 pe4 = *reinterpret_cast<const f32x4 *>(a.pe + (long)tok_of(c, tt) * D + n0);
+                H[n][tt] = acc * c_e + (bv + pe4);
+            }
+        }
+    }
+    TJ_STAMP(1);
+    layer_norm_to_x(c, H, a.n1_w, a.n1_b);
+    TJ_STAMP(2);
+#pragma unroll 1
+    for (int l = 0; l < a.L; ++l) decoder_layer(c, a.layer[l], H, traj, a.Mk, a.scale_log2e);
+    // ---- fc_out + DDIM: eps^T = Wout . h^T + b.  h has no a-priori bound: one power-of-two scale per token
+    {
+        float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
+        float am[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const f32x4 a0 = H[0][tt], a1 = H[1][tt];
+            float m = fmaxf(fmaxf(fabsf(a0[0]), fabsf(a0[1])), fmaxf(fabsf(a0[2]), fabsf(a0[3])));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a1[0]), fabsf(a1[1])), fmaxf(fabsf(a1[2]), fabsf(a1[3]))));
+            am[tt] = rows4_max(m);
+        }
+        if (c.g == 0) {
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt)
+                if (tok_ok(c, tt)) stat[tok_of(c, tt) * 8 + c.w] = am[tt];
+        }
+        __syncthreads();   // also: the X panel's readers (last W2 GEMM) are done
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const float *sp = stat + tok_of(c, tt) * 8;
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
+            const float m = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+            const float s = f16_scale_from_bits(__builtin_bit_cast(unsigned, m));
+            store_x(c, 0, tt, H[0][tt] * s);
+            store_x(c, 1, tt, H[1][tt] * s);
+        }
+        __syncthreads();
+        if (c.w < NTT) {
+            const char *X = c.smem + LDS_X;
+            f32x4 E[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const int tok = c.w < NTT - 1 ? 16 * c.w + c.t : c.tok6;
+            const bool ok = c.w < NTT - 1 || c.ok6;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int m2lo = (ks & 1) << 1;
+                const unsigned b0 = (c.w < NTT - 1 ? c.xa[m2lo] + (unsigned)(c.w * 16 * XROW) : c.xa6[m2lo]) + (unsigned)((ks >> 1) * 256);
+                const unsigned b1 = (c.w < NTT - 1 ? c.xa[m2lo | 1] + (unsigned)(c.w * 16 * XROW) : c.xa6[m2lo | 1]) + (unsigned)((ks >> 1) * 256);
+                const f16x8 bh = lds16(X + b0), bl = lds16(X + b1);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f16 *wp = a.w_out + ((long)(n * 8 + ks) * 2) * 512 + c.lane * 8;
+                    mma3(E[n], *reinterpret_cast<const f16x8 *>(wp), *reinterpret_cast<const f16x8 *>(wp + 512), bh, bl);
+                }
+            }
+            // this lane's token scale again (the statistics are still in LDS)
+            const float *sp = stat + tok * 8;
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
+            const float m = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
+            const float c_o = 1.0f / (f16_scale_from_bits(__builtin_bit_cast(unsigned, m)) * a.sc_io[1]);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int j0 = 16 * n + 4 * c.g;
+                if (!ok || j0 >= J) continue;
+                const f32x4 e = E[n] * c_o + *reinterpret_cast<const f32x4 *>(a.b_out + j0);
+                const long at = (traj * a.T + tok) * J + j0;
+                if (a.eps_out) *reinterpret_cast<f32x4 *>(a.eps_out + at) = e;
+                if (a.update_x) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + at);
+                    f32x4 xn;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // the oracle's fp32 op order (oracle/ddim_ref.py, as fc_out_kernel)
+                        const float x0 = (xv[r] - a.c1 * e[r]) / a.c0;
+                        xn[r] = a.c2 * x0 + a.c3 * e[r];
+                    }
+                    *reinterpret_cast<f32x4 *>(a.x + at) = xn;
+                }
+            }
+        }
+    }
+    TJ_STAMP(40);
+}
+
+}   // namespace tj

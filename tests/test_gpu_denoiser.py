@@ -101,19 +101,21 @@ def test_ddim_sampler_every_step(ops, d, L, T, Mc, B, n_steps):
     coef = ops.ddim_coefficients(ts, acp, n_steps)
     x0, trace = ops.ddim_sample(packed, ctx.cuda() if ctx is not None else None, toks, coef, x_T.cuda(), trace=True)
     errs = [rel_err(trace[i], want[i]) for i in range(n_steps)]
-    assert max(errs) < TOL, errs
+    assert all(e < TOL for e in errs), errs   # (max() would skip NaNs)
     assert torch.equal(x0, trace[-1])
     assert torch.isfinite(x0).all()
 
 
-def test_fp16x3_sampler_is_fp32_grade(ops):
-    """The split-operand fp16 MFMA path (sd_sampler_mode 2) against the FP64 oracle loop: its error over a full
-    50-step rollout must stay at the level of the fp32 CPU path's own error (both ~4e-7), 100x inside the 1e-4
-    tolerance of north_star - i.e. the 3-MFMA products are not a reduced-precision shortcut."""
+@pytest.mark.parametrize("mode", [3, 2])
+def test_fp16x3_sampler_is_fp32_grade(ops, mode):
+    """The split-operand fp16 MFMA paths - sd_sampler_mode 3 (trajectory-owning step kernel, the default at this shape) and
+    2 (panel kernels + separate self-attention) - against the FP64 oracle loop: the error over a full 50-step rollout must
+    stay at the level of the fp32 CPU path's own error (both ~4e-7), 100x inside the 1e-4 tolerance of north_star - i.e.
+    the 3-MFMA products are not a reduced-precision shortcut."""
     from soccerdiffusion_amd import _lib
 
     d, L, T, Mc, B, n_steps, J = 256, 4, 100, 10, 3, 50, 20
-    assert _lib.load().sd_sampler_mode(d, 4, T, Mc, J) == 2
+    assert _lib.load().sd_sampler_mode(d, 4, T, Mc, J) == 3
     sd = ref.synthetic_state_dict(d, J, L, seed=21)
     g = torch.Generator().manual_seed(77)
     x_T = torch.randn(B, T, J, generator=g)
@@ -130,7 +132,7 @@ def test_fp16x3_sampler_is_fp32_grade(ops):
     freq = ops.step_frequencies(d).cuda()
     toks = ops.step_token(torch.tensor(ts).cuda(), freq, sd["step_encoding.token"].cuda()).reshape(n_steps, d)
     coef = ops.ddim_coefficients(ts, acp, n_steps)
-    _, trace = ops.ddim_sample(packed, ctx.cuda(), toks, coef, x_T.cuda(), trace=True)
+    _, trace = ops.ddim_sample(packed, ctx.cuda(), toks, coef, x_T.cuda(), trace=True, max_mode=mode)
 
     def rel64(a, b):
         return float((a.double().cpu() - b).norm() / b.norm())
@@ -141,8 +143,9 @@ def test_fp16x3_sampler_is_fp32_grade(ops):
     assert e_native < 4 * e_cpu32 + 1e-7, (e_native, e_cpu32)
 
 
-@pytest.mark.parametrize("env", [{"SD_SAMPLER_GEMM": "f32"}, {"SD_QKV": "rows"}, {"SD_QKV": "rows", "SD_ATT16": "stream"},
-                                 {"SD_MERGE_HEAD": "0"}, {"SD_H": "rows"}, {"SD_ATT16": "stage2"}])
+@pytest.mark.parametrize("env", [{"SD_SAMPLER_GEMM": "f32"}, {"SD_SAMPLER_TRAJ": "0"}, {"SD_SAMPLER_TRAJ": "0", "SD_QKV": "rows"},
+                                 {"SD_SAMPLER_TRAJ": "0", "SD_QKV": "rows", "SD_ATT16": "stream"}, {"SD_SAMPLER_TRAJ": "0", "SD_MERGE_HEAD": "0"},
+                                 {"SD_SAMPLER_TRAJ": "0", "SD_H": "rows"}, {"SD_SAMPLER_TRAJ": "0", "SD_ATT16": "stage2"}])
 def test_sampler_kernel_variants_agree_with_oracle(env):
     """The alternative kernel selections of sd_ddim_sample (fp32-MFMA fold, row-major q|k|v with the per-head or the
     streaming fp16 attention) are read from the environment once per process: run each in a child process against the
@@ -172,3 +175,33 @@ assert err < 1e-4, err
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ERR" in out.stdout
+
+
+@pytest.mark.parametrize("T,Mc,J,L,B", [(100, 10, 20, 4, 5), (97, 0, 4, 1, 3), (98, 15, 32, 2, 2), (99, 5, 8, 3, 9), (100, 1, 20, 8, 1)])
+def test_trajectory_step_kernel_every_step(ops, T, Mc, J, L, B):
+    """Sampler mode 3 (csrc/sd_traj.h; reference blocks decoder.py:26-54 under the DDIM loop of plot.py:122-131): x after EVERY
+    step against the fp32 oracle, at the edges of what the kernel takes - a last token tile with 1 .. 4 live tokens (T = 97 .. 100),
+    no context rows / a full set of 16 key slots, the smallest and largest joint counts, 1 and 8 layers - and equal to the
+    panel kernels of mode 2 at fp32 rounding level."""
+    from soccerdiffusion_amd import _lib
+
+    d, n_steps = 256, 5
+    assert _lib.load().sd_sampler_mode(d, 4, T, Mc, J) == 3
+    sd = ref.synthetic_state_dict(d, J, L, seed=31 + T)
+    g = torch.Generator().manual_seed(T * 7 + Mc)
+    x_T = torch.randn(B, T, J, generator=g)
+    ctx = torch.randn(B, Mc, d, generator=g) if Mc else None
+    acp = ddim_ref.alphas_cumprod()
+    ts = ddim_ref.timesteps(n_steps).tolist()
+    want = ddim_ref.sample(lambda x, t: ref.forward_with_context(sd, [ctx] if Mc else [], x, torch.full((B,), t, dtype=torch.int64)),
+                           x_T, n_steps, acp)
+    packed = ops.pack_denoiser(sd, "cuda", max_len=T)
+    toks = ops.step_token(torch.tensor(ts).cuda(), ops.step_frequencies(d).cuda(), sd["step_encoding.token"].cuda()).reshape(n_steps, d)
+    coef = ops.ddim_coefficients(ts, acp, n_steps)
+    cg = ctx.cuda() if Mc else None
+    x3, tr3 = ops.ddim_sample(packed, cg, toks, coef, x_T.cuda(), trace=True, max_mode=3)
+    errs = [rel_err(tr3[i], want[i]) for i in range(n_steps)]
+    assert all(e < TOL for e in errs), errs   # (max() would skip NaNs)
+    x2 = ops.ddim_sample(packed, cg, toks, coef, x_T.cuda(), max_mode=2)
+    assert rel_err(x3, x2.cpu()) < 1e-5
+    assert torch.isfinite(x3).all()
