@@ -381,81 +381,82 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     __syncthreads();   // X complete
 }
 
-// acc0[tt] += A0 . X^T for all token tiles, acc1[i] += A1 . X^T for token tiles tt1 + i (tt1 = ODD ? 4 : 0), K = 256.
-// pa0 / pa1: fragment streams [ks][plane][lane][8] of the two n-tiles (wave-uniform pointers)
-template <bool ODD>
-__device__ __forceinline__ void gemm_head(const Ctx &c, f32x4 (&acc0)[NTT], f32x4 (&acc1)[4], const f16 *pa0, const f16 *pa1) {
+// K = 256 GEMM against the X panel as ONE software pipeline over 8 k-steps x 7 token tiles: the B fragment of the next tile
+// (two planes, two ds_read_b128) is requested before the MFMAs of the current tile, the A fragments of the next k-step at the
+// first tile of the current one; the order "issue next loads -> MFMAs" is pinned with sched_barrier (hipcc otherwise issues
+// every load right before its use and waits for it).  A0 / A1: the two n-tiles of this wave (fragment streams
+// [ks][plane][lane][8]); body(tt, a0h, a0l, a1h, a1l, bh, bl) issues the MFMAs of token tile tt.
+template <class Body>
+__device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f16 *pa1, Body body) {
     const char *X = c.smem + LDS_X;
     const unsigned lo = (unsigned)c.lane * 8;
-    f16x8 a0[2][2], a1[2][2];
+    f16x8 a0[2][2], a1[2][2], b[2][2];   // A: [k-step parity][plane]; B: [stage parity][plane]
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         a0[0][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + pl * 512);
         a1[0][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + pl * 512);
+        b[0][pl] = lds16(X + x_at(c, 0, pl, 0));
     }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 8) {
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                a0[nxt][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + ((ks + 1) * 2 + pl) * 512);
-                a1[nxt][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + ((ks + 1) * 2 + pl) * 512);
-            }
-        }
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-            const f16x8 bh = lds16(X + x_at(c, tt, 0, ks));
-            const f16x8 bl = lds16(X + x_at(c, tt, 1, ks));
-            mma3(acc0[tt], a0[cur][0], a0[cur][1], bh, bl);
-            if (ODD ? tt >= 4 : tt < 4) mma3(acc1[ODD ? tt - 4 : tt], a1[cur][0], a1[cur][1], bh, bl);
-            if (tt & 1) __builtin_amdgcn_sched_barrier(0);
+            const int cur = (ks * NTT + tt) & 1, nxt = cur ^ 1;
+            if (tt == 0 && ks + 1 < 8) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    a0[(ks + 1) & 1][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + ((ks + 1) * 2 + pl) * 512);
+                    a1[(ks + 1) & 1][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + ((ks + 1) * 2 + pl) * 512);
+                }
+            }
+            const int nks = tt + 1 < NTT ? ks : ks + 1, ntt = tt + 1 < NTT ? tt + 1 : 0;
+            if (nks < 8) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) b[nxt][pl] = lds16(X + x_at(c, ntt, pl, nks));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            body(tt, a0[ks & 1][0], a0[ks & 1][1], a1[ks & 1][0], a1[ks & 1][1], b[cur][0], b[cur][1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// acc0[tt] += A0 . X^T for all token tiles, acc1[i] += A1 . X^T for token tiles tt1 + i (tt1 = ODD ? 4 : 0), K = 256.
+// pa0 / pa1: fragment streams [ks][plane][lane][8] of the two n-tiles (wave-uniform pointers)
+template <bool ODD>
+__device__ __forceinline__ void gemm_head(const Ctx &c, f32x4 (&acc0)[NTT], f32x4 (&acc1)[4], const f16 *pa0, const f16 *pa1) {
+    gemm_pipe(c, pa0, pa1, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
+        mma3(acc0[tt], a0h, a0l, bh, bl);
+        if (ODD ? tt >= 4 : tt < 4) mma3(acc1[ODD ? (tt >= 4 ? tt - 4 : 0) : (tt < 4 ? tt : 0)], a1h, a1l, bh, bl);
+    });
 }
 
 // acc[a][tt] += A_a . X^T, n-tiles 2 w + a of a 256 x 256 matrix in fragment-major planes
 __device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *wmat) {
-    const char *X = c.smem + LDS_X;
-    const f16 *pa = wmat + (long)(2 * c.w) * (8 * 2 * 512) + (unsigned)c.lane * 8;
-    f16x8 a[2][2][2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) a[0][n][pl] = *reinterpret_cast<const f16x8 *>(pa + n * (8 * 2 * 512) + pl * 512);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 8) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[nxt][n][pl] = *reinterpret_cast<const f16x8 *>(pa + n * (8 * 2 * 512) + ((ks + 1) * 2 + pl) * 512);
-        }
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const f16x8 bh = lds16(X + x_at(c, tt, 0, ks));
-            const f16x8 bl = lds16(X + x_at(c, tt, 1, ks));
-            mma3(acc[0][tt], a[cur][0][0], a[cur][0][1], bh, bl);
-            mma3(acc[1][tt], a[cur][1][0], a[cur][1][1], bh, bl);
-            if (tt & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    const f16 *pa = wmat + (long)(2 * c.w) * (8 * 2 * 512);
+    gemm_pipe(c, pa, pa + 8 * 2 * 512, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
+        mma3(acc[0][tt], a0h, a0l, bh, bl);
+        mma3(acc[1][tt], a1h, a1l, bh, bl);
+    });
 }
 
-// acc[a][tt] += A_a . B^T with B rows of 64 features in a Q-layout buffer (K = 64); pa0 / pa1: streams at the first k-step
-__device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *pa0, const f16 *pa1, const char *Bbuf) {
+// the A fragments of a K = 64 GEMM: n-tiles at pa0 / pa1 (streams at the first k-step), [n-tile][k-step][plane]
+struct AK64 { f16x8 a[2][2][2]; };
+__device__ __forceinline__ void load_k64(const Ctx &c, AK64 &f, const f16 *pa0, const f16 *pa1) {
     const unsigned lo = (unsigned)c.lane * 8;
-    f16x8 a[2][2][2];
+    __builtin_amdgcn_sched_barrier(0);   // not earlier than here (32 registers)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            a[0][kk][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + (kk * 2 + pl) * 512);
-            a[1][kk][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + (kk * 2 + pl) * 512);
+            f.a[0][kk][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + (kk * 2 + pl) * 512);
+            f.a[1][kk][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + (kk * 2 + pl) * 512);
         }
+    __builtin_amdgcn_sched_barrier(0);
+}
+// acc[a][tt] += A_a . B^T with B rows of 64 features in a Q-layout buffer (K = 64)
+__device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const AK64 &f, const char *Bbuf) {
+    const f16x8 (&a)[2][2][2] = f.a;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -565,6 +566,8 @@ __device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x
     }
     __syncthreads();       // B4: V complete
     TJ_STAMP(st0 + 4);
+    AK64 wo;
+    const f16 *po0 = a.w_o + ((long)(2 * w) * 8 + 2 * h) * (2 * 512), *po1 = a.w_o + ((long)(2 * w + 1) * 8 + 2 * h) * (2 * 512);
     if (w < NTT) {
         f32x4 O[4];
 #pragma unroll
@@ -592,6 +595,9 @@ __device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x
                 mma3(O[ft], vf[0], vf[1], ph, pl);
             }
         }
+        // the out-projection's weight fragments are requested now (the score registers are free): their L2 round trip passes
+        // under the O write and the barrier
+        load_k64(c, wo, po0, po1);
         // O^T tile ft: features 16 ft + 4 g + r of query 16 w + t, times ACT / sum -> LDS planes (over Q)
         const float inv = 1.0f / psum;
         const int tok = 16 * w + t;
@@ -603,11 +609,11 @@ __device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x
             }
         }
     }
+    else load_k64(c, wo, po0, po1);
     TJ_STAMP(st0 + 5);
     __syncthreads();       // B5: O complete
     TJ_STAMP(st0 + 6);
-    const f16 *po0 = a.w_o + ((long)(2 * w) * 8 + 2 * h) * (2 * 512), *po1 = a.w_o + ((long)(2 * w + 1) * 8 + 2 * h) * (2 * 512);
-    gemm_k64(c, H, po0, po1, Qb);
+    gemm_k64(c, H, wo, Qb);
 }
 
 __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
@@ -653,6 +659,21 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         unscale_h(c, H, 1.0f / up, L.b_o);
     }
     TJ_STAMP(31);
+    // The folded keys of this wave's head (16 fragments = 64 registers) are requested BEFORE LayerNorm 2 and land under it: a
+    // workgroup is alone on its CU, nothing else hides their HBM / MALL round trips (the score phase took 18 k cycles for 96 MFMAs).
+    // Lanes of slot Mc read the step token's shared row instead of their trajectory's block.
+    f16x8 gfr[8][2];
+    {
+        const int hh = c0.w >> 1, Mc = Mk - 1;
+        const f16 *gp = c0.t == Mc ? L.gstep + (long)hh * (8 * 2 * 32) + c0.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c0.lane * 8;
+        const int gstride = c0.t == Mc ? 32 : 512;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) gfr[ks][pl] = *reinterpret_cast<const f16x8 *>(gp + (ks * 2 + pl) * gstride);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     layer_norm_to_x(c0, H, L.n2_w, L.n2_b);
     TJ_STAMP(32);
     // ---- folded cross-attention: wave w scores head w >> 1 for token tiles tt1 .. (half w & 1)
@@ -666,13 +687,9 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         f32x4 S[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // lanes of slot Mc read the step token's shared row instead of their trajectory's block
-        const f16 *gp = c.t == Mc ? L.gstep + (long)hh * (8 * 2 * 32) + c.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c.lane * 8;
-        const int gstride = c.t == Mc ? 32 : 512;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const f16x8 gh = *reinterpret_cast<const f16x8 *>(gp + (ks * 2) * gstride);
-            const f16x8 gl = *reinterpret_cast<const f16x8 *>(gp + (ks * 2 + 1) * gstride);
+            const f16x8 gh = gfr[ks][0], gl = gfr[ks][1];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= n1) continue;
@@ -682,6 +699,23 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
                 mma3(S[i], gh, gl, bh, bl);
             }
         }
+        // the folded values (48 registers) are requested now: they land under the softmax
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 av[2][3][2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *vp = L.v16 + ((traj * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
+                av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // softmax over the Mk key slots (accumulator rows 4 g + r) of each token (lane column)
         const float c_g = 1.0f / (ACT * L.sc[4]);
         f32x4 cbv = *reinterpret_cast<const f32x4 *>(L.cb + traj * 64 + hh * 16 + 4 * c.g);
@@ -721,20 +755,6 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         // h += V'^T P^T + boc: K = 64 (context slots of 4 heads) + 32 (step columns)
         const float up = PSC * L.sc[5];
         scale_h(H, up);
-        f16x8 av[2][3][2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const f16 *vp = L.v16 + ((traj * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
-                av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll

@@ -330,24 +330,37 @@ int main(int argc, char **argv) {
                                      "h3 scores", "h3 V write", "h3 PV", "h3 B5", "out-proj(h3)+unscale", "LN2", "xattn scores+softmax", "xattn PV'", "LN3",
                                      "W1 gemm", "GELU -> panel", "W2 gemm", "LN1'", "fc_out + DDIM (last layer only)"};
             const int nwg = B < tj::TJ_STAMP_WGS ? B : tj::TJ_STAMP_WGS;
-            for (int wsel = 0; wsel < 2; ++wsel) {
-                const int w0 = wsel == 0 ? 0 : 7;
-                printf("--- last layer of the step, wave %d: mean cycles per phase over %d workgroups\n", w0, nwg);
-                double tot = 0;
-                for (int i = 4; i <= 40; ++i) {
-                    double s = 0;
-                    for (int b = 0; b < nwg; ++b) {
-                        const unsigned long long *p = &st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP];
-                        s += (double)(p[i] - p[i - 1]);
-                    }
-                    s /= nwg;
-                    tot += s;
-                    printf("  %-34s %9.0f\n", names[i], s);
+            auto mean = [&](int w0, int i) {
+                double s = 0;
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long *p = &st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP];
+                    s += (double)(p[i] - p[i - 1]);
                 }
-                double whole = 0;
-                for (int b = 0; b < nwg; ++b) whole += (double)(st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP + 40] - st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP]);
-                printf("  sum of the phases above %.0f;  whole step (L layers) %.0f\n", tot, whole / nwg);
+                return s / nwg;
+            };
+            const char *agg[7] = {"QKV gemm", "B1+QK write+B2", "scores+softmax", "B3+V write+B4", "PV+O write", "B5", "out-proj"};
+            printf("--- last layer of the step: mean cycles per phase over %d workgroups        wave 0    wave 3    wave 4    wave 7\n", nwg);
+            const int ws[4] = {0, 3, 4, 7};
+            for (int k = 0; k < 7; ++k) {
+                printf("  4 heads: %-28s", agg[k]);
+                for (int wi = 0; wi < 4; ++wi) {
+                    double s = 0;
+                    for (int h = 0; h < 4; ++h) {
+                        const int i = 4 + 7 * h + k;   // stamps 4 + 7 h .. 10 + 7 h (out-proj of head h ends at the next head's first stamp)
+                        if (i <= 31) s += mean(ws[wi], i);
+                    }
+                    printf(" %9.0f", s);
+                }
+                printf("\n");
             }
+            for (int i = 32; i <= 40; ++i) {
+                printf("  %-37s", names[i]);
+                for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], i));
+                printf("\n");
+            }
+            double whole = 0;
+            for (int b = 0; b < nwg; ++b) whole += (double)(st[((size_t)b * 8) * tj::TJ_NSTAMP + 40] - st[((size_t)b * 8) * tj::TJ_NSTAMP]);
+            printf("  whole step (L layers), wave 0: %.0f cycles\n", whole / nwg);
             a.update_x = 1;
         }
 #endif
