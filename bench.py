@@ -186,8 +186,9 @@ def cpu_baseline(sd, seconds_budget=25.0):
 
 def cpu_baseline_train(sd, seconds_budget=15.0):
     """The same contract for --mode train: the oracle's training step (forward, MSE, torch CPU autograd backward; no optimizer:
-    AdamW on 2.6 M parameters is noise next to it) at p = 0 on a bounded sample - B = 32 trajectories per step, as many steps as
-    the budget allows after one warm-up step, at the thread count the box's CPU share allows."""
+    AdamW on 2.6 M parameters is noise next to it) at p = 0 at SURVEY 8(d)'s batch, B = 256 trajectories per step - a bounded
+    number of steps (as many as the budget allows after one warm-up step, at least one), at the thread count the box's CPU share
+    allows."""
     import torch
     from oracle import ddim_ref
     from oracle import denoiser_ref as ref
@@ -195,7 +196,7 @@ def cpu_baseline_train(sd, seconds_budget=15.0):
     quota = cpu_quota()
     threads = max(1, min(int(quota), physical_cores()))
     torch.set_num_threads(threads)
-    Bc = 32
+    Bc = TRAIN_B
     g = torch.Generator().manual_seed(4321)
     x0, eps = torch.randn(Bc, T, J, generator=g), torch.randn(Bc, T, J, generator=g)
     ctx = torch.randn(Bc, MC, D, generator=g)
@@ -262,7 +263,7 @@ class TrainLeg:
         torch.manual_seed(0)   # every rank builds the same replica ...
         self.model = cli.build_model(C2_PARAMS).to(dev).train()
         if hasattr(self.model, "set_dropout"):
-            self.model.set_dropout(dropout)
+            self.model.set_dropout(dropout, seed=1234 + 7919 * rank)   # every rank its own Philox key, as cli.cmd_train
         self.dropout = dropout if hasattr(self.model, "set_dropout") else 0.0
         self.opt = training.FusedAdamW(self.model.parameters(), lr=1e-4)
         if world > 1:   # ... and rank 0's parameters are broadcast anyway (cli.cmd_train does the same)
@@ -324,6 +325,43 @@ def time_train(leg: TrainLeg, steps: int, warmup: int, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, float(loss)
+
+
+def train_chain_roofline(leg: "TrainLeg", step_ms: float, n=4):
+    """Roofline of the training step's dominant kernel class, the fused row chains (sd_train_fwd_chain / sd_train_bwd_chain;
+    47 % of the step in profiles/r02_train_step_kernel_stats.txt): n EAGER steps with a HIP-event pair around every launch
+    (the graphed step cannot be instrumented), their summed time per step against the algorithmic FLOPs they own - the row
+    GEMMs of forward and dX, 2 x 16 T d^2 per layer and trajectory (the weight gradients are the grouped GEMM's)."""
+    import ctypes as C
+
+    from soccerdiffusion_amd import _lib
+
+    lib, torch = _lib.load(), leg.torch
+    eager = lambda: leg.training.train_step(leg.model, leg.opt, leg.lr, leg.ns, leg.x0, context=leg.ctx, world_size=leg.world,   # noqa: E731
+                                            generator=leg.g)
+    eager()
+    torch.cuda.synchronize()
+    lib.sd_profile_enable(1)
+    for _ in range(n):
+        eager()
+    torch.cuda.synchronize()
+    lib.sd_profile_enable(0)
+    k = len(_lib.KERNEL_CLASSES)
+    ms, cnt = (C.c_double * k)(), (C.c_long * k)()
+    _lib.check(lib.sd_profile_collect(ms, cnt, k), "sd_profile_collect")
+    ch = _lib.KERNEL_CLASSES.index("decoder_layer_kernel")
+    chain_ms = ms[ch] / n
+    flops = leg.B * L * 32 * T * D * D
+    ach = flops / max(chain_ms, 1e-9) / 1e9
+    return {"bound": "mfma", "kernel": "fused row chains (train_fwd_chain_kernel / train_bwd_chain_kernel, csrc/sd_train_chain.hip)",
+            "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
+            "vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
+            "definition": "algorithmic row-GEMM FLOPs of forward + dX (2 x 16 T d^2 per layer and trajectory) / summed HIP-event time "
+                          "of the chain launches in one eager step",
+            "chain_ms_per_step": round(chain_ms, 4), "chain_launches_per_step": int(cnt[ch] // n),
+            "share_of_graphed_step": round(chain_ms / max(step_ms, 1e-9), 4),
+            "class_ms_per_eager_step": {nm: round(ms[i] / n, 4) for i, nm in enumerate(_lib.KERNEL_CLASSES) if ms[i] > 0},
+            "traffic": None}
 
 
 def train_record(elapsed, steps, world, B, loss, allreduce_ms, dropout, n_params):
@@ -402,10 +440,18 @@ def run_train(args, rank, world, dev, dist):
     leg = TrainLeg(dev, rank, world, B, steps + warmup, dropout=args.dropout, graph=not args.no_graph)
     elapsed, loss = time_train(leg, steps, max(warmup, 3 if leg.graphed is not None else 0), dist)   # capture happens on call 3
     ar = leg.allreduce_ms()
+    chain = None
+    if world == 1 and not args.no_kernel_timing:
+        try:
+            chain = train_chain_roofline(leg, elapsed / steps * 1e3)
+        except Exception as e:  # noqa: BLE001 - a sub-record must not take the line down
+            chain = {"error": repr(e)[:300]}
     leg.close()
     if rank != 0:
         return
     rec = train_record(elapsed, steps, world, B, loss, ar, leg.dropout, leg.opt.flat_param.numel())
+    if world > 1:
+        rec["note"] = "N > 1: correct by construction and rehearsed with two ranks on one GPU (gloo); no multi-GPU hardware run exists"
     line = {
         "metric": "training trajectories/s (fwd + bwd + AdamW per trajectory; denoiser d=256 L=4, H=100, J=20)",
         "value": rec["value"], "unit": "trajectories/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -419,10 +465,12 @@ def run_train(args, rank, world, dev, dist):
                                f"{'the step replayed from a hipGraph' if leg.graphed is not None else 'launches issued eagerly'}",
                    "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "joints": J, "hidden_dim": D, "decoder_layers": L,
                    "memory_tokens": M, "parallelism": f"dp{world}" + (" (one flat-gradient all-reduce per step)" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": "whole training step (no single dominant kernel: profiles/r02_train_step_kernel_stats.txt)",
-                     "achieved": rec["algorithmic_tflops_per_gpu"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": rec["frac_of_f16_mfma_peak"], "traffic": None,
+        "roofline": chain if chain and "error" not in chain else
+                    {"bound": "mfma", "kernel": "whole training step", "achieved": rec["algorithmic_tflops_per_gpu"], "peak": PEAK_F16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": rec["frac_of_f16_mfma_peak"], "traffic": None,
                      "definition": "3 x F_step (SURVEY 8(d)) x trajectories / wall time, per GPU"},
+        "whole_step": {"achieved": rec["algorithmic_tflops_per_gpu"], "unit": "TFLOP/s", "frac_of_f16_mfma_peak": rec["frac_of_f16_mfma_peak"],
+                       "definition": "3 x F_step (SURVEY 8(d)) x trajectories / wall time, per GPU"},
         "train": rec,
         "cpu_baseline": None,
     }
@@ -762,6 +810,13 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
         leg.close()
         out["train"] = train_record(elapsed, 30, 1, TRAIN_B, loss, 0.0, leg.dropout, leg.opt.flat_param.numel())
         out["train"]["hipgraph"] = leg.graphed is not None
+        try:
+            leg2 = TrainLeg(dev, 0, 1, TRAIN_B, 40, graph=False)
+            out["train"]["roofline"] = train_chain_roofline(leg2, out["train"]["ms_per_step"])
+            del leg2
+        except Exception as e:  # noqa: BLE001
+            out["train"]["roofline"] = {"error": repr(e)[:300]}
+        out["train"]["cpu_baseline"] = cpu_baseline_train(sd, seconds_budget=10.0)
         out["train"]["workload"] = "BASELINE.json configs[1]: C2 training step, B=256, d=256 L=4 T=100 J=20 M=11 (bench.py --mode train)"
     except Exception as e:  # noqa: BLE001
         out["train"] = {"error": repr(e)[:300]}

@@ -316,6 +316,10 @@ typedef struct sd_gemm_tn_problem {
     int32_t N, K, ldy, ldx, ldw;
 } sd_gemm_tn_problem;
 int sd_gemm_tn_grouped(const sd_gemm_tn_problem *problems, int n_problems, void *stream);
+/* Host-only: the slabs-per-workgroup sd_gemm_tn_grouped would choose for cnt (<= 64) problems of R[i] rows and N[i] x K[i]
+ * outputs, and the workgroups that makes (*total_wgs, may exceed one chip-full for very large groups).  No launch; -1 on bad
+ * arguments.  (CPU unit test of the partitioning arithmetic.) */
+long sd_gemm_tn_grouped_plan(const long *R, const long *N, const long *K, int cnt, long *total_wgs);
 int sd_op_absmax(const float *x, int64_t rows, int width, int ld, uint32_t *amax, void *stream);
 
 /* sd_op_attention_lse / sd_op_attention_bwd with dropout on the probabilities: O = (softmax(S) o mask) V, the softmax

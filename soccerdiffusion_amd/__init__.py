@@ -4,4 +4,4 @@ Python mirrors the reference's module API; all computation is hand-written HIP f
 behind the C ABI in ``include/soccerdiffusion_hip.h``.  There is no CPU fallback.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"

@@ -111,6 +111,7 @@ SIGNATURES = {
     "sd_train_fwd_chain": (C.c_int, [C.POINTER(TrainFwdChainArgs), C.c_void_p]),
     "sd_train_bwd_chain": (C.c_int, [C.POINTER(TrainBwdChainArgs), C.c_void_p]),
     "sd_gemm_tn_grouped": (C.c_int, [C.POINTER(GemmTnProblem), C.c_int, C.c_void_p]),
+    "sd_gemm_tn_grouped_plan": (C.c_long, [C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int, C.POINTER(C.c_long)]),
     "sd_op_absmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sd_pack_weight_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_linear_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

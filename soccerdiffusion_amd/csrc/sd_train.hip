@@ -12,6 +12,7 @@
 
 #include "../../include/soccerdiffusion_hip.h"
 #include "sd_common.h"
+#include <algorithm>
 
 // ======================================================================================
 // gemm_tn:  dW[N,K] += dY[R,N]^T X[R,K]   and   db[N] += sum_r dY[r,:]
@@ -862,6 +863,37 @@ extern "C" int sd_op_absmax(const float *x, int64_t rows, int width, int ld, uin
     return 0;
 }
 
+// workgroups of a grouped launch when every workgroup takes (at most) per_wg 32-row slabs of one 128 x 128 tile (even counts)
+static long tng_total_wgs(const sd_gemm_tn_problem *pr, int cnt, long per_wg) {
+    long total = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const sd_gemm_tn_problem &q = pr[i];
+        const long slabs = (q.R + 31) / 32;
+        long cs = per_wg < slabs ? per_wg : slabs;
+        cs += cs & 1;
+        total += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((slabs + cs - 1) / cs);
+    }
+    return total;
+}
+// exported for the CPU-side unit test of the partitioning arithmetic: the per_wg the launch would use for `cnt` problems
+// (<= 16) of R rows and N x K outputs each; never launches anything
+extern "C" long sd_gemm_tn_grouped_plan(const long *R, const long *N, const long *K, int cnt, long *total_wgs) {
+    if (!R || !N || !K || cnt <= 0 || cnt > 64) return -1;
+    sd_gemm_tn_problem pr[64] = {};
+    long slab_tiles = 0, max_slabs = 1;
+    for (int i = 0; i < cnt; ++i) {
+        pr[i].R = R[i]; pr[i].N = (int)N[i]; pr[i].K = (int)K[i];
+        slab_tiles += (long)((N[i] + 127) / 128) * ((K[i] + 127) / 128) * ((R[i] + 31) / 32);
+        max_slabs = std::max(max_slabs, (long)((R[i] + 31) / 32));
+    }
+    long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
+    if (per_wg < 8) per_wg = 8;
+    for (;; ++per_wg)
+        if (tng_total_wgs(pr, cnt, per_wg) <= SD_TNG_WGS || per_wg >= max_slabs) break;
+    if (total_wgs) *total_wgs = tng_total_wgs(pr, cnt, per_wg);
+    return per_wg;
+}
+
 extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *stream) {
     if (!pr || n <= 0) return fail(SD_E_BADARG, "sd_gemm_tn_grouped: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -883,16 +915,13 @@ extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *str
         // chip made a second round, +30 % on the launch)
         long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
         if (per_wg < 8) per_wg = 8;
+        // Once per_wg has reached every problem's slab count the total no longer shrinks: a group with more than SD_TNG_WGS
+        // output tiles (e.g. eight 1152 x 1152 gradients) then simply runs as more than one round of workgroups (this
+        // loop used to spin forever on such a group).
+        long max_slabs = 1;
+        for (int i = 0; i < cnt; ++i) max_slabs = std::max(max_slabs, (long)((pr[first + i].R + 31) / 32));
         for (;; ++per_wg) {
-            long total = 0;
-            for (int i = 0; i < cnt; ++i) {
-                const sd_gemm_tn_problem &q = pr[first + i];
-                const long slabs = (q.R + 31) / 32;
-                long cs = per_wg < slabs ? per_wg : slabs;
-                cs += cs & 1;
-                total += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((slabs + cs - 1) / cs);
-            }
-            if (total <= SD_TNG_WGS) break;
+            if (tng_total_wgs(pr + first, cnt, per_wg) <= SD_TNG_WGS || per_wg >= max_slabs) break;
         }
         int wgs = 0;
         for (int i = 0; i < cnt; ++i) {

@@ -324,30 +324,28 @@ class _CrossAttention(Function):
 
 
 # abs-max words of tensors that cross from a fused stack to the embedding / fc_out nodes around it (the last layer's output, the
-# gradient of the first layer's input): data_ptr -> (weakref to the stack's table, address of the tensor's words, address of a free
-# slot of the same table for the node's own small operand).  An entry dies with its table, i.e. with the step's autograd graph.
-_AMAX_REG: dict = {}
-
-
+# gradient of the first layer's input).  The slot travels WITH the tensor object, as an attribute (weakref to the stack's table,
+# address of the tensor's words, address of a free slot of the same table for the node's own small operand): an address-keyed
+# registry could hand a reused allocation the stale maximum of a freed tensor.  The consumer reads the attribute
+# from the very object it was handed (before any view) and also checks the shape; anything else takes the block-floating GEMM.
 def _amax_register(t: Tensor, table: Tensor, slot_addr: int, scratch_addr: int) -> None:
     import weakref
-    if len(_AMAX_REG) > 256:   # entries of finished steps
-        for k in [k for k, v in _AMAX_REG.items() if v[0]() is None]:
-            del _AMAX_REG[k]
-    _AMAX_REG[t.data_ptr()] = (weakref.ref(table), slot_addr, scratch_addr)
+    t._sd_amax = (weakref.ref(table), slot_addr, scratch_addr, tuple(t.shape))
 
 
 def _amax_lookup(t: Tensor):
-    ent = _AMAX_REG.get(t.data_ptr())
-    if ent is None or ent[0]() is None:
+    ent = getattr(t, "_sd_amax", None)
+    if ent is None or ent[0]() is None or ent[3] != tuple(t.shape):
         return None
     return ent[1], ent[2]
 
 
-def _dw_skinny(dY: Tensor, X: Tensor, dW: Tensor, db, known: Tensor, small: Tensor) -> None:
-    """dW += dY^T X where one operand (``known``) carries registered abs-max words and the other (``small``) is cheap to scan:
-    the grouped fp16 GEMM with ragged tiles instead of the block-floating-point kernel (67 -> ~20 us for the J = 20 gradients)."""
-    ent = _amax_lookup(known) if os.environ.get("SD_TRAIN_GROUPED_DW", "1") != "0" else None
+def _dw_skinny(dY: Tensor, X: Tensor, dW: Tensor, db, known: Tensor, small: Tensor, ent=None) -> None:
+    """dW += dY^T X where one operand (``known``) carries registered abs-max words (``ent``: what _amax_lookup returned for the
+    tensor ``known`` is a view of) and the other (``small``) is cheap to scan: the grouped fp16 GEMM with ragged tiles instead
+    of the block-floating-point kernel (67 -> ~20 us for the J = 20 gradients)."""
+    if os.environ.get("SD_TRAIN_GROUPED_DW", "1") == "0":
+        ent = None
     ok = ent is not None and dY.shape[-1] % 4 == 0 and X.shape[-1] % 4 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
     if not ok:
         ops.gemm_tn(dY, X, dW, db)
@@ -387,8 +385,9 @@ class _PatchEmbed(Function):
             n = S // p
             patches = x[:, : n * p].reshape(B, n, p, C).permute(0, 1, 3, 2).reshape(B * n, C * p).contiguous()
         (dW, db), (rW, rb) = _grad_targets(W, b)
+        ent = _amax_lookup(dy) if dy.is_contiguous() else None   # the very tensor the stack's backward produced
         dy2 = dy.contiguous().view(-1, d)
-        _dw_skinny(dy2, patches, dW.view(d, patches.shape[1]), db, known=dy2, small=patches)
+        _dw_skinny(dy2, patches, dW.view(d, patches.shape[1]), db, known=dy2, small=patches, ent=ent)
         dx = None
         if ctx.needs_input_grad[0]:
             # only the image tokens are a differentiable input (they come from the ResNet): kernel size 1, C = d
@@ -406,6 +405,7 @@ class _FcOut(Function):
     def forward(ctx, h, W, b):
         h2 = h.reshape(-1, h.shape[-1])
         ctx.save_for_backward(h2, W, b)
+        ctx.amax = _amax_lookup(h) if h.is_contiguous() else None   # the stack's output object itself (h2 is then a view of it)
         ctx.shape = h.shape
         return ops.fc_out(h2, W, b).view(*h.shape[:-1], W.shape[0])
 
@@ -414,7 +414,7 @@ class _FcOut(Function):
         h2, W, b = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
         (dW, db), (rW, rb) = _grad_targets(W, b)
-        _dw_skinny(dy2, h2, dW, db, known=h2, small=dy2)
+        _dw_skinny(dy2, h2, dW, db, known=h2, small=dy2, ent=ctx.amax)
         dh = ops.small_k_matmul(dy2, W)
         return dh.view(ctx.shape), rW, rb
 

@@ -189,3 +189,41 @@ def test_swin_image_encoders_follow_torchvision():
     assert y.shape == (1, 2, 64) and torch.isfinite(y).all()
     s = image_encoder_factory(ImageEncoderType.SWIN_TRANSFORMER_SMALL, 64, True, 224)
     assert sum(p.numel() for p in s.parameters()) == 49_606_258 - (768 * 1000 + 1000) + 768 * 64 + 64
+
+
+def test_grouped_weight_gradient_partition_terminates_and_covers():
+    """sd_gemm_tn_grouped's search for slabs-per-workgroup must end for ANY group - also one with more output
+    tiles than a chip-full of workgroups (it used to spin forever there).  Host arithmetic only, no launch."""
+    import ctypes as C
+
+    from soccerdiffusion_amd import _lib
+
+    lib = _lib.load()
+
+    def plan(probs):
+        n = len(probs)
+        R = (C.c_long * n)(*[p[0] for p in probs])
+        N = (C.c_long * n)(*[p[1] for p in probs])
+        K = (C.c_long * n)(*[p[2] for p in probs])
+        tot = C.c_long(0)
+        per = lib.sd_gemm_tn_grouped_plan(R, N, K, n, C.byref(tot))
+        return per, tot.value
+
+    # the training step's layer launch: six d x d gradients over 25 600 rows + two ragged J = 20 ones -> one chip-full
+    per, tot = plan([(25600, 256, 256)] * 6 + [(25600, 20, 256), (25600, 256, 20)])
+    assert per >= 8 and 0 < tot <= 512
+    # more tiles than workgroups fit: eight 1152 x 1152 gradients (81 tiles each) - terminates, runs as several rounds
+    per, tot = plan([(4096, 1152, 1152)] * 8)
+    assert per >= 128 and tot == 8 * 81          # every workgroup takes a whole tile's 128 slabs
+    per, tot = plan([(64, 4096, 4096)])          # one large matrix, two slabs: 1024 tiles
+    assert per >= 2 and tot == 1024
+    # coverage: chunks x per-workgroup slabs cover every slab of every problem
+    for probs in ([(1000, 256, 256)], [(37, 128, 20), (100000, 256, 768)], [(25600, 256, 256)] * 16):
+        per, tot = plan(probs)
+        want = 0
+        for R_, N_, K_ in probs:
+            slabs = (R_ + 31) // 32
+            cs = min(per, slabs)
+            cs += cs & 1
+            want += ((N_ + 127) // 128) * ((K_ + 127) // 128) * ((slabs + cs - 1) // cs)
+        assert tot == want

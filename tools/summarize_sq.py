@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+TOP = int(sys.argv[2]) if len(sys.argv) > 2 else int(os.environ.get("SD_SQ_TOP", "6"))   # kernels listed (by total duration)
 files = glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)
 if not files:
     sys.exit("no counter_collection.csv under " + out)
@@ -23,7 +24,7 @@ names = sorted({c for v in agg.values() for c in v})
 summary = {}
 print("per-dispatch averages (counter units as rocprofv3 reports them: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, "
       "SQ_VALU_MFMA_BUSY_CYCLES in cycles, MI355X_MICROARCH.md)")
-for k in sorted(agg, key=lambda k: -dur[k])[:6]:
+for k in sorted(agg, key=lambda k: -dur[k])[:TOP]:
     n = len(cnt[k])
     v = {c: agg[k][c] / n for c in names}
     print(f"\n{k}   dispatches {n}   avg duration under the counter pass {dur[k] / n / 1e3:.1f} us")
