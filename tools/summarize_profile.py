@@ -72,7 +72,8 @@ if "FETCH_SIZE" in report and "WRITE_SIZE" in report:
         per[k] = {"hbm_bytes_per_launch": (2 * fv["total"] / fv["dispatches"] + wv["total"] / wv["dispatches"]) * 1024,
                   "dispatches": fv["dispatches"]}
     layer = [k for k in per if k.startswith("decoder_layer")]
-    dom = max(layer, key=lambda k: per[k]["dispatches"]) if layer else None
+    traj = [k for k in per if "traj_step_kernel" in k]
+    dom = traj[0] if traj else (max(layer, key=lambda k: per[k]["dispatches"]) if layer else None)
     traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_gpu.sh); FETCH_SIZE doubled per the "
                          "gfx950 note in MI355X_MICROARCH.md; KiB units",
                "workload": "bench.py --steps 1 (B=4096)", "dominant_kernel": dom,
@@ -80,6 +81,9 @@ if "FETCH_SIZE" in report and "WRITE_SIZE" in report:
                "decoder_layer_kernel_bytes_per_launch":
                    (sum(per[k]["hbm_bytes_per_launch"] * per[k]["dispatches"] for k in layer) / sum(per[k]["dispatches"] for k in layer))
                    if layer else None,
+               # sampler mode 3: one launch per DDIM step carries the whole denoiser step
+               "traj_step_kernel_bytes_per_launch": per[traj[0]]["hbm_bytes_per_launch"] if traj else None,
+               "round": os.environ.get("SD_PROFILE_ROUND", "r03"),
                "per_kernel": per}
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("\n== HBM bytes per launch (2 x FETCH + WRITE):")

@@ -49,8 +49,16 @@ for k in sorted(agg, key=lambda k: -dur[k])[:TOP]:
         print(f"   LDS bank-conflict cycles / LDS active cycles: {100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / v['SQ_LDS_IDX_ACTIVE']:.1f} %")
 
 import json
+traj = [k for k in summary if "traj_step_kernel" in k]
+if traj:
+    k = traj[0]
+    json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE (tools/profile_sq.sh); busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+               "round": os.environ.get("SD_PROFILE_ROUND", "r03"),
+               "traj_step_kernel_mfma_busy": summary[k]["mfma_busy_frac_of_simd_cycles"],
+               "traj_step_kernel_effective_clock_ghz": summary[k]["effective_shader_clock_ghz"],
+               "per_kernel": summary}, open(os.path.join(out, "pmc_sq.json"), "w"), indent=1)
 layer = [k for k in summary if k.startswith("decoder_layer")]
-if layer:
+if layer and not traj:
     tot = sum(summary[k]["dispatches"] for k in layer)
     json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE (tools/profile_sq.sh); busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
                "decoder_layer_kernel_mfma_busy": sum(summary[k]["mfma_busy_frac_of_simd_cycles"] * summary[k]["dispatches"] for k in layer) / tot,
