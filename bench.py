@@ -361,7 +361,21 @@ def train_chain_roofline(leg: "TrainLeg", step_ms: float, n=4):
             "chain_ms_per_step": round(chain_ms, 4), "chain_launches_per_step": int(cnt[ch] // n),
             "share_of_graphed_step": round(chain_ms / max(step_ms, 1e-9), 4),
             "class_ms_per_eager_step": {nm: round(ms[i] / n, 4) for i, nm in enumerate(_lib.KERNEL_CLASSES) if ms[i] > 0},
-            "traffic": None}
+            **train_traffic_record(chain_ms)}
+
+
+def train_traffic_record(chain_ms):
+    """HBM bytes the chain launches of ONE step move, from the committed FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic_train.json:
+    another box and run than this line) - and what they are algorithmically: the row tensors the chains read and write."""
+    p = os.path.join(REPO, "profiles", "pmc_traffic_train.json")
+    if not os.path.exists(p):
+        return {"traffic": None}
+    with open(p) as fh:
+        t = json.load(fh)
+    tr = t.get("chain_bytes_per_step")
+    return {"traffic": tr, "traffic_unit": "HBM bytes per step over the chain launches (2 x FETCH_SIZE + WRITE_SIZE)",
+            "hbm_gbs_over_chain_time": round(tr / max(chain_ms, 1e-9) / 1e6, 1) if tr else None,
+            "traffic_source": t.get("source"), "traffic_round": t.get("round")}
 
 
 def train_record(elapsed, steps, world, B, loss, allreduce_ms, dropout, n_params):

@@ -873,6 +873,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx c;
     ctx_init(c, smem, a.T);
+#ifdef TJ_PRIO_YOUNG   // A/B: static priority for the second-dispatched quartet (it loses every MFMA arbitration to its SIMD partner)
+    if (c.w >= 4) __builtin_amdgcn_s_setprio(TJ_PRIO_YOUNG);
+#endif
+#ifdef TJ_PRIO_OLD
+    if (c.w < 4) __builtin_amdgcn_s_setprio(TJ_PRIO_OLD);
+#endif
     const long traj = blockIdx.x;
     const int J = a.J;
     TJ_STAMP(0);

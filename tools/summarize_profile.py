@@ -18,6 +18,7 @@ def find(sub, pat):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "")
     return name[:110]
