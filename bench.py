@@ -288,6 +288,25 @@ class TrainLeg:
         if self.graphed is not None:
             self.graphed.close()
 
+    def exposed_allreduce_ms(self, steps=10):
+        """Step time with the exchange minus step time without it (the same eager step with world_size = 1 semantics on this
+        rank's shard): what the overlapped, per-layer all-reduce still costs on the critical path."""
+        torch = self.torch
+        if self.world <= 1:
+            return 0.0
+
+        def timed(world):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.training.train_step(self.model, self.opt, self.lr, self.ns, self.x0, context=self.ctx, world_size=world, generator=self.g)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        with_x = timed(self.world)
+        without = timed(1)   # replicas diverge from here on: call this last
+        return with_x - without
+
     def allreduce_ms(self, iters=10):
         """The gradient exchange alone (flat fp32 buffer, sum + mean) timed with events on the current stream."""
         torch = self.torch
@@ -454,6 +473,7 @@ def run_train(args, rank, world, dev, dist):
     leg = TrainLeg(dev, rank, world, B, steps + warmup, dropout=args.dropout, graph=not args.no_graph)
     elapsed, loss = time_train(leg, steps, max(warmup, 3 if leg.graphed is not None else 0), dist)   # capture happens on call 3
     ar = leg.allreduce_ms()
+    ar_exposed = leg.exposed_allreduce_ms() if world > 1 else 0.0
     chain = None
     if world == 1 and not args.no_kernel_timing:
         try:
@@ -464,7 +484,11 @@ def run_train(args, rank, world, dev, dist):
     if rank != 0:
         return
     rec = train_record(elapsed, steps, world, B, loss, ar, leg.dropout, leg.opt.flat_param.numel())
+    rec["allreduce_exposed_ms"] = round(ar_exposed, 4)
     if world > 1:
+        rec["allreduce_form"] = ("per-layer buckets started from gradient hooks and overlapped with the rest of the backward (training.BucketedAllReduce; "
+                                 "the step is issued eagerly at N > 1, the same step cli train runs); allreduce_ms = the flat exchange alone, "
+                                 "allreduce_exposed_ms = step time with minus without the exchange")
         rec["note"] = "N > 1: correct by construction and rehearsed with two ranks on one GPU (gloo); no multi-GPU hardware run exists"
     line = {
         "metric": "training trajectories/s (fwd + bwd + AdamW per trajectory; denoiser d=256 L=4, H=100, J=20)",

@@ -1124,7 +1124,13 @@ class GraphedTrainStep:
       * timesteps and noise come from ``generator`` (registered with the graph: torch advances its Philox offset per replay).
     The first ``eager_steps`` calls run the ordinary ``train_step`` (they are real training steps and warm every lazy
     initialisation up); the next call captures, and from then on every call replays.
-    With ``world_size`` > 1 the graph ends after the backward; the all-reduce and the update follow eagerly."""
+    Data parallel (``world_size`` > 1): EVERY call is the eager ``train_step`` with its per-layer ``BucketedAllReduce`` - the one
+    data-parallel step of this package (``cli train`` runs the same).  Overlapping the exchange with the backward needs the host
+    to issue layer l's all-reduce while the GPU still runs the backward of layers l-1 .. 0; a single captured graph cannot
+    signal the host or a side stream in mid-replay on this stack (torch refuses external event-record nodes on ROCm,
+    tools/exp/graph_event.py), and since the fused row chains (~60 launches per step) the eager step is within 1 % of the
+    replay (1 000-step soak: 3.67 vs 3.65 ms).  ``split_update=True`` keeps the round-2 form (graph up to the end of the
+    backward, then ONE flat all-reduce and the update) for A/B runs and its parity test."""
 
     def __init__(self, model, optimizer: FusedAdamW, lr_scheduler, scheduler, world_size: int = 1,
                  generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None,
@@ -1134,8 +1140,9 @@ class GraphedTrainStep:
         # (rocprofv3: 1.0 of 5.2 ms of kernel time concurrent) but both kernels slow down by as much - 5.85 vs 5.83 ms - so off
         self.fork_dw = fork_dw
         self.world, self.gen, self.eager_left = world_size, generator, eager_steps
-        # data parallel: the captured part ends after the backward, the all-reduce and the update follow eagerly
-        self.split = (world_size > 1) if split_update is None else bool(split_update)
+        # data parallel: the eager bucketed step (see the class comment) unless split_update is forced
+        self.split = False if split_update is None else bool(split_update)
+        self.eager_dp = world_size > 1 and not self.split
         self.graph = None
         dev = optimizer.flat_param.device
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)       # 7 AdamW scalars + the dropout epoch word
@@ -1195,8 +1202,8 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, joint_targets: Tensor, context=None, input_data=None) -> Tensor:
-        if self.eager_left > 0:
-            self.eager_left -= 1
+        if self.eager_left > 0 or self.eager_dp:
+            self.eager_left = max(self.eager_left - 1, 0)
             return train_step(self.model, self.opt, self.lr_sched, self.sched, joint_targets, context=context,
                               input_data=input_data, world_size=self.world, generator=self.gen)
         self._stage(joint_targets, context, input_data)

@@ -172,3 +172,22 @@ def test_two_rank_train_and_distill_rehearsal_on_one_gpu(tmp_path):
     r = torchrun("distill", str(cfg), str(ckpt), "-o", str(tmp_path / "student.pth"), "--synthetic", "130")
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert torch.load(tmp_path / "student.pth", weights_only=True)["hyperparams"]["distilled_decoder"] is True
+
+
+@pytest.mark.timeout(900)
+def test_train_image_conditioned_non_square_frames(tmp_path):
+    """BASELINE configs[4] in miniature through `cli train`: NON-square frames (96 x 128; the benchmark's are
+    480 x 640) with image_use_final_avgpool True - the reference's no-avgpool head assumes square frames
+    (ml/model/encoder/image.py:69-83) - ResNet-18 per frame -> token -> 8-head HIP sequence encoder -> denoiser d = 256, B = 4."""
+    cfg = dict(CFG, hidden_dim=256, epochs=2, batch_size=4, use_images=True, image_context_length=3, image_resolution=96,
+               image_use_final_avgpool=True, use_imu=False, use_joint_states=False, use_action_history=False, num_decoder_layers=2,
+               trajectory_prediction_length=100)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    ckpt = tmp_path / "m.pth"
+    r = _run("train", "-c", str(path), "-o", str(ckpt), "--synthetic", "12", "--image-size", "96x128")
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert len(losses) >= 2 and all(math.isfinite(x) for x in losses)   # one line per epoch (every 20th iteration)
+    sd = torch.load(ckpt, weights_only=True)["model_state_dict"]
+    assert sd["image_sequence_encoder.image_encoder.encoder.conv1.weight"].shape == (64, 3, 7, 7)

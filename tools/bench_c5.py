@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--size", type=str, default="480x640")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--channels-last", action="store_true", help="backbone and frames in torch.channels_last (NHWC): A/B of the MIOpen layout")
     args = ap.parse_args()
     H, W = (int(v) for v in args.size.split("x"))
     t_start = time.time()
@@ -42,6 +43,9 @@ def main():
     g = torch.Generator(device=dev).manual_seed(2)
     B, F = args.batch, args.frames
     frames = torch.rand(B, F, 3, H, W, device=dev, generator=g)
+    if args.channels_last:   # the per-frame encoder sees (B * F, 3, H, W): NHWC storage for it and for its weights
+        model.image_sequence_encoder.image_encoder.to(memory_format=torch.channels_last)
+        frames = frames.view(B * F, 3, H, W).contiguous(memory_format=torch.channels_last).view(B, F, 3, H, W)
     x0 = torch.randn(B, bench.T, bench.J, device=dev, generator=g)
     inp = {"image_data": frames}
 
@@ -78,7 +82,7 @@ def main():
     db = (time.perf_counter() - t0) / args.steps
     phase[0] = "done"
     print(json.dumps({"workload": f"BASELINE configs[4] on 1 GPU: ResNet-18 + denoiser training step, B={B} x {F} frames of {H}x{W}, "
-                                  f"d=256 L=4 T=100 J=20, avgpool head, dropout 0.1",
+                                  f"d=256 L=4 T=100 J=20, avgpool head, dropout 0.1, backbone layout {'channels_last' if args.channels_last else 'NCHW'}",
                       "ms_per_step": round(dt * 1e3, 1), "trajectories_per_s": round(B / dt, 1), "frames_per_s": round(B * F / dt, 1),
                       "backbone_fwd_bwd_ms": round(db * 1e3, 1), "backbone_share": round(db / dt, 3),
                       "per_step_ms": [round(v * 1e3, 1) for v in per_step],
