@@ -39,13 +39,19 @@ constexpr float PSC = 1024.0f;              // scale of the cross-attention prob
 constexpr float XSC = 1.0f;                 // scale of the trajectory values x at the embedding: x has no a-priori bound (an untrained
                                             // denoiser drives |x| into the hundreds); |x| < 65 504, and below 0.125 the lo part's
                                             // absolute error is 3e-8 - under fp32's own rounding of an O(1) sum
-constexpr int XROW = 1024, QROW = 256, VROW = 288, PROW = 512;
+constexpr int XROW = 1024, X1ROW = 512, QROW = 256, VROW = 288, PROW = 512;
+// LDS map.  Outside the self-attention block: [X panel 100 x 1 KiB (hi | lo)] [cross-attention probabilities 100 x 512 B] [stats].
+// Inside it the panel holds LayerNorm 1's output as ONE plane (100 x 512 B: the Q | K | V projection reads the hi part only,
+// see sa_block) and the freed half takes Q and O, so that Q, K, V and O of a head each have a buffer of their own.
 constexpr int LDS_X = 0;
-constexpr int LDS_Q = LDS_X + TMAX * XROW;  // Q of the current head, later its O; x rows at the embedding
-constexpr int LDS_K = LDS_Q + TMAX * QROW;  // K of the current head, later its V
-constexpr int LDS_P = LDS_Q;                // cross-attention probabilities: 100 x 512 B over Q and K
+constexpr int LDS_SQ = LDS_X + TMAX * X1ROW;   // Q of the current head          (inside the X panel's second half)
+constexpr int LDS_SO = LDS_SQ + TMAX * QROW;   // attention output of the head   (likewise)
+constexpr int LDS_Q = LDS_X + TMAX * XROW;     // K of the current head; the x rows at the embedding
+constexpr int LDS_K = LDS_Q + TMAX * QROW;     // V of the current head
+constexpr int LDS_P = LDS_Q;                   // cross-attention probabilities: 100 x 512 B over both
 constexpr int LDS_STAT = LDS_K + TMAX * VROW;
 constexpr int LDS_BYTES = LDS_STAT + TMAX * 8 * 8;
+static_assert(LDS_SO + TMAX * QROW <= LDS_Q, "Q and O fit the freed half of the panel");
 static_assert(LDS_BYTES <= 163840 && LDS_P + TMAX * PROW <= LDS_STAT, "LDS budget");
 constexpr long HFRAG_FLOATS = 8L * 2 * NTT * 256;   // residual stream of one trajectory in fragment order (Stage-A kernel)
 
@@ -65,10 +71,20 @@ __device__ unsigned long long *g_tj_stamps;
 #endif
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-// c += (ah + al) (bh + bl) without lo.lo, small terms first
+// c += (ah + al) (bh + bl) without lo.lo, small terms first.
+// Precision experiment (tools/exp/precision_sites.sh): -DTJ_DROP_ALO=<mask> / -DTJ_DROP_BLO=<mask> drop the
+// A-lo x B-hi / A-hi x B-lo product at the GEMM sites whose bit is set (A = weights, K, V^T, G, V'^T; B = activations, Q, P).
+#ifndef TJ_DROP_ALO
+#define TJ_DROP_ALO 0
+#endif
+#ifndef TJ_DROP_BLO
+#define TJ_DROP_BLO 0
+#endif
+enum Site { S_QKV = 1, S_SCORES = 2, S_PV = 4, S_OUT = 8, S_XSC = 16, S_XPV = 32, S_W1 = 64, S_W2 = 128, S_EMB = 256, S_FC = 512 };
+template <int SITE = 0>
 __device__ __forceinline__ void mma3(f32x4 &c, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
-    c = mfma16(al, bh, c);
-    c = mfma16(ah, bl, c);
+    if constexpr (!(TJ_DROP_ALO & SITE)) c = mfma16(al, bh, c);
+    if constexpr (!(TJ_DROP_BLO & SITE)) c = mfma16(ah, bl, c);
     c = mfma16(ah, bh, c);
 }
 
@@ -315,6 +331,12 @@ __device__ __forceinline__ unsigned p_at(const Ctx &c, int tt, int pl, int kk) {
     return (tt < NTT - 1 ? c.xa[m2] - (unsigned)(c.t * (XROW - PROW)) + (unsigned)(tt * 16 * PROW) : c.xa6[m2] - (unsigned)(c.tok6 * (XROW - PROW))) +
            (unsigned)((kk >> 1) * 256);
 }
+// one-plane panel of the self-attention block (512-byte rows, chunk = g | ks << 2): the same in-row swizzle as the full panel
+__device__ __forceinline__ unsigned x1_at(const Ctx &c, int tt, int ks) {
+    return (tt < NTT - 1 ? c.xa[ks & 3] - (unsigned)(c.t * (XROW - X1ROW)) + (unsigned)(tt * 16 * X1ROW) : c.xa6[ks & 3] - (unsigned)(c.tok6 * (XROW - X1ROW))) +
+           (unsigned)((ks >> 2) * 256);
+}
+__device__ __forceinline__ unsigned x1_off(int tok, int chunk) { return (unsigned)(tok * X1ROW + ((chunk ^ (tok & 15)) << 4)); }
 // generic forms (writers: the chunk's low two bits are not the lane's g).  chunk = gk | plane << 2 | kstep << 3
 __device__ __forceinline__ unsigned x_off(int tok, int chunk) { return (unsigned)(tok * XROW + ((chunk ^ (tok & 15)) << 4)); }
 __device__ __forceinline__ unsigned q_off(int tok, int chunk) { return (unsigned)(tok * QROW + ((chunk ^ (tok & 15)) << 4)); }
@@ -331,9 +353,18 @@ __device__ __forceinline__ void store_x(const Ctx &c, int a, int tt, const f32x4
     split_store(X + x_off(tok, chunk) + 8 * (c.g & 1), X + x_off(tok, chunk | 4) + 8 * (c.g & 1), v);
 }
 
+// the same value as ONE fp16 plane of the one-plane panel (k-step w -> chunk bits 2..4)
+__device__ __forceinline__ void store_x1(const Ctx &c, int a, int tt, const f32x4 &v) {
+    if (!tok_ok(c, tt)) return;
+    const int chunk = (2 * a + (c.g >> 1)) | (c.w << 2), tok = tok_of(c, tt);
+    *reinterpret_cast<f16x4 *>(c.smem + LDS_X + x1_off(tok, chunk) + 8 * (c.g & 1)) = __builtin_convertvector(v, f16x4);
+}
+
 // LayerNorm over the 256 features of H -> split planes of the X panel (scaled by ACT).  Per wave: mean and centred sum of
 // squares of its 32 features (two-pass, in registers + two row all-reduces), then Chan's combination of the 8 waves' pairs:
 // one exchange, two barriers (the first also fences the X panel's previous readers).
+// HI_ONLY: the one-plane panel of the self-attention block (LayerNorm 1).
+template <bool HI_ONLY = false>
 __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
     const Ctx c = ctx_local(c0);
     float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
@@ -374,7 +405,8 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
         const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + n0) * ACT, gb = *reinterpret_cast<const f32x4 *>(ln_b + n0) * ACT;
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-            store_x(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
+            if constexpr (HI_ONLY) store_x1(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
+            else store_x(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
             __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 14 and spills
         }
     }
@@ -421,22 +453,61 @@ __device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f1
     }
 }
 
-// acc0[tt] += A0 . X^T for all token tiles, acc1[i] += A1 . X^T for token tiles tt1 + i (tt1 = ODD ? 4 : 0), K = 256.
-// pa0 / pa1: fragment streams [ks][plane][lane][8] of the two n-tiles (wave-uniform pointers)
-template <bool ODD>
-__device__ __forceinline__ void gemm_head(const Ctx &c, f32x4 (&acc0)[NTT], f32x4 (&acc1)[4], const f16 *pa0, const f16 *pa1) {
-    gemm_pipe(c, pa0, pa1, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
-        mma3(acc0[tt], a0h, a0l, bh, bl);
-        if (ODD ? tt >= 4 : tt < 4) mma3(acc1[ODD ? (tt >= 4 ? tt - 4 : 0) : (tt < 4 ? tt : 0)], a1h, a1l, bh, bl);
-    });
+// Q | K | V projection of one head.  acc0[tt] += A0 . X^T for all token tiles, acc1[i] += A1 . X^T for token tiles tt1 + i
+// (tt1 = 4 for odd waves, else 0), K = 256, against the ONE-plane panel: two MFMAs per product (W_lo X_hi + W_hi X_hi).  The
+// lo part of LayerNorm 1's output is dropped here and only here: measured over the 50-step rollout against the fp64 oracle
+// 5.1e-6 (three products: 4.2e-7; bar 1e-4; dropping the WEIGHTS' lo part instead: 2.8e-5 - tools/exp/precision_sites.sh,
+// DESIGN.md).  Same software pipeline as gemm_pipe; the token half of A1 is a wave-uniform run-time predicate so that
+// the code exists once.
+struct HeadAcc { f32x4 a0[NTT], a1[4]; };
+__device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 *pa0, const f16 *pa1, bool odd) {
+    const char *X = c.smem + LDS_X;
+    const unsigned lo = (unsigned)c.lane * 8;
+    f16x8 a0[2][2], a1[2][2], b[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        a0[0][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + pl * 512);
+        a1[0][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + pl * 512);
+    }
+    b[0] = lds16(X + x1_at(c, 0, 0));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int cur = (ks * NTT + tt) & 1, nxt = cur ^ 1;
+            if (tt == 0 && ks + 1 < 8) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    a0[(ks + 1) & 1][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + ((ks + 1) * 2 + pl) * 512);
+                    a1[(ks + 1) & 1][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + ((ks + 1) * 2 + pl) * 512);
+                }
+            }
+            const int nks = tt + 1 < NTT ? ks : ks + 1, ntt = tt + 1 < NTT ? tt + 1 : 0;
+            if (nks < 8) b[nxt] = lds16(X + x1_at(c, ntt, nks));
+            __builtin_amdgcn_sched_barrier(0);
+            acc.a0[tt] = mfma16(a0[ks & 1][1], b[cur], acc.a0[tt]);
+            acc.a0[tt] = mfma16(a0[ks & 1][0], b[cur], acc.a0[tt]);
+            if (tt < 4) {
+                if (!odd) {
+                    acc.a1[tt] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt]);
+                    acc.a1[tt] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt]);
+                }
+            } else if (odd) {
+                acc.a1[tt - 4] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt - 4]);
+                acc.a1[tt - 4] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt - 4]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // acc[a][tt] += A_a . X^T, n-tiles 2 w + a of a 256 x 256 matrix in fragment-major planes
+template <int SITE>
 __device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *wmat) {
     const f16 *pa = wmat + (long)(2 * c.w) * (8 * 2 * 512);
     gemm_pipe(c, pa, pa + 8 * 2 * 512, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
-        mma3(acc[0][tt], a0h, a0l, bh, bl);
-        mma3(acc[1][tt], a1h, a1l, bh, bl);
+        mma3<SITE>(acc[0][tt], a0h, a0l, bh, bl);
+        mma3<SITE>(acc[1][tt], a1h, a1l, bh, bl);
     });
 }
 
@@ -463,8 +534,8 @@ __device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], con
         for (int kk = 0; kk < 2; ++kk) {
             const f16x8 bh = lds16(Bbuf + q_at(c, tt, 0, kk));
             const f16x8 bl = lds16(Bbuf + q_at(c, tt, 1, kk));
-            mma3(acc[0][tt], a[0][kk][0], a[0][kk][1], bh, bl);
-            mma3(acc[1][tt], a[1][kk][0], a[1][kk][1], bh, bl);
+            mma3<S_OUT>(acc[0][tt], a[0][kk][0], a[0][kk][1], bh, bl);
+            mma3<S_OUT>(acc[1][tt], a[1][kk][0], a[1][kk][1], bh, bl);
         }
 }
 
@@ -476,45 +547,67 @@ struct SaW {
     float scale_log2e;    // log2(e) / sqrt(head dim)
 };
 
-// One head of self-attention: H (residual accumulators, pre-scaled by ACT * s_o) += Wo[:, head] . O_head^T
-__device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x4 (&H)[2][NTT], int st0) {
+// ---------------------------------------------------------------------------------------------------
+// The self-attention block: H (residual accumulators, pre-scaled by ACT * s_o) += sum over heads of Wo[:, head] . O_head^T.
+// Q, K, V and O of a head each have an LDS buffer of their own, so a head needs two barriers: after its Q | K | V are written and
+// after its attention output is.  Between them two INDEPENDENT jobs run, in opposite order on the two waves of a SIMD (waves
+// w and w + 4), so that one wave's MFMA stream overlaps the other's VALU work:
+//   phase W:  [out-projection of head h-1 (MFMA)]      ||  [Q | K | V of head h: accumulators -> split planes in LDS (VALU)]
+//   phase X:  [Q | K | V projection of head h+1 (MFMA)] ||  [attention of head h: scores, softmax, P V, O -> LDS (MFMA + VALU)]
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_zero(HeadAcc &acc) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc.a0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc.a1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void head_gemm(const Ctx &c0, const SaW &a, int h, HeadAcc &acc) {
     const Ctx c = ctx_local(c0);
-    char *Qb = c.smem + LDS_Q, *Kb = c.smem + LDS_K;
-    const int w = c.w, g = c.g, t = c.t;
-    f32x4 acc0[NTT], acc1[4];
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w = c.w;
     const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
     const int nt1 = 32 + 4 * h + (w >> 1);                   // V tile, token half w & 1
-    const f16 *pa0 = a.w_in + (long)nt0 * (8 * 2 * 512), *pa1 = a.w_in + (long)nt1 * (8 * 2 * 512);
-    const bool odd = w & 1;
-    TJ_STAMP(st0);
-    if (odd) gemm_head<true>(c, acc0, acc1, pa0, pa1);
-    else gemm_head<false>(c, acc0, acc1, pa0, pa1);
-    TJ_STAMP(st0 + 1);
+    head_zero(acc);
+    gemm_head(c, acc, a.w_in + (long)nt0 * (8 * 2 * 512), a.w_in + (long)nt1 * (8 * 2 * 512), w & 1);
+}
+// accumulators of head h -> Q or K tile and V piece as split planes
+__device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int h, const HeadAcc &acc) {
+    const Ctx c = ctx_local(c0);
+    const int w = c.w, g = c.g, t = c.t, w3 = w & 3;
     const float c_in = 1.0f / a.s_in;   // accumulator -> ACT * value
-    {   // Q or K tile -> LDS planes (features 16 (w & 3) + 4 g + r of the head)
-        const int w3 = w & 3;
+    {
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + (w < 4 ? 0 : D) + HD * h + 16 * w3 + 4 * g) * ACT;
-        char *dst = w < 4 ? Qb : Kb;
+        char *dst = c.smem + (w < 4 ? LDS_SQ : LDS_Q);
         const int chunk = (2 * (w3 & 1) + (g >> 1)) | ((w3 >> 1) << 3);
-        __syncthreads();   // B1: the previous head's readers of Q / O and K / V are done
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             if (!tok_ok(c, tt)) continue;
             const int tok = tok_of(c, tt);
-            split_store(dst + q_off(tok, chunk) + 8 * (g & 1), dst + q_off(tok, chunk | 4) + 8 * (g & 1), acc0[tt] * c_in + bv);
+            split_store(dst + q_off(tok, chunk) + 8 * (g & 1), dst + q_off(tok, chunk | 4) + 8 * (g & 1), acc.a0[tt] * c_in + bv);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __syncthreads();       // B2: Q, K complete
-    TJ_STAMP(st0 + 2);
-    // ---- scores of query tile w (waves 0..6): S^T[key][query] = K Q^T
+    {   // V piece -> rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r)
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
+        const int tt1 = (w & 1) ? 4 : 0, n1 = (w & 1) ? 3 : 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n1) continue;
+            const int tok = 16 * (tt1 + i) + t;
+            if (tok >= c.T) continue;
+            char *at = c.smem + LDS_K + tok * VROW + 2 * (16 * (w >> 1) + 4 * g);
+            split_store(at, at + 128, acc.a1[i] * c_in + bv);
+        }
+    }
+}
+// attention of query tile w (waves 0..6) of the head whose Q, K, V are in LDS: O -> LDS
+__device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
+    const Ctx c = ctx_local(c0);
+    const int w = c.w, g = c.g, t = c.t;
+    const char *Qb = c.smem + LDS_SQ, *Kb = c.smem + LDS_Q, *Vb = c.smem + LDS_K;
+    char *Ob = c.smem + LDS_SO;
+    // ---- scores S^T[key][query] = K Q^T
     f32x4 S[NTT];
-    float psum = 0.f;
-    if (w < NTT) {
+    {
         f16x8 qf[2][2];
         const int qtok = min(16 * w + t, c.T - 1);
 #pragma unroll
@@ -528,92 +621,97 @@ __device__ __forceinline__ void sa_head(const Ctx &c0, const SaW &a, int h, f32x
             for (int kk = 0; kk < 2; ++kk) {
                 const f16x8 kh = lds16(Kb + q_at(c, kt, 0, kk));
                 const f16x8 kl = lds16(Kb + q_at(c, kt, 1, kk));
-                mma3(S[kt], kh, kl, qf[kk][0], qf[kk][1]);
+                mma3<S_SCORES>(S[kt], kh, kl, qf[kk][0], qf[kk][1]);
             }
         }
-        // softmax over the keys of this lane's query: registers r of tile kt are keys 16 kt + 4 g + r (only tile 6 has masked keys)
-        const float c_s = a.scale_log2e / (ACT * ACT);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (96 + 4 * g + r >= c.T) S[NTT - 1][r] = -INFINITY;
-        f32x4 m4 = S[0];
-#pragma unroll
-        for (int kt = 1; kt < NTT; ++kt) m4 = f32x4{fmaxf(m4[0], S[kt][0]), fmaxf(m4[1], S[kt][1]), fmaxf(m4[2], S[kt][2]), fmaxf(m4[3], S[kt][3])};
-        const float m = rows4_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
-        const float mb = m * c_s - 10.0f;   // probabilities carry 2^10 (fp16 lo parts stay normal)
-        f32x4 ps = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < NTT; ++kt) {
-            const f32x4 e = S[kt] * c_s - mb;
-            S[kt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
-            ps = ps + S[kt];
-        }
-        psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
     }
-    TJ_STAMP(st0 + 3);
-    __syncthreads();       // B3: K is dead
-    {   // V piece -> LDS rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r)
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
-        const int tt1 = odd ? 4 : 0, n1 = odd ? 3 : 4;
+    // ---- softmax over the keys of this lane's query: registers r of tile kt are keys 16 kt + 4 g + r (only tile 6 has masked keys)
+    const float c_s = a.scale_log2e / (ACT * ACT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i >= n1) continue;
-            const int tok = 16 * (tt1 + i) + t;
-            if (tok >= c.T) continue;
-            char *at = Kb + tok * VROW + 2 * (16 * (w >> 1) + 4 * g);
-            split_store(at, at + 128, acc1[i] * c_in + bv);
+    for (int r = 0; r < 4; ++r)
+        if (96 + 4 * g + r >= c.T) S[NTT - 1][r] = -INFINITY;
+    f32x4 m4 = S[0];
+#pragma unroll
+    for (int kt = 1; kt < NTT; ++kt) m4 = f32x4{fmaxf(m4[0], S[kt][0]), fmaxf(m4[1], S[kt][1]), fmaxf(m4[2], S[kt][2]), fmaxf(m4[3], S[kt][3])};
+    const float m = rows4_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+    const float mb = m * c_s - 10.0f;   // probabilities carry 2^10 (fp16 lo parts stay normal)
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NTT; ++kt) {
+        const f32x4 e = S[kt] * c_s - mb;
+        S[kt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+        ps = ps + S[kt];
+    }
+    const float psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
+    // ---- O^T = V^T P^T: P^T straight from the score accumulators, V^T through transposing LDS reads
+    f32x4 O[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) O[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q4 = t >> 2, p4 = t & 3;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+        // P fragment of keys 32 kp ..: elements 0..3 = tile 2 kp, 4..7 = tile 2 kp + 1 (beyond the last tile: zero)
+        const f32x4 pa4 = S[2 * kp], pb4 = 2 * kp + 1 < NTT ? S[2 * kp + 1 < NTT ? 2 * kp + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x4 pah, pal, pbh, pbl;
+        split4(pa4, pah, pal);
+        split4(pb4, pbh, pbl);
+        const f16x8 ph = __builtin_shufflevector(pah, pbh, 0, 1, 2, 3, 4, 5, 6, 7), pl = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
+        const char *v0 = Vb + r0 * VROW + 8 * p4, *v1 = Vb + r1 * VROW + 8 * p4;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            f16x8 vf[2];
+#pragma unroll
+            for (int pn = 0; pn < 2; ++pn) {
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v0 + pn * 128 + ft * 32));
+                const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v1 + pn * 128 + ft * 32));
+                vf[pn] = __builtin_shufflevector(__builtin_bit_cast(f16x4, x0), __builtin_bit_cast(f16x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            mma3<S_PV>(O[ft], vf[0], vf[1], ph, pl);
         }
     }
-    __syncthreads();       // B4: V complete
-    TJ_STAMP(st0 + 4);
+    // O^T tile ft: features 16 ft + 4 g + r of query 16 w + t, times ACT / sum -> LDS planes
+    const float inv = 1.0f / psum;
+    const int tok = 16 * w + t;
+    if (tok < c.T) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int chunk = (2 * (ft & 1) + (g >> 1)) | ((ft >> 1) << 3);
+            split_store(Ob + q_off(tok, chunk) + 8 * (g & 1), Ob + q_off(tok, chunk | 4) + 8 * (g & 1), O[ft] * inv);
+        }
+    }
+}
+__device__ __forceinline__ void head_out_proj(const Ctx &c0, const SaW &a, int h, f32x4 (&H)[2][NTT]) {
+    const Ctx c = ctx_local(c0);
     AK64 wo;
-    const f16 *po0 = a.w_o + ((long)(2 * w) * 8 + 2 * h) * (2 * 512), *po1 = a.w_o + ((long)(2 * w + 1) * 8 + 2 * h) * (2 * 512);
-    if (w < NTT) {
-        f32x4 O[4];
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) O[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int q4 = t >> 2, p4 = t & 3;
-#pragma unroll
-        for (int kp = 0; kp < 4; ++kp) {
-            // P fragment of keys 32 kp ..: elements 0..3 = tile 2 kp, 4..7 = tile 2 kp + 1 (beyond the last tile: zero)
-            const f32x4 pa4 = S[2 * kp], pb4 = 2 * kp + 1 < NTT ? S[2 * kp + 1 < NTT ? 2 * kp + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
-            f16x4 pah, pal, pbh, pbl;
-            split4(pa4, pah, pal);
-            split4(pb4, pbh, pbl);
-            const f16x8 ph = __builtin_shufflevector(pah, pbh, 0, 1, 2, 3, 4, 5, 6, 7), pl = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
-            const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
-            const char *v0 = Kb + r0 * VROW + 8 * p4, *v1 = Kb + r1 * VROW + 8 * p4;
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                f16x8 vf[2];
-#pragma unroll
-                for (int pn = 0; pn < 2; ++pn) {
-                    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v0 + pn * 128 + ft * 32));
-                    const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v1 + pn * 128 + ft * 32));
-                    vf[pn] = __builtin_shufflevector(__builtin_bit_cast(f16x4, x0), __builtin_bit_cast(f16x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                mma3(O[ft], vf[0], vf[1], ph, pl);
-            }
-        }
-        // the out-projection's weight fragments are requested now (the score registers are free): their L2 round trip passes
-        // under the O write and the barrier
-        load_k64(c, wo, po0, po1);
-        // O^T tile ft: features 16 ft + 4 g + r of query 16 w + t, times ACT / sum -> LDS planes (over Q)
-        const float inv = 1.0f / psum;
-        const int tok = 16 * w + t;
-        if (tok < c.T) {
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                const int chunk = (2 * (ft & 1) + (g >> 1)) | ((ft >> 1) << 3);
-                split_store(Qb + q_off(tok, chunk) + 8 * (g & 1), Qb + q_off(tok, chunk | 4) + 8 * (g & 1), O[ft] * inv);
-            }
-        }
+    load_k64(c, wo, a.w_o + ((long)(2 * c.w) * 8 + 2 * h) * (2 * 512), a.w_o + ((long)(2 * c.w + 1) * 8 + 2 * h) * (2 * 512));
+    gemm_k64(c, H, wo, c.smem + LDS_SO);
+}
+
+// X (one plane) holds LayerNorm 1's output on entry
+__device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT]) {
+    const bool first = c.w < 4;   // the quartet that runs the MFMA job of a phase first
+    HeadAcc acc;
+    TJ_STAMP(3);
+    head_gemm(c, a, 0, acc);
+    TJ_STAMP(4);
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+        // phase W (the MFMA job exists twice in the code, before and after the VALU job: each quartet runs one copy)
+        if (first && h > 0) head_out_proj(c, a, h - 1, H);
+        head_write_qkv(c, a, h, acc);
+        if (!first && h > 0) head_out_proj(c, a, h - 1, H);
+        __syncthreads();                                // Q, K, V of head h complete (and every reader of head h-1's O is done)
+        TJ_STAMP(5 + 3 * h);
+        // phase X
+        if (first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
+        if (c.w < NTT) head_attention(c, a);
+        if (!first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
+        TJ_STAMP(6 + 3 * h);
+        __syncthreads();                                // O of head h complete; Q, K, V free
+        TJ_STAMP(7 + 3 * h);
     }
-    else load_k64(c, wo, po0, po1);
-    TJ_STAMP(st0 + 5);
-    __syncthreads();       // B5: O complete
-    TJ_STAMP(st0 + 6);
-    gemm_k64(c, H, wo, Qb);
+    head_out_proj(c, a, NH - 1, H);
 }
 
 __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
@@ -654,8 +752,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         const float s_o = L.sc[0], up = ACT * s_o;
         scale_h(H, up);
         const SaW sw{L.w_in, L.b_in, L.w_o, L.sc[3], scale_log2e};
-#pragma unroll 1
-        for (int h = 0; h < NH; ++h) sa_head(c, sw, h, H, 3 + 7 * h);
+        sa_block(c, sw, H);
         unscale_h(c, H, 1.0f / up, L.b_o);
     }
     TJ_STAMP(31);
@@ -696,7 +793,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
                 // token tile tt1 + i: compile-time for each parity
                 const f16x8 bh = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 0, ks)) : lds16(X + x_at(c, i, 0, ks));
                 const f16x8 bl = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 1, ks)) : lds16(X + x_at(c, i, 1, ks));
-                mma3(S[i], gh, gl, bh, bl);
+                mma3<S_XSC>(S[i], gh, gl, bh, bl);
             }
         }
         // the folded values (48 registers) are requested now: they land under the softmax
@@ -761,8 +858,8 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
             for (int kk = 0; kk < 3; ++kk) {
                 const f16x8 bh = lds16(Pb + p_at(c, tt, 0, kk));
                 const f16x8 bl = lds16(Pb + p_at(c, tt, 1, kk));
-                mma3(H[0][tt], av[0][kk][0], av[0][kk][1], bh, bl);
-                mma3(H[1][tt], av[1][kk][0], av[1][kk][1], bh, bl);
+                mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], bh, bl);
+                mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], bh, bl);
             }
         unscale_h(c, H, 1.0f / up, L.b_oc);
     }
@@ -777,7 +874,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) U[a][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_x2(c, U, L.w_1);
+        gemm_x2<S_W1>(c, U, L.w_1);
         TJ_STAMP(36);
         const float c1 = 1.0f / (ACT * L.sc[1]);
         __syncthreads();   // every wave has read LN3(h): the panel receives gelu(u)
@@ -796,11 +893,11 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         TJ_STAMP(37);
         const float up = ACT * L.sc[2];
         scale_h(H, up);
-        gemm_x2(c, H, L.w_2);
+        gemm_x2<S_W2>(c, H, L.w_2);
         unscale_h(c, H, 1.0f / up, L.b_2);
     }
     TJ_STAMP(38);
-    if (L.nln_w) layer_norm_to_x(c0, H, L.nln_w, L.nln_b);
+    if (L.nln_w) layer_norm_to_x<true>(c0, H, L.nln_w, L.nln_b);
     TJ_STAMP(39);
 }
 
@@ -833,13 +930,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) H[aa][tt] = *reinterpret_cast<const f32x4 *>(hin + (aa * NTT + tt) * 256);
     TJ_STAMP(1);
-    layer_norm_to_x(c, H, a.ln_w, a.ln_b);
+    layer_norm_to_x<true>(c, H, a.ln_w, a.ln_b);
     const float up = ACT * a.s_o;
     scale_h(H, up);
     TJ_STAMP(2);
     const SaW sw{a.w_in, a.b_in, a.w_o, a.s_in, a.scale_log2e};
-#pragma unroll 1
-    for (int h = 0; h < NH; ++h) sa_head(c, sw, h, H, 3 + 7 * h);
+    sa_block(c, sw, H);
     TJ_STAMP(31);
     unscale_h(c, H, 1.0f / up, a.b_o);
     float *hout = a.h_out + traj * HFRAG_FLOATS + (long)c.w * (2 * NTT * 256) + c.lane * 4;
@@ -912,14 +1008,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                mma3(acc, ah, al, lds16(Qb + q_at(c, tt, 0, 0)), lds16(Qb + q_at(c, tt, 1, 0)));
+                mma3<S_EMB>(acc, ah, al, lds16(Qb + q_at(c, tt, 0, 0)), lds16(Qb + q_at(c, tt, 1, 0)));
                 const f32x4 pe4 = *reinterpret_cast<const f32x4 *>(a.pe + (long)tok_of(c, tt) * D + n0);
                 H[n][tt] = acc * c_e + (bv + pe4);
             }
         }
     }
     TJ_STAMP(1);
-    layer_norm_to_x(c, H, a.n1_w, a.n1_b);
+    layer_norm_to_x<true>(c, H, a.n1_w, a.n1_b);
     TJ_STAMP(2);
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) decoder_layer(c, a.layer[l], H, traj, a.Mk, a.scale_log2e);
@@ -964,7 +1060,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const f16 *wp = a.w_out + ((long)(n * 8 + ks) * 2) * 512 + c.lane * 8;
-                    mma3(E[n], *reinterpret_cast<const f16x8 *>(wp), *reinterpret_cast<const f16x8 *>(wp + 512), bh, bl);
+                    mma3<S_FC>(E[n], *reinterpret_cast<const f16x8 *>(wp), *reinterpret_cast<const f16x8 *>(wp + 512), bh, bl);
                 }
             }
             // this lane's token scale again (the statistics are still in LDS)

@@ -139,8 +139,13 @@ def test_fp16x3_sampler_is_fp32_grade(ops, mode):
 
     e_native = max(rel64(trace[i], want64[i]) for i in range(n_steps))
     e_cpu32 = max(rel64(want32[i], want64[i]) for i in range(n_steps))
-    assert e_native < 2e-6, e_native
-    assert e_native < 4 * e_cpu32 + 1e-7, (e_native, e_cpu32)
+    if mode == 2:
+        assert e_native < 2e-6, e_native
+        assert e_native < 4 * e_cpu32 + 1e-7, (e_native, e_cpu32)
+    else:
+        # mode 3 reads ONE fp16 plane of LayerNorm 1's output in the Q | K | V projection (two MFMAs per product there, three
+        # everywhere else): measured 5.1e-6 over the rollout; the adoption rule is <= 2e-5, a fifth of north_star's 1e-4
+        assert e_native < 2e-5, e_native
 
 
 @pytest.mark.parametrize("env", [{"SD_SAMPLER_GEMM": "f32"}, {"SD_SAMPLER_TRAJ": "0"}, {"SD_SAMPLER_TRAJ": "0", "SD_QKV": "rows"},
@@ -203,5 +208,5 @@ def test_trajectory_step_kernel_every_step(ops, T, Mc, J, L, B):
     errs = [rel_err(tr3[i], want[i]) for i in range(n_steps)]
     assert all(e < TOL for e in errs), errs   # (max() would skip NaNs)
     x2 = ops.ddim_sample(packed, cg, toks, coef, x_T.cuda(), max_mode=2)
-    assert rel_err(x3, x2.cpu()) < 1e-5
+    assert rel_err(x3, x2.cpu()) < 5e-5   # mode 2 keeps three products in the Q | K | V projection, mode 3 two
     assert torch.isfinite(x3).all()

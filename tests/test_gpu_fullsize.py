@@ -60,7 +60,7 @@ def test_b4096_trajectories_match_oracle_and_small_batch(ops, mode):
     assert all(e < 1e-4 for e in errs), errs
     small = ops.ddim_sample(packed, cs.cuda(), toks, coef, xs.cuda(), max_mode=mode)
     inv = [rel_err(got[b], small[i]) for i, b in enumerate(picks)]
-    assert all(e < 1e-5 for e in inv), inv
+    assert all(e < 1e-5 for e in inv), inv   # the same kernels on the same trajectory: batch-size independent
     # nothing else in the batch is degenerate: per-trajectory norms are in a sane band
     norms = got.flatten(1).norm(dim=1)
     assert float(norms.min()) > 0.0 and float(norms.max()) < 1e4

