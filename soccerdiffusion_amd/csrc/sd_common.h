@@ -153,6 +153,26 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 u) {
     return u * 0.5f * w;
 }
 
+// erf-GELU through Abramowitz & Stegun 7.1.26: erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2), t = 1 / (1 + p z),
+// z >= 0, |error| <= 1.5e-7 (absolute): gelu(u) = 0.5 u (1 + sign(u) erf(|u| / sqrt 2)).  Seven instructions per value fewer than
+// gelu_erf_fast2 (a degree-5 instead of a degree-9 polynomial); absolute error of the GELU <= 0.75e-7 |u| + fp32 rounding (measured
+// max 3.3e-7 on [-8, 8] against fp64 erf, tools/exp/gelu_check.py; gelu_erf_fast2: 3.8e-7).  Used by the trajectory step kernel.
+__device__ __forceinline__ f32x2 gelu_erf_as2(f32x2 u) {
+    const f32x2 z = f32x2{fabsf(u[0]), fabsf(u[1])} * 0.70710678118654752440f;
+    const f32x2 d = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    p = p * t;
+    const f32x2 x = z * z * (-1.44269504088896340736f);
+    const f32x2 e = {p[0] * __builtin_amdgcn_exp2f(x[0]), p[1] * __builtin_amdgcn_exp2f(x[1])};   // 1 - erf(z) = erfc(z)
+    // 0.5 u (1 + sign(u) (1 - e)) = u - 0.5 u e for u >= 0, 0.5 u e for u < 0
+    const f32x2 hu = u * 0.5f;
+    return f32x2{u[0] >= 0.f ? fmaf(-hu[0], e[0], u[0]) : hu[0] * e[0], u[1] >= 0.f ? fmaf(-hu[1], e[1], u[1]) : hu[1] * e[1]};
+}
+
 // x*scale as an fp16 pair: hi = fp16(x*scale), lo = fp16(x*scale - hi)  (22 mantissa bits)
 __device__ __forceinline__ void f16_split4(const f32x4 &x, float scale, f16x4 &h, f16x4 &l) {
 #pragma unroll

@@ -681,10 +681,13 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
         }
     }
 }
-__device__ __forceinline__ void head_out_proj(const Ctx &c0, const SaW &a, int h, f32x4 (&H)[2][NTT]) {
-    const Ctx c = ctx_local(c0);
-    AK64 wo;
+// out-projection of head h: its weight fragments (32 registers) are requested at the end of the head's phase X - their L2 round
+// trip passes under the barrier and the other wave's job - and consumed in the next phase W
+__device__ __forceinline__ void head_out_load(const Ctx &c, const SaW &a, int h, AK64 &wo) {
     load_k64(c, wo, a.w_o + ((long)(2 * c.w) * 8 + 2 * h) * (2 * 512), a.w_o + ((long)(2 * c.w + 1) * 8 + 2 * h) * (2 * 512));
+}
+__device__ __forceinline__ void head_out_proj(const Ctx &c0, const AK64 &wo, f32x4 (&H)[2][NTT]) {
+    const Ctx c = ctx_local(c0);
     gemm_k64(c, H, wo, c.smem + LDS_SO);
 }
 
@@ -692,26 +695,28 @@ __device__ __forceinline__ void head_out_proj(const Ctx &c0, const SaW &a, int h
 __device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT]) {
     const bool first = c.w < 4;   // the quartet that runs the MFMA job of a phase first
     HeadAcc acc;
+    AK64 wo;
     TJ_STAMP(3);
     head_gemm(c, a, 0, acc);
     TJ_STAMP(4);
 #pragma unroll 1
     for (int h = 0; h < NH; ++h) {
         // phase W (the MFMA job exists twice in the code, before and after the VALU job: each quartet runs one copy)
-        if (first && h > 0) head_out_proj(c, a, h - 1, H);
+        if (first && h > 0) head_out_proj(c, wo, H);
         head_write_qkv(c, a, h, acc);
-        if (!first && h > 0) head_out_proj(c, a, h - 1, H);
+        if (!first && h > 0) head_out_proj(c, wo, H);
         __syncthreads();                                // Q, K, V of head h complete (and every reader of head h-1's O is done)
         TJ_STAMP(5 + 3 * h);
         // phase X
         if (first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
         if (c.w < NTT) head_attention(c, a);
         if (!first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
+        head_out_load(c, a, h, wo);
         TJ_STAMP(6 + 3 * h);
         __syncthreads();                                // O of head h complete; Q, K, V free
         TJ_STAMP(7 + 3 * h);
     }
-    head_out_proj(c, a, NH - 1, H);
+    head_out_proj(c, wo, H);
 }
 
 __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
@@ -884,7 +889,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 const f32x4 pre = U[a][tt] * c1 + bv;
-                const f32x2 g0 = gelu_erf_fast2(f32x2{pre[0], pre[1]}) * ACT, g1 = gelu_erf_fast2(f32x2{pre[2], pre[3]}) * ACT;
+                const f32x2 g0 = gelu_erf_as2(f32x2{pre[0], pre[1]}) * ACT, g1 = gelu_erf_as2(f32x2{pre[2], pre[3]}) * ACT;
                 store_x(c, a, tt, f32x4{g0[0], g0[1], g1[0], g1[1]});
                 __builtin_amdgcn_sched_barrier(0);
             }
