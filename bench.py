@@ -66,11 +66,12 @@ def executed_flops_per_traj():
 
 def traj_step_flops_per_traj_step():
     """Sampler mode 3 (csrc/sd_traj.h): one launch per DDIM step owns everything of SURVEY 8(d)'s F_step except the memory K/V
-    projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product, on 7 token tiles of
-    16 (T = 100 padded to 112), the cross-attention in its folded form."""
+    projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product (two at the Q | K | V
+    projection), on 7 token tiles of 16 (T = 100 padded to 112), the cross-attention in its folded form."""
     f = flops_per_traj_step()
-    per_layer = 4 * (84 * 8 + 49 * 2 + 28 * 4 + 112 * 2) + 28 * 8 + 112 * 3 + 2 * 112 * 8   # products of 16x16x32 tiles
-    mfma = 3 * (L * per_layer + 16 * 7 + 14 * 8)                                                # + embedding + fc_out
+    qkv = 4 * 84 * 8                                                            # products of 16x16x32 tiles: Q | K | V projection, per layer
+    rest = 4 * (49 * 2 + 28 * 4 + 112 * 2) + 28 * 8 + 112 * 3 + 2 * 112 * 8    # scores, PV, out-projection; folded cross-attention; W1, W2
+    mfma = L * (2 * qkv + 3 * rest) + 3 * (16 * 7 + 14 * 8)                     # Q | K | V reads one activation plane; + embedding + fc_out
     return {"algorithmic": f["total"] - f["kv"], "executed": mfma * 16384.0, "mfma_instructions": mfma}
 
 
@@ -268,15 +269,14 @@ class TrainLeg:
         self.opt = training.FusedAdamW(self.model.parameters(), lr=1e-4)
         if world > 1:   # ... and rank 0's parameters are broadcast anyway (cli.cmd_train does the same)
             training.broadcast_parameters(self.opt, self.model)
-        self.lr = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=1e-4, total_steps=total_steps + 8)
+        self.lr = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=1e-4, total_steps=total_steps + 64)   # + the graph's eager calls and exposed_allreduce_ms' 2 x 10 steps
         self.ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
         self.g = torch.Generator(device=dev).manual_seed(1 + rank)
         self.x0 = torch.randn(batch, T, J, device=dev, generator=self.g)
         self.ctx = [torch.randn(batch, MC, D, device=dev, generator=self.g)]
         self.graphed = None
         if graph:   # the step replayed from a hipGraph (training.GraphedTrainStep); the first two calls run eagerly
-            self.graphed = training.GraphedTrainStep(self.model, self.opt, self.lr, self.ns, world_size=world, generator=self.g,
-                                                     fork_dw=os.environ.get("SD_TRAIN_FORK_DW", "0") == "1")
+            self.graphed = training.GraphedTrainStep(self.model, self.opt, self.lr, self.ns, world_size=world, generator=self.g)
 
     def step(self):
         if self.graphed is not None:

@@ -249,11 +249,7 @@ int linear(const float *A, const float *W, const float *bias, const float *ln_w,
     if (lda < d || lda % 4 != 0) return fail(SD_E_BADARG, "linear: row stride must be >= d and a multiple of 4");
     if (!A || !W || !out || R <= 0 || N <= 0) return fail(SD_E_BADARG, "linear: null pointer or empty shape");
     if (N % d != 0) return fail(SD_E_BADDIM, "linear: N must be a multiple of d");
-    {   // split-fp16 kernel (sd_f16x3.h) unless SD_LINEAR=f32 asks for the fp32 MFMA
-        static const char *env = getenv("SD_LINEAR");
-        if (!(env && strcmp(env, "f32") == 0)) return linear16(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);
-    }
-    return linear32(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);
+    return linear16(A, W, bias, ln_w, ln_b, res, out, R, N, d, act, s, lda);   // split-fp16 kernel (sd_f16x3.h)
 }
 
 // the same layer on v_mfma_f32_32x32x2_f32 only (exact fp32 fma chain, no operand range limits): the sampler's
@@ -1450,11 +1446,7 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     if (fa.g.a.R <= 0) return fail(SD_E_BADARG, "decoder_layer_f16: empty shape");
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((fa.g.a.R + 63) / 64)), block(256);
-    // SD_LAYER_LDS_PAD=<bytes>: occupancy experiment - request more LDS than the panel needs so that only ONE
-    // workgroup fits a CU (pad >= 16 KB) and compare with the normal two
-    static const char *padenv = getenv("SD_LAYER_LDS_PAD");
-    static const size_t pad = padenv ? (size_t)atol(padenv) : 0;
-    const size_t lds = PanelCfg<256>::LDS_BYTES + pad;
+    const size_t lds = PanelCfg<256>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2021,8 +2013,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     dim3 grid(B * heads), block(256);
     // small batches (the robot: B = 1): one workgroup per (sample, head) instead of one per sample walking its heads
     // in sequence - the rollout there is a chain of kernel latencies (robot shape: 11.6 -> 9.4 ms per rollout)
-    static const char *penv = getenv("SD_ATT_PIPE_MIN_B");
-    static const int pipe_min_b = penv ? atoi(penv) : 64;
+    constexpr int pipe_min_b = 64;
     if (Tq <= 128 && !k_extra && S > 0 && B >= pipe_min_b && !da.thresh) {
         dim3 gridp(B);
 #define SD_ATTNP(HD_)                                                                                            \
@@ -3234,11 +3225,8 @@ extern "C" int sd_op_linear_strided(const float *A, int lda, const float *W, con
 }
 
 // Self-attention over a packed q|k|v row buffer ([B*T][3d], head dim 64, T <= 128): the fp16x3 kernel of the sampler
-// (SD_ATT_OP=f32: always the fp32-MFMA kernels; A/B runs)
 static bool att_op_f16(const float *q, int ldq, const float *k, const float *v, int ldkv, int ldo, int B, int Tq, int S, int d,
                        int heads, const float *out) {
-    static const char *env = getenv("SD_ATT_OP");
-    if (env && strcmp(env, "f32") == 0) return false;
     return q && out && B > 0 && heads > 0 && d == heads * 64 && Tq == S && Tq >= 1 && Tq <= 128 && ldq == 3 * d && ldkv == 3 * d &&
            ldo == d && k == q + d && v == q + 2 * d;
 }

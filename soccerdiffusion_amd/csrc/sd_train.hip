@@ -28,104 +28,8 @@
 #ifndef TN_RC
 #define TN_RC 256
 #endif
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ dY, int ldy,
-                                                       const float *__restrict__ X, int ldx, float *dW, int ldw,
-                                                       float *db, long R, int N, int K) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_k = (K + 127) / 128;
-    const int n0 = (blockIdx.x / tiles_k) * 128 + wm * 64;
-    const int k0 = (blockIdx.x % tiles_k) * 128 + wn * 64;
-    const long rbeg = (long)blockIdx.y * TN_RC;
-    long rend = rbeg + TN_RC;
-    if (rend > R) rend = R;
-    if (n0 >= N || k0 >= K) return;  // wave-uniform: this wave's 64 x 64 block is empty
-
-    int ncol[2], kcol[2];
-    float nmask[2], kmask[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = n0 + t * 32 + l31, k = k0 + t * 32 + l31;
-        nmask[t] = n < N ? 1.f : 0.f;
-        kmask[t] = k < K ? 1.f : 0.f;
-        ncol[t] = n < N ? n : 0;
-        kcol[t] = k < K ? k : 0;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
-
-    auto load = [&](long r, float (&a)[2][4], float (&b)[2][4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long row = r + 2 * j + half;
-            const bool ok = row < rend;
-            const long rr = ok ? row : rbeg;
-            const float m = ok ? 1.f : 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t][j] = dY[rr * ldy + ncol[t]] * (m * nmask[t]);
-                b[t][j] = X[rr * ldx + kcol[t]] * (m * kmask[t]);
-            }
-        }
-    };
-    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
-    load(rbeg, a0, b0);
-    for (long r = rbeg; r < rend; r += 16) {
-        load(r + 8, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                bsum[tm] += a0[tm][j];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[tm][j], b0[tn][j], acc[tm][tn], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load(r + 16, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                bsum[tm] += a1[tm][j];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tm][j], b1[tn][j], acc[tm][tn], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int k = k0 + tn * 32 + l31;
-            if (k >= K) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (n < N) atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r]);
-            }
-        }
-    if (db && (blockIdx.x % tiles_k) == 0 && wn == 0) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const float v = bsum[tm] + __shfl_xor(bsum[tm], 32, 64);
-            const int n = n0 + tm * 32 + l31;
-            if (half == 0 && n < N) atomicAdd(db + n, v);
-        }
-    }
-}
+// (the fp32-MFMA kernel that implemented this description in round 1 lost every A/B against the fp16 forms below and is gone;
+//  the geometry - 128 x 128 tile of dW per workgroup, row chunks of TN_RC, fp32 atomics - is theirs too)
 
 // --------------------------------------------------------------------------------------
 // The same product on the fp16 pipe.  The contraction runs over the rows, so an operand scale must be
@@ -308,130 +212,7 @@ __device__ __forceinline__ f16x8 tns_frag(const f16 *plane, int row0, int col0, 
     return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn16s_kernel(const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
-                                                             float *dW, int ldw, float *db, long R, int N, int K) {
-    __shared__ __attribute__((aligned(16))) f16 sT[4 * TNS_PLANE];   // dY hi, dY lo, X hi, X lo
-    __shared__ float sMax[2][4];
-    __shared__ float sB[8][128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_k = K / 128;
-    const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
-    const long rbeg = (long)blockIdx.y * TN_RC;
-    long rend = rbeg + TN_RC;
-    if (rend > R) rend = R;
-    // staging map: thread -> rows (tid >> 5) + 8 v, columns 4 (tid & 31) .. +3
-    const int srow = tid >> 5, scol = (tid & 31) * 4;
-    // running pointers of this thread's first row of the next slab (64-bit row * stride products are quarter-rate multiplies:
-    // 64 of them per slab before)
-    const float *yp = dY + (rbeg + srow) * (long)ldy + n0 + scol, *xp = X + (rbeg + srow) * (long)ldx + k0 + scol;
-    const long ystep = 8L * ldy, xstep = 8L * ldx;
-    f32x4 yv[4], xv[4];
-    auto load = [&](long r) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int left = (int)(rend - r) - srow;    // rows of this slab from this thread's first one to the chunk's end
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            yv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(yp + v * ystep) : z;
-            xv[v] = 8 * v < left ? *reinterpret_cast<const f32x4 *>(xp + v * xstep) : z;
-        }
-        yp += 4 * ystep;
-        xp += 4 * xstep;
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    load(rbeg);
-    for (long r = rbeg; r < rend; r += 32) {
-        float my = 0.f, mx = 0.f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            bsum = bsum + yv[v];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                my = fmaxf(my, fabsf(yv[v][e]));
-                mx = fmaxf(mx, fabsf(xv[v][e]));
-            }
-        }
-        my = wave_max(my);
-        mx = wave_max(mx);
-        if (lane == 0) {
-            sMax[0][wave] = my;
-            sMax[1][wave] = mx;
-        }
-        __syncthreads();   // maxima visible; every wave is done reading the previous slab's planes
-        const float sy = f16_scale_from_bits(__builtin_bit_cast(unsigned, fmaxf(fmaxf(sMax[0][0], sMax[0][1]), fmaxf(sMax[0][2], sMax[0][3]))));
-        const float sx = f16_scale_from_bits(__builtin_bit_cast(unsigned, fmaxf(fmaxf(sMax[1][0], sMax[1][1]), fmaxf(sMax[1][2], sMax[1][3]))));
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            f16x4 h, l;
-            f16 *o = sT + (srow + 8 * v) * TNS_PITCH + scol;
-            f16_split4(yv[v], sy, h, l);
-            *reinterpret_cast<f16x4 *>(o) = h;
-            *reinterpret_cast<f16x4 *>(o + TNS_PLANE) = l;
-            f16_split4(xv[v], sx, h, l);
-            *reinterpret_cast<f16x4 *>(o + 2 * TNS_PLANE) = h;
-            *reinterpret_cast<f16x4 *>(o + 3 * TNS_PLANE) = l;
-        }
-        if (r + 32 < rend) load(r + 32);
-        __syncthreads();
-        f32x16 sub[2][2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
-            const int row0 = 16 * st + 8 * half;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ah[t] = tns_frag(sT, row0, wm * 64 + t * 32, lane);
-                al[t] = tns_frag(sT + TNS_PLANE, row0, wm * 64 + t * 32, lane);
-                bh[t] = tns_frag(sT + 2 * TNS_PLANE, row0, wn * 64 + t * 32, lane);
-                bl[t] = tns_frag(sT + 3 * TNS_PLANE, row0, wn * 64 + t * 32, lane);
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    if (st == 0) sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], zero16, 0, 0, 0);
-                    else sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], sub[tm][tn], 0, 0, 0);
-                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], sub[tm][tn], 0, 0, 0);
-                    sub[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], sub[tm][tn], 0, 0, 0);
-                }
-        }
-        const float un = 1.0f / (sy * sx);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = acc[tm][tn] + sub[tm][tn] * un;
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int k = k0 + wn * 64 + tn * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(dW + (long)n * ldw + k, acc[tm][tn][r]);
-            }
-        }
-    if (db && (blockIdx.x % tiles_k) == 0) {   // column sums of dY: 8 row groups x 128 columns through LDS
-        *reinterpret_cast<f32x4 *>(&sB[srow][scol]) = bsum;
-        __syncthreads();
-        if (tid < 128) {
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) v += sB[g][tid];
-            atomicAdd(db + n0 + tid, v);
-        }
-    }
-}
+// (the 4-wave kernel described above was superseded by gemm_tn16d_kernel below, which keeps its slab loop; removed)
 
 
 // --------------------------------------------------------------------------------------
@@ -951,16 +732,12 @@ extern "C" int sd_op_gemm_tn(const float *dY, int ldy, const float *X, int ldx, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_PANEL_GEMM, s);
     dim3 grid(((N + 127) / 128) * ((K + 127) / 128), (unsigned)((R + TN_RC - 1) / TN_RC));
-    static const char *env = getenv("SD_GEMM_TN");   // "f32": the fp32-MFMA kernel; "regs": the register-staged fp16 one (A/B runs)
     const bool staged = N % 128 == 0 && K % 128 == 0 && ldy % 4 == 0 && ldx % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-    if (env && strcmp(env, "f32") == 0) SD_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
-    else if (staged && !(env && (strcmp(env, "regs") == 0 || strcmp(env, "quartet") == 0))) {   // "quartet": the 4-wave staged kernel (A/B runs)
+    if (staged) {
         dim3 gridd(((N + 127) / 128) * ((K + 127) / 128), (unsigned)((R + 2 * TN_RC - 1) / (2 * TN_RC)));
         SD_LAUNCH(gemm_tn16d_kernel, gridd, dim3(512), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
-    }
-    else if (staged && !(env && strcmp(env, "regs") == 0)) SD_LAUNCH(gemm_tn16s_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
-    else SD_LAUNCH(gemm_tn16_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);
+    } else SD_LAUNCH(gemm_tn16_kernel, grid, dim3(256), 0, s, dY, ldy, X, ldx, dW, ldw, db, R, N, K);   // ragged shapes (J = 20 columns, odd strides)
     SD_CHECK_LAUNCH("gemm_tn_kernel");
     return 0;
 }
@@ -1980,14 +1757,13 @@ extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(SD_KCLASS_ATTENTION, s);
     dim3 grid(B * heads), block(256);
-    {   // head dim 64, <= 128 queries and keys, 16-byte aligned rows: the fp16-pipe kernel (SD_ATT_BWD=f32: the fp32-MFMA one)
-        static const char *env = getenv("SD_ATT_BWD");
+    {   // head dim 64, <= 128 queries and keys, 16-byte aligned rows: the fp16-pipe kernel; anything else: the fp32-MFMA one
         auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         const bool lds_ok = ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddkv % 4 == 0;
         // (up to 32 keys - the cross-attention over 11 memory rows - only one wave owns keys in pass B; with one workgroup per CU
         // the fp32 kernel was faster there, 60 vs 83 us at B = 256; with two it is 54 vs 62)
         if (hd == 64 && Tq <= 128 && S <= 128 && lds_ok && al16(q) && al16(k) && al16(v) && al16(o) && al16(dO) && al16(dq) && al16(dk) &&
-            al16(dv) && !(env && strcmp(env, "f32") == 0)) {
+            al16(dv)) {
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void *)attention_bwd16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS);

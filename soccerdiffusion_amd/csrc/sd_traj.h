@@ -15,16 +15,19 @@
 //   * the residual stream lives in registers for the whole step, pre-multiplied by the (power of two) scale of the
 //     GEMM that accumulates into it.
 // Self-attention, per head: [Q_h | K_h | V_h]^T = 12 n-tiles; wave w computes Q tile w (w < 4) or K tile w-4 for all tokens
-// and a half (by tokens) of V tile w>>1.  Q, K go to LDS as split planes; S^T = K Q^T (keys x queries) per query tile on
-// waves 0..6, softmax in registers (a query is a lane column), V replaces K in LDS, O^T = V^T P^T with P^T straight
-// from the score accumulators (B operand) and V^T through ds_read_b64_tr_b16, O -> LDS (over Q), then the out-projection
-// of this head (K = 64) accumulates into the residual registers.
+// and a half (by tokens) of V tile w>>1, from ONE fp16 plane of LayerNorm 1's output (2 MFMAs per product: the only site
+// where the measured rollout error allows it).  Q, K, V, O have an LDS buffer each (split planes), so a head is
+// two barrier-delimited phases: W = write Q | K | V of head h (+ out-projection of head h-1 into the residual registers),
+// X = S^T = K Q^T (keys x queries) per query tile on waves 0..6, softmax in registers (a query is a lane column), O^T = V^T P^T
+// with P^T straight from the score accumulators (B operand) and V^T through ds_read_b64_tr_b16, O -> LDS; the projection GEMM
+// of head h+1 is issued BEFORE the attention by waves 0..3 and AFTER it by waves 4..7, so that the two waves of a SIMD are in
+// complementary (matrix / vector) jobs most of the time.
 // Folded cross-attention: S^T_h = G_h LN2(h)^T is ONE 16 x 16 tile per (head, token tile) (16 key slots); softmax over the
 // accumulator rows; P -> LDS [token][head*16 + slot | step columns]; H += V'^T P^T as a column-split GEMM with K = 96.
 //
-// LDS (163 200 B of 163 840): X panel 100 x 1 KiB (hi | lo, 16-byte chunks XOR-swizzled by token & 15: every ds_read_b128 of
-// a fragment is conflict-free), Q / O 100 x 256 B, K / V 100 x 288 B (together: the 100 x 512 B probabilities of the
-// cross-attention), LayerNorm partials.  Rows >= T are never stored; reads of padded tokens clamp to row T-1 (finite values;
+// LDS (163 200 B of 163 840, map below): X panel 100 x 1 KiB (hi | lo, 16-byte chunks XOR-swizzled by token & 15: every
+// ds_read_b128 of a fragment is conflict-free), K 100 x 256 B, V 100 x 288 B (together: the 100 x 512 B probabilities of the
+// cross-attention), Q / O 100 x 256 B each inside the panel's second half during the self-attention block, LayerNorm partials.  Rows >= T are never stored; reads of padded tokens clamp to row T-1 (finite values;
 // padded keys are masked, padded queries never leave the workgroup).
 #pragma once
 #include "sd_common.h"

@@ -107,39 +107,12 @@ def _linear(A: Tensor, W: Tensor, b, ln=None, res=None, drop=None) -> Tensor:
     return ops.linear(A, W, b, ln=ln, res=res)
 
 
-# ---- weight gradients off the critical path ---------------------------------------------------------------------
-# dW += dY^T X depends on dY and on a saved activation only; nothing in the rest of the backward depends on it.  While
-# a side stream is armed (GraphedTrainStep arms it during capture, so the graph gets a parallel branch per weight
-# gradient), these GEMMs are enqueued there and joined once after loss.backward().  Both kinds of kernel are latency-
-# bound on their own (one wave of 400 workgroups each, section 5.9 of DESIGN.md) and fit a CU together (45 KB + 66.5 KB of
-# LDS), so the chip overlaps them.  The operands are kept alive until the join: the caching allocator must not hand their
-# blocks to a later main-stream allocation while the side stream still reads them, and autograd must not accumulate
-# into a gradient buffer in place (it only does so when it holds the last reference).
-_SIDE = {"stream": None, "keep": [], "dirty": False}
-
-
-def arm_side_stream(stream) -> None:
-    _SIDE["stream"] = stream
-
-
-def join_side_stream() -> None:
-    """Main stream waits for the weight-gradient branch; the operand references are dropped."""
-    if _SIDE["dirty"]:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
-        _SIDE["dirty"] = False
-    _SIDE["keep"].clear()
-
-
+# ---- weight gradients ----------------------------------------------------------------------------------------------
+# dW += dY^T X depends on dY and on a saved activation only.  (Round 2 could enqueue these GEMMs on a parallel branch of the captured
+# graph; the branch overlapped - 1.0 of 5.2 ms of kernel time concurrent - but both sides slowed down by as much, 5.85 vs
+# 5.83 ms per step, so the variant and its switch are gone.)
 def _dw(dY: Tensor, X: Tensor, dW: Tensor, db: Optional[Tensor]) -> None:
-    side = _SIDE["stream"]
-    if side is None:
-        ops.gemm_tn(dY, X, dW, db)
-        return
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        ops.gemm_tn(dY, X, dW, db)
-    _SIDE["keep"].append((dY, X))
-    _SIDE["dirty"] = True
+    ops.gemm_tn(dY, X, dW, db)
 
 
 def _dx_through_weight(dy2d: Tensor, W: Tensor) -> Tensor:
@@ -344,8 +317,6 @@ def _dw_skinny(dY: Tensor, X: Tensor, dW: Tensor, db, known: Tensor, small: Tens
     """dW += dY^T X where one operand (``known``) carries registered abs-max words (``ent``: what _amax_lookup returned for the
     tensor ``known`` is a view of) and the other (``small``) is cheap to scan: the grouped fp16 GEMM with ragged tiles instead
     of the block-floating-point kernel (67 -> ~20 us for the J = 20 gradients)."""
-    if os.environ.get("SD_TRAIN_GROUPED_DW", "1") == "0":
-        ent = None
     ok = ent is not None and dY.shape[-1] % 4 == 0 and X.shape[-1] % 4 == 0 and dY.data_ptr() % 16 == 0 and X.data_ptr() % 16 == 0
     if not ok:
         ops.gemm_tn(dY, X, dW, db)
@@ -582,13 +553,10 @@ def _new(*shape, like: Tensor) -> Tensor:
 # The memory side of a decoder layer - K/V projection of 11 rows per trajectory, its dX, the abs-max of dkv - is 44 panels per
 # launch: 12 launches of ~17 us per step that leave five CUs in six idle.  They run on a second stream (a parallel branch of the
 # captured graph) beside the 400-panel chains of the trajectory rows and are joined where their results are needed.
-# SD_TRAIN_MEM_SIDE=0 keeps them in line.
 _MEM_SIDE: dict = {}
 
 
 def _mem_side(device):
-    if os.environ.get("SD_TRAIN_MEM_SIDE", "1") == "0":
-        return None
     s = _MEM_SIDE.get(device)
     if s is None:
         s = _MEM_SIDE[device] = torch.cuda.Stream(device=device)
@@ -689,7 +657,7 @@ class _FusedLayer(Function):
                             dres=dh3, dg=g[nf_name + ".weight"], db=g[nf_name + ".bias"], p=p, seed=seed,
                             sites=(cfg.site(SITE_FFN_OUT), cfg.site(SITE_FFN_ACT)), amax=(cfg.ax(_AX_DY2), cfg.ax(_AX_DPRE)))
         # the weight gradients of the layer: one grouped launch at the end (hidden_dim a multiple of 128), else one each
-        grouped = d % 128 == 0 and os.environ.get("SD_TRAIN_GROUPED_DW", "1") != "0"
+        grouped = d % 128 == 0
         dws = [(dym, u, g["linear2.weight"], g["linear2.bias"], cfg.ax(_AX_DY2), cfg.ax(_AX_U)),
                (dpre, nf, g["linear1.weight"], g["linear1.bias"], cfg.ax(_AX_DPRE), cfg.ax(_AX_NF))]
 
@@ -743,15 +711,7 @@ class _FusedLayer(Function):
         if dec and _mem_side(h.device) is not None:
             torch.cuda.current_stream().wait_stream(_mem_side(h.device))   # dmem and the abs-max of dkv
         if grouped:
-            side = _SIDE["stream"]
-            if side is None:
-                ops.gemm_tn_grouped(dws)
-            else:   # a parallel branch of the captured graph (GraphedTrainStep(fork_dw=True)); operands kept alive until the join
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    ops.gemm_tn_grouped(dws)
-                _SIDE["keep"].append(dws)
-                _SIDE["dirty"] = True
+            ops.gemm_tn_grouped(dws)
         else:
             for dY, X, dW, db, _, _ in dws:
                 _dw(dY, X, dW, db)
@@ -1133,12 +1093,8 @@ class GraphedTrainStep:
     backward, then ONE flat all-reduce and the update) for A/B runs and its parity test."""
 
     def __init__(self, model, optimizer: FusedAdamW, lr_scheduler, scheduler, world_size: int = 1,
-                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None,
-                 fork_dw: bool = False):
+                 generator: Optional[torch.Generator] = None, eager_steps: int = 2, split_update: Optional[bool] = None):
         self.model, self.opt, self.lr_sched, self.sched = model, optimizer, lr_scheduler, scheduler
-        # weight-gradient GEMMs on a parallel branch of the graph (see _dw).  Measured at B = 256: the branch does overlap
-        # (rocprofv3: 1.0 of 5.2 ms of kernel time concurrent) but both kernels slow down by as much - 5.85 vs 5.83 ms - so off
-        self.fork_dw = fork_dw
         self.world, self.gen, self.eager_left = world_size, generator, eager_steps
         # data parallel: the eager bucketed step (see the class comment) unless split_update is forced
         self.split = False if split_update is None else bool(split_update)
@@ -1196,7 +1152,6 @@ class GraphedTrainStep:
             pred = self.model(st["input"], noisy, t)
         loss = mse_loss(pred, noise)
         loss.backward()
-        join_side_stream()
         if not self.split:
             self.opt.step_from_device_hyper(self.hyper[:7])
         return loss.detach()
@@ -1213,15 +1168,8 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             if self.gen is not None:
                 self.graph.register_generator_state(self.gen)
-            if self.fork_dw:
-                arm_side_stream(torch.cuda.Stream(device=self.hyper.device))
-            try:
-                with torch.cuda.graph(self.graph):
-                    self._loss = self._body()
-            finally:
-                arm_side_stream(None)
-                _SIDE["keep"].clear()
-                _SIDE["dirty"] = False
+            with torch.cuda.graph(self.graph):
+                self._loss = self._body()
         self._upload_hyper()
         self.graph.replay()
         if self.split:
