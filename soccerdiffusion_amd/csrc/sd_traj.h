@@ -62,15 +62,26 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // diagnostic build (-DTJ_STAMPS): every wave of the first TJ_STAMP_WGS workgroups records the shader clock at phase boundaries
 #ifdef TJ_STAMPS
-constexpr int TJ_NSTAMP = 64, TJ_STAMP_WGS = 512;
+constexpr int TJ_NSTAMP = 96, TJ_STAMP_WGS = 512;
 __device__ unsigned long long *g_tj_stamps;
 #define TJ_STAMP(i)                                                                                                            \
     do {                                                                                                                       \
         if (blockIdx.x < TJ_STAMP_WGS && (threadIdx.x & 63) == 0)                                                              \
             g_tj_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * TJ_NSTAMP + (i)] = __builtin_amdgcn_s_memtime();        \
     } while (0)
+// TJ_SYNC(site): a workgroup barrier that adds the cycles this wave spent in it to slot 64 + site (sites: 0 / 1 LayerNorm
+// exchange / panel complete, 2 / 3 self-attention phase W / X, 4 / 5 cross-attention, 6 / 7 feed-forward, 8 .. 10 embedding, tail)
+template <int SITE>
+__device__ __forceinline__ void tj_sync() {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x < TJ_STAMP_WGS && (threadIdx.x & 63) == 0) g_tj_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * TJ_NSTAMP + 64 + SITE] += t1 - t0;
+}
+#define TJ_SYNC(site) tj_sync<site>()
 #else
 #define TJ_STAMP(i) do {} while (0)
+#define TJ_SYNC(site) __syncthreads()
 #endif
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -388,7 +399,9 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
         for (int tt = 0; tt < NTT; ++tt)
             if (tok_ok(c, tt)) *reinterpret_cast<f32x2 *>(stat + (tok_of(c, tt) * 8 + c.w) * 2) = f32x2{mw[tt], qw[tt]};
     }
-    __syncthreads();
+    TJ_STAMP(49);
+    TJ_SYNC(0);
+    TJ_STAMP(50);
     float mean[NTT], rstd[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -402,6 +415,7 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
         mean[tt] = m;
         rstd[tt] = __builtin_amdgcn_rsqf(m2 * (1.0f / D) + SD_LN_EPS);
     }
+    TJ_STAMP(51);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int n0 = 32 * c.w + 16 * a + 4 * c.g;
@@ -413,7 +427,25 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
             __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 14 and spills
         }
     }
-    __syncthreads();   // X complete
+    TJ_STAMP(52);
+    TJ_SYNC(1);   // X complete
+}
+
+// Short GEMM loops (K = 64 / 96 / 112: the attention and the out-projections) as a software pipeline: load(s) fills ring slot
+// s % DEPTH with the LDS operands of step s and is issued DEPTH - 1 steps before mma(s) consumes them (hipcc places every
+// ds_read right before its first use and waits for it: ~100 cycles of LDS round trip per 48 - 96 cycles of MFMAs).
+template <int NSTEP, int DEPTH, class Load, class Mma>
+__device__ __forceinline__ void ring_pipe(Load load, Mma mma) {
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+        if (s < NSTEP) load(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        if (s + DEPTH - 1 < NSTEP) load(s + DEPTH - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // K = 256 GEMM against the X panel as ONE software pipeline over 8 k-steps x 7 token tiles: the B fragment of the next tile
@@ -461,9 +493,10 @@ __device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f1
 // lo part of LayerNorm 1's output is dropped here and only here: measured over the 50-step rollout against the fp64 oracle
 // 5.1e-6 (three products: 4.2e-7; bar 1e-4; dropping the WEIGHTS' lo part instead: 2.8e-5 - tools/exp/precision_sites.sh,
 // DESIGN.md).  Same software pipeline as gemm_pipe; the token half of A1 is a wave-uniform run-time predicate so that
-// the code exists once.
+// the code exists once per parity.
 struct HeadAcc { f32x4 a0[NTT], a1[4]; };
-__device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 *pa0, const f16 *pa1, bool odd) {
+template <bool odd>
+__device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 *pa0, const f16 *pa1) {
     const char *X = c.smem + LDS_X;
     const unsigned lo = (unsigned)c.lane * 8;
     f16x8 a0[2][2], a1[2][2], b[2];
@@ -490,12 +523,12 @@ __device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 
             __builtin_amdgcn_sched_barrier(0);
             acc.a0[tt] = mfma16(a0[ks & 1][1], b[cur], acc.a0[tt]);
             acc.a0[tt] = mfma16(a0[ks & 1][0], b[cur], acc.a0[tt]);
-            if (tt < 4) {
-                if (!odd) {
+            if constexpr (!odd) {
+                if (tt < 4) {
                     acc.a1[tt] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt]);
                     acc.a1[tt] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt]);
                 }
-            } else if (odd) {
+            } else if (tt >= 4) {
                 acc.a1[tt - 4] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt - 4]);
                 acc.a1[tt - 4] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt - 4]);
             }
@@ -531,15 +564,17 @@ __device__ __forceinline__ void load_k64(const Ctx &c, AK64 &f, const f16 *pa0, 
 // acc[a][tt] += A_a . B^T with B rows of 64 features in a Q-layout buffer (K = 64)
 __device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const AK64 &f, const char *Bbuf) {
     const f16x8 (&a)[2][2][2] = f.a;
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const f16x8 bh = lds16(Bbuf + q_at(c, tt, 0, kk));
-            const f16x8 bl = lds16(Bbuf + q_at(c, tt, 1, kk));
-            mma3<S_OUT>(acc[0][tt], a[0][kk][0], a[0][kk][1], bh, bl);
-            mma3<S_OUT>(acc[1][tt], a[1][kk][0], a[1][kk][1], bh, bl);
-        }
+    f16x8 b[3][2];
+    ring_pipe<2 * NTT, 3>(
+        [&](int s) __attribute__((always_inline)) {
+            b[s % 3][0] = lds16(Bbuf + q_at(c, s >> 1, 0, s & 1));
+            b[s % 3][1] = lds16(Bbuf + q_at(c, s >> 1, 1, s & 1));
+        },
+        [&](int s) __attribute__((always_inline)) {
+            const int tt = s >> 1, kk = s & 1;
+            mma3<S_OUT>(acc[0][tt], a[0][kk][0], a[0][kk][1], b[s % 3][0], b[s % 3][1]);
+            mma3<S_OUT>(acc[1][tt], a[1][kk][0], a[1][kk][1], b[s % 3][0], b[s % 3][1]);
+        });
 }
 
 struct SaW {
@@ -570,7 +605,10 @@ __device__ __forceinline__ void head_gemm(const Ctx &c0, const SaW &a, int h, He
     const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
     const int nt1 = 32 + 4 * h + (w >> 1);                   // V tile, token half w & 1
     head_zero(acc);
-    gemm_head(c, acc, a.w_in + (long)nt0 * (8 * 2 * 512), a.w_in + (long)nt1 * (8 * 2 * 512), w & 1);
+    // the token half of the V tile is a wave-uniform predicate: as a run-time condition inside the pipeline it costs a branch per step
+    // (2 - 4 MFMAs), so the loop exists once per parity
+    if (w & 1) gemm_head<true>(c, acc, a.w_in + (long)nt0 * (8 * 2 * 512), a.w_in + (long)nt1 * (8 * 2 * 512));
+    else gemm_head<false>(c, acc, a.w_in + (long)nt0 * (8 * 2 * 512), a.w_in + (long)nt1 * (8 * 2 * 512));
 }
 // accumulators of head h -> Q or K tile and V piece as split planes
 __device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int h, const HeadAcc &acc) {
@@ -618,15 +656,14 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) qf[kk][pl] = lds16(Qb + q_off(qtok, g | (pl << 2) | (kk << 3)));
 #pragma unroll
-        for (int kt = 0; kt < NTT; ++kt) {
-            S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const f16x8 kh = lds16(Kb + q_at(c, kt, 0, kk));
-                const f16x8 kl = lds16(Kb + q_at(c, kt, 1, kk));
-                mma3<S_SCORES>(S[kt], kh, kl, qf[kk][0], qf[kk][1]);
-            }
-        }
+        for (int kt = 0; kt < NTT; ++kt) S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x8 kf[4][2];
+        ring_pipe<2 * NTT, 4>(
+            [&](int s) __attribute__((always_inline)) {
+                kf[s & 3][0] = lds16(Kb + q_at(c, s >> 1, 0, s & 1));
+                kf[s & 3][1] = lds16(Kb + q_at(c, s >> 1, 1, s & 1));
+            },
+            [&](int s) __attribute__((always_inline)) { mma3<S_SCORES>(S[s >> 1], kf[s & 3][0], kf[s & 3][1], qf[s & 1][0], qf[s & 1][1]); });
     }
     // ---- softmax over the keys of this lane's query: registers r of tile kt are keys 16 kt + 4 g + r (only tile 6 has masked keys)
     const float c_s = a.scale_log2e / (ACT * ACT);
@@ -651,6 +688,8 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) O[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q4 = t >> 2, p4 = t & 3;
+    // 16 steps (key pair kp, feature tile ft) of three MFMAs; the V^T fragments (four transposing reads) come three steps ahead
+    f16x8 ph[4], pl[4];
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) {
         // P fragment of keys 32 kp ..: elements 0..3 = tile 2 kp, 4..7 = tile 2 kp + 1 (beyond the last tile: zero)
@@ -658,21 +697,23 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
         f16x4 pah, pal, pbh, pbl;
         split4(pa4, pah, pal);
         split4(pb4, pbh, pbl);
-        const f16x8 ph = __builtin_shufflevector(pah, pbh, 0, 1, 2, 3, 4, 5, 6, 7), pl = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
-        const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
-        const char *v0 = Vb + r0 * VROW + 8 * p4, *v1 = Vb + r1 * VROW + 8 * p4;
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            f16x8 vf[2];
+        ph[kp] = __builtin_shufflevector(pah, pbh, 0, 1, 2, 3, 4, 5, 6, 7);
+        pl[kp] = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    f16x8 vf[4][2];
+    ring_pipe<16, 4>(
+        [&](int s) __attribute__((always_inline)) {
+            const int kp = s >> 2, ft = s & 3;
+            const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
+            const char *v0 = Vb + r0 * VROW + 8 * p4, *v1 = Vb + r1 * VROW + 8 * p4;
 #pragma unroll
             for (int pn = 0; pn < 2; ++pn) {
                 const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v0 + pn * 128 + ft * 32));
                 const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(v1 + pn * 128 + ft * 32));
-                vf[pn] = __builtin_shufflevector(__builtin_bit_cast(f16x4, x0), __builtin_bit_cast(f16x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
+                vf[s & 3][pn] = __builtin_shufflevector(__builtin_bit_cast(f16x4, x0), __builtin_bit_cast(f16x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
             }
-            mma3<S_PV>(O[ft], vf[0], vf[1], ph, pl);
-        }
-    }
+        },
+        [&](int s) __attribute__((always_inline)) { mma3<S_PV>(O[s & 3], vf[s & 3][0], vf[s & 3][1], ph[s >> 2], pl[s >> 2]); });
     // O^T tile ft: features 16 ft + 4 g + r of query 16 w + t, times ACT / sum -> LDS planes
     const float inv = 1.0f / psum;
     const int tok = 16 * w + t;
@@ -706,17 +747,22 @@ __device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[
     for (int h = 0; h < NH; ++h) {
         // phase W (the MFMA job exists twice in the code, before and after the VALU job: each quartet runs one copy)
         if (first && h > 0) head_out_proj(c, wo, H);
+        TJ_STAMP(25 + h);
         head_write_qkv(c, a, h, acc);
+        TJ_STAMP(41 + h);
         if (!first && h > 0) head_out_proj(c, wo, H);
-        __syncthreads();                                // Q, K, V of head h complete (and every reader of head h-1's O is done)
+        TJ_STAMP(45 + h);
+        TJ_SYNC(2);                                // Q, K, V of head h complete (and every reader of head h-1's O is done)
         TJ_STAMP(5 + 3 * h);
         // phase X
         if (first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
+        TJ_STAMP(17 + h);
         if (c.w < NTT) head_attention(c, a);
+        TJ_STAMP(21 + h);
         if (!first && h + 1 < NH) head_gemm(c, a, h + 1, acc);
         head_out_load(c, a, h, wo);
         TJ_STAMP(6 + 3 * h);
-        __syncthreads();                                // O of head h complete; Q, K, V free
+        TJ_SYNC(3);                                // O of head h complete; Q, K, V free
         TJ_STAMP(7 + 3 * h);
     }
     head_out_proj(c, wo, H);
@@ -828,7 +874,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * c.g + r == Mc) cbv[r] = cs;
-        __syncthreads();   // the previous readers of Q / K (out-projection, PV) are done: P may be written
+        TJ_SYNC(4);   // the previous readers of Q / K (out-projection, PV) are done: P may be written
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i >= n1) continue;
@@ -855,20 +901,22 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
                 *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | 4 | (2 << 3))) = z8l;
             }
         }
-        __syncthreads();   // P complete
+        TJ_SYNC(5);   // P complete
         TJ_STAMP(33);
         // h += V'^T P^T + boc: K = 64 (context slots of 4 heads) + 32 (step columns)
         const float up = PSC * L.sc[5];
         scale_h(H, up);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const f16x8 bh = lds16(Pb + p_at(c, tt, 0, kk));
-                const f16x8 bl = lds16(Pb + p_at(c, tt, 1, kk));
-                mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], bh, bl);
-                mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], bh, bl);
-            }
+        f16x8 pb[3][2];
+        ring_pipe<3 * NTT, 3>(
+            [&](int s) __attribute__((always_inline)) {
+                pb[s % 3][0] = lds16(Pb + p_at(c, s / 3, 0, s % 3));
+                pb[s % 3][1] = lds16(Pb + p_at(c, s / 3, 1, s % 3));
+            },
+            [&](int s) __attribute__((always_inline)) {
+                const int tt = s / 3, kk = s % 3;
+                mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], pb[s % 3][0], pb[s % 3][1]);
+                mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], pb[s % 3][0], pb[s % 3][1]);
+            });
         unscale_h(c, H, 1.0f / up, L.b_oc);
     }
     TJ_STAMP(34);
@@ -885,7 +933,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         gemm_x2<S_W1>(c, U, L.w_1);
         TJ_STAMP(36);
         const float c1 = 1.0f / (ACT * L.sc[1]);
-        __syncthreads();   // every wave has read LN3(h): the panel receives gelu(u)
+        TJ_SYNC(6);   // every wave has read LN3(h): the panel receives gelu(u)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_1 + 32 * c.w + 16 * a + 4 * c.g);
@@ -897,7 +945,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
+        TJ_SYNC(7);
         TJ_STAMP(37);
         const float up = ACT * L.sc[2];
         scale_h(H, up);
@@ -1005,7 +1053,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
                 }
             }
         }
-        __syncthreads();
+        TJ_SYNC(8);
         const float c_e = 1.0f / (XSC * a.sc_io[0]);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -1043,7 +1091,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
             for (int tt = 0; tt < NTT; ++tt)
                 if (tok_ok(c, tt)) stat[tok_of(c, tt) * 8 + c.w] = am[tt];
         }
-        __syncthreads();   // also: the X panel's readers (last W2 GEMM) are done
+        TJ_SYNC(9);   // also: the X panel's readers (last W2 GEMM) are done
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const float *sp = stat + tok_of(c, tt) * 8;
@@ -1053,7 +1101,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
             store_x(c, 0, tt, H[0][tt] * s);
             store_x(c, 1, tt, H[1][tt] * s);
         }
-        __syncthreads();
+        TJ_SYNC(10);
         if (c.w < NTT) {
             const char *X = c.smem + LDS_X;
             f32x4 E[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};

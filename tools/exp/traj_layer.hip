@@ -320,6 +320,7 @@ int main(int argc, char **argv) {
 #ifdef TJ_STAMPS
         {
             a.update_x = 0;
+            CK(hipMemset(d_st, 0, n_st * 8));
             hipLaunchKernelGGL(tj::traj_step_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
             CK(hipDeviceSynchronize());
             std::vector<unsigned long long> st(n_st);
@@ -351,6 +352,42 @@ int main(int argc, char **argv) {
                 }
                 printf("\n");
             }
+            {   // inside phase W of heads 1..3 (head 0 has no out-projection)
+                const char *jn[4] = {"  W: out-projection (waves 0-3 first)", "  W: write Q|K|V", "  W: out-projection (waves 4-7 after)", "  W: barrier"};
+                for (int k = 0; k < 4; ++k) {
+                    printf("  heads 1-3 %-27s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            for (int h = 1; h < 4; ++h) {
+                                const unsigned long long t0 = p[7 + 3 * (h - 1)], t1 = p[25 + h], t2 = p[41 + h], t3 = p[45 + h], t4 = p[5 + 3 * h];
+                                sum += (double)(k == 0 ? t1 - t0 : k == 1 ? t2 - t1 : k == 2 ? t3 - t2 : t4 - t3);
+                            }
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
+            {   // inside phase X of heads 0..2 (head 3 has no projection GEMM): first job, attention, second job
+                const char *jn[3] = {"  X: projection GEMM (waves 0-3 first)", "  X: attention", "  X: projection GEMM (waves 4-7 after)"};
+                for (int k = 0; k < 3; ++k) {
+                    printf("  heads 0-2 %-27s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            for (int h = 0; h < 3; ++h) {
+                                const unsigned long long t0 = p[5 + 3 * h], t1 = p[17 + h], t2 = p[21 + h], t3 = p[6 + 3 * h];
+                                sum += (double)(k == 0 ? t1 - t0 : k == 1 ? t2 - t1 : t3 - t2);
+                            }
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
             printf("  %-37s", "out-proj(h3) + unscale");
             for (int wi = 0; wi < 4; ++wi) {
                 double s = 0;
@@ -366,9 +403,43 @@ int main(int argc, char **argv) {
                 for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], i));
                 printf("\n");
             }
+            {   // inside the last LayerNorm executed (LN3 of the last layer; stamp 34 precedes it)
+                const char *jn[4] = {"  LN3: per-wave statistics", "  LN3: exchange barrier", "  LN3: combine 8 waves", "  LN3: normalise, split, store"};
+                const int from[4] = {34, 49, 50, 51}, to[4] = {49, 50, 51, 52};
+                for (int k = 0; k < 4; ++k) {
+                    printf("  %-37s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            sum += (double)(p[to[k]] - p[from[k]]);
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
             double whole = 0;
             for (int b = 0; b < nwg; ++b) whole += (double)(st[((size_t)b * 8) * tj::TJ_NSTAMP + 40] - st[((size_t)b * 8) * tj::TJ_NSTAMP]);
             printf("  whole step (L layers), wave 0: %.0f cycles\n", whole / nwg);
+            const char *sites[11] = {"LayerNorm: statistics exchange", "LayerNorm: panel complete", "self-attention: Q|K|V written (phase W)",
+                                     "self-attention: O written (phase X)", "cross-attention: before P", "cross-attention: P complete",
+                                     "feed-forward: before GELU", "feed-forward: GELU stored", "embedding (1)", "tail: before fc_out", "tail (2)"};
+            printf("--- cycles spent INSIDE barriers over the whole step, mean over %d workgroups   wave:  0      1      2      3      4      5      6      7\n", nwg);
+            double tot[8] = {0};
+            for (int sidx = 0; sidx < 11; ++sidx) {
+                printf("  %-44s", sites[sidx]);
+                for (int w0 = 0; w0 < 8; ++w0) {
+                    double sum = 0;
+                    for (int b = 0; b < nwg; ++b) sum += (double)st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP + 64 + sidx];
+                    printf(" %6.0f", sum / nwg);
+                    tot[w0] += sum / nwg;
+                }
+                printf("\n");
+            }
+            printf("  %-44s", "all barriers");
+            for (int w0 = 0; w0 < 8; ++w0) printf(" %6.0f", tot[w0]);
+            printf("\n");
             a.update_x = 1;
         }
 #endif
