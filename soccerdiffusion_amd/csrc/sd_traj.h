@@ -402,18 +402,33 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     TJ_STAMP(49);
     TJ_SYNC(0);
     TJ_STAMP(50);
-    float mean[NTT], rstd[NTT];
+    // Chan's combination of the 8 waves' pairs, once per (token, wave) instead of once per lane: lane (t, g) combines token tiles
+    // g and g + 4 (tile 7 does not exist: those lanes repeat tile 6), publishes (mean, rstd) in a scratch row of its own wave -
+    // LDS operations of one wave execute in order, no barrier - and every lane reads back the seven pairs of its token.
+    // The scratch (8 waves x 16 tokens x 80 B in the K / V / P region) is free between this LayerNorm's two barriers: every reader
+    // of that region has passed the first one.
+    char *scr = c.smem + LDS_P + c.w * 1280 + c.t * 80;
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) {
-        const float *sp = stat + tok_of(c, tt) * 16;
+    for (int j = 0; j < 2; ++j) {
+        const int tl = c.g + 4 * j;
+        const float *sp = stat + (tl < NTT - 1 ? 16 * tl + c.t : c.tok6) * 16;
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(sp + 8), p3 = *reinterpret_cast<const f32x4 *>(sp + 12);
         const float m = (((p0[0] + p0[2]) + (p1[0] + p1[2])) + ((p2[0] + p2[2]) + (p3[0] + p3[2]))) * 0.125f;
         const f32x4 e0 = f32x4{p0[0], p0[2], p1[0], p1[2]} - m, e1 = f32x4{p2[0], p2[2], p3[0], p3[2]} - m;
         const f32x4 ee = e0 * e0 + e1 * e1;
         const float m2 = (((p0[1] + p0[3]) + (p1[1] + p1[3])) + ((p2[1] + p2[3]) + (p3[1] + p3[3]))) + 32.0f * ((ee[0] + ee[1]) + (ee[2] + ee[3]));
-        mean[tt] = m;
-        rstd[tt] = __builtin_amdgcn_rsqf(m2 * (1.0f / D) + SD_LN_EPS);
+        *reinterpret_cast<f32x2 *>(scr + 8 * tl) = f32x2{m, __builtin_amdgcn_rsqf(m2 * (1.0f / D) + SD_LN_EPS)};
+    }
+    __builtin_amdgcn_wave_barrier();
+    float mean[NTT], rstd[NTT];
+    {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(scr), v1 = *reinterpret_cast<const f32x4 *>(scr + 16);
+        const f32x4 v2 = *reinterpret_cast<const f32x4 *>(scr + 32), v3 = *reinterpret_cast<const f32x4 *>(scr + 48);
+        mean[0] = v0[0]; rstd[0] = v0[1]; mean[1] = v0[2]; rstd[1] = v0[3];
+        mean[2] = v1[0]; rstd[2] = v1[1]; mean[3] = v1[2]; rstd[3] = v1[3];
+        mean[4] = v2[0]; rstd[4] = v2[1]; mean[5] = v2[2]; rstd[5] = v2[3];
+        mean[6] = v3[0]; rstd[6] = v3[1];
     }
     TJ_STAMP(51);
 #pragma unroll
