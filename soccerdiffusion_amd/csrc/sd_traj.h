@@ -31,6 +31,7 @@
 // padded keys are masked, padded queries never leave the workgroup).
 #pragma once
 #include "sd_common.h"
+#include <type_traits>
 
 namespace tj {
 
@@ -853,18 +854,21 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         f32x4 S[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const f16x8 gh = gfr[ks][0], gl = gfr[ks][1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i >= n1) continue;
-                // token tile tt1 + i: compile-time for each parity
-                const f16x8 bh = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 0, ks)) : lds16(X + x_at(c, i, 0, ks));
-                const f16x8 bl = odd ? lds16(X + x_at(c, 4 + (i < 3 ? i : 0), 1, ks)) : lds16(X + x_at(c, i, 1, ks));
-                mma3<S_XSC>(S[i], gh, gl, bh, bl);
-            }
-        }
+        // (8 k-steps x 4 or 3 token tiles) steps of three MFMAs, the panel fragments two steps ahead; once per parity: the tile
+        // numbers are compile-time
+        auto scores = [&](auto odd_c) __attribute__((always_inline)) {
+            constexpr bool OD = decltype(odd_c)::value;
+            constexpr int N1 = OD ? 3 : 4, T1 = OD ? 4 : 0;
+            f16x8 xb[3][2];
+            ring_pipe<8 * N1, 3>(
+                [&](int s) __attribute__((always_inline)) {
+                    xb[s % 3][0] = lds16(X + x_at(c, T1 + s % N1, 0, s / N1));
+                    xb[s % 3][1] = lds16(X + x_at(c, T1 + s % N1, 1, s / N1));
+                },
+                [&](int s) __attribute__((always_inline)) { mma3<S_XSC>(S[s % N1], gfr[s / N1][0], gfr[s / N1][1], xb[s % 3][0], xb[s % 3][1]); });
+        };
+        if (odd) scores(std::true_type{});
+        else scores(std::false_type{});
         // the folded values (48 registers) are requested now: they land under the softmax
         __builtin_amdgcn_sched_barrier(0);
         f16x8 av[2][3][2];
