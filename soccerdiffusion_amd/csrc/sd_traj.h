@@ -383,6 +383,14 @@ template <bool HI_ONLY = false>
 __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
     const Ctx c = ctx_local(c0);
     float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
+    // the affine parameters are requested first: their L2 round trip passes under the statistics (a workgroup is alone on its CU)
+    f32x4 gwv[2], gbv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        gwv[a] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a + 4 * c.g);
+        gbv[a] = *reinterpret_cast<const f32x4 *>(ln_b + 32 * c.w + 16 * a + 4 * c.g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float mw[NTT], qw[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -434,8 +442,7 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     TJ_STAMP(51);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        const int n0 = 32 * c.w + 16 * a + 4 * c.g;
-        const f32x4 gw = *reinterpret_cast<const f32x4 *>(ln_w + n0) * ACT, gb = *reinterpret_cast<const f32x4 *>(ln_b + n0) * ACT;
+        const f32x4 gw = gwv[a] * ACT, gb = gbv[a] * ACT;
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             if constexpr (HI_ONLY) store_x1(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
@@ -751,8 +758,24 @@ __device__ __forceinline__ void head_out_proj(const Ctx &c0, const AK64 &wo, f32
     gemm_k64(c, H, wo, c.smem + LDS_SO);
 }
 
-// X (one plane) holds LayerNorm 1's output on entry
-__device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT]) {
+// H = H * f + bias[feature]; the bias is requested (bias_load) before the GEMM whose result it completes
+struct Bias2 { f32x4 v[2]; };
+__device__ __forceinline__ Bias2 bias_load(const Ctx &c, const float *bias) {
+    Bias2 b;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) b.v[a] = *reinterpret_cast<const f32x4 *>(bias + 32 * c.w + 16 * a + 4 * c.g);
+    __builtin_amdgcn_sched_barrier(0);
+    return b;
+}
+__device__ __forceinline__ void unscale_h(f32x4 (&H)[2][NTT], float f, const Bias2 &b) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + b.v[a];
+}
+
+// X (one plane) holds LayerNorm 1's output on entry; b_o: the out-projection bias, requested before the last head's projection
+__device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT], const float *b_o, Bias2 &bo) {
     const bool first = c.w < 4;   // the quartet that runs the MFMA job of a phase first
     HeadAcc acc;
     AK64 wo;
@@ -781,6 +804,7 @@ __device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[
         TJ_SYNC(3);                                // O of head h complete; Q, K, V free
         TJ_STAMP(7 + 3 * h);
     }
+    bo = bias_load(c, b_o);
     head_out_proj(c, wo, H);
 }
 
@@ -790,15 +814,7 @@ __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f;
 }
-// H = H * f + bias[feature]
-__device__ __forceinline__ void unscale_h(const Ctx &c, f32x4 (&H)[2][NTT], float f, const float *bias) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 32 * c.w + 16 * a + 4 * c.g);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + bv;
-    }
-}
+
 
 // ---------------------------------------------------------------------------------------------------
 // one decoder layer on the residual registers (X holds LN1(h) on entry; on exit LN1 of the next layer if nln_w)
@@ -821,9 +837,10 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         const Ctx &c = c0;
         const float s_o = L.sc[0], up = ACT * s_o;
         scale_h(H, up);
+        Bias2 bo;
         const SaW sw{L.w_in, L.b_in, L.w_o, L.sc[3], scale_log2e};
-        sa_block(c, sw, H);
-        unscale_h(c, H, 1.0f / up, L.b_o);
+        sa_block(c, sw, H, L.b_o, bo);
+        unscale_h(H, 1.0f / up, bo);
     }
     TJ_STAMP(31);
     // The folded keys of this wave's head (16 fragments = 64 registers) are requested BEFORE LayerNorm 2 and land under it: a
@@ -924,6 +941,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         TJ_STAMP(33);
         // h += V'^T P^T + boc: K = 64 (context slots of 4 heads) + 32 (step columns)
         const float up = PSC * L.sc[5];
+        const Bias2 boc = bias_load(c, L.b_oc);
         scale_h(H, up);
         f16x8 pb[3][2];
         ring_pipe<3 * NTT, 3>(
@@ -936,7 +954,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
                 mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], pb[s % 3][0], pb[s % 3][1]);
                 mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], pb[s % 3][0], pb[s % 3][1]);
             });
-        unscale_h(c, H, 1.0f / up, L.b_oc);
+        unscale_h(H, 1.0f / up, boc);
     }
     TJ_STAMP(34);
     layer_norm_to_x(c0, H, L.n3_w, L.n3_b);
@@ -949,13 +967,15 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) U[a][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const Bias2 b1 = bias_load(c, L.b_1);
         gemm_x2<S_W1>(c, U, L.w_1);
         TJ_STAMP(36);
         const float c1 = 1.0f / (ACT * L.sc[1]);
+        const Bias2 b2 = bias_load(c, L.b_2);   // lands under the GELU
         TJ_SYNC(6);   // every wave has read LN3(h): the panel receives gelu(u)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_1 + 32 * c.w + 16 * a + 4 * c.g);
+            const f32x4 bv = b1.v[a];
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 const f32x4 pre = U[a][tt] * c1 + bv;
@@ -969,7 +989,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         const float up = ACT * L.sc[2];
         scale_h(H, up);
         gemm_x2<S_W2>(c, H, L.w_2);
-        unscale_h(c, H, 1.0f / up, L.b_2);
+        unscale_h(H, 1.0f / up, b2);
     }
     TJ_STAMP(38);
     if (L.nln_w) layer_norm_to_x<true>(c0, H, L.nln_w, L.nln_b);
@@ -1010,9 +1030,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
     scale_h(H, up);
     TJ_STAMP(2);
     const SaW sw{a.w_in, a.b_in, a.w_o, a.s_in, a.scale_log2e};
-    sa_block(c, sw, H);
+    Bias2 bo;
+    sa_block(c, sw, H, a.b_o, bo);
     TJ_STAMP(31);
-    unscale_h(c, H, 1.0f / up, a.b_o);
+    unscale_h(H, 1.0f / up, bo);
     float *hout = a.h_out + traj * HFRAG_FLOATS + (long)c.w * (2 * NTT * 256) + c.lane * 4;
 #pragma unroll
     for (int aa = 0; aa < 2; ++aa)
@@ -1057,6 +1078,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
     // ---- embedding: h^T = Wemb . x^T + b + pe^T.  x rows -> Q region as split planes (k = joint, zero-padded to 32)
     {
         char *Qb = c.smem + LDS_Q;
+        // weights, bias and the positional rows of this wave's tokens are requested first (they land while x is staged)
+        f16x8 we[2][2];
+        f32x4 be[2], pe4[2][NTT];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *wp = a.w_emb + (long)(2 * c.w + n) * (2 * 512) + c.lane * 8;
+            we[n][0] = *reinterpret_cast<const f16x8 *>(wp);
+            we[n][1] = *reinterpret_cast<const f16x8 *>(wp + 512);
+            const int n0 = 32 * c.w + 16 * n + 4 * c.g;
+            be[n] = *reinterpret_cast<const f32x4 *>(a.b_emb + n0);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) pe4[n][tt] = *reinterpret_cast<const f32x4 *>(a.pe + (long)tok_of(c, tt) * D + n0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const float *xr = a.x + traj * (long)a.T * J;
         const int nvec = a.T * J / 4;            // J % 4 == 0
         for (int i = threadIdx.x; i < nvec; i += NTHREADS) {
@@ -1076,16 +1111,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
         const float c_e = 1.0f / (XSC * a.sc_io[0]);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const f16 *wp = a.w_emb + (long)(2 * c.w + n) * (2 * 512) + c.lane * 8;
-            const f16x8 ah = *reinterpret_cast<const f16x8 *>(wp), al = *reinterpret_cast<const f16x8 *>(wp + 512);
-            const int n0 = 32 * c.w + 16 * n + 4 * c.g;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_emb + n0);
+            const f16x8 ah = we[n][0], al = we[n][1];
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 mma3<S_EMB>(acc, ah, al, lds16(Qb + q_at(c, tt, 0, 0)), lds16(Qb + q_at(c, tt, 1, 0)));
-                const f32x4 pe4 = *reinterpret_cast<const f32x4 *>(a.pe + (long)tok_of(c, tt) * D + n0);
-                H[n][tt] = acc * c_e + (bv + pe4);
+                H[n][tt] = acc * c_e + (be[n] + pe4[n][tt]);
             }
         }
     }
@@ -1120,6 +1151,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
             store_x(c, 0, tt, H[0][tt] * s);
             store_x(c, 1, tt, H[1][tt] * s);
         }
+        // all 32 weight fragments of fc_out (the residual registers are free now) are requested before the barrier
+        f16x8 wf[2][8][2];
+        if (c.w < NTT) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) wf[n][ks][pl] = *reinterpret_cast<const f16x8 *>(a.w_out + ((long)(n * 8 + ks) * 2 + pl) * 512 + c.lane * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         TJ_SYNC(10);
         if (c.w < NTT) {
             const char *X = c.smem + LDS_X;
@@ -1133,10 +1175,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
                 const unsigned b1 = (c.w < NTT - 1 ? c.xa[m2lo | 1] + (unsigned)(c.w * 16 * XROW) : c.xa6[m2lo | 1]) + (unsigned)((ks >> 1) * 256);
                 const f16x8 bh = lds16(X + b0), bl = lds16(X + b1);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const f16 *wp = a.w_out + ((long)(n * 8 + ks) * 2) * 512 + c.lane * 8;
-                    mma3<S_FC>(E[n], *reinterpret_cast<const f16x8 *>(wp), *reinterpret_cast<const f16x8 *>(wp + 512), bh, bl);
-                }
+                for (int n = 0; n < 2; ++n) mma3<S_FC>(E[n], wf[n][ks][0], wf[n][ks][1], bh, bl);
             }
             // this lane's token scale again (the statistics are still in LDS)
             const float *sp = stat + tok * 8;
