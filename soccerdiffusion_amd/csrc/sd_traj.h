@@ -323,10 +323,25 @@ __device__ __forceinline__ void ctx_init(Ctx &c, char *smem, int T) {
 // computed inside the loop iteration / phase that uses it.  Without this hipcc hoists ~100 loop-invariant LDS addresses out
 // of the head and layer loops, keeps them live across everything and spills as many registers.
 __device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
-    Ctx d = c;
-    asm volatile("" : "+v"(d.t), "+v"(d.g), "+v"(d.tok6), "+v"(d.lane));
-    asm volatile("" : "+v"(d.xa[0]), "+v"(d.xa[1]), "+v"(d.xa[2]), "+v"(d.xa[3]));
-    asm volatile("" : "+v"(d.xa6[0]), "+v"(d.xa6[1]), "+v"(d.xa6[2]), "+v"(d.xa6[3]));
+    // recomputed from the lane number (one laundered register) rather than copied: the 12 per-lane values of the caller's
+    // context then need not stay in registers across the phases (~25 VALU instructions per phase entry)
+    Ctx d;
+    d.smem = c.smem;
+    d.lane = c.lane;
+    asm volatile("" : "+v"(d.lane));
+    d.w = c.w;
+    d.g = d.lane >> 4;
+    d.t = d.lane & 15;
+    d.T = c.T;
+    d.ok6 = 96 + d.t < d.T;
+    d.tok6 = d.ok6 ? 96 + d.t : d.T - 1;
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        const unsigned in_row = (unsigned)(((d.g ^ (d.t & 3)) << 4) + ((m2 ^ (d.t >> 2)) << 6));
+        const unsigned in_row6 = (unsigned)(((d.g ^ (d.tok6 & 3)) << 4) + ((m2 ^ ((d.tok6 >> 2) & 3)) << 6));
+        d.xa[m2] = (unsigned)(d.t * XROW) + in_row;
+        d.xa6[m2] = (unsigned)(d.tok6 * XROW) + in_row6;
+    }
     return d;
 }
 
