@@ -1,6 +1,6 @@
 // Stage-A / Stage-B experiment: the trajectory-owning kernels of soccerdiffusion_amd/csrc/sd_traj.h on random
 // data, checked against an fp64 host restatement of the blocks they replace and timed per 4096 trajectories.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value -I include -I soccerdiffusion_amd/csrc tools/exp/traj_layer.hip -o tools/exp/traj_layer
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value -Xclang -target-feature -Xclang -packed-fp32-ops -I include -I soccerdiffusion_amd/csrc tools/exp/traj_layer.hip -o tools/exp/traj_layer
 //   tools/exp/traj_layer [B=4096] [iters=20] [check=2] [L=4]
 // Prints (a) traj_sa_kernel: h + SelfAttention(LN1(h)) alone (Stage A), (b) traj_step_kernel: one whole denoiser step
 // (embedding, L layers with folded cross-attention and FFN, fc_out, DDIM update).  -DTJ_STAMPS adds the phase profile.
