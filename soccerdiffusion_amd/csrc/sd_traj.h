@@ -143,6 +143,15 @@ __device__ __forceinline__ void split_store(char *hi_at, char *lo_at, const f32x
 // W (N x K row-major fp32, zero-padded to Np x Kp with Np % 16 == 0, Kp % 32 == 0) -> [n-tile][k-step][plane][lane][8]:
 // lane = 16 g + i holds W[16 nt + i][32 ks + 8 g + 0..7] * scale as hi / lo.  maxbits: abs-max word (scale derived on the
 // device) or NULL with a fixed scale.
+// The order of the contraction index inside the activation panels.  A lane of an accumulator tile holds four consecutive
+// features of its token for EACH of the wave's two n-tiles (32 w + 4 g + r and 32 w + 16 + 4 g + r): stored side by side they are one
+// 16-byte slot, i.e. one ds_write_b128 per plane and token tile, conflict-free (8-lane groups over 32 banks), where two
+// ds_write_b64 - 16-lane groups sharing the same half of their slots - always collide two-way (- 6 % of the step with conflict-free
+// stores in a timing experiment).  So position 8 g + e of a 32-feature k-step holds feature 16 (e >> 2) + 4 g + (e & 3); every weight
+// matrix whose contraction runs over such a panel (K = 256: in_proj, out_proj, linear1, linear2, fc_out, the folded keys) is packed in
+// that order.
+__device__ __forceinline__ int kperm(int k8, int e) { return (k8 >> 2) * 32 + 16 * (e >> 2) + 4 * (k8 & 3) + (e & 3); }
+
 __global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int Np, int Kp, const unsigned *maxbits, float fixed_scale,
                                 f16 *__restrict__ dst, float *scale_out) {
     const float scale = maxbits ? f16_scale_from_bits(*maxbits) : fixed_scale;
@@ -154,7 +163,7 @@ __global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int N
         f16 hh[8], ll[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = k8 * 8 + e;
+            const int k = Kp == D ? kperm(k8, e) : k8 * 8 + e;
             const float v = (n < N && k < K) ? W[(long)n * K + k] * scale : 0.f;
             hh[e] = (f16)v;
             ll[e] = (f16)(v - (float)hh[e]);
@@ -181,9 +190,9 @@ __global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_
         const long ih = i / (D / 8) / 16;
         f16x4 h0 = {0, 0, 0, 0}, l0 = h0, h1 = h0, l1 = h0;
         if (slot < n_slots) {
-            const float *row = gv + (ih * 16 + slot) * 2 * D + k8 * 8;
+            const float *row = gv + (ih * 16 + slot) * 2 * D + kperm(k8, 0);   // features .. + 3 and + 16 .. + 19 (kperm)
             f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
-            f16_split4(*reinterpret_cast<const f32x4 *>(row + 4), scale, h1, l1);
+            f16_split4(*reinterpret_cast<const f32x4 *>(row + 16), scale, h1, l1);
         }
         f16 *o = dst + ih * (8 * 2 * 512) + ((k8 >> 2) * 2) * 512 + ((k8 & 3) * 16 + slot) * 8;
         *reinterpret_cast<f16x4 *>(o) = h0;
@@ -202,9 +211,9 @@ __global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, long items
         const int k8 = (int)(i % (D / 8));
         const long ih = i / (D / 8);
         f16x4 h0, l0, h1, l1;
-        const float *row = gvstep + ih * 2 * D + k8 * 8;
+        const float *row = gvstep + ih * 2 * D + kperm(k8, 0);
         f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
-        f16_split4(*reinterpret_cast<const f32x4 *>(row + 4), scale, h1, l1);
+        f16_split4(*reinterpret_cast<const f32x4 *>(row + 16), scale, h1, l1);
         f16 *o = dst + ih * (8 * 2 * 32) + ((k8 >> 2) * 2) * 32 + (k8 & 3) * 8;
         *reinterpret_cast<f16x4 *>(o) = h0;
         *reinterpret_cast<f16x4 *>(o + 4) = h1;
@@ -374,20 +383,28 @@ __device__ __forceinline__ unsigned p_off(int tok, int chunk) { return (unsigned
 
 __device__ __forceinline__ f16x8 lds16(const char *p) { return *reinterpret_cast<const f16x8 *>(p); }
 
-// H[a][tt] (features 32 w + 16 a + 4 g + r of this lane's token in tile tt) -> X panel, as split planes of value * ACT.
-// k = feature: k-step w, 8-group 2 a + g / 2, position 4 (g & 1) + r
-__device__ __forceinline__ void store_x(const Ctx &c, int a, int tt, const f32x4 &v) {
+// H[0][tt], H[1][tt] (features 32 w + 4 g + r and 32 w + 16 + 4 g + r of this lane's token in tile tt) -> X panel, as split planes
+// of value * ACT: slot g of k-step w (kperm), one 16-byte store per plane
+__device__ __forceinline__ void split_store8(char *hi_at, char *lo_at, const f32x4 &v0, const f32x4 &v1) {
+    f16x4 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    *reinterpret_cast<f16x8 *>(hi_at) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<f16x8 *>(lo_at) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void store_x(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
     if (!tok_ok(c, tt)) return;
-    const int chunk = (2 * a + (c.g >> 1)) | (c.w << 3), tok = tok_of(c, tt);
+    const int chunk = c.g | (c.w << 3), tok = tok_of(c, tt);
     char *X = c.smem + LDS_X;
-    split_store(X + x_off(tok, chunk) + 8 * (c.g & 1), X + x_off(tok, chunk | 4) + 8 * (c.g & 1), v);
+    split_store8(X + x_off(tok, chunk), X + x_off(tok, chunk | 4), v0, v1);
 }
 
-// the same value as ONE fp16 plane of the one-plane panel (k-step w -> chunk bits 2..4)
-__device__ __forceinline__ void store_x1(const Ctx &c, int a, int tt, const f32x4 &v) {
+// the same values as ONE fp16 plane of the one-plane panel (k-step w -> chunk bits 2..4)
+__device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
     if (!tok_ok(c, tt)) return;
-    const int chunk = (2 * a + (c.g >> 1)) | (c.w << 2), tok = tok_of(c, tt);
-    *reinterpret_cast<f16x4 *>(c.smem + LDS_X + x1_off(tok, chunk) + 8 * (c.g & 1)) = __builtin_convertvector(v, f16x4);
+    const int chunk = c.g | (c.w << 2), tok = tok_of(c, tt);
+    *reinterpret_cast<f16x8 *>(c.smem + LDS_X + x1_off(tok, chunk)) =
+        __builtin_shufflevector(__builtin_convertvector(v0, f16x4), __builtin_convertvector(v1, f16x4), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // LayerNorm over the 256 features of H -> split planes of the X panel (scaled by ACT).  Per wave: mean and centred sum of
@@ -455,15 +472,13 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
         mean[6] = v3[0]; rstd[6] = v3[1];
     }
     TJ_STAMP(51);
+    const f32x4 gw0 = gwv[0] * ACT, gb0 = gbv[0] * ACT, gw1 = gwv[1] * ACT, gb1 = gbv[1] * ACT;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const f32x4 gw = gwv[a] * ACT, gb = gbv[a] * ACT;
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            if constexpr (HI_ONLY) store_x1(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
-            else store_x(c, a, tt, ((H[a][tt] - mean[tt]) * rstd[tt]) * gw + gb);
-            __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 14 and spills
-        }
+    for (int tt = 0; tt < NTT; ++tt) {
+        const f32x4 y0 = ((H[0][tt] - mean[tt]) * rstd[tt]) * gw0 + gb0, y1 = ((H[1][tt] - mean[tt]) * rstd[tt]) * gw1 + gb1;
+        if constexpr (HI_ONLY) store_x1(c, tt, y0, y1);
+        else store_x(c, tt, y0, y1);
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 7 and spills
     }
     TJ_STAMP(52);
     TJ_SYNC(1);   // X complete
@@ -757,9 +772,9 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
     const int tok = 16 * w + t;
     if (tok < c.T) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const int chunk = (2 * (ft & 1) + (g >> 1)) | ((ft >> 1) << 3);
-            split_store(Ob + q_off(tok, chunk) + 8 * (g & 1), Ob + q_off(tok, chunk | 4) + 8 * (g & 1), O[ft] * inv);
+        for (int kk = 0; kk < 2; ++kk) {   // features 32 kk + 4 g + r and 32 kk + 16 + 4 g + r: slot g of k-step kk (kperm)
+            const int chunk = g | (kk << 3);
+            split_store8(Ob + q_off(tok, chunk), Ob + q_off(tok, chunk | 4), O[2 * kk] * inv, O[2 * kk + 1] * inv);
         }
     }
 }
@@ -989,15 +1004,16 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         const Bias2 b2 = bias_load(c, L.b_2);   // lands under the GELU
         TJ_SYNC(6);   // every wave has read LN3(h): the panel receives gelu(u)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const f32x4 bv = b1.v[a];
+        for (int tt = 0; tt < NTT; ++tt) {
+            f32x4 gl[2];
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                const f32x4 pre = U[a][tt] * c1 + bv;
+            for (int a = 0; a < 2; ++a) {
+                const f32x4 pre = U[a][tt] * c1 + b1.v[a];
                 const f32x2 g0 = gelu_erf_as2(f32x2{pre[0], pre[1]}) * ACT, g1 = gelu_erf_as2(f32x2{pre[2], pre[3]}) * ACT;
-                store_x(c, a, tt, f32x4{g0[0], g0[1], g1[0], g1[1]});
-                __builtin_amdgcn_sched_barrier(0);
+                gl[a] = f32x4{g0[0], g0[1], g1[0], g1[1]};
             }
+            store_x(c, tt, gl[0], gl[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         TJ_SYNC(7);
         TJ_STAMP(37);
@@ -1163,8 +1179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
             const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
             const float m = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
             const float s = f16_scale_from_bits(__builtin_bit_cast(unsigned, m));
-            store_x(c, 0, tt, H[0][tt] * s);
-            store_x(c, 1, tt, H[1][tt] * s);
+            store_x(c, tt, H[0][tt] * s, H[1][tt] * s);
         }
         // all 32 weight fragments of fc_out (the residual registers are free now) are requested before the barrier
         f16x8 wf[2][8][2];
