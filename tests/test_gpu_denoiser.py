@@ -182,7 +182,8 @@ assert err < 1e-4, err
     assert "ERR" in out.stdout
 
 
-@pytest.mark.parametrize("T,Mc,J,L,B", [(100, 10, 20, 4, 5), (97, 0, 4, 1, 3), (98, 15, 32, 2, 2), (99, 5, 8, 3, 9), (100, 1, 20, 8, 1)])
+@pytest.mark.parametrize("T,Mc,J,L,B", [(100, 10, 20, 4, 5), (97, 0, 4, 1, 3), (98, 15, 32, 2, 2), (99, 5, 8, 3, 9), (100, 1, 20, 8, 1),
+                                       (100, 15, 32, 8, 2), (97, 7, 12, 2, 4), (99, 0, 28, 5, 3)])
 def test_trajectory_step_kernel_every_step(ops, T, Mc, J, L, B):
     """Sampler mode 3 (csrc/sd_traj.h; reference blocks decoder.py:26-54 under the DDIM loop of plot.py:122-131): x after EVERY
     step against the fp32 oracle, at the edges of what the kernel takes - a last token tile with 1 .. 4 live tokens (T = 97 .. 100),
