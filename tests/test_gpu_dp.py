@@ -146,3 +146,23 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(mode):
     if mode == "train":
         assert d["train"]["allreduce_bytes"] > 10_000_000 and d["train"]["allreduce_ms"] > 0
         assert "all-reduce" in d["config"]["parallelism"]
+        # the step the N-rank benchmark times is the one cli train runs: eager, per-layer buckets overlapped with the backward;
+        # the exchange is reported alone and as what it still costs on the critical path
+        assert "overlapped" in d["train"]["allreduce_form"] and isinstance(d["train"]["allreduce_exposed_ms"], float)
+        assert "no multi-GPU hardware run" in d["train"]["note"]
+
+
+def test_data_parallel_step_is_the_eager_bucketed_one():
+    """At world_size > 1 GraphedTrainStep does not capture: every call is training.train_step with the per-layer bucketed all-reduce
+    (a captured graph cannot signal a side stream in mid-replay on ROCm torch), so cli train and bench.py --mode train share ONE
+    data-parallel step; split_update=True keeps the older graph + flat all-reduce form selectable."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    m = _model(layers=1)
+    opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+    ns = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    dp = training.GraphedTrainStep(m, opt, None, ns, world_size=2)
+    assert dp.eager_dp and not dp.split and dp.graph is None
+    assert not training.GraphedTrainStep(m, opt, None, ns, world_size=2, split_update=True).eager_dp
+    assert not training.GraphedTrainStep(m, opt, None, ns, world_size=1).eager_dp
