@@ -901,6 +901,25 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         f32x4 S[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The score biases, the step token's value columns and the folded values of this trajectory (48 registers, HBM) are requested before
+        // the score GEMM: an HBM round trip under load is longer than the softmax, and a load consumed before an older one has returned
+        // waits for that one too (loads return in order).
+        f32x4 cbv = *reinterpret_cast<const f32x4 *>(L.cb + traj * 64 + hh * 16 + 4 * c.g);
+        const float cs = L.cstep[hh];
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 av[2][3][2];
+        f16 svv[2][2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *vp = L.v16 + ((traj * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) svv[n][pl] = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // (8 k-steps x 4 or 3 token tiles) steps of three MFMAs, the panel fragments two steps ahead; once per parity: the tile
         // numbers are compile-time
         auto scores = [&](auto odd_c) __attribute__((always_inline)) {
@@ -916,27 +935,12 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         };
         if (odd) scores(std::true_type{});
         else scores(std::false_type{});
-        // the folded values (48 registers) are requested now: they land under the softmax
-        __builtin_amdgcn_sched_barrier(0);
-        f16x8 av[2][3][2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const f16 *vp = L.v16 + ((traj * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
-                av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int pl = 0; pl < 2; ++pl) av[n][2][pl] = f16x8{svv[n][pl], 0, 0, 0, 0, 0, 0, 0};
         // softmax over the Mk key slots (accumulator rows 4 g + r) of each token (lane column)
         const float c_g = 1.0f / (ACT * L.sc[4]);
-        f32x4 cbv = *reinterpret_cast<const f32x4 *>(L.cb + traj * 64 + hh * 16 + 4 * c.g);
-        const float cs = L.cstep[hh];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * c.g + r == Mc) cbv[r] = cs;
