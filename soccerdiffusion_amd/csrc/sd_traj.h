@@ -411,18 +411,32 @@ __device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x4 &v0, 
 // squares of its 32 features (two-pass, in registers + two row all-reduces), then Chan's combination of the 8 waves' pairs:
 // one exchange, two barriers (the first also fences the X panel's previous readers).
 // HI_ONLY: the one-plane panel of the self-attention block (LayerNorm 1).
-template <bool HI_ONLY = false>
-__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
-    const Ctx c = ctx_local(c0);
-    float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
-    // the affine parameters are requested first: their L2 round trip passes under the statistics (a workgroup is alone on its CU)
-    f32x4 gwv[2], gbv[2];
+// a LayerNorm's affine parameters of this lane's features: requested first - their L2 round trip passes under the statistics (a
+// workgroup is alone on its CU) - and, where a request to HBM is also due (the folded keys before LayerNorm 2), BEFORE it: loads
+// return in order, a parameter requested after 16 KB of HBM reads would arrive behind them
+struct LnAffine { f32x4 w[2], b[2]; };
+__device__ __forceinline__ void ln_affine_load(const Ctx &c, const float *ln_w, const float *ln_b, LnAffine &p) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        gwv[a] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a + 4 * c.g);
-        gbv[a] = *reinterpret_cast<const f32x4 *>(ln_b + 32 * c.w + 16 * a + 4 * c.g);
+        p.w[a] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a + 4 * c.g);
+        p.b[a] = *reinterpret_cast<const f32x4 *>(ln_b + 32 * c.w + 16 * a + 4 * c.g);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+template <bool HI_ONLY = false>
+__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff);
+template <bool HI_ONLY = false>
+__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
+    LnAffine aff;
+    ln_affine_load(c0, ln_w, ln_b, aff);
+    layer_norm_to_x<HI_ONLY>(c0, H, aff);
+}
+template <bool HI_ONLY>
+__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff) {
+    const Ctx c = ctx_local(c0);
+    float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
+    const f32x4 (&gwv)[2] = aff.w, (&gbv)[2] = aff.b;
     float mw[NTT], qw[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -876,6 +890,8 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
     // The folded keys of this wave's head (16 fragments = 64 registers) are requested BEFORE LayerNorm 2 and land under it: a
     // workgroup is alone on its CU, nothing else hides their HBM / MALL round trips (the score phase took 18 k cycles for 96 MFMAs).
     // Lanes of slot Mc read the step token's shared row instead of their trajectory's block.
+    LnAffine aff2;
+    ln_affine_load(c0, L.n2_w, L.n2_b, aff2);
     f16x8 gfr[8][2];
     {
         const int hh = c0.w >> 1, Mc = Mk - 1;
@@ -888,7 +904,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
             for (int pl = 0; pl < 2; ++pl) gfr[ks][pl] = *reinterpret_cast<const f16x8 *>(gp + (ks * 2 + pl) * gstride);
         __builtin_amdgcn_sched_barrier(0);
     }
-    layer_norm_to_x(c0, H, L.n2_w, L.n2_b);
+    layer_norm_to_x(c0, H, aff2);
     TJ_STAMP(32);
     // ---- folded cross-attention: wave w scores head w >> 1 for token tiles tt1 .. (half w & 1)
     {
