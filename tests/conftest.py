@@ -39,3 +39,8 @@ def g2():
 @pytest.fixture(scope="session")
 def g3():
     return load_golden("g3_c2_decoder.pt")
+
+
+@pytest.fixture(scope="session")
+def g4():
+    return load_golden("g4_dataset.pt")

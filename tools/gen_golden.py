@@ -103,6 +103,98 @@ def randomise(model: nn.Module, seed: int):
         model.std.copy_(0.5 + torch.rand(model.std.shape, generator=g))
 
 
+def gen_dataset_golden(out_dir: str = OUT) -> str:
+    """G4: the reference's OWN data feed (soccer_diffusion/dataset/pytorch.py:40-414) run on a small SQLite file whose tables are
+    created from the reference's own SQLAlchemy schema (dataset/models.py).  The fixture holds the database file's bytes (data), the
+    constructor arguments and what the reference class returned: items at the window edges (start-up padding, last samples of a
+    recording, the first of the next), a collated batch, `len`, `sample_boundaries`, the joint order and `Normalizer.fit`.
+    Image path excluded (cv2 / torchvision absent: `use_images=False`, stubs are import-only); IMU in quaternion mode
+    (`quats_to_5d` needs transforms3d, absent)."""
+    import math
+    import sqlite3
+    import tempfile
+
+    import numpy as np
+
+    if "soccer_diffusion" not in sys.modules:
+        import_reference()
+    # import-only stand-ins for packages the image lacks; none of them is called with use_images=False / quaternion IMU
+    _stub("cv2", resize=None, INTER_AREA=3)
+    _stub("torchvision.transforms", v2=types.SimpleNamespace())
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    _stub("transforms3d")
+    _stub("transforms3d.quaternions", quat2axangle=None)
+    _stub("soccer_diffusion.utils", REF + "/utils")
+    import logging
+
+    sys.modules["soccer_diffusion.dataset"].logger = logging.getLogger("dataset")   # what dataset/__init__.py:27 would define
+    models = importlib.import_module("soccer_diffusion.dataset.models")
+    pyt = importlib.import_module("soccer_diffusion.dataset.pytorch")
+    imu = importlib.import_module("soccer_diffusion.ml.model.encoder.imu")
+    from sqlalchemy import create_engine
+
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "g4.sqlite3")
+    engine = create_engine(f"sqlite:///{path}")
+    models.Base.metadata.create_all(engine)   # the reference's schema, every table
+    engine.dispose()
+    names = models.JointStates.get_ordered_joint_names()
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    rng = np.random.default_rng(4)
+    lengths = (140, 61)
+    for rid, n in enumerate(lengths, start=1):
+        cur.execute("INSERT INTO Recording (_id, allow_public, original_file, team_name, robot_type, simulated, img_width, img_height, "
+                    "img_width_scaling, img_height_scaling, location) VALUES (?, 0, ?, 'team', 'wolfgang', 0, 480, 480, 1.0, 1.0, 'lab')",
+                    (rid, f"rec{rid}.mcap"))
+        for i in rng.permutation(n):   # inserted out of order: only ORDER BY stamp gives the sequence
+            stamp = float(i) / 100.0
+            for table, off in (("JointCommands", 0.0), ("JointStates", 0.37)):
+                vals = [float((math.pi + math.sin(0.07 * i + 0.9 * j + off + rid)) % (2 * math.pi)) for j in range(len(names))]
+                cols = ", ".join(f'"{c}"' for c in names)
+                cur.execute(f"INSERT INTO {table} (stamp, recording_id, {cols}) VALUES (?, ?, {', '.join('?' * len(names))})", (stamp, rid, *vals))
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            cur.execute("INSERT INTO Rotation (stamp, recording_id, x, y, z, w) VALUES (?, ?, ?, ?, ?, ?)", (stamp, rid, *[float(v) for v in q]))
+    for stamp, state in ((0.25, "POSITIONING"), (0.60, "PLAYING"), (1.10, "STOPPED")):   # recording 2 has no game state: UNKNOWN
+        cur.execute("INSERT INTO GameState (stamp, recording_id, state) VALUES (?, 1, ?)", (stamp, state))
+    con.commit()
+    con.close()
+    kw = dict(num_samples_imu=25, num_samples_joint_states=20, num_samples_joint_trajectory=30, num_samples_joint_trajectory_future=10,
+              sampling_rate=100, trajectory_stride=1, num_joints=len(names), use_images=False, use_imu=True, use_joint_states=True,
+              use_action_history=True, use_game_state=True)
+    con = sqlite3.connect(path)
+    ds = pyt.SoccerDiffusionDataset(db_connection=con, imu_representation=imu.IMUEncoder.OrientationEmbeddingMethod.QUATERNION, **kw)
+    idxs = [0, 1, 9, 19, 20, 24, 25, 29, 30, 31, 60, 110, 129, 130, 131, 150, 180]
+    items = {}
+    for i in idxs:
+        r = ds[i]
+        items[i] = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in pyt.asdict(r).items() if v is not None}
+    batch = pyt.SoccerDiffusionDataset.collate_fn([ds[i] for i in idxs])
+    norm_idx = [3, 77, 140, 5, 129, 42]
+    normalizer = pyt.Normalizer.fit(torch.cat([ds[i].joint_command for i in norm_idx], dim=0))   # train.py:106-110
+    # a strided view of the same file (trajectory_stride 3), two items
+    ds3 = pyt.SoccerDiffusionDataset(db_connection=con, imu_representation=imu.IMUEncoder.OrientationEmbeddingMethod.QUATERNION,
+                                     **dict(kw, trajectory_stride=3, use_game_state=False))
+    items3 = {i: {k: v.clone() for k, v in pyt.asdict(ds3[i]).items() if v is not None} for i in (2, 44, 50)}
+    con.close()
+    out = os.path.join(out_dir, "g4_dataset.pt")
+    torch.save(
+        {
+            "sqlite_bytes": torch.frombuffer(bytearray(open(path, "rb").read()), dtype=torch.uint8).clone(),
+            "kwargs": kw, "imu_representation": "quaternion",
+            "joint_names": [str(n) for n in ds.joint_names], "len": len(ds), "sample_boundaries": [list(b) for b in ds.sample_boundaries],
+            "idxs": idxs, "items": items,
+            "batch": {k: v.clone() for k, v in pyt.asdict(batch).items() if v is not None},
+            "norm_idx": norm_idx, "norm_mean": normalizer.mean.clone(), "norm_std": normalizer.std.clone(),
+            "stride3_len": len(ds3), "stride3_boundaries": [list(b) for b in ds3.sample_boundaries], "stride3_items": items3,
+            "robot_state_values": [str(v) for v in models.RobotState.values()],
+        },
+        out,
+    )
+    return out
+
+
 def main():
     warnings.filterwarnings("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -211,7 +303,12 @@ def main():
         os.path.join(OUT, "g3_c2_decoder.pt"),
     )
     print("g3", float(eps.abs().mean()), float(checksum))
+    print("g4", gen_dataset_golden())
 
 
 if __name__ == "__main__":
+    if "--dataset-only" in sys.argv:
+        warnings.filterwarnings("ignore")
+        print(gen_dataset_golden())
+        sys.exit(0)
     main()
