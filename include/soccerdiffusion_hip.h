@@ -105,9 +105,19 @@ size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
  *   1 = fp32 MFMA with the cross-attention Q/out projections folded into the cached memory (heads 4, Mc + 1 <= 16, T >= 64);
  *   2 = mode 1 with every row GEMM and the self-attention as 3 fp16 MFMAs on split (hi + lo) operands, fp32
  *       accumulate (hidden_dim 256; SD_SAMPLER_GEMM=f32 in the environment selects mode 1 instead);
- *   3 = mode 2's arithmetic in ONE launch per step: a workgroup owns a trajectory (embedding, every layer with its
- *       self-attention, fc_out, DDIM update; q | k | v and the residual stream never leave the CU; soccerdiffusion_amd/csrc/
- *       sd_traj.h).  hidden_dim 256, 4 heads, 96 < T <= 100, Mc + 1 <= 16, J <= 32, <= 8 layers; SD_SAMPLER_TRAJ=0 selects mode 2. */
+ *   3 = ONE launch per step: a workgroup owns a trajectory (embedding, every layer with its self-attention, fc_out, DDIM
+ *       update; q | k | v and the residual stream never leave the CU; soccerdiffusion_amd/csrc/sd_traj.h).  Mode 2's
+ *       arithmetic: three fp16 MFMAs per product on hi + lo operands at EVERY site.  hidden_dim 256, 4 heads, T <= 100 (one
+ *       instantiation per ceil(T / 16) token tiles), Mc + 1 <= 16, J <= 32, J % 4 == 0; the layer count (<= 8) is checked
+ *       at the call - a deeper model runs mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
+ *   4 = mode 3 with ONE exception: the Q | K | V projection of the self-attention reads a single fp16 plane of LayerNorm
+ *       1's output (two MFMAs per product there, 11-bit activation operand), which frees the LDS that lets the four images
+ *       of a head live side by side (two barriers per head instead of five; ~ 1.15 x mode 3).  The error this leaves in a
+ *       logit grows with the logit: measured noise-prediction error against fp64 ~ 1e-5 x max |logit| (1.6e-5 on freshly
+ *       initialised weights, 1e-4 at |logit| ~ 9, 1e-3 at 25; mode 3: 1e-6 throughout - tools/exp/eps_stress.py,
+ *       profiles/r04_eps_stress.txt), so the kernel reports SD_STATUS_SHARP_LOGITS (below) when a logit leaves
+ *       SD_SHARP_LOGIT_LIMIT and the caller repeats the rollout on mode 3.
+ * Returns the mode an automatic call (max_mode = -1) runs: 3 where the trajectory kernel applies - mode 4 is opt-in. */
 int sd_sampler_mode(int d, int heads, int T, int Mc, int J);
 
 /* StepToken.forward — soccer_diffusion/ml/model/misc.py:25-35.
@@ -170,13 +180,30 @@ int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *
  *     fp16 infinity, its products NaN, and the NaN stays in its trajectory down to x - so a set bit means "operand
  *     range of mode 2 exceeded (e.g. a LayerNorm weight in the thousands) or non-finite input", never silently wrong
  *     finite numbers.  No synchronisation: read the word after the stream has drained.
- *   max_mode: -1 = automatic (sd_sampler_mode); 0 / 1 / 2 / 3 = never use a mode above this one.  max_mode <= 1 also keeps
- *     the memory K/V projections on the exact-fp32 MFMA: the rerun path after a set status bit
- *     (soccerdiffusion_amd.ops.ddim_sample_guarded does exactly that). */
+ *   max_mode: 0 .. 4 = never use a mode above this one; -1 = automatic = sd_sampler_mode (at most 3: valid for any weights).
+ *     max_mode = 4 opts in to mode 4 where the shape allows it and REQUIRES `status` (its SD_STATUS_SHARP_LOGITS bit);
+ *     max_mode <= 1 also keeps the memory K/V projections on the exact-fp32 MFMA: the rerun path after SD_STATUS_NONFINITE
+ *     (soccerdiffusion_amd.ops.ddim_sample_guarded does both reruns). */
 #define SD_STATUS_NONFINITE 1
+/* Mode 4 only: some self-attention logit q.k / sqrt(hd) exceeded SD_SHARP_LOGIT_LIMIT in magnitude.  The two-product Q | K | V
+ * site of mode 4 (see sd_sampler_mode) is validated against the fp64 oracle up to that sharpness (tests/test_gpu_denoiser.py::
+ * test_mode3_noise_prediction_*: <= 5e-5, half of north_star's 1e-4); beyond it the caller repeats the rollout with max_mode = 3
+ * (three products everywhere), which soccerdiffusion_amd.ops.ddim_sample_guarded does - and remembers for that model.  The
+ * result of a flagged call is finite; the bit says "not validated", not "wrong". */
+#define SD_STATUS_SHARP_LOGITS 2
+#define SD_SHARP_LOGIT_LIMIT 5.0f
 int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
                       const float *coef, float *x, float *trace, float *workspace,
                       int B, int T, int Mc, int n_steps, int32_t *status, int max_mode, void *stream);
+
+/* sd_ddim_sample_ex that also hands back the denoiser's noise prediction of every step - the reference's
+ * `model.forward_with_context(...)` value inside the loop (soccer_diffusion/ml/inference/plot.py:128, ml/training/distill.py:186),
+ * i.e. exactly what the DDIM update of that step consumed, from whichever kernels the call selected.
+ *   eps_trace (n_steps,B,T,J) or NULL.  SURVEY 8(d)'s parity gate (i) "single eps-hat" for the sampler kernels: with n_steps = 1
+ *   it is one forward of mode 3's trajectory kernel (sd_denoiser_forward runs the row-panel kernels instead). */
+int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                       const float *coef, float *x, float *trace, float *eps_trace, float *workspace,
+                       int B, int T, int Mc, int n_steps, int32_t *status, int max_mode, void *stream);
 
 /* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
 

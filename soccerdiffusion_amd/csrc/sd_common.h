@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +39,25 @@ int fail(int code, const char *msg);
         (void)hipGetLastError();          \
         hipLaunchKernelGGL(__VA_ARGS__);  \
     } while (0)
+
+// "Done on the CURRENT device": hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting and one process may drive
+// several devices, so a call site's once-flag is one flag per device.  Used as `static DevFlag attr_set;  if (!attr_set) { ...;
+// attr_set = true; }` - a race at worst sets the attribute twice.
+struct DevFlag {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<bool> f[MAX_DEV];
+    DevFlag() { for (auto &x : f) x.store(false, std::memory_order_relaxed); }
+    static int dev() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) d = 0;
+        return d;
+    }
+    bool operator!() const { return !f[dev()].load(std::memory_order_acquire); }
+    DevFlag &operator=(bool v) {
+        f[dev()].store(v, std::memory_order_release);
+        return *this;
+    }
+};
 
 // --------------------------------------------------------------------------------------
 // Optional per-launch timing (bench.py's roofline leg): when enabled, every kernel launch

@@ -217,7 +217,7 @@ static int launch_panel(const float *A, int lda, const float *W, const float *bi
 #define SD_PANEL(LN_, ACT_, RES_)                                                                              \
     do {                                                                                                       \
         auto kfn = panel_gemm_kernel<D, LN_, ACT_, RES_>;                                                      \
-        static bool attr_set = false;                                                                          \
+        static DevFlag attr_set;                                                                                 \
         if (lds > 64 * 1024 && !attr_set) {                                                                    \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
@@ -1264,7 +1264,7 @@ static int launch_chain(const Args &g, int d, KA k64, KB k128, KC k256, KD k512,
 #define SD_CHAIN(D_, K_)                                                                                        \
     do {                                                                                                        \
         const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                             \
-        static bool attr_set = false;                                                                           \
+        static DevFlag attr_set;                                                                                  \
         if (lds > 64 * 1024 && !attr_set) {                                                                     \
             (void)hipFuncSetAttribute((const void *)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             attr_set = true;                                                                                    \
@@ -1305,7 +1305,7 @@ static int launch_panel16(const float *A, int lda, const float *W, const float *
     if (da.thresh) {   // training: out = res + dropout(A W^T + bias)
         if (ln_w || act != 0 || !res || N % 4 != 0) return fail(SD_E_BADARG, "sd_op_linear_dropout: needs res, no LayerNorm, no activation, N % 4 == 0");
         auto kfn = panel_gemm16_kernel<D, false, 0, true, true>;
-        static bool attr_set = false;
+        static DevFlag attr_set;
         if (lds > 64 * 1024 && !attr_set) {
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
@@ -1317,7 +1317,7 @@ static int launch_panel16(const float *A, int lda, const float *W, const float *
 #define SD_PANEL16(LN_, ACT_, RES_)                                                                            \
     do {                                                                                                       \
         auto kfn = panel_gemm16_kernel<D, LN_, ACT_, RES_>;                                                    \
-        static bool attr_set = false;                                                                          \
+        static DevFlag attr_set;                                                                                 \
         if (lds > 64 * 1024 && !attr_set) {                                                                    \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
@@ -1361,7 +1361,7 @@ static int launch_panel16_packed(const float *A, int lda, const void *wpk, const
 #define SD_PANEL16P(LN_, ACT_, RES_, DROP_)                                                                    \
     do {                                                                                                       \
         auto kfn = panel_gemm16_kernel<D, LN_, ACT_, RES_, DROP_, true>;                                       \
-        static bool attr_set = false;                                                                          \
+        static DevFlag attr_set;                                                                                 \
         if (lds > 64 * 1024 && !attr_set) {                                                                    \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                   \
@@ -1447,7 +1447,7 @@ static int decoder_layer_f16(const F16LayerArgs &fa, hipStream_t s) {
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((fa.g.a.R + 63) / 64)), block(256);
     const size_t lds = PanelCfg<256>::LDS_BYTES;
-    static bool attr_set = false;
+    static DevFlag attr_set;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)decoder_layer_f16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1484,7 +1484,7 @@ static int attention_f16(const float *qkv, float *out, int B, int T, int d, int 
         SD_CHECK_LAUNCH("attention_f16_head_lv_kernel");
         return 0;
     }
-    static bool attr_set = false;
+    static DevFlag attr_set;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
         (void)hipFuncSetAttribute((const void *)attention_f16_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT16H_LDS);
@@ -1503,7 +1503,7 @@ static int chain_f16_launch(const F16ChainArgs &fa, int kind, hipStream_t s) {
     ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
     dim3 grid((unsigned)((R + 63) / 64)), block(256);
     const size_t lds = PanelCfg<D>::LDS_BYTES;
-    static bool attr_set = false;
+    static DevFlag attr_set;
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute((const void *)chain_f16_kernel<D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)chain_f16_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1528,7 +1528,7 @@ static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s, int d = 256) {
         else SD_LAUNCH((decoder_head_f16_kernel<128, false>), grid, block, PanelCfg<128>::LDS_BYTES, s, fa);
     } else if (d == 512) {
         const size_t lds = PanelCfg<512>::LDS_BYTES;
-        static bool attr_set512 = false;
+        static DevFlag attr_set512;
         if (!attr_set512) {
             (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1538,7 +1538,7 @@ static int decoder_head_f16(const F16HeadArgs &fa, hipStream_t s, int d = 256) {
         else SD_LAUNCH((decoder_head_f16_kernel<512, false>), grid, block, lds, s, fa);
     } else {
         const size_t lds = PanelCfg<256>::LDS_BYTES;
-        static bool attr_set = false;
+        static DevFlag attr_set;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void *)decoder_head_f16_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1573,7 +1573,7 @@ static int decoder_layer(const DecoderLayerArgs &g, int d, hipStream_t s) {
         auto kfn = g.gv ? (g.fo_w ? decoder_layer_kernel<D_, true, true> : decoder_layer_kernel<D_, false, true>)  \
                         : (g.fo_w ? decoder_layer_kernel<D_, true, false> : decoder_layer_kernel<D_, false, false>); \
         const size_t lds = PanelCfg<D_>::LDS_BYTES;                                                              \
-        static bool attr_set = false;                                                                            \
+        static DevFlag attr_set;                                                                                   \
         if (lds > 64 * 1024 && !attr_set) {                                                                      \
             (void)hipFuncSetAttribute((const void *)decoder_layer_kernel<D_, true, true>,                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
@@ -2020,7 +2020,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
     do {                                                                                                         \
         auto kfn = attention_pipe_kernel<HD_>;                                                                   \
         const size_t lds = AttnCfg<HD_>::LDS_BYTES;                                                              \
-        static bool attr_set = false;                                                                            \
+        static DevFlag attr_set;                                                                                   \
         if (lds > 64 * 1024 && !attr_set) {                                                                      \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             attr_set = true;                                                                                     \
@@ -2044,7 +2044,7 @@ static int attention(const float *q, int ldq, const float *k, const float *v, in
         const int s_all = S + (k_extra ? 1 : 0);                                                                 \
         const int rows_cap = std::min((int)AttnCfg<HD_>::KC, ((s_all + 31) / 32) * 32);                           \
         const size_t lds = (size_t)rows_cap * (AttnCfg<HD_>::LDK + AttnCfg<HD_>::LDV) * sizeof(float);           \
-        static bool attr_set[2] = {false, false};                                                                \
+        static DevFlag attr_set[2];                                                                                \
         if (!attr_set[da.thresh ? 1 : 0]) {                                                                      \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                       (int)AttnCfg<HD_>::LDS_BYTES);                                             \
@@ -2250,7 +2250,7 @@ static int fc_out(const float *h, const float *W, const float *b, float *eps, fl
     do {                                                                                                        \
         auto kfn = fc_out_kernel<D_>;                                                                           \
         const size_t lds = (size_t)64 * (D_ + 4) * sizeof(float);                                               \
-        static bool attr_set = false;                                                                           \
+        static DevFlag attr_set;                                                                                  \
         if (lds > 64 * 1024 && !attr_set) {                                                                     \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                    \
@@ -2772,7 +2772,7 @@ static int f16_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, in
 
 // one denoiser step + DDIM update on the fp16x3 kernels (step index i selects the step-token blocks)
 static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
-                             const float *coef, hipStream_t st) {
+                             const float *coef, hipStream_t st, float *eps = nullptr) {
     const int d = w->d, heads = w->heads, L = w->L, Mk = Mc + 1;
     const long R = (long)B * T;
     const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
@@ -2808,6 +2808,7 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
             fa.g.fo_w = w->out_w;
             fa.g.fo_b = w->out_b;
             fa.g.x_io = x;
+            fa.g.eps = eps;
             fa.g.c0 = coef[0]; fa.g.c1 = coef[1]; fa.g.c2 = coef[2]; fa.g.c3 = coef[3];
             fa.next_head = merge && i + 1 < n_steps;
             fa.head = fh;
@@ -2841,7 +2842,23 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
 static bool traj_ok(int d, int heads, int T, int Mk, int J, int L) {
     static const char *env = getenv("SD_SAMPLER_TRAJ");
     if (env && strcmp(env, "0") == 0) return false;
-    return d == 256 && heads == 4 && T > 96 && T <= tj::TMAX && Mk >= 1 && Mk <= 16 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+    return d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 16 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+}
+
+// the instantiation for ceil(T / 16) token tiles; precise = three fp16 products at the Q | K | V site too (sampler mode 3), else two (mode 4)
+typedef void (*TrajStepFn)(tj::StepArgs);
+template <bool PRECISE>
+static TrajStepFn traj_step_fn(int ntt) {
+    switch (ntt) {
+        case 1: return tj::traj_step_kernel<1, PRECISE>;
+        case 2: return tj::traj_step_kernel<2, PRECISE>;
+        case 3: return tj::traj_step_kernel<3, PRECISE>;
+        case 4: return tj::traj_step_kernel<4, PRECISE>;
+        case 5: return tj::traj_step_kernel<5, PRECISE>;
+        case 6: return tj::traj_step_kernel<6, PRECISE>;
+        case 7: return tj::traj_step_kernel<7, PRECISE>;
+        default: return nullptr;
+    }
 }
 
 static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
@@ -2897,12 +2914,13 @@ static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, i
 
 // one denoiser step + DDIM update in ONE launch (step index i selects the step-token blocks)
 static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
-                             const float *coef, hipStream_t st) {
+                             const float *coef, hipStream_t st, bool precise, float *eps = nullptr, int32_t *status = nullptr) {
     const int d = w->d, L = w->L;
     const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
     tj::StepArgs a{};
+    a.status = status;
     a.x = x;
-    a.eps_out = nullptr;
+    a.eps_out = eps;
     a.w_emb = s.wio;
     a.b_emb = w->emb_b;
     a.pe = w->pe;
@@ -2931,13 +2949,17 @@ static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scrat
         q.nln_w = l + 1 < L ? w->layers[l + 1].n1_w : nullptr;
         q.nln_b = l + 1 < L ? w->layers[l + 1].n1_b : nullptr;
     }
+    const int ntt = (T + 15) / 16;
+    const TrajStepFn fn = precise ? traj_step_fn<true>(ntt) : traj_step_fn<false>(ntt);
+    if (!fn) return fail(SD_E_BADARG, "traj_step_kernel: horizon out of range");
     ProfScope prof(SD_KCLASS_TRAJ_STEP, st);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)tj::traj_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
-        attr_set = true;
+    static DevFlag attr_set[2][8];
+    if (!attr_set[precise ? 1 : 0][ntt]) {
+        const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
+        if (e != hipSuccess) return fail((int)e, "traj_step_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        attr_set[precise ? 1 : 0][ntt] = true;
     }
-    SD_LAUNCH(tj::traj_step_kernel, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, st, a);
+    SD_LAUNCH(fn, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, st, a);
     SD_CHECK_LAUNCH("traj_step_kernel");
     return 0;
 }
@@ -3016,26 +3038,36 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
 
 extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
     const int Mk = Mc + 1;
+    if (f16_ok(d, J) && traj_ok(d, heads, T, Mk, J, 1)) return 3;   // (the layer count is checked at the call: <= 8; mode 4 is opt-in)
     if (!(fold_ok(d, heads, T, Mk) && fused_layer_ok(d, heads, T, Mk))) return 0;
     if (!f16_ok(d, J)) return 1;
-    return traj_ok(d, heads, T, Mk, J, 1) ? 3 : 2;   // (the layer count is checked at the call: <= 8)
+    return 2;
 }
 
 extern "C" int sd_ddim_sample(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
                               const float *coef, float *x, float *trace, float *workspace, int B, int T, int Mc,
                               int n_steps, void *stream) {
-    return sd_ddim_sample_ex(w, ctx, step_tokens, coef, x, trace, workspace, B, T, Mc, n_steps, nullptr, -1, stream);
+    return sd_ddim_sample_eps(w, ctx, step_tokens, coef, x, trace, nullptr, workspace, B, T, Mc, n_steps, nullptr, -1, stream);
 }
 
 extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
                                  const float *coef, float *x, float *trace, float *workspace, int B, int T, int Mc,
                                  int n_steps, int32_t *status, int max_mode, void *stream) {
+    return sd_ddim_sample_eps(w, ctx, step_tokens, coef, x, trace, nullptr, workspace, B, T, Mc, n_steps, status, max_mode, stream);
+}
+
+extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
+                                  const float *coef, float *x, float *trace, float *eps_trace, float *workspace, int B, int T, int Mc,
+                                  int n_steps, int32_t *status, int max_mode, void *stream) {
     int rc = check_denoiser(w);
     if (rc) return rc;
     if (!step_tokens || !coef || !x || !workspace || B <= 0 || T <= 0 || Mc < 0 || n_steps <= 0 || (Mc > 0 && !ctx))
         return fail(SD_E_BADARG, "sd_ddim_sample: null pointer or empty shape");
-    if (max_mode < -1 || max_mode > 3) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode must be -1, 0, 1, 2 or 3");
+    if (max_mode < -1 || max_mode > 4) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode must be -1, 0, 1, 2, 3 or 4");
+    // automatic = the highest mode that is valid for ANY weights: 3.  Mode 4's two-product Q | K | V site is opt-in (max_mode = 4):
+    // it is validated up to SD_SHARP_LOGIT_LIMIT and reports through `status` when a logit leaves that range
     if (max_mode < 0) max_mode = 3;
+    if (max_mode == 4 && !status) return fail(SD_E_BADARG, "sd_ddim_sample_ex: max_mode 4 needs a status word (SD_STATUS_SHARP_LOGITS)");
     if (T > w->T_max) return fail(SD_E_TOOBIG, "sd_ddim_sample: horizon exceeds positional table");
     hipStream_t st = (hipStream_t)stream;
     const int d = w->d, R = B * T, L = w->L;
@@ -3044,11 +3076,13 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
     // [Mk][2d] block, Mk = Mc + 1) and of all n_steps step tokens, per layer
     const int Mk = Mc + 1;
     const size_t kvstride = (size_t)B * Mk * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
-    const bool fold = max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && (long)B * Mk * 2 * d < (1L << 30);
+    const bool small = (long)B * Mk * 2 * d < (1L << 30);
+    // the trajectory kernel (modes 3 / 4) takes any horizon <= 100: it needs the folded blocks, not the row-panel kernels' T >= 64
+    const bool traj = max_mode >= 3 && small && f16_ok(d, w->J) && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wf != nullptr && s.wio != nullptr;
+    const bool fold = traj || (max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && small);
     const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
-    const bool f16 = max_mode >= 2 && fold && f16_ok(d, w->J) && s.wf != nullptr;
-    const bool traj = max_mode >= 3 && f16 && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wio != nullptr;
+    const bool f16 = traj || (max_mode >= 2 && fold && f16_ok(d, w->J) && s.wf != nullptr);
     const bool chain16 = max_mode >= 2 && !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
     if (status) {
         if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
@@ -3098,17 +3132,19 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
         SD_CHECK_LAUNCH("kv_place_kernel");
     }
     for (int i = 0; i < n_steps; ++i) {
+        // the noise prediction of this step (the very values the DDIM update consumes), when the caller asked for them
+        float *eps_i = eps_trace ? eps_trace + (size_t)i * R * w->J : nullptr;
         // this step's token row -> row Mc of every trajectory, all layers in one launch
         if (traj) {
-            if ((rc = decoder_step_traj(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st))) return rc;
+            if ((rc = decoder_step_traj(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st, max_mode == 3, eps_i, max_mode == 3 ? nullptr : status))) return rc;
         } else if (f16) {
-            if ((rc = decoder_stack_f16(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st))) return rc;
+            if ((rc = decoder_stack_f16(w, x, s, B, T, Mc, i, n_steps, coef + 4 * i, st, eps_i))) return rc;
         } else if (fold) {
             SD_LAUNCH(fold_place_kernel, dim3(grid_for((long)B * 4 * 2 * d), L), dim3(256), 0, st, s.gvstep + (size_t)i * 4 * 2 * d,
                       s.cstep + (size_t)i * 4, (long)gvsstride, (long)cssstride, s.gv, s.cb, (long)gvstride, (long)cbstride, B, Mc,
                       2 * d);
             SD_CHECK_LAUNCH("fold_place_kernel");
-            rc = decoder_stack(w, x, s, B, T, Mk, [=](int) { return (const float *)nullptr; }, TailArgs{nullptr, x, coef + 4 * i}, st,
+            rc = decoder_stack(w, x, s, B, T, Mk, [=](int) { return (const float *)nullptr; }, TailArgs{eps_i, x, coef + 4 * i}, st,
                                FoldArgs{s.gv, s.cb, gvstride, cbstride});
             if (rc) return rc;
         } else {
@@ -3116,7 +3152,7 @@ extern "C" int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx,
                       s.kv, (long)kvstride, B, Mc, Mk, 2 * d, 1);
             SD_CHECK_LAUNCH("kv_place_kernel");
             const float *kvbase = s.kv;
-            rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{nullptr, x, coef + 4 * i}, st,
+            rc = decoder_stack(w, x, s, B, T, Mk, [=](int l) { return kvbase + l * kvstride; }, TailArgs{eps_i, x, coef + 4 * i}, st,
                                FoldArgs{nullptr, nullptr, 0, 0}, chain16);
             if (rc) return rc;
         }

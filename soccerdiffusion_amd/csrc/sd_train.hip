@@ -1174,7 +1174,7 @@ extern "C" int sd_op_small_k_matmul(const float *A, const float *Bm, float *out,
         return fail(SD_E_BADARG, "sd_op_small_k_matmul: bad argument (K <= 64, N <= 512)");
     const size_t lds = ((size_t)16 * K + (size_t)K * N) * sizeof(float);
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
+        static DevFlag attr_set;       
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)small_k_matmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
@@ -1764,7 +1764,7 @@ extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float 
         // the fp32 kernel was faster there, 60 vs 83 us at B = 256; with two it is 54 vs 62)
         if (hd == 64 && Tq <= 128 && S <= 128 && lds_ok && al16(q) && al16(k) && al16(v) && al16(o) && al16(dO) && al16(dq) && al16(dk) &&
             al16(dv)) {
-            static bool attr_set = false;
+            static DevFlag attr_set;       
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void *)attention_bwd16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS);
                 (void)hipFuncSetAttribute((const void *)attention_bwd16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AB_LDS);
@@ -1780,7 +1780,7 @@ extern "C" int sd_op_attention_bwd_dropout(const float *q, int ldq, const float 
     do {                                                                                                         \
         auto kfn = da.thresh ? attention_bwd_kernel<HD_, true> : attention_bwd_kernel<HD_, false>;               \
         const size_t lds = AttnBwdCfg<HD_>::LDS_BYTES;                                                           \
-        static bool attr_set[2] = {false, false};                                                                \
+        static DevFlag attr_set[2];                                                                                \
         if (lds > 64 * 1024 && !attr_set[da.thresh ? 1 : 0]) {                                                   \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
             attr_set[da.thresh ? 1 : 0] = true;                                                                  \

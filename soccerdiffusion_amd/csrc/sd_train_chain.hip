@@ -515,7 +515,7 @@ size_t chain_lds() {
     do {                                                                                                           \
         auto kfn = KFN;                                                                                            \
         const size_t lds = chain_lds<D_>();                                                                        \
-        static bool attr_set = false;                                                                              \
+        static DevFlag attr_set;                                                                                     \
         if (lds > 64 * 1024 && !attr_set) {                                                                        \
             (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             attr_set = true;                                                                                       \

@@ -31,11 +31,13 @@
 // padded keys are masked, padded queries never leave the workgroup).
 #pragma once
 #include "sd_common.h"
+#include "soccerdiffusion_hip.h"   // SD_STATUS_SHARP_LOGITS, SD_SHARP_LOGIT_LIMIT
 #include <type_traits>
 
 namespace tj {
 
-constexpr int D = 256, HD = 64, NH = 4, NTT = 7, TMAX = 100;
+constexpr int D = 256, HD = 64, NH = 4, TMAX = 100;
+constexpr int NTT_A = 7;                    // token tiles of the Stage-A experiment kernel (T = 97 .. 100)
 constexpr int NTHREADS = 512;
 constexpr int MAX_L = 8;
 constexpr float ACT = 8.0f;                 // scale of LayerNorm outputs, q, k, v, attention / GELU outputs (as sd_f16x3.h)
@@ -57,7 +59,7 @@ constexpr int LDS_STAT = LDS_K + TMAX * VROW;
 constexpr int LDS_BYTES = LDS_STAT + TMAX * 8 * 8;
 static_assert(LDS_SO + TMAX * QROW <= LDS_Q, "Q and O fit the freed half of the panel");
 static_assert(LDS_BYTES <= 163840 && LDS_P + TMAX * PROW <= LDS_STAT, "LDS budget");
-constexpr long HFRAG_FLOATS = 8L * 2 * NTT * 256;   // residual stream of one trajectory in fragment order (Stage-A kernel)
+constexpr long HFRAG_FLOATS = 8L * 2 * NTT_A * 256;   // residual stream of one trajectory in fragment order (Stage-A kernel)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -265,11 +267,11 @@ __global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items
 // row-major [B][T][256] <-> fragment order [B][wave][a][tt][lane][4] (Stage-A kernel and tests): element r of lane 16 g + t
 // is feature 32 w + 16 a + 4 g + r of token 16 tt + t (tokens >= T: zero)
 __global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restrict__ frag, int B, int T) {
-    const long total = (long)B * 8 * 2 * NTT * 64;
+    const long total = (long)B * 8 * 2 * NTT_A * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         long j = i >> 6;
-        const int tt = (int)(j % NTT); j /= NTT;
+        const int tt = (int)(j % NTT_A); j /= NTT_A;
         const int a = (int)(j & 1); j >>= 1;
         const int w = (int)(j & 7);
         const long b = j >> 3;
@@ -280,11 +282,11 @@ __global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restric
     }
 }
 __global__ void from_hfrag_kernel(const float *__restrict__ frag, float *__restrict__ rows, int B, int T) {
-    const long total = (long)B * 8 * 2 * NTT * 64;
+    const long total = (long)B * 8 * 2 * NTT_A * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         long j = i >> 6;
-        const int tt = (int)(j % NTT); j /= NTT;
+        const int tt = (int)(j % NTT_A); j /= NTT_A;
         const int a = (int)(j & 1); j >>= 1;
         const int w = (int)(j & 7);
         const long b = j >> 3;
@@ -310,15 +312,139 @@ struct Ctx {
     // in-row part as the X panel at a smaller row pitch: derived from xa where they are used (one VALU instruction per address)
 };
 
-__device__ __forceinline__ void ctx_init(Ctx &c, char *smem, int T) {
+struct LnAffine { f32x4 w[2], b[2]; };
+__device__ __forceinline__ void ln_affine_load(const Ctx &c, const float *ln_w, const float *ln_b, LnAffine &p) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        p.w[a] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a + 4 * c.g);
+        p.b[a] = *reinterpret_cast<const f32x4 *>(ln_b + 32 * c.w + 16 * a + 4 * c.g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+
+// Short GEMM loops (K = 64 / 96 / 112: the attention and the out-projections) as a software pipeline: load(s) fills ring slot
+// s % DEPTH with the LDS operands of step s and is issued DEPTH - 1 steps before mma(s) consumes them (hipcc places every
+// ds_read right before its first use and waits for it: ~100 cycles of LDS round trip per 48 - 96 cycles of MFMAs).
+template <int NSTEP, int DEPTH, class Load, class Mma>
+__device__ __forceinline__ void ring_pipe(Load load, Mma mma) {
+#pragma unroll
+    for (int s = 0; s < DEPTH - 1; ++s)
+        if (s < NSTEP) load(s);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        if (s + DEPTH - 1 < NSTEP) load(s + DEPTH - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct AK64 { f16x8 a[2][2][2]; };
+__device__ __forceinline__ void load_k64(const Ctx &c, AK64 &f, const f16 *pa0, const f16 *pa1) {
+    const unsigned lo = (unsigned)c.lane * 8;
+    __builtin_amdgcn_sched_barrier(0);   // not earlier than here (32 registers)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            f.a[0][kk][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + (kk * 2 + pl) * 512);
+            f.a[1][kk][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + (kk * 2 + pl) * 512);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct SaW {
+    const f16 *w_in;      // in_proj (768 x 256) planes
+    const float *b_in;    // 768
+    const f16 *w_o;       // out_proj (256 x 256) planes
+    float s_in;           // power-of-two scale of w_in
+    float scale_log2e;    // log2(e) / sqrt(head dim)
+    int *status;          // range-guard word of sd_ddim_sample_ex or NULL: SD_STATUS_SHARP_LOGITS
+};
+
+struct Bias2 { f32x4 v[2]; };
+__device__ __forceinline__ Bias2 bias_load(const Ctx &c, const float *bias) {
+    Bias2 b;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) b.v[a] = *reinterpret_cast<const f32x4 *>(bias + 32 * c.w + 16 * a + 4 * c.g);
+    __builtin_amdgcn_sched_barrier(0);
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one decoder layer on the residual registers (X holds LN1(h) on entry; on exit LN1 of the next layer if nln_w)
+// ---------------------------------------------------------------------------------------------------
+struct LayerW {
+    const float *n2_w, *n2_b, *n3_w, *n3_b;
+    const f16 *w_in, *w_o, *w_1, *w_2;            // fragment-major planes
+    const float *b_in, *b_o, *b_1, *b_2, *b_oc;
+    const float *sc;                              // [0] Wo, [1] W1, [2] W2, [3] in_proj, [4] G, [5] V'
+    const f16 *g16, *v16;                         // folded context blocks of this layer, all trajectories
+    const float *cb;                              // [B][64] score biases
+    const f16 *gstep, *vstep;                     // this layer and step
+    const float *cstep;                           // 4 score biases of the step token
+    const float *nln_w, *nln_b;                   // LayerNorm that follows (next layer's norm1), or NULL
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Stage-A experiment kernel (tools/exp/traj_layer.hip): h' = h + SelfAttention(LN1(h)), h in fragment order
+// ---------------------------------------------------------------------------------------------------
+struct SaArgs {
+    const float *h_in;
+    float *h_out;
+    const float *ln_w, *ln_b;
+    const f16 *w_in;
+    const float *b_in;
+    const f16 *w_o;
+    const float *b_o;
+    float s_in, s_o;
+    float scale_log2e;
+    int T, B;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// One whole denoiser step of the sampler per launch: x -> embedding + positional rows -> L decoder layers -> fc_out -> DDIM update
+// of x in place (reference loop: soccer_diffusion/ml/inference/plot.py:122-131 around model.py:159-179)
+// ---------------------------------------------------------------------------------------------------
+struct StepArgs {
+    float *x;                      // [B][T][J] in / out
+    float *eps_out;                // [B][T][J] or NULL (noise prediction, for tests)
+    const f16 *w_emb;              // [16 n-tiles][1][2][64][8] (K = J padded to 32), scale s_emb
+    const float *b_emb, *pe;       // bias [256], positional table [>= T][256]
+    const float *n1_w, *n1_b;      // layer 0's norm1
+    const f16 *w_out;              // [2 n-tiles][8][2][64][8] (rows >= J zero), scale s_out
+    const float *b_out;            // [J]
+    const float *sc_io;            // [0] s_emb, [1] s_out
+    float c0, c1, c2, c3;          // DDIM coefficients of this step (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev))
+    float scale_log2e;
+    int T, B, J, L, Mk, update_x;
+    int *status;                   // range-guard word (SD_STATUS_SHARP_LOGITS) or NULL
+    LayerW layer[MAX_L];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// The kernel family.  NTT = ceil(T / 16) token tiles (T <= 100: 1 .. 7; tiles 0 .. NTT-2 are full, the last holds tokens
+// 16 (NTT-1) .. T-1 and its other lanes clamp to T-1).  PRECISE: the Q | K | V projection reads both planes of LayerNorm 1 (three
+// products, as every other site) - see sa_block_precise.
+// ---------------------------------------------------------------------------------------------------
+template <int NTT, bool PRECISE>
+struct TJ {
+static constexpr int LAST0 = 16 * (NTT - 1);   // first token of the last tile
+static constexpr int NH0 = (NTT + 1) / 2;       // token tiles of the first half (even waves); the odd waves take NTT - NH0
+static constexpr int NKP = (NTT + 1) / 2;       // key-tile pairs (32 keys) of the P V product
+
+
+static __device__ __forceinline__ void ctx_init(Ctx &c, char *smem, int T) {
     c.smem = smem;
     c.lane = threadIdx.x & 63;
     c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.g = c.lane >> 4;
     c.t = c.lane & 15;
     c.T = T;
-    c.ok6 = 96 + c.t < T;
-    c.tok6 = c.ok6 ? 96 + c.t : T - 1;
+    c.ok6 = LAST0 + c.t < T;
+    c.tok6 = c.ok6 ? LAST0 + c.t : T - 1;
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) {
         const unsigned in_row = (unsigned)(((c.g ^ (c.t & 3)) << 4) + ((m2 ^ (c.t >> 2)) << 6));
@@ -331,7 +457,7 @@ __device__ __forceinline__ void ctx_init(Ctx &c, char *smem, int T) {
 // A copy of the context whose per-lane values the compiler must treat as new: every address derived from them is then
 // computed inside the loop iteration / phase that uses it.  Without this hipcc hoists ~100 loop-invariant LDS addresses out
 // of the head and layer loops, keeps them live across everything and spills as many registers.
-__device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
+static __device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
     // recomputed from the lane number (one laundered register) rather than copied: the 12 per-lane values of the caller's
     // context then need not stay in registers across the phases (~25 VALU instructions per phase entry)
     Ctx d;
@@ -342,8 +468,8 @@ __device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
     d.g = d.lane >> 4;
     d.t = d.lane & 15;
     d.T = c.T;
-    d.ok6 = 96 + d.t < d.T;
-    d.tok6 = d.ok6 ? 96 + d.t : d.T - 1;
+    d.ok6 = LAST0 + d.t < d.T;
+    d.tok6 = d.ok6 ? LAST0 + d.t : d.T - 1;
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) {
         const unsigned in_row = (unsigned)(((d.g ^ (d.t & 3)) << 4) + ((m2 ^ (d.t >> 2)) << 6));
@@ -354,45 +480,45 @@ __device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
     return d;
 }
 
-__device__ __forceinline__ bool tok_ok(const Ctx &c, int tt) { return tt < NTT - 1 || c.ok6; }
-__device__ __forceinline__ int tok_of(const Ctx &c, int tt) { return tt < NTT - 1 ? 16 * tt + c.t : c.tok6; }
+static __device__ __forceinline__ bool tok_ok(const Ctx &c, int tt) { return tt < NTT - 1 || c.ok6; }
+static __device__ __forceinline__ int tok_of(const Ctx &c, int tt) { return tt < NTT - 1 ? 16 * tt + c.t : c.tok6; }
 // reader addresses: chunk (g, plane, k-step) of this lane's token in tile tt
-__device__ __forceinline__ unsigned x_at(const Ctx &c, int tt, int pl, int ks) {
+static __device__ __forceinline__ unsigned x_at(const Ctx &c, int tt, int pl, int ks) {
     const int m2 = pl | ((ks & 1) << 1);
     return (tt < NTT - 1 ? c.xa[m2] + (unsigned)(tt * 16 * XROW) : c.xa6[m2]) + (unsigned)((ks >> 1) * 256);
 }
-__device__ __forceinline__ unsigned q_at(const Ctx &c, int tt, int pl, int kk) {
+static __device__ __forceinline__ unsigned q_at(const Ctx &c, int tt, int pl, int kk) {
     const int m2 = pl | (kk << 1);   // xa = row * 1024 + in_row: the row part shrinks to row * 256
     return tt < NTT - 1 ? c.xa[m2] - (unsigned)(c.t * (XROW - QROW)) + (unsigned)(tt * 16 * QROW) : c.xa6[m2] - (unsigned)(c.tok6 * (XROW - QROW));
 }
-__device__ __forceinline__ unsigned p_at(const Ctx &c, int tt, int pl, int kk) {
+static __device__ __forceinline__ unsigned p_at(const Ctx &c, int tt, int pl, int kk) {
     const int m2 = pl | ((kk & 1) << 1);
     return (tt < NTT - 1 ? c.xa[m2] - (unsigned)(c.t * (XROW - PROW)) + (unsigned)(tt * 16 * PROW) : c.xa6[m2] - (unsigned)(c.tok6 * (XROW - PROW))) +
            (unsigned)((kk >> 1) * 256);
 }
 // one-plane panel of the self-attention block (512-byte rows, chunk = g | ks << 2): the same in-row swizzle as the full panel
-__device__ __forceinline__ unsigned x1_at(const Ctx &c, int tt, int ks) {
+static __device__ __forceinline__ unsigned x1_at(const Ctx &c, int tt, int ks) {
     return (tt < NTT - 1 ? c.xa[ks & 3] - (unsigned)(c.t * (XROW - X1ROW)) + (unsigned)(tt * 16 * X1ROW) : c.xa6[ks & 3] - (unsigned)(c.tok6 * (XROW - X1ROW))) +
            (unsigned)((ks >> 2) * 256);
 }
-__device__ __forceinline__ unsigned x1_off(int tok, int chunk) { return (unsigned)(tok * X1ROW + ((chunk ^ (tok & 15)) << 4)); }
+static __device__ __forceinline__ unsigned x1_off(int tok, int chunk) { return (unsigned)(tok * X1ROW + ((chunk ^ (tok & 15)) << 4)); }
 // generic forms (writers: the chunk's low two bits are not the lane's g).  chunk = gk | plane << 2 | kstep << 3
-__device__ __forceinline__ unsigned x_off(int tok, int chunk) { return (unsigned)(tok * XROW + ((chunk ^ (tok & 15)) << 4)); }
-__device__ __forceinline__ unsigned q_off(int tok, int chunk) { return (unsigned)(tok * QROW + ((chunk ^ (tok & 15)) << 4)); }
-__device__ __forceinline__ unsigned p_off(int tok, int chunk) { return (unsigned)(tok * PROW + ((chunk ^ (tok & 15)) << 4)); }
+static __device__ __forceinline__ unsigned x_off(int tok, int chunk) { return (unsigned)(tok * XROW + ((chunk ^ (tok & 15)) << 4)); }
+static __device__ __forceinline__ unsigned q_off(int tok, int chunk) { return (unsigned)(tok * QROW + ((chunk ^ (tok & 15)) << 4)); }
+static __device__ __forceinline__ unsigned p_off(int tok, int chunk) { return (unsigned)(tok * PROW + ((chunk ^ (tok & 15)) << 4)); }
 
-__device__ __forceinline__ f16x8 lds16(const char *p) { return *reinterpret_cast<const f16x8 *>(p); }
+static __device__ __forceinline__ f16x8 lds16(const char *p) { return *reinterpret_cast<const f16x8 *>(p); }
 
 // H[0][tt], H[1][tt] (features 32 w + 4 g + r and 32 w + 16 + 4 g + r of this lane's token in tile tt) -> X panel, as split planes
 // of value * ACT: slot g of k-step w (kperm), one 16-byte store per plane
-__device__ __forceinline__ void split_store8(char *hi_at, char *lo_at, const f32x4 &v0, const f32x4 &v1) {
+static __device__ __forceinline__ void split_store8(char *hi_at, char *lo_at, const f32x4 &v0, const f32x4 &v1) {
     f16x4 h0, l0, h1, l1;
     split4(v0, h0, l0);
     split4(v1, h1, l1);
     *reinterpret_cast<f16x8 *>(hi_at) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     *reinterpret_cast<f16x8 *>(lo_at) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ void store_x(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
+static __device__ __forceinline__ void store_x(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
     if (!tok_ok(c, tt)) return;
     const int chunk = c.g | (c.w << 3), tok = tok_of(c, tt);
     char *X = c.smem + LDS_X;
@@ -400,7 +526,7 @@ __device__ __forceinline__ void store_x(const Ctx &c, int tt, const f32x4 &v0, c
 }
 
 // the same values as ONE fp16 plane of the one-plane panel (k-step w -> chunk bits 2..4)
-__device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
+static __device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x4 &v0, const f32x4 &v1) {
     if (!tok_ok(c, tt)) return;
     const int chunk = c.g | (c.w << 2), tok = tok_of(c, tt);
     *reinterpret_cast<f16x8 *>(c.smem + LDS_X + x1_off(tok, chunk)) =
@@ -414,26 +540,8 @@ __device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x4 &v0, 
 // a LayerNorm's affine parameters of this lane's features: requested first - their L2 round trip passes under the statistics (a
 // workgroup is alone on its CU) - and, where a request to HBM is also due (the folded keys before LayerNorm 2), BEFORE it: loads
 // return in order, a parameter requested after 16 KB of HBM reads would arrive behind them
-struct LnAffine { f32x4 w[2], b[2]; };
-__device__ __forceinline__ void ln_affine_load(const Ctx &c, const float *ln_w, const float *ln_b, LnAffine &p) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        p.w[a] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a + 4 * c.g);
-        p.b[a] = *reinterpret_cast<const f32x4 *>(ln_b + 32 * c.w + 16 * a + 4 * c.g);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
 template <bool HI_ONLY = false>
-__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff);
-template <bool HI_ONLY = false>
-__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
-    LnAffine aff;
-    ln_affine_load(c0, ln_w, ln_b, aff);
-    layer_norm_to_x<HI_ONLY>(c0, H, aff);
-}
-template <bool HI_ONLY>
-__device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff) {
+static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff) {
     const Ctx c = ctx_local(c0);
     float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
     const f32x4 (&gwv)[2] = aff.w, (&gbv)[2] = aff.b;
@@ -464,7 +572,7 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     // of that region has passed the first one.
     char *scr = c.smem + LDS_P + c.w * 1280 + c.t * 80;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < (NTT > 4 ? 2 : 1); ++j) {
         const int tl = c.g + 4 * j;
         const float *sp = stat + (tl < NTT - 1 ? 16 * tl + c.t : c.tok6) * 16;
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(sp), p1 = *reinterpret_cast<const f32x4 *>(sp + 4);
@@ -477,13 +585,15 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     }
     __builtin_amdgcn_wave_barrier();
     float mean[NTT], rstd[NTT];
-    {
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(scr), v1 = *reinterpret_cast<const f32x4 *>(scr + 16);
-        const f32x4 v2 = *reinterpret_cast<const f32x4 *>(scr + 32), v3 = *reinterpret_cast<const f32x4 *>(scr + 48);
-        mean[0] = v0[0]; rstd[0] = v0[1]; mean[1] = v0[2]; rstd[1] = v0[3];
-        mean[2] = v1[0]; rstd[2] = v1[1]; mean[3] = v1[2]; rstd[3] = v1[3];
-        mean[4] = v2[0]; rstd[4] = v2[1]; mean[5] = v2[2]; rstd[5] = v2[3];
-        mean[6] = v3[0]; rstd[6] = v3[1];
+#pragma unroll
+    for (int i = 0; i < (NTT + 1) / 2; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(scr + 16 * i);
+        mean[2 * i] = v[0];
+        rstd[2 * i] = v[1];
+        if (2 * i + 1 < NTT) {
+            mean[2 * i + 1] = v[2];
+            rstd[2 * i + 1] = v[3];
+        }
     }
     TJ_STAMP(51);
     const f32x4 gw0 = gwv[0] * ACT, gb0 = gbv[0] * ACT, gw1 = gwv[1] * ACT, gb1 = gbv[1] * ACT;
@@ -497,22 +607,11 @@ __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[
     TJ_STAMP(52);
     TJ_SYNC(1);   // X complete
 }
-
-// Short GEMM loops (K = 64 / 96 / 112: the attention and the out-projections) as a software pipeline: load(s) fills ring slot
-// s % DEPTH with the LDS operands of step s and is issued DEPTH - 1 steps before mma(s) consumes them (hipcc places every
-// ds_read right before its first use and waits for it: ~100 cycles of LDS round trip per 48 - 96 cycles of MFMAs).
-template <int NSTEP, int DEPTH, class Load, class Mma>
-__device__ __forceinline__ void ring_pipe(Load load, Mma mma) {
-#pragma unroll
-    for (int s = 0; s < DEPTH - 1; ++s)
-        if (s < NSTEP) load(s);
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-        if (s + DEPTH - 1 < NSTEP) load(s + DEPTH - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(s);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+template <bool HI_ONLY = false>
+static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
+    LnAffine aff;
+    ln_affine_load(c0, ln_w, ln_b, aff);
+    layer_norm_to_x<HI_ONLY>(c0, H, aff);
 }
 
 // K = 256 GEMM against the X panel as ONE software pipeline over 8 k-steps x 7 token tiles: the B fragment of the next tile
@@ -521,7 +620,7 @@ __device__ __forceinline__ void ring_pipe(Load load, Mma mma) {
 // every load right before its use and waits for it).  A0 / A1: the two n-tiles of this wave (fragment streams
 // [ks][plane][lane][8]); body(tt, a0h, a0l, a1h, a1l, bh, bl) issues the MFMAs of token tile tt.
 template <class Body>
-__device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f16 *pa1, Body body) {
+static __device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f16 *pa1, Body body) {
     const char *X = c.smem + LDS_X;
     const unsigned lo = (unsigned)c.lane * 8;
     f16x8 a0[2][2], a1[2][2], b[2][2];   // A: [k-step parity][plane]; B: [stage parity][plane]
@@ -561,9 +660,9 @@ __device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, const f1
 // 5.1e-6 (three products: 4.2e-7; bar 1e-4; dropping the WEIGHTS' lo part instead: 2.8e-5 - tools/exp/precision_sites.sh,
 // DESIGN.md).  Same software pipeline as gemm_pipe; the token half of A1 is a wave-uniform run-time predicate so that
 // the code exists once per parity.
-struct HeadAcc { f32x4 a0[NTT], a1[4]; };
+struct HeadAcc { f32x4 a0[NTT], a1[NH0]; };
 template <bool odd>
-__device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 *pa0, const f16 *pa1) {
+static __device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 *pa0, const f16 *pa1) {
     const char *X = c.smem + LDS_X;
     const unsigned lo = (unsigned)c.lane * 8;
     f16x8 a0[2][2], a1[2][2], b[2];
@@ -591,13 +690,13 @@ __device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 
             acc.a0[tt] = mfma16(a0[ks & 1][1], b[cur], acc.a0[tt]);
             acc.a0[tt] = mfma16(a0[ks & 1][0], b[cur], acc.a0[tt]);
             if constexpr (!odd) {
-                if (tt < 4) {
+                if (tt < NH0) {
                     acc.a1[tt] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt]);
                     acc.a1[tt] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt]);
                 }
-            } else if (tt >= 4) {
-                acc.a1[tt - 4] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt - 4]);
-                acc.a1[tt - 4] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt - 4]);
+            } else if (tt >= NH0) {
+                acc.a1[tt - NH0] = mfma16(a1[ks & 1][1], b[cur], acc.a1[tt - NH0]);
+                acc.a1[tt - NH0] = mfma16(a1[ks & 1][0], b[cur], acc.a1[tt - NH0]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -606,7 +705,7 @@ __device__ __forceinline__ void gemm_head(const Ctx &c, HeadAcc &acc, const f16 
 
 // acc[a][tt] += A_a . X^T, n-tiles 2 w + a of a 256 x 256 matrix in fragment-major planes
 template <int SITE>
-__device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *wmat) {
+static __device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], const f16 *wmat) {
     const f16 *pa = wmat + (long)(2 * c.w) * (8 * 2 * 512);
     gemm_pipe(c, pa, pa + 8 * 2 * 512, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
         mma3<SITE>(acc[0][tt], a0h, a0l, bh, bl);
@@ -615,21 +714,8 @@ __device__ __forceinline__ void gemm_x2(const Ctx &c, f32x4 (&acc)[2][NTT], cons
 }
 
 // the A fragments of a K = 64 GEMM: n-tiles at pa0 / pa1 (streams at the first k-step), [n-tile][k-step][plane]
-struct AK64 { f16x8 a[2][2][2]; };
-__device__ __forceinline__ void load_k64(const Ctx &c, AK64 &f, const f16 *pa0, const f16 *pa1) {
-    const unsigned lo = (unsigned)c.lane * 8;
-    __builtin_amdgcn_sched_barrier(0);   // not earlier than here (32 registers)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            f.a[0][kk][pl] = *reinterpret_cast<const f16x8 *>(pa0 + lo + (kk * 2 + pl) * 512);
-            f.a[1][kk][pl] = *reinterpret_cast<const f16x8 *>(pa1 + lo + (kk * 2 + pl) * 512);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-}
 // acc[a][tt] += A_a . B^T with B rows of 64 features in a Q-layout buffer (K = 64)
-__device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const AK64 &f, const char *Bbuf) {
+static __device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], const AK64 &f, const char *Bbuf) {
     const f16x8 (&a)[2][2][2] = f.a;
     f16x8 b[3][2];
     ring_pipe<2 * NTT, 3>(
@@ -644,13 +730,6 @@ __device__ __forceinline__ void gemm_k64(const Ctx &c, f32x4 (&acc)[2][NTT], con
         });
 }
 
-struct SaW {
-    const f16 *w_in;      // in_proj (768 x 256) planes
-    const float *b_in;    // 768
-    const f16 *w_o;       // out_proj (256 x 256) planes
-    float s_in;           // power-of-two scale of w_in
-    float scale_log2e;    // log2(e) / sqrt(head dim)
-};
 
 // ---------------------------------------------------------------------------------------------------
 // The self-attention block: H (residual accumulators, pre-scaled by ACT * s_o) += sum over heads of Wo[:, head] . O_head^T.
@@ -660,13 +739,13 @@ struct SaW {
 //   phase W:  [out-projection of head h-1 (MFMA)]      ||  [Q | K | V of head h: accumulators -> split planes in LDS (VALU)]
 //   phase X:  [Q | K | V projection of head h+1 (MFMA)] ||  [attention of head h: scores, softmax, P V, O -> LDS (MFMA + VALU)]
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void head_zero(HeadAcc &acc) {
+static __device__ __forceinline__ void head_zero(HeadAcc &acc) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) acc.a0[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc.a1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NH0; ++i) acc.a1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void head_gemm(const Ctx &c0, const SaW &a, int h, HeadAcc &acc) {
+static __device__ __forceinline__ void head_gemm(const Ctx &c0, const SaW &a, int h, HeadAcc &acc) {
     const Ctx c = ctx_local(c0);
     const int w = c.w;
     const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
@@ -678,7 +757,7 @@ __device__ __forceinline__ void head_gemm(const Ctx &c0, const SaW &a, int h, He
     else gemm_head<false>(c, acc, a.w_in + (long)nt0 * (8 * 2 * 512), a.w_in + (long)nt1 * (8 * 2 * 512));
 }
 // accumulators of head h -> Q or K tile and V piece as split planes
-__device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int h, const HeadAcc &acc) {
+static __device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int h, const HeadAcc &acc) {
     const Ctx c = ctx_local(c0);
     const int w = c.w, g = c.g, t = c.t, w3 = w & 3;
     const float c_in = 1.0f / a.s_in;   // accumulator -> ACT * value
@@ -696,9 +775,9 @@ __device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int 
     }
     {   // V piece -> rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r)
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
-        const int tt1 = (w & 1) ? 4 : 0, n1 = (w & 1) ? 3 : 4;
+        const int tt1 = (w & 1) ? NH0 : 0, n1 = (w & 1) ? NTT - NH0 : NH0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NH0; ++i) {
             if (i >= n1) continue;
             const int tok = 16 * (tt1 + i) + t;
             if (tok >= c.T) continue;
@@ -707,14 +786,12 @@ __device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &a, int 
         }
     }
 }
-// attention of query tile w (waves 0..6) of the head whose Q, K, V are in LDS: O -> LDS
-__device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
-    const Ctx c = ctx_local(c0);
+// attention of query tile w (waves 0 .. NTT-1) of the head whose Q, K (att_scores) and V (att_pv) are in LDS: O -> LDS.  Two
+// pieces, so that the precise variant can put a barrier (K's buffer becomes V's) between them.
+// att_scores: S^T = K Q^T, softmax numerators in S (times 2^10), their sum in psum
+static __device__ __forceinline__ void att_scores(const Ctx &c, const SaW &a, const char *Qb, const char *Kb, f32x4 (&S)[NTT], float &psum) {
     const int w = c.w, g = c.g, t = c.t;
-    const char *Qb = c.smem + LDS_SQ, *Kb = c.smem + LDS_Q, *Vb = c.smem + LDS_K;
-    char *Ob = c.smem + LDS_SO;
     // ---- scores S^T[key][query] = K Q^T
-    f32x4 S[NTT];
     {
         f16x8 qf[2][2];
         const int qtok = min(16 * w + t, c.T - 1);
@@ -736,11 +813,19 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
     const float c_s = a.scale_log2e / (ACT * ACT);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (96 + 4 * g + r >= c.T) S[NTT - 1][r] = -INFINITY;
+        if (LAST0 + 4 * g + r >= c.T) S[NTT - 1][r] = -INFINITY;
     f32x4 m4 = S[0];
 #pragma unroll
     for (int kt = 1; kt < NTT; ++kt) m4 = f32x4{fmaxf(m4[0], S[kt][0]), fmaxf(m4[1], S[kt][1]), fmaxf(m4[2], S[kt][2]), fmaxf(m4[3], S[kt][3])};
     const float m = rows4_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+    // The Q | K | V projection read ONE fp16 plane of LayerNorm 1's output: the error that leaves in a logit grows with the logit.  The
+    // path is validated up to |q.k| / sqrt(hd) = SD_SHARP_LOGIT_LIMIT; a larger top logit sets a status bit (never taken on the
+    // validated range: one compare and a scalar branch per query tile) and the host repeats the rollout with three products.
+    if constexpr (!PRECISE) {
+        if (a.status && __builtin_amdgcn_ballot_w64(fabsf(m) * c_s > SD_SHARP_LOGIT_LIMIT * 1.44269504088896340736f) != 0) {
+            if (c.lane == 0) atomicOr(a.status, SD_STATUS_SHARP_LOGITS);
+        }
+    }
     const float mb = m * c_s - 10.0f;   // probabilities carry 2^10 (fp16 lo parts stay normal)
     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -749,16 +834,19 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
         S[kt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
         ps = ps + S[kt];
     }
-    const float psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
-    // ---- O^T = V^T P^T: P^T straight from the score accumulators, V^T through transposing LDS reads
+    psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
+}
+// att_pv: O^T = V^T P^T with P^T straight from the score accumulators, V^T through transposing LDS reads; O / psum -> LDS planes
+static __device__ __forceinline__ void att_pv(const Ctx &c, const f32x4 (&S)[NTT], float psum, const char *Vb, char *Ob) {
+    const int w = c.w, g = c.g, t = c.t;
     f32x4 O[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) O[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q4 = t >> 2, p4 = t & 3;
     // 16 steps (key pair kp, feature tile ft) of three MFMAs; the V^T fragments (four transposing reads) come three steps ahead
-    f16x8 ph[4], pl[4];
+    f16x8 ph[NKP], pl[NKP];
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
         // P fragment of keys 32 kp ..: elements 0..3 = tile 2 kp, 4..7 = tile 2 kp + 1 (beyond the last tile: zero)
         const f32x4 pa4 = S[2 * kp], pb4 = 2 * kp + 1 < NTT ? S[2 * kp + 1 < NTT ? 2 * kp + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
         f16x4 pah, pal, pbh, pbl;
@@ -768,7 +856,7 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
         pl[kp] = __builtin_shufflevector(pal, pbl, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     f16x8 vf[4][2];
-    ring_pipe<16, 4>(
+    ring_pipe<4 * NKP, 4>(
         [&](int s) __attribute__((always_inline)) {
             const int kp = s >> 2, ft = s & 3;
             const int r0 = min(32 * kp + 4 * g + q4, c.T - 1), r1 = min(32 * kp + 16 + 4 * g + q4, c.T - 1);
@@ -792,34 +880,110 @@ __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
         }
     }
 }
+static __device__ __forceinline__ void head_attention(const Ctx &c0, const SaW &a) {
+    const Ctx c = ctx_local(c0);
+    f32x4 S[NTT];
+    float psum;
+    att_scores(c, a, c.smem + LDS_SQ, c.smem + LDS_Q, S, psum);
+    att_pv(c, S, psum, c.smem + LDS_K, c.smem + LDS_SO);
+}
 // out-projection of head h: its weight fragments (32 registers) are requested at the end of the head's phase X - their L2 round
 // trip passes under the barrier and the other wave's job - and consumed in the next phase W
-__device__ __forceinline__ void head_out_load(const Ctx &c, const SaW &a, int h, AK64 &wo) {
+static __device__ __forceinline__ void head_out_load(const Ctx &c, const SaW &a, int h, AK64 &wo) {
     load_k64(c, wo, a.w_o + ((long)(2 * c.w) * 8 + 2 * h) * (2 * 512), a.w_o + ((long)(2 * c.w + 1) * 8 + 2 * h) * (2 * 512));
 }
-__device__ __forceinline__ void head_out_proj(const Ctx &c0, const AK64 &wo, f32x4 (&H)[2][NTT]) {
+static __device__ __forceinline__ void head_out_proj(const Ctx &c0, const AK64 &wo, f32x4 (&H)[2][NTT]) {
     const Ctx c = ctx_local(c0);
     gemm_k64(c, H, wo, c.smem + LDS_SO);
 }
 
 // H = H * f + bias[feature]; the bias is requested (bias_load) before the GEMM whose result it completes
-struct Bias2 { f32x4 v[2]; };
-__device__ __forceinline__ Bias2 bias_load(const Ctx &c, const float *bias) {
-    Bias2 b;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) b.v[a] = *reinterpret_cast<const f32x4 *>(bias + 32 * c.w + 16 * a + 4 * c.g);
-    __builtin_amdgcn_sched_barrier(0);
-    return b;
-}
-__device__ __forceinline__ void unscale_h(f32x4 (&H)[2][NTT], float f, const Bias2 &b) {
+static __device__ __forceinline__ void unscale_h(f32x4 (&H)[2][NTT], float f, const Bias2 &b) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + b.v[a];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PRECISE self-attention block: three fp16 products at the Q | K | V projection too (22-bit operands at every site: the result does
+// not depend on how sharp the attention is - tests/test_gpu_denoiser.py::test_mode3_noise_prediction_*).  LayerNorm 1's output keeps
+// both planes, i.e. the whole X panel, which leaves TWO buffers for the four images of a head: Q, later O, in LDS_Q; K, later V, in
+// LDS_K.  Five barriers per head, every wave in the same phase (the fast variant's two-barrier, complementary-job structure needs
+// the 51 KB that the second plane occupies).
+// ---------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void sa_head_precise(const Ctx &c0, const SaW &a, int h, f32x4 (&H)[2][NTT]) {
+    const Ctx c = ctx_local(c0);
+    char *Qb = c.smem + LDS_Q, *Kb = c.smem + LDS_K;
+    const int w = c.w, g = c.g, t = c.t;
+    HeadAcc acc;
+    head_zero(acc);
+    {
+        const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
+        const int nt1 = 32 + 4 * h + (w >> 1);                   // V tile, token half w & 1
+        const f16 *pa0 = a.w_in + (long)nt0 * (8 * 2 * 512), *pa1 = a.w_in + (long)nt1 * (8 * 2 * 512);
+        auto run = [&](auto odd_c) __attribute__((always_inline)) {
+            constexpr bool OD = decltype(odd_c)::value;
+            gemm_pipe(c, pa0, pa1, [&](int tt, f16x8 a0h, f16x8 a0l, f16x8 a1h, f16x8 a1l, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
+                mma3<S_QKV>(acc.a0[tt], a0h, a0l, bh, bl);
+                if constexpr (!OD) {
+                    if (tt < NH0) mma3<S_QKV>(acc.a1[tt < NH0 ? tt : 0], a1h, a1l, bh, bl);
+                } else {
+                    if (tt >= NH0) mma3<S_QKV>(acc.a1[tt >= NH0 ? tt - NH0 : 0], a1h, a1l, bh, bl);
+                }
+            });
+        };
+        if (w & 1) run(std::true_type{});
+        else run(std::false_type{});
+    }
+    const float c_in = 1.0f / a.s_in;   // accumulator -> ACT * value
+    TJ_SYNC(2);            // B1: the previous head's readers of Q / O and K / V are done
+    {   // Q or K tile -> LDS planes (features 16 (w & 3) + 4 g + r of the head, natural order on both operands of the scores)
+        const int w3 = w & 3;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + (w < 4 ? 0 : D) + HD * h + 16 * w3 + 4 * g) * ACT;
+        char *dst = w < 4 ? Qb : Kb;
+        const int chunk = (2 * (w3 & 1) + (g >> 1)) | ((w3 >> 1) << 3);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            if (!tok_ok(c, tt)) continue;
+            const int tok = tok_of(c, tt);
+            split_store(dst + q_off(tok, chunk) + 8 * (g & 1), dst + q_off(tok, chunk | 4) + 8 * (g & 1), acc.a0[tt] * c_in + bv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    TJ_SYNC(2);            // B2: Q, K complete
+    f32x4 S[NTT];
+    float psum = 1.f;
+    if (w < NTT) att_scores(ctx_local(c0), a, Qb, Kb, S, psum);
+    TJ_SYNC(3);            // B3: K is dead
+    {   // V piece -> rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r) over K
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
+        const int tt1 = (w & 1) ? NH0 : 0, n1 = (w & 1) ? NTT - NH0 : NH0;
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            if (i >= n1) continue;
+            const int tok = 16 * (tt1 + i) + t;
+            if (tok >= c.T) continue;
+            char *at = Kb + tok * VROW + 2 * (16 * (w >> 1) + 4 * g);
+            split_store(at, at + 128, acc.a1[i] * c_in + bv);
+        }
+    }
+    TJ_SYNC(3);            // B4: V complete (every wave has read its Q fragments: O may overwrite Q)
+    AK64 wo;
+    if (w < NTT) att_pv(ctx_local(c0), S, psum, Kb, Qb);
+    // the out-projection's weight fragments: their L2 round trip passes under the barrier
+    head_out_load(c, a, h, wo);
+    TJ_SYNC(3);            // B5: O complete
+    gemm_k64(ctx_local(c0), H, wo, Qb);
+}
+static __device__ __forceinline__ void sa_block_precise(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT], const float *b_o, Bias2 &bo) {
+    bo = bias_load(c, b_o);
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) sa_head_precise(c, a, h, H);
+}
+
 // X (one plane) holds LayerNorm 1's output on entry; b_o: the out-projection bias, requested before the last head's projection
-__device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT], const float *b_o, Bias2 &bo) {
+static __device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT], const float *b_o, Bias2 &bo) {
     const bool first = c.w < 4;   // the quartet that runs the MFMA job of a phase first
     HeadAcc acc;
     AK64 wo;
@@ -852,7 +1016,7 @@ __device__ __forceinline__ void sa_block(const Ctx &c, const SaW &a, f32x4 (&H)[
     head_out_proj(c, wo, H);
 }
 
-__device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
+static __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -860,30 +1024,17 @@ __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// one decoder layer on the residual registers (X holds LN1(h) on entry; on exit LN1 of the next layer if nln_w)
-// ---------------------------------------------------------------------------------------------------
-struct LayerW {
-    const float *n2_w, *n2_b, *n3_w, *n3_b;
-    const f16 *w_in, *w_o, *w_1, *w_2;            // fragment-major planes
-    const float *b_in, *b_o, *b_1, *b_2, *b_oc;
-    const float *sc;                              // [0] Wo, [1] W1, [2] W2, [3] in_proj, [4] G, [5] V'
-    const f16 *g16, *v16;                         // folded context blocks of this layer, all trajectories
-    const float *cb;                              // [B][64] score biases
-    const f16 *gstep, *vstep;                     // this layer and step
-    const float *cstep;                           // 4 score biases of the step token
-    const float *nln_w, *nln_b;                   // LayerNorm that follows (next layer's norm1), or NULL
-};
 
-__device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e) {
+static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e, int *status) {
     // ---- self-attention block: h += Wo . SA(LN1(h)) + bo
     {
         const Ctx &c = c0;
         const float s_o = L.sc[0], up = ACT * s_o;
         scale_h(H, up);
         Bias2 bo;
-        const SaW sw{L.w_in, L.b_in, L.w_o, L.sc[3], scale_log2e};
-        sa_block(c, sw, H, L.b_o, bo);
+        const SaW sw{L.w_in, L.b_in, L.w_o, L.sc[3], scale_log2e, status};
+        if constexpr (PRECISE) sa_block_precise(c, sw, H, L.b_o, bo);
+        else sa_block(c, sw, H, L.b_o, bo);
         unscale_h(H, 1.0f / up, bo);
     }
     TJ_STAMP(31);
@@ -911,12 +1062,12 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         const Ctx c = ctx_local(c0);
         const int hh = c.w >> 1, Mc = Mk - 1;
         const bool odd = c.w & 1;
-        const int tt1 = odd ? 4 : 0, n1 = odd ? 3 : 4;
+        const int tt1 = odd ? NH0 : 0, n1 = odd ? NTT - NH0 : NH0;
         char *Pb = c.smem + LDS_P;
         const char *X = c.smem + LDS_X;
-        f32x4 S[4];
+        f32x4 S[NH0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NH0; ++i) S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // The score biases, the step token's value columns and the folded values of this trajectory (48 registers, HBM) are requested before
         // the score GEMM: an HBM round trip under load is longer than the softmax, and a load consumed before an older one has returned
         // waits for that one too (loads return in order).
@@ -940,14 +1091,15 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         // numbers are compile-time
         auto scores = [&](auto odd_c) __attribute__((always_inline)) {
             constexpr bool OD = decltype(odd_c)::value;
-            constexpr int N1 = OD ? 3 : 4, T1 = OD ? 4 : 0;
+            constexpr int N1 = OD ? NTT - NH0 : NH0, T1 = OD ? NH0 : 0;
+            constexpr int N1D = N1 > 0 ? N1 : 1;   // (one token tile: the odd waves have none)
             f16x8 xb[3][2];
             ring_pipe<8 * N1, 3>(
                 [&](int s) __attribute__((always_inline)) {
-                    xb[s % 3][0] = lds16(X + x_at(c, T1 + s % N1, 0, s / N1));
-                    xb[s % 3][1] = lds16(X + x_at(c, T1 + s % N1, 1, s / N1));
+                    xb[s % 3][0] = lds16(X + x_at(c, T1 + s % N1D, 0, s / N1D));
+                    xb[s % 3][1] = lds16(X + x_at(c, T1 + s % N1D, 1, s / N1D));
                 },
-                [&](int s) __attribute__((always_inline)) { mma3<S_XSC>(S[s % N1], gfr[s / N1][0], gfr[s / N1][1], xb[s % 3][0], xb[s % 3][1]); });
+                [&](int s) __attribute__((always_inline)) { mma3<S_XSC>(S[s % N1D], gfr[s / N1D][0], gfr[s / N1D][1], xb[s % 3][0], xb[s % 3][1]); });
         };
         if (odd) scores(std::true_type{});
         else scores(std::false_type{});
@@ -962,7 +1114,7 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
             if (4 * c.g + r == Mc) cbv[r] = cs;
         TJ_SYNC(4);   // the previous readers of Q / K (out-projection, PV) are done: P may be written
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NH0; ++i) {
             if (i >= n1) continue;
             f32x4 v = S[i] * c_g + cbv;
 #pragma unroll
@@ -1043,27 +1195,12 @@ __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f3
         unscale_h(H, 1.0f / up, b2);
     }
     TJ_STAMP(38);
-    if (L.nln_w) layer_norm_to_x<true>(c0, H, L.nln_w, L.nln_b);
+    if (L.nln_w) layer_norm_to_x<!PRECISE>(c0, H, L.nln_w, L.nln_b);
     TJ_STAMP(39);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Stage-A experiment kernel (tools/exp/traj_layer.hip): h' = h + SelfAttention(LN1(h)), h in fragment order
-// ---------------------------------------------------------------------------------------------------
-struct SaArgs {
-    const float *h_in;
-    float *h_out;
-    const float *ln_w, *ln_b;
-    const f16 *w_in;
-    const float *b_in;
-    const f16 *w_o;
-    const float *b_o;
-    float s_in, s_o;
-    float scale_log2e;
-    int T, B;
-};
 
-__global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
+static __device__ __forceinline__ void sa_body(const SaArgs &a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx c;
     ctx_init(c, smem, a.T);
@@ -1080,7 +1217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
     const float up = ACT * a.s_o;
     scale_h(H, up);
     TJ_STAMP(2);
-    const SaW sw{a.w_in, a.b_in, a.w_o, a.s_in, a.scale_log2e};
+    const SaW sw{a.w_in, a.b_in, a.w_o, a.s_in, a.scale_log2e, nullptr};
     Bias2 bo;
     sa_block(c, sw, H, a.b_o, bo);
     TJ_STAMP(31);
@@ -1093,26 +1230,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
     TJ_STAMP(32);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// One whole denoiser step of the sampler per launch: x -> embedding + positional rows -> L decoder layers -> fc_out -> DDIM update
-// of x in place (reference loop: soccer_diffusion/ml/inference/plot.py:122-131 around model.py:159-179)
-// ---------------------------------------------------------------------------------------------------
-struct StepArgs {
-    float *x;                      // [B][T][J] in / out
-    float *eps_out;                // [B][T][J] or NULL (noise prediction, for tests)
-    const f16 *w_emb;              // [16 n-tiles][1][2][64][8] (K = J padded to 32), scale s_emb
-    const float *b_emb, *pe;       // bias [256], positional table [>= T][256]
-    const float *n1_w, *n1_b;      // layer 0's norm1
-    const f16 *w_out;              // [2 n-tiles][8][2][64][8] (rows >= J zero), scale s_out
-    const float *b_out;            // [J]
-    const float *sc_io;            // [0] s_emb, [1] s_out
-    float c0, c1, c2, c3;          // DDIM coefficients of this step (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev))
-    float scale_log2e;
-    int T, B, J, L, Mk, update_x;
-    LayerW layer[MAX_L];
-};
-
-__global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
+static __device__ __forceinline__ void step_body(const StepArgs &a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx c;
     ctx_init(c, smem, a.T);
@@ -1172,10 +1290,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
         }
     }
     TJ_STAMP(1);
-    layer_norm_to_x<true>(c, H, a.n1_w, a.n1_b);
+    layer_norm_to_x<!PRECISE>(c, H, a.n1_w, a.n1_b);
     TJ_STAMP(2);
 #pragma unroll 1
-    for (int l = 0; l < a.L; ++l) decoder_layer(c, a.layer[l], H, traj, a.Mk, a.scale_log2e);
+    for (int l = 0; l < a.L; ++l) decoder_layer(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status);
     // ---- fc_out + DDIM: eps^T = Wout . h^T + b.  h has no a-priori bound: one power-of-two scale per token
     {
         float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
@@ -1254,5 +1372,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) {
     }
     TJ_STAMP(40);
 }
+};   // struct TJ
+
+__global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) { TJ<NTT_A, false>::sa_body(a); }
+
+// sampler mode 3: NTT token tiles; PRECISE = three fp16 products at the Q | K | V site too
+template <int NTT, bool PRECISE>
+__global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) { TJ<NTT, PRECISE>::step_body(a); }
+
 
 }   // namespace tj

@@ -183,12 +183,13 @@ class End2EndDiffusionTransformer(nn.Module):
         if use_graph and not return_trace:
             B, T, _ = x_T.shape
             Mc = 0 if ctx is None else ctx.shape[1]
+            cap = getattr(packed, "sampler_cap", 4)   # as ops.ddim_sample_guarded: mode 4 until its guard tripped on these weights
             key = (B, T, Mc, num_inference_steps, x_T.device, self.diffusion_action_generator._signature(),
-                   self.step_encoding.token._version)
+                   self.step_encoding.token._version, cap)
             cache = self.__dict__.setdefault("_graphs", {})
             if key not in cache:
                 cache.clear()  # one shape at a time: a graph pins its workspace
-                cache[key] = ops.GraphedSampler(packed, B, T, Mc, self.step_encoding.table(ts, x_T.device), coef)
+                cache[key] = ops.GraphedSampler(packed, B, T, Mc, self.step_encoding.table(ts, x_T.device), coef, max_mode=cap)
             out = cache[key](ctx, x_T)
             if int(cache[key].status.item()) == 0:
                 return out

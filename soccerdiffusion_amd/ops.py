@@ -297,6 +297,7 @@ def ddim_step(eps: Tensor, x: Tensor, coef4) -> Tensor:
 
 
 STATUS_NONFINITE = 1  # SD_STATUS_NONFINITE
+STATUS_SHARP_LOGITS = 2  # SD_STATUS_SHARP_LOGITS (sampler mode 3: a self-attention logit beyond the validated range)
 
 
 class GraphedSampler:
@@ -349,9 +350,12 @@ class GraphedSampler:
 
 
 def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
-                trace: bool = False, inplace: bool = False, status: Optional[Tensor] = None, max_mode: int = -1):
+                trace: bool = False, inplace: bool = False, status: Optional[Tensor] = None, max_mode: int = -1,
+                eps_trace: bool = False):
     """The reference's sampling loop (ml/inference/plot.py:122-131, ml/training/distill.py:179-189)
-    as ONE native call.  Returns the sample, or (sample, per-step trace) when ``trace``.
+    as ONE native call.  Returns the sample, or (sample, per-step trace) when ``trace``; with ``eps_trace`` the
+    noise prediction of every step (n_steps, B, T, J) - the value of ``forward_with_context`` inside the loop - is
+    appended to the returned tuple.
     ``status`` (int32 tensor of one element on the device) receives the range-guard word of
     ``sd_ddim_sample_ex`` - not read here, so the call stays asynchronous; ``max_mode`` caps the kernel selection
     (see ``ddim_sample_guarded``)."""
@@ -372,25 +376,39 @@ def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coe
         _req(status, "status", torch.int32)
     x = x_T if inplace else x_T.clone()
     tr = torch.empty(n_steps, B, T, J, dtype=torch.float32, device=x.device) if trace else None
+    et = torch.empty(n_steps, B, T, J, dtype=torch.float32, device=x.device) if eps_trace else None
     ws = workspace(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, n_steps), x.device)
-    check(lib.sd_ddim_sample_ex(C.byref(packed.struct), _ptr(ctx), step_tokens.data_ptr(),
-                                coef.ctypes.data_as(_lib.c_float_p), x.data_ptr(), _ptr(tr), ws.data_ptr(),
-                                B, T, Mc, n_steps, _ptr(status), int(max_mode), _stream()), "sd_ddim_sample_ex")
-    return (x, tr) if trace else x
+    check(lib.sd_ddim_sample_eps(C.byref(packed.struct), _ptr(ctx), step_tokens.data_ptr(),
+                                 coef.ctypes.data_as(_lib.c_float_p), x.data_ptr(), _ptr(tr), _ptr(et), ws.data_ptr(),
+                                 B, T, Mc, n_steps, _ptr(status), int(max_mode), _stream()), "sd_ddim_sample_eps")
+    out = (x,) + ((tr,) if trace else ()) + ((et,) if eps_trace else ())
+    return out if len(out) > 1 else x
 
 
 def ddim_sample_guarded(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
                         trace: bool = False):
     """``ddim_sample`` with the range guard read back (one host synchronisation): when the split-fp16 kernels of
-    sampler mode 2 were driven out of their operand range (|8 v| >= 65520 for a LayerNorm / attention / GELU output -
+    sampler modes 2 .. 4 were driven out of their operand range (|8 v| >= 65520 for a LayerNorm / attention / GELU output -
     e.g. a checkpoint with LayerNorm weights in the thousands), the rollout is repeated on the exact-fp32 MFMA kernels
-    (``max_mode`` 1), which have no such limit.  Raises if that result is not finite either (non-finite inputs)."""
+    (``max_mode`` 1), which have no such limit.  Raises if that result is not finite either (non-finite inputs).
+    Mode 4's own guard (SD_STATUS_SHARP_LOGITS: a self-attention logit beyond the range its two-product Q | K | V site is
+    validated on) repeats the rollout on mode 3 and pins ``packed.sampler_cap`` there."""
     import warnings
 
     status = torch.zeros(1, dtype=torch.int32, device=x_T.device)
-    out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status)
-    if int(status.item()) == 0:
+    cap = getattr(packed, "sampler_cap", 4)   # mode 4 (opt-in, guarded by the status word) until these weights tripped its guard
+    out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=cap)
+    word = int(status.item())
+    if word == 0:
         return out
+    if word == STATUS_SHARP_LOGITS:
+        # sampler mode 4 met a self-attention logit beyond the range its two-product Q | K | V projection is validated on
+        # (SD_SHARP_LOGIT_LIMIT): the same rollout with three fp16 products at every site (mode 3).  Sharpness is a property
+        # of the checkpoint, so later calls with these weights start there.
+        packed.sampler_cap = 3
+        out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=3)
+        if int(status.item()) == 0:
+            return out
     mode = _lib.load().sd_sampler_mode(packed.d, packed.heads, x_T.shape[1], 0 if ctx is None else ctx.shape[1], packed.J)
     if mode < 2 and _chain16_possible(packed):
         mode = 2   # the unfused row chains run on the split-fp16 pipe as well

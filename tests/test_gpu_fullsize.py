@@ -30,7 +30,7 @@ def _setup(ops, sd, n_steps, d=D):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("mode", [3, 2])
+@pytest.mark.parametrize("mode", [4, 3, 2])
 def test_b4096_trajectories_match_oracle_and_small_batch(ops, mode):
     """The bench shape itself: 6 400 panels through the XCD relabelling, the 7-GB workspace carve and the fold gate.
     Trajectory i of the 4096-batch must equal (a) the fp32 CPU oracle run on that trajectory alone - after EVERY
@@ -41,7 +41,7 @@ def test_b4096_trajectories_match_oracle_and_small_batch(ops, mode):
     from soccerdiffusion_amd import _lib
 
     B = 4096
-    assert _lib.load().sd_sampler_mode(D, 4, T, MC, J) == 3   # mode 3 = one workgroup per trajectory (4096 workgroups); 2 = 6 400 panels
+    assert _lib.load().sd_sampler_mode(D, 4, T, MC, J) == 3   # modes 3 / 4 = one workgroup per trajectory (4096 workgroups); 2 = 6 400 panels
     sd = ref.synthetic_state_dict(D, J, L, seed=7)
     acp, ts, toks, coef = _setup(ops, sd, N)
     x_T = torch.randn(B, T, J, generator=torch.Generator().manual_seed(1234))
@@ -58,7 +58,7 @@ def test_b4096_trajectories_match_oracle_and_small_batch(ops, mode):
     want = ddim_ref.sample(lambda x, t: ref.forward_with_context(sd, [cs], x, torch.full((n,), t, dtype=torch.int64)), xs, N, acp)[-1]
     errs = [rel_err(got[b], want[i]) for i, b in enumerate(picks)]
     assert all(e < 1e-4 for e in errs), errs
-    small = ops.ddim_sample(packed, cs.cuda(), toks, coef, xs.cuda(), max_mode=mode)
+    small = ops.ddim_sample(packed, cs.cuda(), toks, coef, xs.cuda(), max_mode=mode, status=status)
     inv = [rel_err(got[b], small[i]) for i, b in enumerate(picks)]
     assert all(e < 1e-5 for e in inv), inv   # the same kernels on the same trajectory: batch-size independent
     # nothing else in the batch is degenerate: per-trajectory norms are in a sane band

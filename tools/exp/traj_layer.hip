@@ -5,6 +5,11 @@
 // Prints (a) traj_sa_kernel: h + SelfAttention(LN1(h)) alone (Stage A), (b) traj_step_kernel: one whole denoiser step
 // (embedding, L layers with folded cross-attention and FFN, fc_out, DDIM update).  -DTJ_STAMPS adds the phase profile.
 #include "sd_traj.h"
+// -DTL_PRECISE=1: the three-product variant of the step kernel (sa_block_precise)
+#ifndef TL_PRECISE
+#define TL_PRECISE 0
+#endif
+#define TL_STEP_KERNEL tj::traj_step_kernel<7, (TL_PRECISE != 0)>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -137,7 +142,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(tj::g_tj_stamps), &d_st, sizeof(d_st)));
 #endif
     CK(hipFuncSetAttribute((const void *)tj::traj_sa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES));
-    CK(hipFuncSetAttribute((const void *)tj::traj_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *)(TL_STEP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -246,7 +251,7 @@ int main(int argc, char **argv) {
             w.nln_w = l + 1 < L ? dev(hl[l + 1].n1w) : nullptr;
             w.nln_b = l + 1 < L ? dev(hl[l + 1].n1b) : nullptr;
         }
-        hipLaunchKernelGGL(tj::traj_step_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
         const int nc = ncheck < B ? ncheck : B;
@@ -321,7 +326,7 @@ int main(int argc, char **argv) {
         {
             a.update_x = 0;
             CK(hipMemset(d_st, 0, n_st * 8));
-            hipLaunchKernelGGL(tj::traj_step_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+            hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
             CK(hipDeviceSynchronize());
             std::vector<unsigned long long> st(n_st);
             CK(hipMemcpy(st.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
@@ -445,9 +450,9 @@ int main(int argc, char **argv) {
 #endif
         a.update_x = 0;   // timing: x stays put (the same work; only the final store differs)
         a.eps_out = nullptr;
-        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(tj::traj_step_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
         CK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(tj::traj_step_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
