@@ -64,14 +64,14 @@ def executed_flops_per_traj():
             "rollout": N_DDIM * (layer_chain + head + attn) + once}
 
 
-def traj_step_flops_per_traj_step():
-    """Sampler mode 3 (csrc/sd_traj.h): one launch per DDIM step owns everything of SURVEY 8(d)'s F_step except the memory K/V
-    projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product (two at the Q | K | V
-    projection), on 7 token tiles of 16 (T = 100 padded to 112), the cross-attention in its folded form."""
+def traj_step_flops_per_traj_step(mode: int = 4):
+    """Sampler modes 3 / 4 (csrc/sd_traj.h): one launch per DDIM step owns everything of SURVEY 8(d)'s F_step except the memory
+    K/V projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product - in mode 4 two at the
+    Q | K | V projection - on 7 token tiles of 16 (T = 100 padded to 112), the cross-attention in its folded form."""
     f = flops_per_traj_step()
     qkv = 4 * 84 * 8                                                            # products of 16x16x32 tiles: Q | K | V projection, per layer
     rest = 4 * (49 * 2 + 28 * 4 + 112 * 2) + 28 * 8 + 112 * 3 + 2 * 112 * 8    # scores, PV, out-projection; folded cross-attention; W1, W2
-    mfma = L * (2 * qkv + 3 * rest) + 3 * (16 * 7 + 14 * 8)                     # Q | K | V reads one activation plane; + embedding + fc_out
+    mfma = L * ((2 if mode == 4 else 3) * qkv + 3 * rest) + 3 * (16 * 7 + 14 * 8)   # mode 4: Q | K | V reads one activation plane; + embedding + fc_out
     return {"algorithmic": f["total"] - f["kv"], "executed": mfma * 16384.0, "mfma_instructions": mfma}
 
 
@@ -421,6 +421,10 @@ def main():
     ap.add_argument("--mode", choices=("sample", "train"), default="sample")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU per step (default 4096 sample / 256 train)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference: 0.1)")
+    ap.add_argument("--sampler-mode", type=int, choices=(0, 1, 2, 3, 4), default=4,
+                    help="sample mode: cap of sd_ddim_sample_ex's kernel selection.  4 (default) = what End2EndDiffusionTransformer.sample runs: "
+                         "the trajectory kernel with the two-product Q|K|V site, its SD_STATUS_SHARP_LOGITS guard read after the timed region; "
+                         "3 = three fp16 products at every site (valid for any weights)")
     ap.add_argument("--no-graph", action="store_true", help="train mode: issue the step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -542,9 +546,13 @@ def run_sample(args, rank, world, dev, dist):
     x = torch.empty_like(x_T)
     guard = torch.zeros(1, dtype=torch.int32, device=dev)   # range-guard word of sd_ddim_sample_ex, read after the timed region
 
-    def rollout():
+    # the kernels this call runs: sd_sampler_mode (3 where the trajectory kernel applies) capped by --sampler-mode; 4 is opt-in
+    auto_mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
+    mode = args.sampler_mode if (auto_mode == 3 and args.sampler_mode >= 3) else min(auto_mode, args.sampler_mode)
+
+    def rollout(m=mode):
         x.copy_(x_T)
-        ops.ddim_sample(packed, ctx, toks, coef, x, inplace=True, status=guard)
+        ops.ddim_sample(packed, ctx, toks, coef, x, inplace=True, status=guard, max_mode=m)
 
     for _ in range(warmup):
         rollout()
@@ -569,9 +577,8 @@ def run_sample(args, rank, world, dev, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(x).all(), "sampler produced non-finite values"
-    assert int(guard.item()) == 0, "sampler range guard tripped: non-finite sample"
+    assert int(guard.item()) == 0, "sampler range guard tripped (non-finite sample, or mode 4 outside its validated logit range)"
 
-    mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
     roofline = None
     if timing:
         n = len(_lib.KERNEL_CLASSES)
@@ -584,7 +591,7 @@ def run_sample(args, rank, world, dev, dist):
         return
     extras = {}
     if world == 1 and not args.no_extras:
-        extras = sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev)
+        extras = sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode, guard)
     value = world * B * steps / elapsed
     line = {
         "metric": "denoised joint-trajectories/s (50-step DDIM, H=100, J=20)",
@@ -597,16 +604,15 @@ def run_sample(args, rank, world, dev, dist):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if mode < 2 else
-                 "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate: 22-bit operands; "
-                 "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
+        "dtype": DTYPE_BY_MODE[mode],
         "data": "synthetic",
         "config": {
             "workload": "BASELINE.json configs[2]: 50-step DDIM sampling, B=%d parallel rollouts per GPU, "
                         "transformer denoiser d=256 L=4 heads=4, horizon T=100, J=20, memory M=11 "
                         "(10 context tokens + step token); one step = one full rollout; the timed region issues the rollout's "
                         "launches eagerly with a HIP-event pair around each (the roofline leg); the hipGraph replay of the same "
-                        "rollout is timed right after it (`hipgraph`)" % B,
+                        "rollout is timed right after it (`hipgraph`).  Kernel selection: sampler mode %d (--sampler-mode; "
+                        "`other_traj_mode` holds the same rollout in the other trajectory-kernel mode)" % (B, mode),
             "batch_per_gpu": B, "ddim_steps": N_DDIM, "horizon": T, "joints": J, "hidden_dim": D,
             "decoder_layers": L, "memory_tokens": M, "parallelism": f"dp{world} (independent rollouts, no collective)",
         },
@@ -617,12 +623,28 @@ def run_sample(args, rank, world, dev, dist):
     print(json.dumps(line), flush=True)
 
 
+DTYPE_BY_MODE = {
+    0: "f32",
+    1: "f32",
+    2: "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product at every site, fp32 accumulate: 22-bit operands; "
+       "50-step rollout error vs the fp64 oracle 3.6e-7, the fp32 CPU oracle's own 3.6e-7)",
+    3: "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product at every site, fp32 accumulate: 22-bit operands; single "
+       "noise prediction vs the fp64 oracle 8e-7 on these weights and 2e-6 on weights stressed to |logit| ~ 60 "
+       "(tests/test_gpu_denoiser.py::test_mode3_noise_prediction_single_step); valid for any weights)",
+    4: "f32 (operands split into fp16 hi+lo, fp32 accumulate; 3 fp16 MFMAs per product EXCEPT the self-attention's Q|K|V projection, "
+       "which reads ONE fp16 plane of LayerNorm 1's output: 2 MFMAs per product, 11-bit activation operand at that site.  Error of a "
+       "noise prediction vs the fp64 oracle ~ 1e-5 x max|attention logit|: 1.7e-5 on these weights (max |logit| 1.6; 50-step rollout "
+       "5.1e-6), 1e-4 at |logit| ~ 9.  The kernel sets SD_STATUS_SHARP_LOGITS beyond |logit| 5 - checked == 0 after this timed region - "
+       "and ops.ddim_sample_guarded then repeats on mode 3; `other_traj_mode` is mode 3's rate for the same rollout)",
+}
+
+
 def sample_roofline(ms, cnt, steps, B, elapsed, mode):
     from soccerdiffusion_amd import _lib
 
     names = _lib.KERNEL_CLASSES
-    if mode == 3:
-        return traj_roofline(ms, cnt, steps, B, elapsed)
+    if mode >= 3:
+        return traj_roofline(ms, cnt, steps, B, elapsed, mode)
     dl = names.index("decoder_layer_kernel")
     at = names.index("attention_kernel")
     f = flops_per_traj_step()
@@ -695,15 +717,15 @@ def sample_roofline(ms, cnt, steps, B, elapsed, mode):
     }
 
 
-def traj_roofline(ms, cnt, steps, B, elapsed):
-    """Roofline record of sampler mode 3: ONE kernel (traj_step_kernel) per DDIM step carries a trajectory through the
+def traj_roofline(ms, cnt, steps, B, elapsed, mode=4):
+    """Roofline record of sampler modes 3 / 4: ONE kernel (traj_step_kernel) per DDIM step carries a trajectory through the
     whole denoiser step, so the dominant kernel IS the path."""
     from soccerdiffusion_amd import _lib
 
     names = _lib.KERNEL_CLASSES
     k = names.index("traj_step_kernel")
     f = flops_per_traj_step()
-    tf = traj_step_flops_per_traj_step()
+    tf = traj_step_flops_per_traj_step(mode)
     launches = max(int(cnt[k]), 1)
     k_s = ms[k] / 1e3
     avg_s = k_s / launches
@@ -727,7 +749,7 @@ def traj_roofline(ms, cnt, steps, B, elapsed):
         hbm["traffic_bytes_per_trajectory_step"] = round(traffic / B, 1)
     return {
         "bound": "mfma",
-        "kernel": "traj_step_kernel",
+        "kernel": "traj_step_kernel<7, %s>" % ("true" if mode == 3 else "false"),
         "achieved": round(achieved, 2),
         "peak": peak,
         "unit": "TFLOP/s",
@@ -738,8 +760,9 @@ def traj_roofline(ms, cnt, steps, B, elapsed):
         "algorithmic_flops_per_launch_avg": alg_flops / launches,
         "launches": launches,
         "avg_launch_ms": round(avg_s * 1e3, 5),
-        "sampler_mode": "3: trajectory-owning step kernel (one workgroup per trajectory, self-attention inside; fp16x3 split-operand "
-                        "MFMA, fp32 accumulate, folded cross-attention)",
+        "sampler_mode": "%d: trajectory-owning step kernel (one workgroup per trajectory, self-attention inside; fp16x3 split-operand "
+                        "MFMA, fp32 accumulate, folded cross-attention; %s)"
+                        % (mode, "three products at every site" if mode == 3 else "two products at the Q|K|V projection, guarded"),
         "mfma_pipe_occupancy": round(executed / peak, 4),
         "executed_mfma_tflops": round(executed, 2),
         "executed_mfma_flops_per_algorithmic_flop": round(tf["executed"] / tf["algorithmic"], 3),
@@ -789,7 +812,7 @@ def profiles_record():
     return out or None
 
 
-def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
+def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=None):
     """After the headline region, N = 1: (a) the same rollout replayed from a hipGraph (BASELINE configs[2] names a
     hipGraph-captured step), checked bit for bit against the eager result; (b) north_star's B = 256 sampling shape;
     (c) the C2 training step."""
@@ -797,9 +820,29 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
 
     out = {}
     B = x_T.shape[0]
+    # (0) the same rollout in the OTHER trajectory-kernel mode (3: three products everywhere / 4: two at the Q|K|V projection)
+    if mode >= 3:
+        try:
+            other = 7 - mode
+            y = torch.empty_like(x)
+            st = torch.zeros(1, dtype=torch.int32, device=dev)
+            for i in range(3):
+                if i == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                y.copy_(x_T)
+                ops.ddim_sample(packed, ctx, toks, coef, y, inplace=True, status=st, max_mode=other)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            out["other_traj_mode"] = {"sampler_mode": other, "ms_per_rollout": round(dt * 1e3, 3), "value": round(B / dt, 2),
+                                      "unit": "trajectories/s", "status_word": int(st.item()),
+                                      "max_rel_diff_to_headline": float(((y - x).flatten(1).norm(dim=1) / x.flatten(1).norm(dim=1)).max()),
+                                      "dtype": DTYPE_BY_MODE[other]}
+        except Exception as e:  # noqa: BLE001
+            out["other_traj_mode"] = {"error": repr(e)[:300]}
     # (a) hipGraph replay at the headline batch
     try:
-        gs = ops.GraphedSampler(packed, B, T, MC, toks, coef)
+        gs = ops.GraphedSampler(packed, B, T, MC, toks, coef, max_mode=mode)
         y = gs(ctx, x_T)
         torch.cuda.synchronize()
         same = bool(torch.equal(y, x))
@@ -818,7 +861,7 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
     try:
         Bs = 256
         xs, cs = x_T[:Bs].contiguous(), ctx[:Bs].contiguous()
-        gs = ops.GraphedSampler(packed, Bs, T, MC, toks, coef)
+        gs = ops.GraphedSampler(packed, Bs, T, MC, toks, coef, max_mode=mode)
         gs(cs, xs)
         torch.cuda.synchronize()
         n = 10
@@ -831,7 +874,7 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev):
         t0 = time.perf_counter()
         for _ in range(n):
             xe.copy_(xs)
-            ops.ddim_sample(packed, cs, toks, coef, xe, inplace=True)
+            ops.ddim_sample(packed, cs, toks, coef, xe, inplace=True, status=guard, max_mode=mode)
         torch.cuda.synchronize()
         de = (time.perf_counter() - t0) / n
         out["b256"] = {"workload": "north_star shape: B=256, 50 DDIM steps, T=100, J=20 (one rollout = one step)",

@@ -22,8 +22,8 @@ CFG = dict(hidden_dim=64, action_context_length=20, trajectory_prediction_length
            distill_teacher_inference_steps=30, use_gamestate=True, encoder_patch_size=5)
 
 
-def _run(*argv):
-    env = dict(os.environ, PYTHONPATH=REPO)
+def _run(*argv, **extra_env):
+    env = dict(os.environ, PYTHONPATH=REPO, **extra_env)
     return subprocess.run([sys.executable, "-m", "soccerdiffusion_amd.cli", *argv], cwd=REPO, env=env, capture_output=True, text=True)
 
 
@@ -191,3 +191,60 @@ def test_train_image_conditioned_non_square_frames(tmp_path):
     assert len(losses) >= 2 and all(math.isfinite(x) for x in losses)   # one line per epoch (every 20th iteration)
     sd = torch.load(ckpt, weights_only=True)["model_state_dict"]
     assert sd["image_sequence_encoder.image_encoder.encoder.conv1.weight"].shape == (64, 3, 7, 7)
+
+
+@pytest.mark.timeout(1500)
+def test_configs4_per_gpu_share_at_full_frame_size(tmp_path):
+    """BASELINE configs[4]'s per-GPU share AT SIZE (VERDICT r3 #1c): B = 128 over 8 GPUs = 16 trajectories x 10 frames of 480 x 640 RGB,
+    ResNet-18 per frame (torch.nn / MIOpen: parity unpinned vs torchvision) -> token -> 8-head HIP sequence encoder -> denoiser d = 256,
+    L = 4, T = 100, J = 20.  (a) through `cli train` (reference loop ml/training/train.py:204-240): finite, decreasing-or-equal loss
+    lines and a checkpoint that holds the backbone; (b) the hand-written half - sequence encoder + step token + denoiser - against the
+    oracle GIVEN the backbone's tokens (reference wiring ml/model/model.py:159-179, ml/model/encoder/image.py:38-52, 107-128), 1e-4."""
+    from oracle import denoiser_ref as ref
+
+    import bench
+    from soccerdiffusion_amd import cli
+
+    # (a)
+    cfg = dict(CFG, hidden_dim=256, epochs=2, batch_size=16, use_images=True, image_context_length=10, image_resolution=480,
+               image_use_final_avgpool=True, use_imu=False, use_joint_states=False, use_action_history=False, use_gamestate=False,
+               num_decoder_layers=4, trajectory_prediction_length=100, num_image_sequence_encoder_layers=2, lr=1e-4)
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    ckpt = tmp_path / "c5.pth"
+    r = _run("train", "-c", str(path), "-o", str(ckpt), "--synthetic", "16", "--image-size", "480x640", MIOPEN_FIND_MODE="FAST")
+    assert r.returncode == 0, r.stderr[-2000:]
+    losses = [float(l.split("Loss:")[1].split(",")[0]) for l in r.stdout.splitlines() if "Loss:" in l]
+    assert len(losses) >= 2 and all(math.isfinite(x) and 0.0 < x < 10.0 for x in losses), losses
+    back = torch.load(ckpt, weights_only=True)
+    sd = back["model_state_dict"]
+    assert sd["image_sequence_encoder.image_encoder.encoder.conv1.weight"].shape == (64, 3, 7, 7)
+    assert sd["image_sequence_encoder.image_encoder.encoder.fc.weight"].shape[0] == 256
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    # (b) the trained weights, eval mode, fresh frames
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    dev = torch.device("cuda:0")
+    params = dict(bench.C2_PARAMS, **{k: cfg[k] for k in ("use_images", "image_context_length", "image_resolution", "image_use_final_avgpool",
+                                                          "num_image_sequence_encoder_layers")})
+    model = cli.build_model(dict(back["hyperparams"])).to(dev).eval()
+    model.load_state_dict(sd)
+    assert params["image_context_length"] == 10
+    B, F, T_, J_ = 16, 10, 100, 20
+    g = torch.Generator().manual_seed(11)
+    frames = torch.rand(B, F, 3, 480, 640, generator=g).to(dev)
+    x = torch.randn(B, T_, J_, generator=g)
+    step = torch.randint(0, 1000, (B,), generator=g)
+    with torch.no_grad():
+        tokens = model.image_sequence_encoder.image_encoder(frames)          # the backbone (library convolutions)
+        got = model({"image_data": frames}, x.to(dev), step.to(dev))
+        ctx = model.encode_input_data({"image_data": frames})
+    assert tokens.shape == (B, F, 256) and [tuple(c.shape) for c in ctx] == [(B, F, 256)]
+    cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    seq_sd = {k[len("image_sequence_encoder.transformer_encoder."):]: v for k, v in cpu_sd.items()
+              if k.startswith("image_sequence_encoder.transformer_encoder.")}
+    # BaseEncoder(input_dim = d, patch 1, 8 heads) on the tokens: k = 1 embedding, PE, 2 x (self-attention + FFN) (image.py:107-128)
+    assert "transformer_encoder.layers.1.norm1.weight" in seq_sd and not any(".layers.2." in k for k in seq_sd)
+    h = ref.encoder_forward(seq_sd, tokens.cpu(), "", heads=8)
+    assert rel_err(ctx[0], h) < 1e-4
+    want = ref.forward_with_context(cpu_sd, [h], x, step)
+    assert rel_err(got, want) < 1e-4
