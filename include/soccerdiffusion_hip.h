@@ -205,6 +205,23 @@ int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const flo
                        const float *coef, float *x, float *trace, float *eps_trace, float *workspace,
                        int B, int T, int Mc, int n_steps, int32_t *status, int max_mode, void *stream);
 
+/* ---- image path: ResNet basic-block convolution -------------------------------------------------------
+ * y = act(BatchNorm_eval(conv3x3(x, w; stride 1, padding 1)) [+ res]) - torchvision BasicBlock's conv1/bn1/relu and
+ * conv2/bn2 (+ identity) / relu as the reference configures them (soccer_diffusion/ml/model/encoder/image.py:55-83), inference mode.
+ * Tensors are NHWC fp32: x (N,H,W,Cin), res / y (N,H,W,Cout); Cin, Cout multiples of 64.  bn_scale = gamma / sqrt(var + eps),
+ * bn_shift = beta - mean * bn_scale (per output channel).  Implicit GEMM with three fp16 MFMAs per product on hi + lo operands,
+ * fp32 accumulate (fp32-grade results; soccerdiffusion_amd/csrc/sd_conv.hip).
+ *   sd_conv3x3_pack: w (Cout,Cin,3,3) fp32 -> sd_conv3x3_packed_halfs(Cout,Cin) fp16 values in fragment order + the power-of-two
+ *     scale they carry (device float) - once per weight update; amax_word: one uint32 of device scratch.
+ *   x_amax / y_amax: device words holding the bits of max|x| / receiving max|y| (atomic max: zero y_amax before the call; NULL =
+ *     not needed).  sd_absmax_word computes such a word for a tensor no convolution produced (n % 4 == 0). */
+size_t sd_conv3x3_packed_halfs(int Cout, int Cin);
+int sd_conv3x3_pack(const float *w, int Cout, int Cin, void *planes, float *scale, uint32_t *amax_word, void *stream);
+int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                      const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
+                      int relu, void *stream);
+int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream);
+
 /* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
 
 /* out[R,N] = act(LN?(A)[R,d] @ W[N,d]^T + bias) (+ res).  ln_w/ln_b NULL = no LayerNorm;

@@ -134,6 +134,10 @@ SIGNATURES = {
     "sd_adamw_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p, C.c_void_p]),
     "sd_adamw_hyper": (C.c_int, [C.c_double] * 5 + [C.c_long, c_float_p]),
     "sd_set_dropout_epoch": (C.c_int, [C.c_void_p]),
+    "sd_conv3x3_packed_halfs": (C.c_size_t, [C.c_int, C.c_int]),
+    "sd_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sd_conv3x3_bn_act": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
+    "sd_absmax_word": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sd_profile_enable": (C.c_int, [C.c_int]),
     "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }

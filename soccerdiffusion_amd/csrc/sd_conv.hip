@@ -1,0 +1,232 @@
+// SoccerDiffusion image path: the 3 x 3, stride-1, padding-1 convolutions of ResNet-18's basic blocks with the
+// inference-mode BatchNorm, the residual and the ReLU in their epilogue - reference: torchvision's BasicBlock as configured by
+// soccer_diffusion/ml/model/encoder/image.py:55-83 (ResNetImageEncoder), 13 of the backbone's 20 convolutions and ~ 80 % of its FLOPs
+// at 480 x 640.  Interface and citations: include/soccerdiffusion_hip.h (sd_conv3x3_*).
+//
+// Implicit GEMM on the fp16 matrix pipe with split operands: out[pixel][co] = sum over (tap, ci) of
+// in[pixel + tap][ci] w[co][ci][tap] as three v_mfma_f32_32x32x16_f16 per product (lo.hi, hi.lo, hi.hi; fp32 accumulate), so the
+// result is fp32-grade (parity with torch's fp32 CPU convolution at 1e-6), at the fp16 pipe's rate.
+//   * Activations are NHWC fp32 in HBM: a pixel's channels are contiguous, so the contraction index of a tap is a 16-byte LDS
+//     read and an output row is a 128-byte store.
+//   * One workgroup (4 waves) owns an 8 x 16 pixel tile x 64 output channels.  Per 64-channel chunk of the input the 10 x 18
+//     halo tile is staged ONCE through LDS as fp16 hi | lo planes (x scale: a power of two from the tensor's abs-max word, which the
+//     producing launch left behind) and serves all 9 taps: 1.4 x the tile's own bytes instead of 9 x.  The planes are two arrays of
+//     144-byte pixels (128 + 16: 9 sixteen-byte units, odd, so the 16 consecutive pixels of a ds_read_b128 lane group hit 16
+//     distinct 16-byte bank groups).
+//   * Wave (w & 1, w >> 1) = (pixel half: 4 x 16 pixels = two 32-row MFMA tiles, output-channel half: one 32-column tile).  Weight
+//     fragments come straight from L2 in fragment-major planes ([co tile][tap][k-step][plane][lane][8 halfs], packed once per weight
+//     update by conv3x3_pack_kernel), requested one k-step ahead; halo fragments likewise from LDS.
+//   * Epilogue: acc / (s_in s_w) * bn_scale[co] + bn_shift[co] (+ residual) -> ReLU -> NHWC store, and the tile's abs-max into the
+//     output's word for the next convolution.
+// 52 KB of LDS: three workgroups per CU, so another workgroup's MFMAs cover a workgroup's halo staging.
+#include "../../include/soccerdiffusion_hip.h"
+#include "sd_common.h"
+
+namespace cv {
+
+constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2;   // output tile and its halo
+constexpr int CK = 64;                                      // input channels per chunk
+constexpr int PIX = 2 * CK + 16;                            // bytes of a halo pixel in one fp16 plane (+ 16: bank spread)
+constexpr int PLANE = HH * HW * PIX;                        // the lo plane follows the hi plane
+constexpr int LDS_BYTES = 2 * PLANE;                        // 51 840
+constexpr int COT = 64;                                     // output channels per workgroup
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// abs-max of a tensor into ONE word (bits of a non-negative float: unsigned order = float order)
+__global__ void absmax_word_kernel(const float *__restrict__ x, long n4, unsigned *word) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + 4 * i);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __builtin_bit_cast(unsigned, m));
+}
+// (a hipMemsetAsync node replays garbage from a captured graph on this stack - DESIGN.md 5.7: zero fills are kernels)
+__global__ void zero_words_kernel(unsigned *p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+
+// W (Cout, Cin, 3, 3) fp32 (torch layout) -> [co tile 32][tap 9][k-step Cin/16][plane][lane][8]: lane = 32 kg + j holds
+// W[32 ct + j][16 ks + 8 kg + e][tap] * scale as hi / lo, e = 0..7.  scale: power of two from the weights' abs-max word.
+__global__ void conv3x3_pack_kernel(const float *__restrict__ W, int Cout, int Cin, const unsigned *maxbits, f16 *__restrict__ dst, float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    const int nks = Cin / 16;
+    const long total = (long)Cout * 9 * (Cin / 8);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % (Cin / 8));
+        const int tap = (int)((i / (Cin / 8)) % 9);
+        const int co = (int)(i / (Cin / 8) / 9);
+        f16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = W[((long)co * Cin + (c8 * 8 + e)) * 9 + tap] * scale;
+            hh[e] = (f16)v;
+            ll[e] = (f16)(v - (float)hh[e]);
+        }
+        const int ct = co >> 5, j = co & 31, ks = c8 >> 1, kg = c8 & 1;
+        f16 *o = dst + ((((long)ct * 9 + tap) * nks + ks) * 2) * 512 + (32 * kg + j) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = hh[e];
+            o[512 + e] = ll[e];
+        }
+    }
+}
+
+struct ConvArgs {
+    const float *x;          // [N][H][W][Cin]
+    const f16 *w;            // packed planes
+    const float *w_scale;    // device word written by the pack kernel
+    const unsigned *x_amax;  // abs-max word of x
+    const float *bn_scale, *bn_shift;   // [Cout]
+    const float *res;        // [N][H][W][Cout] or NULL
+    float *y;                // [N][H][W][Cout]
+    unsigned *y_amax;        // abs-max word of y, or NULL
+    int N, H, W, Cin, Cout, relu, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int ph = w & 1, ch = w >> 1;                 // pixel half, output-channel half of this wave
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int co0 = blockIdx.y * COT + ch * 32;        // this wave's 32 output channels
+    const float s_in = f16_scale_from_bits(*a.x_amax);
+    const int nks = a.Cin / 16;
+    const f16 *wbase = a.w + (long)(co0 >> 5) * 9 * nks * 1024 + lane * 8;   // [tap][ks][plane]: 1024 halfs per (tap, ks)
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    // this lane's A rows: pixel (row 4 ph + 2 m + (j >> 4), column j & 15) of the tile, as a halo offset for tap (0, 0)
+    unsigned abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) abase[m] = (unsigned)(((4 * ph + 2 * m + (j >> 4)) * HW + (j & 15)) * PIX + 16 * kg);
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0 > 0) __syncthreads();   // every wave has consumed the previous chunk
+        // ---- stage the halo tile of channels c0 .. c0 + 63: 180 pixels x 16 vectors of 4 channels
+        for (int i = tid; i < HH * HW * (CK / 4); i += 256) {
+            const int c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            const int hy = p / HW, hx = p - hy * HW;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+            f16x4 h, l;
+            f16_split4(v, s_in, h, l);
+            char *at = smem + p * PIX + 8 * c4;
+            *reinterpret_cast<f16x4 *>(at) = h;
+            *reinterpret_cast<f16x4 *>(at + PLANE) = l;
+        }
+        __syncthreads();
+        // ---- 9 taps x 4 k-steps: weight fragments (global / L2) and halo fragments (LDS) one step ahead
+        const f16 *wp = wbase + (long)(c0 / 16) * 1024;
+        f16x8 bw[2][2], af[2][2][2];   // [stage][plane], [stage][tile][plane]
+        auto load = [&](int s, int st) __attribute__((always_inline)) {
+            const int tap = s >> 2, ks = s & 3;
+            const f16 *q = wp + ((long)tap * nks + ks) * 1024;
+            bw[st][0] = *reinterpret_cast<const f16x8 *>(q);
+            bw[st][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+            const unsigned toff = (unsigned)(((tap / 3) * HW + (tap % 3)) * PIX + 32 * ks);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                af[st][m][0] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff);
+                af[st][m][1] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff + PLANE);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const int st = s & 1;
+            if (s + 1 < 36) load(s + 1, st ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = mfma32(af[st][m][1], bw[st][0], acc[m]);   // lo . hi
+                acc[m] = mfma32(af[st][m][0], bw[st][1], acc[m]);   // hi . lo
+                acc[m] = mfma32(af[st][m][0], bw[st][0], acc[m]);   // hi . hi
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: un-scale, BatchNorm (inference: y = conv * s + t), residual, ReLU, NHWC store, abs-max
+    const float un = 1.0f / (s_in * *a.w_scale);
+    const int co = co0 + j;
+    const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
+    float mx = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;           // accumulator row = A row
+            const int gy = y0 + 4 * ph + 2 * m + (i >> 4), gx = x0 + (i & 15);
+            if (gy >= a.H || gx >= a.W) continue;
+            const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co;
+            float v = acc[m][r] * bs + bt;
+            if (a.res) v += a.res[at];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.y[at] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+    if (a.y_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > 0.f) atomicMax(a.y_amax, __builtin_bit_cast(unsigned, mx));
+    }
+}
+
+}   // namespace cv
+
+extern "C" int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream) {
+    if (!x || !word || n <= 0 || n % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(SD_E_BADARG, "sd_absmax_word: x must be 16-byte aligned, n a multiple of 4");
+    long blocks = (n / 4 + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    SD_LAUNCH(cv::absmax_word_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), word);
+    SD_CHECK_LAUNCH("absmax_word_kernel");
+    return 0;
+}
+
+extern "C" size_t sd_conv3x3_packed_halfs(int Cout, int Cin) { return (size_t)Cout * Cin * 9 * 2; }
+
+extern "C" int sd_conv3x3_pack(const float *w, int Cout, int Cin, void *planes, float *scale, uint32_t *amax_word, void *stream) {
+    if (!w || !planes || !scale || !amax_word || Cout <= 0 || Cin <= 0 || Cout % 64 || Cin % 64)
+        return fail(SD_E_BADARG, "sd_conv3x3_pack: channels must be positive multiples of 64");
+    hipStream_t st = (hipStream_t)stream;
+    SD_LAUNCH(cv::zero_words_kernel, dim3(1), dim3(64), 0, st, amax_word, 1);
+    SD_CHECK_LAUNCH("zero_words_kernel");
+    const long n = (long)Cout * Cin * 9;
+    int rc = sd_absmax_word(w, n, amax_word, stream);
+    if (rc) return rc;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    SD_LAUNCH(cv::conv3x3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, amax_word, (f16 *)planes, scale);
+    SD_CHECK_LAUNCH("conv3x3_pack_kernel");
+    return 0;
+}
+
+extern "C" int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                                 const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
+                                 int relu, void *stream) {
+    if (!x || !w_planes || !w_scale || !x_amax || !bn_scale || !bn_shift || !y || N <= 0 || H <= 0 || W <= 0)
+        return fail(SD_E_BADARG, "sd_conv3x3_bn_act: null pointer or empty shape");
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv3x3_bn_act: channels must be positive multiples of 64");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv3x3_bn_act: x must be 16-byte aligned and distinct from y");
+    cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu,
+                   (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH};
+    const long tiles = (long)a.tiles_x * a.tiles_y * N;
+    if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv3x3_bn_act: too many tiles");
+    SD_LAUNCH(cv::conv3x3_kernel, dim3((unsigned)tiles, (unsigned)(Cout / cv::COT)), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
+    SD_CHECK_LAUNCH("conv3x3_kernel");
+    return 0;
+}

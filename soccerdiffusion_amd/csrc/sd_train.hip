@@ -656,23 +656,44 @@ static long tng_total_wgs(const sd_gemm_tn_problem *pr, int cnt, long per_wg) {
     }
     return total;
 }
-// exported for the CPU-side unit test of the partitioning arithmetic: the per_wg the launch would use for `cnt` problems
-// (<= 16) of R rows and N x K outputs each; never launches anything
-extern "C" long sd_gemm_tn_grouped_plan(const long *R, const long *N, const long *K, int cnt, long *total_wgs) {
-    if (!R || !N || !K || cnt <= 0 || cnt > 64) return -1;
-    sd_gemm_tn_problem pr[64] = {};
+// The 32-row slabs every workgroup of ONE launch (cnt <= TNG_MAX problems) takes: ~2 workgroups per CU (256 CUs), each with the same
+// number of slabs, and no more workgroups than fit at once (chunks are rounded up per problem: nine extra workgroups behind a full
+// chip made a second round, +30 % on the launch).  Once per_wg has reached every problem's slab count the total no longer shrinks:
+// a group with more than SD_TNG_WGS output tiles (e.g. eight 1152 x 1152 gradients) then simply runs as more than one round of
+// workgroups (this search used to spin forever on such a group).  Shared by the launch and by the exported plan function,
+// so the CPU test of the latter exercises the loop the launch runs.
+static long tng_per_wg(const sd_gemm_tn_problem *pr, int cnt) {
     long slab_tiles = 0, max_slabs = 1;
     for (int i = 0; i < cnt; ++i) {
-        pr[i].R = R[i]; pr[i].N = (int)N[i]; pr[i].K = (int)K[i];
-        slab_tiles += (long)((N[i] + 127) / 128) * ((K[i] + 127) / 128) * ((R[i] + 31) / 32);
-        max_slabs = std::max(max_slabs, (long)((R[i] + 31) / 32));
+        const sd_gemm_tn_problem &q = pr[i];
+        slab_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((q.R + 31) / 32);
+        max_slabs = std::max(max_slabs, (long)((q.R + 31) / 32));
     }
     long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
     if (per_wg < 8) per_wg = 8;
     for (;; ++per_wg)
         if (tng_total_wgs(pr, cnt, per_wg) <= SD_TNG_WGS || per_wg >= max_slabs) break;
-    if (total_wgs) *total_wgs = tng_total_wgs(pr, cnt, per_wg);
     return per_wg;
+}
+// exported for the CPU-side unit test of the partitioning arithmetic: the per_wg the FIRST launch of sd_gemm_tn_grouped would use
+// for `cnt` problems of R rows and N x K outputs each (the call splits its problems into launches of at most TNG_MAX, as
+// sd_gemm_tn_grouped does; total_wgs: the workgroups of all launches); never launches anything
+extern "C" long sd_gemm_tn_grouped_plan(const long *R, const long *N, const long *K, int cnt, long *total_wgs) {
+    if (!R || !N || !K || cnt <= 0 || cnt > 64) return -1;
+    sd_gemm_tn_problem pr[64] = {};
+    for (int i = 0; i < cnt; ++i) {
+        if (R[i] <= 0 || N[i] <= 0 || K[i] <= 0) return -1;
+        pr[i].R = R[i]; pr[i].N = (int)N[i]; pr[i].K = (int)K[i];
+    }
+    long first_per_wg = 0, total = 0;
+    for (int first = 0; first < cnt; first += TNG_MAX) {
+        const int c = cnt - first < TNG_MAX ? cnt - first : TNG_MAX;
+        const long per_wg = tng_per_wg(pr + first, c);
+        if (first == 0) first_per_wg = per_wg;
+        total += tng_total_wgs(pr + first, c, per_wg);
+    }
+    if (total_wgs) *total_wgs = total;
+    return first_per_wg;
 }
 
 extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *stream) {
@@ -683,27 +704,13 @@ extern "C" int sd_gemm_tn_grouped(const sd_gemm_tn_problem *pr, int n, void *str
         const int cnt = n - first < TNG_MAX ? n - first : TNG_MAX;
         TnGroup g;
         g.n = cnt;
-        long slab_tiles = 0;
         for (int i = 0; i < cnt; ++i) {
             const sd_gemm_tn_problem &q = pr[first + i];
             if (!q.dY || !q.X || !q.dW || !q.amax_dy || !q.amax_x || q.R <= 0 || q.N <= 0 || q.K <= 0 || q.N % 4 || q.K % 4 || q.ldy < q.N ||
                 q.ldx < q.K || q.ldw < q.K || q.ldy % 4 || q.ldx % 4 || (reinterpret_cast<uintptr_t>(q.dY) & 15) || (reinterpret_cast<uintptr_t>(q.X) & 15))
                 return fail(SD_E_BADARG, "sd_gemm_tn_grouped: operands must be 16-byte aligned with N, K and the row strides multiples of 4, and carry their abs-max words");
-            slab_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * ((q.R + 31) / 32);
         }
-        // ~2 workgroups per CU (256 CUs), each with the same number of 32-row slabs
-        // ... and no more workgroups than fit at once (chunks are rounded up per problem: nine extra workgroups behind a full
-        // chip made a second round, +30 % on the launch)
-        long per_wg = (slab_tiles + SD_TNG_WGS - 1) / SD_TNG_WGS;
-        if (per_wg < 8) per_wg = 8;
-        // Once per_wg has reached every problem's slab count the total no longer shrinks: a group with more than SD_TNG_WGS
-        // output tiles (e.g. eight 1152 x 1152 gradients) then simply runs as more than one round of workgroups (this
-        // loop used to spin forever on such a group).
-        long max_slabs = 1;
-        for (int i = 0; i < cnt; ++i) max_slabs = std::max(max_slabs, (long)((pr[first + i].R + 31) / 32));
-        for (;; ++per_wg) {
-            if (tng_total_wgs(pr + first, cnt, per_wg) <= SD_TNG_WGS || per_wg >= max_slabs) break;
-        }
+        const long per_wg = tng_per_wg(pr + first, cnt);
         int wgs = 0;
         for (int i = 0; i < cnt; ++i) {
             const sd_gemm_tn_problem &q = pr[first + i];

@@ -2,10 +2,15 @@
 
 Per frame a ResNet-18/50 turns an image into one token; a BaseEncoder with 8 heads
 (image.py:116) lets the frames' tokens talk to each other.  The sequence transformer runs
-on this package's HIP kernels.  The ResNet backbone is SURVEY §8 f2 "next" scope and NOT
-hand-written: it is the torchvision architecture (absent offline, so restated here layer for
-layer with torchvision's ``state_dict`` keys) built from ``torch.nn`` layers, i.e. MIOpen
-convolutions through PyTorch-ROCm.  Pretrained ImageNet weights cannot be fetched offline
+on this package's HIP kernels.  The ResNet backbone is SURVEY §8 f2 "next" scope: it is the
+torchvision architecture (absent offline, so restated here layer for layer with torchvision's
+``state_dict`` keys).  In INFERENCE (eval mode, no autograd tape, CUDA) the 3 x 3 stride-1
+convolutions of ResNet-18's basic blocks - 13 of its 20 convolutions, ~80 % of its FLOPs -
+run on the hand-written implicit-GEMM kernel ``sd_conv3x3_bn_act`` (csrc/sd_conv.hip) with
+the folded BatchNorm, the residual and the ReLU in its epilogue, on NHWC tensors; everything
+else of the backbone (the 7 x 7 stem, the three stride-2 convolutions and 1 x 1 shortcuts, and
+the whole training path) is ``torch.nn``, i.e. MIOpen convolutions through PyTorch-ROCm
+(``SD_CONV=torch`` in the environment keeps the inference path on them too).  Pretrained ImageNet weights cannot be fetched offline
 (``weights=...DEFAULT`` in the reference): load them from a reference checkpoint.
 The Swin-T/S encoders are restated the same way (shifted-window attention with torch ops).
 Parity of the backbones is unpinned (no torchvision here, no reference fixture).
@@ -15,9 +20,12 @@ from __future__ import annotations
 
 from enum import Enum
 
+import os
+
 import torch
 from torch import nn
 
+from .... import ops
 from .encoders import BaseEncoder
 
 
@@ -53,6 +61,35 @@ class _BasicBlock(nn.Module):
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         return self.relu(self.bn2(self.conv2(out)) + idt)
+
+    @staticmethod
+    def _bn_fold(bn: nn.BatchNorm2d):
+        """Inference BatchNorm as y = x * s + t per channel."""
+        s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous()
+
+    def _packed(self, name: str, conv: nn.Conv2d) -> "ops.PackedConv3x3":
+        pk = self.__dict__.get(name)
+        if pk is None or pk.planes.device != conv.weight.device:
+            pk = self.__dict__[name] = ops.PackedConv3x3(conv.weight)
+        return pk.refresh(conv.weight)
+
+    def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
+        """Inference on the hand-written kernel: h (N, H, W, C) fp32 NHWC with its abs-max word -> (h', its abs-max word).
+        conv2 / bn2 / + identity / relu always; conv1 / bn1 / relu too unless it strides (then it and the 1 x 1 shortcut are
+        torch convolutions on an NCHW copy)."""
+        if self.downsample is None:
+            a1 = torch.zeros(1, dtype=torch.int32, device=h.device)
+            out = ops.conv3x3_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1)
+            idt = h
+        else:
+            x = h.permute(0, 3, 1, 2).contiguous()
+            idt = self.downsample(x).permute(0, 2, 3, 1).contiguous()
+            out = self.relu(self.bn1(self.conv1(x))).permute(0, 2, 3, 1).contiguous()
+            a1 = ops.absmax_word(out)
+        a2 = torch.zeros(1, dtype=torch.int32, device=h.device)
+        y = ops.conv3x3_bn_act(out, a1, self._packed("_pk2", self.conv2), *self._bn_fold(self.bn2), res=idt, relu=True, y_amax=a2)
+        return y, a2
 
 
 class _Bottleneck(nn.Module):
@@ -96,9 +133,22 @@ class _ResNet(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
+    def _hip_inference(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and isinstance(self.layer1[0], _BasicBlock)
+                and os.environ.get("SD_CONV", "hip") != "torch")
+
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        if self._hip_inference(x):
+            # basic blocks on NHWC tensors through sd_conv3x3_bn_act; back to an NCHW view for the head
+            h = x.permute(0, 2, 3, 1).contiguous()
+            amax = ops.absmax_word(h)
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in layer:
+                    h, amax = blk.forward_nhwc(h, amax)
+            x = h.permute(0, 3, 1, 2).contiguous()
+        else:
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 

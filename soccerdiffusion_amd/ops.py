@@ -836,3 +836,63 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: flo
         _req(t, n)
     check(lib.sd_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                             weight_decay, step, _stream()), "sd_adamw_step")
+
+
+# ---- image path: ResNet basic-block convolution (csrc/sd_conv.hip) -------------------------------------
+class PackedConv3x3:
+    """A 3 x 3 convolution weight (Cout, Cin, 3, 3) in the fragment order of ``sd_conv3x3_bn_act`` plus the power-of-two scale the
+    fp16 planes carry; repacked when the weight's version counter moves."""
+
+    def __init__(self, weight: Tensor):
+        lib = _lib.load()
+        _req(weight, "weight")
+        Cout, Cin, kh, kw = weight.shape
+        if (kh, kw) != (3, 3) or Cout % 64 or Cin % 64:
+            raise ValueError("3 x 3 kernels with channel counts that are multiples of 64")
+        self.Cout, self.Cin = Cout, Cin
+        self.planes = torch.empty(lib.sd_conv3x3_packed_halfs(Cout, Cin), dtype=torch.float16, device=weight.device)
+        self.scale = torch.empty(1, dtype=torch.float32, device=weight.device)
+        self._word = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        self.version = None
+        self.refresh(weight)
+
+    def refresh(self, weight: Tensor) -> "PackedConv3x3":
+        if self.version != weight._version:
+            w = weight.detach().contiguous()
+            check(_lib.load().sd_conv3x3_pack(w.data_ptr(), self.Cout, self.Cin, self.planes.data_ptr(), self.scale.data_ptr(),
+                                              self._word.data_ptr(), _stream()), "sd_conv3x3_pack")
+            self.version = weight._version
+        return self
+
+
+def absmax_word(x: Tensor, word: Optional[Tensor] = None) -> Tensor:
+    """The bits of max |x| in one int32 device word (the activation scale ``conv3x3_bn_act`` derives for its fp16 planes)."""
+    _req(x, "x")
+    if word is None:
+        word = torch.zeros(1, dtype=torch.int32, device=x.device)
+    else:
+        word.zero_()
+    check(_lib.load().sd_absmax_word(x.data_ptr(), x.numel(), word.data_ptr(), _stream()), "sd_absmax_word")
+    return word
+
+
+def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor, bn_shift: Tensor, res: Optional[Tensor] = None,
+                   relu: bool = True, y_amax: Optional[Tensor] = None) -> Tensor:
+    """relu(conv3x3(x) * bn_scale + bn_shift (+ res)) on NHWC fp32 tensors (stride 1, padding 1) - torchvision BasicBlock's
+    conv / bn / relu in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83).  ``x_amax``: word from
+    ``absmax_word`` or the ``y_amax`` of the launch that produced x; ``y_amax`` (zeroed here) receives max |y|."""
+    _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
+    N, H, W, Cin = x.shape
+    if Cin != w.Cin:
+        raise ValueError("channel mismatch")
+    y = torch.empty(N, H, W, w.Cout, dtype=torch.float32, device=x.device)
+    if res is not None:
+        _req(res, "res")
+        if res.shape != y.shape:
+            raise ValueError("residual shape mismatch")
+    if y_amax is not None:
+        y_amax.zero_()
+    check(_lib.load().sd_conv3x3_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
+                                        bn_shift.data_ptr(), _ptr(res), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, int(relu), _stream()),
+          "sd_conv3x3_bn_act")
+    return y

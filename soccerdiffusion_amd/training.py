@@ -300,15 +300,17 @@ class _CrossAttention(Function):
 # gradient of the first layer's input).  The slot travels WITH the tensor object, as an attribute (weakref to the stack's table,
 # address of the tensor's words, address of a free slot of the same table for the node's own small operand): an address-keyed
 # registry could hand a reused allocation the stale maximum of a freed tensor.  The consumer reads the attribute
-# from the very object it was handed (before any view) and also checks the shape; anything else takes the block-floating GEMM.
+# from the very object it was handed (before any view) and also checks the shape and the tensor's version counter - an in-place
+# update after registration (autograd's InputBuffer accumulating into a gradient it holds the last reference to, an in-place hook)
+# would leave a stale, too-small maximum behind; anything else takes the block-floating GEMM.
 def _amax_register(t: Tensor, table: Tensor, slot_addr: int, scratch_addr: int) -> None:
     import weakref
-    t._sd_amax = (weakref.ref(table), slot_addr, scratch_addr, tuple(t.shape))
+    t._sd_amax = (weakref.ref(table), slot_addr, scratch_addr, tuple(t.shape), t._version)
 
 
 def _amax_lookup(t: Tensor):
     ent = getattr(t, "_sd_amax", None)
-    if ent is None or ent[0]() is None or ent[3] != tuple(t.shape):
+    if ent is None or ent[0]() is None or ent[3] != tuple(t.shape) or ent[4] != t._version:
         return None
     return ent[1], ent[2]
 

@@ -1,0 +1,142 @@
+"""SURVEY 8 row f2, first hand-written kernel of the image backbone: the 3 x 3 stride-1 convolution + inference BatchNorm (+ residual)
++ ReLU of ResNet-18's basic blocks (reference: torchvision BasicBlock as configured by soccer_diffusion/ml/model/encoder/image.py:55-83)
+through the C ABI (sd_conv3x3_bn_act, csrc/sd_conv.hip) against the same operation in torch on the CPU in fp32 / fp64.
+torchvision itself is absent offline: parity of the restated ARCHITECTURE stays unpinned; what is pinned here is
+the arithmetic of the block."""
+
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from soccerdiffusion_amd import ops as o
+
+    return o
+
+
+def _case(C_in, C_out, N, H, W, seed, act_scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C_in, H, W, generator=g).abs() * act_scale          # post-ReLU activations
+    w = torch.randn(C_out, C_in, 3, 3, generator=g) * (2.0 / (9 * C_out)) ** 0.5   # kaiming, fan_out
+    gamma = 0.5 + torch.rand(C_out, generator=g)
+    beta = 0.2 * torch.randn(C_out, generator=g)
+    mean = 0.3 * torch.randn(C_out, generator=g)
+    var = 0.5 + torch.rand(C_out, generator=g)
+    res = torch.randn(N, C_out, H, W, generator=g).abs() * act_scale
+    return x, w, gamma, beta, mean, var, res
+
+
+def _torch_block(x, w, gamma, beta, mean, var, res, relu, dtype):
+    y = F.conv2d(x.to(dtype), w.to(dtype), padding=1)
+    y = F.batch_norm(y, mean.to(dtype), var.to(dtype), gamma.to(dtype), beta.to(dtype), training=False, eps=1e-5)
+    if res is not None:
+        y = y + res.to(dtype)
+    return F.relu(y) if relu else y
+
+
+# the four basic-block shapes of ResNet-18 on a 480 x 640 frame (120 x 160 after the stem) + ragged maps and a non-square channel pair
+@pytest.mark.parametrize("C_in,C_out,N,H,W", [(64, 64, 2, 120, 160), (128, 128, 2, 60, 80), (256, 256, 2, 30, 40), (512, 512, 3, 15, 20),
+                                             (64, 128, 1, 13, 23), (128, 64, 2, 8, 16), (64, 64, 1, 1, 1), (192, 64, 1, 9, 17)])
+@pytest.mark.parametrize("with_res,relu", [(True, True), (False, True), (False, False)])
+def test_conv3x3_bn_act_matches_torch_cpu(ops, C_in, C_out, N, H, W, with_res, relu):
+    x, w, gamma, beta, mean, var, res = _case(C_in, C_out, N, H, W, seed=C_in + H)
+    want64 = _torch_block(x, w, gamma, beta, mean, var, res if with_res else None, relu, torch.float64)
+    want32 = _torch_block(x, w, gamma, beta, mean, var, res if with_res else None, relu, torch.float32)
+    dev = "cuda"
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    s = (gamma * torch.rsqrt(var + 1e-5)).to(dev)
+    t = (beta - mean * gamma * torch.rsqrt(var + 1e-5)).to(dev)
+    pk = ops.PackedConv3x3(w.to(dev))
+    xa = ops.absmax_word(xh)
+    assert xa.view(torch.float32).item() == float(x.abs().max())
+    ya = torch.zeros(1, dtype=torch.int32, device=dev)
+    rh = res.permute(0, 2, 3, 1).contiguous().to(dev) if with_res else None
+    y = ops.conv3x3_bn_act(xh, xa, pk, s, t, res=rh, relu=relu, y_amax=ya)
+    got = y.permute(0, 3, 1, 2).cpu()
+    e = rel_err(got, want64)
+    e32 = rel_err(want32, want64)
+    assert e < 2e-6, (e, e32)                     # fp32-grade: three fp16 products on 22-bit operands, fp32 accumulation
+    assert e < 8 * e32 + 2e-7, (e, e32)            # and at the level of torch's own fp32 convolution
+    assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
+
+
+def test_conv3x3_large_and_tiny_activations(ops):
+    """One scale per tensor from its abs-max word: activations in the hundreds (an untrained backbone's deep layers) and of 1e-3."""
+    for scale in (300.0, 1e-3):
+        x, w, gamma, beta, mean, var, res = _case(64, 64, 1, 20, 24, seed=5, act_scale=scale)
+        want = _torch_block(x, w, gamma, beta, mean * scale, var * scale * scale, None, True, torch.float64)
+        xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+        inv = torch.rsqrt(var * scale * scale + 1e-5)
+        y = ops.conv3x3_bn_act(xh, ops.absmax_word(xh), ops.PackedConv3x3(w.cuda()), (gamma * inv).cuda(),
+                               (beta - mean * scale * gamma * inv).cuda(), relu=True)
+        assert rel_err(y.permute(0, 3, 1, 2), want) < 2e-6
+
+
+def test_packed_weight_follows_updates(ops):
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    pk = ops.PackedConv3x3(w)
+    before = pk.planes.clone()
+    with torch.no_grad():
+        w.mul_(2.0)
+    pk.refresh(w)
+    assert not torch.equal(before, pk.planes) or float(pk.scale) != 0.0
+    x = torch.rand(1, 5, 7, 64, device="cuda")
+    one, zero = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    y = ops.conv3x3_bn_act(x, ops.absmax_word(x), pk, one, zero, relu=False)
+    want = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.detach().cpu().double(), padding=1)
+    assert rel_err(y.permute(0, 3, 1, 2), want) < 2e-6
+
+
+@pytest.mark.parametrize("avgpool,HW", [(True, (96, 128)), (False, (64, 64))])
+def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW):
+    """The module-level route (ml/model/encoder/image.py): in eval mode without a tape the basic blocks go through
+    sd_conv3x3_bn_act (13 of the 20 convolutions); tokens equal the same torch.nn modules on the CPU in fp32 (1e-4) and the
+    all-MIOpen route on the GPU."""
+    import copy
+
+    from soccerdiffusion_amd import ops as o
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+    H, W = HW
+    torch.manual_seed(0)
+    enc = image_encoder_factory(ImageEncoderType.RESNET18, 64, avgpool, H)
+    # non-trivial running statistics (a fresh BatchNorm has mean 0 / var 1)
+    enc.train()
+    with torch.no_grad():
+        enc(torch.rand(2, 2, 3, H, W))
+    enc.eval()
+    x = torch.rand(2, 3, 3, H, W, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = enc(x)
+    g = copy.deepcopy(enc).cuda().eval()
+    calls = []
+    orig = o.conv3x3_bn_act
+    o.conv3x3_bn_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            got = g(x.cuda())
+    finally:
+        o.conv3x3_bn_act = orig
+    assert len(calls) == 13, len(calls)     # layer1: 4, layers 2-4: 3 each (their first conv strides)
+    assert got.shape == (2, 3, 64)
+    assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
+    os.environ["SD_CONV"] = "torch"
+    try:
+        with torch.no_grad():
+            lib = g(x.cuda())
+    finally:
+        del os.environ["SD_CONV"]
+    assert float((got - lib).abs().max() / lib.abs().max()) < 1e-4
+    # with a tape (training / fine-tuning) the library path runs: gradients flow
+    xg = x.cuda().requires_grad_(True)
+    g(xg).square().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
