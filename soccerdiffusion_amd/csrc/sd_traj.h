@@ -154,7 +154,7 @@ __device__ __forceinline__ void split_store(char *hi_at, char *lo_at, const f32x
 // that order.
 __device__ __forceinline__ int kperm(int k8, int e) { return (k8 >> 2) * 32 + 16 * (e >> 2) + 4 * (k8 & 3) + (e & 3); }
 
-__global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int Np, int Kp, const unsigned *maxbits, float fixed_scale,
+static __global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int Np, int Kp, const unsigned *maxbits, float fixed_scale,
                                 f16 *__restrict__ dst, float *scale_out) {
     const float scale = maxbits ? f16_scale_from_bits(*maxbits) : fixed_scale;
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -182,7 +182,7 @@ __global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K, int N
 
 // Folded keys of the context rows: gv rows [(item * 4 + head) * 16 + slot][2 D] (G in the first D columns) ->
 // per (item, head) blocks [ks 8][plane][lane = 16 g + slot][8], k = 32 ks + 8 g + e.  Slots >= n_slots are zero.
-__global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
+static __global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
                                 float *scale_out) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -204,7 +204,7 @@ __global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_
     }
 }
 // Folded keys of the step tokens: gvstep rows [item * 4 + head][2 D] -> [item][head][ks][plane][g][8]
-__global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst,
+static __global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst,
                                     float *scale_out) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -225,7 +225,7 @@ __global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, long items
 }
 // Folded values of the context rows -> per item [n-tile 16][kk 2][plane][lane = 16 g + i][8]: V'^T[n = 16 nt + i][k = 32 kk + 8 g + e],
 // k = head * 16 + slot
-__global__ void pack_v16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
+static __global__ void pack_v16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
                                 float *scale_out) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
@@ -251,7 +251,7 @@ __global__ void pack_v16_kernel(const float *__restrict__ gv, long items, int n_
     }
 }
 // Folded values of the step tokens -> [item][plane][head][n]
-__global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst) {
+static __global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst) {
     const float scale = f16_scale_from_bits(*maxbits);
     const long total = items * 4 * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -266,7 +266,7 @@ __global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items
 
 // row-major [B][T][256] <-> fragment order [B][wave][a][tt][lane][4] (Stage-A kernel and tests): element r of lane 16 g + t
 // is feature 32 w + 16 a + 4 g + r of token 16 tt + t (tokens >= T: zero)
-__global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restrict__ frag, int B, int T) {
+static __global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restrict__ frag, int B, int T) {
     const long total = (long)B * 8 * 2 * NTT_A * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
@@ -281,7 +281,7 @@ __global__ void to_hfrag_kernel(const float *__restrict__ rows, float *__restric
         *reinterpret_cast<f32x4 *>(frag + i * 4) = v;
     }
 }
-__global__ void from_hfrag_kernel(const float *__restrict__ frag, float *__restrict__ rows, int B, int T) {
+static __global__ void from_hfrag_kernel(const float *__restrict__ frag, float *__restrict__ rows, int B, int T) {
     const long total = (long)B * 8 * 2 * NTT_A * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
@@ -540,8 +540,10 @@ static __device__ __forceinline__ void store_x1(const Ctx &c, int tt, const f32x
 // a LayerNorm's affine parameters of this lane's features: requested first - their L2 round trip passes under the statistics (a
 // workgroup is alone on its CU) - and, where a request to HBM is also due (the folded keys before LayerNorm 2), BEFORE it: loads
 // return in order, a parameter requested after 16 KB of HBM reads would arrive behind them
+// rows_out (training): the normalised rows also go to HBM (this trajectory's [T][256] block, unscaled); amax: running max |.| of them
 template <bool HI_ONLY = false>
-static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff) {
+static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const LnAffine &aff, float *rows_out = nullptr,
+                                                       float *amax = nullptr) {
     const Ctx c = ctx_local(c0);
     float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
     const f32x4 (&gwv)[2] = aff.w, (&gbv)[2] = aff.b;
@@ -602,16 +604,27 @@ static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x
         const f32x4 y0 = ((H[0][tt] - mean[tt]) * rstd[tt]) * gw0 + gb0, y1 = ((H[1][tt] - mean[tt]) * rstd[tt]) * gw1 + gb1;
         if constexpr (HI_ONLY) store_x1(c, tt, y0, y1);
         else store_x(c, tt, y0, y1);
+        if (rows_out && tok_ok(c, tt)) {
+            const f32x4 u0 = y0 * (1.0f / ACT), u1 = y1 * (1.0f / ACT);
+            float *at = rows_out + (long)tok_of(c, tt) * D + 32 * c.w + 4 * c.g;
+            *reinterpret_cast<f32x4 *>(at) = u0;
+            *reinterpret_cast<f32x4 *>(at + 16) = u1;
+            if (amax) {
+                const f32x4 m4 = f32x4{fmaxf(fabsf(u0[0]), fabsf(u1[0])), fmaxf(fabsf(u0[1]), fabsf(u1[1])), fmaxf(fabsf(u0[2]), fabsf(u1[2])), fmaxf(fabsf(u0[3]), fabsf(u1[3]))};
+                *amax = fmaxf(*amax, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hipcc otherwise interleaves all 7 and spills
     }
     TJ_STAMP(52);
     TJ_SYNC(1);   // X complete
 }
 template <bool HI_ONLY = false>
-static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b) {
+static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[2][NTT], const float *ln_w, const float *ln_b, float *rows_out = nullptr,
+                                                       float *amax = nullptr) {
     LnAffine aff;
     ln_affine_load(c0, ln_w, ln_b, aff);
-    layer_norm_to_x<HI_ONLY>(c0, H, aff);
+    layer_norm_to_x<HI_ONLY>(c0, H, aff, rows_out, amax);
 }
 
 // K = 256 GEMM against the X panel as ONE software pipeline over 8 k-steps x 7 token tiles: the B fragment of the next tile
@@ -789,7 +802,9 @@ static __device__ __forceinline__ void head_write_qkv(const Ctx &c0, const SaW &
 // attention of query tile w (waves 0 .. NTT-1) of the head whose Q, K (att_scores) and V (att_pv) are in LDS: O -> LDS.  Two
 // pieces, so that the precise variant can put a barrier (K's buffer becomes V's) between them.
 // att_scores: S^T = K Q^T, softmax numerators in S (times 2^10), their sum in psum
-static __device__ __forceinline__ void att_scores(const Ctx &c, const SaW &a, const char *Qb, const char *Kb, f32x4 (&S)[NTT], float &psum) {
+// lse2 (training): log2-sum-exp of the scaled scores of this lane's query, the value attention_bwd16_kernel recomputes the probabilities from
+static __device__ __forceinline__ void att_scores(const Ctx &c, const SaW &a, const char *Qb, const char *Kb, f32x4 (&S)[NTT], float &psum,
+                                                  float *lse2 = nullptr) {
     const int w = c.w, g = c.g, t = c.t;
     // ---- scores S^T[key][query] = K Q^T
     {
@@ -835,9 +850,12 @@ static __device__ __forceinline__ void att_scores(const Ctx &c, const SaW &a, co
         ps = ps + S[kt];
     }
     psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
+    if (lse2) *lse2 = mb + __builtin_amdgcn_logf(psum);   // v_log_f32 is log2
 }
 // att_pv: O^T = V^T P^T with P^T straight from the score accumulators, V^T through transposing LDS reads; O / psum -> LDS planes
-static __device__ __forceinline__ void att_pv(const Ctx &c, const f32x4 (&S)[NTT], float psum, const char *Vb, char *Ob) {
+// rows_out (training): the attention output of this head also goes to HBM, [token][ld] at the head's 64 columns (unscaled); amax: running max |.| of it
+static __device__ __forceinline__ void att_pv(const Ctx &c, const f32x4 (&S)[NTT], float psum, const char *Vb, char *Ob, float *rows_out = nullptr,
+                                              int ld = 0, float *amax = nullptr) {
     const int w = c.w, g = c.g, t = c.t;
     f32x4 O[4];
 #pragma unroll
@@ -877,6 +895,15 @@ static __device__ __forceinline__ void att_pv(const Ctx &c, const f32x4 (&S)[NTT
         for (int kk = 0; kk < 2; ++kk) {   // features 32 kk + 4 g + r and 32 kk + 16 + 4 g + r: slot g of k-step kk (kperm)
             const int chunk = g | (kk << 3);
             split_store8(Ob + q_off(tok, chunk), Ob + q_off(tok, chunk | 4), O[2 * kk] * inv, O[2 * kk + 1] * inv);
+        }
+        if (rows_out) {
+            const float inv1 = inv * (1.0f / ACT);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const f32x4 v = O[ft] * inv1;
+                *reinterpret_cast<f32x4 *>(rows_out + (long)tok * ld + 16 * ft + 4 * g) = v;
+                if (amax) *amax = fmaxf(*amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
         }
     }
 }
@@ -1374,7 +1401,7 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
 }
 };   // struct TJ
 
-__global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) { TJ<NTT_A, false>::sa_body(a); }
+static __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) { TJ<NTT_A, false>::sa_body(a); }
 
 // sampler mode 3: NTT token tiles; PRECISE = three fp16 products at the Q | K | V site too
 template <int NTT, bool PRECISE>
