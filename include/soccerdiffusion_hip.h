@@ -348,6 +348,38 @@ typedef struct sd_train_bwd_chain_args {
 int sd_train_fwd_chain(const sd_train_fwd_chain_args *args, void *stream);
 int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
 
+/* The forward of ONE decoder layer for training with a workgroup per trajectory (soccerdiffusion_amd/csrc/sd_train_traj.hip): the self-attention
+ * core, [h1 = h + drop(a_sa Wo^T + bo); n2 = LN2(h1); q = n2 Wq^T + bq], the cross-attention core over the M projected memory rows,
+ * [h2 = h1 + drop(a_ca Woc^T + boc); nf = LN3(h2); pre = nf W1^T + b1; u = drop(gelu(pre)); h3 = h2 + drop(u W2^T + b2)] and - when w_n
+ * is given - the next layer's [nn1 = LN1'(h3); qkv2 = nn1 Wn^T + bn] in one launch, i.e. sd_op_attention_lse_dropout x 2 +
+ * sd_train_fwd_chain x 2 of the same layer (reference: nn.TransformerDecoderLayer, norm_first, as built by
+ * soccer_diffusion/ml/model/decoder.py:26-33; training loop ml/training/train.py:204-240).  It stores the same tensors in the same layouts
+ * (rows [B*T, 256]; qkv / qkv2 [B*T, 768]; lse [B, 4, T] as sd_op_attention_lse; kv [B, M, 512] = the memory's K | V projection) and the
+ * same abs-max words, with dropout masks at the same (site, row, column) indices, so sd_train_bwd_chain / sd_op_attention_bwd_dropout /
+ * sd_gemm_tn_grouped consume them unchanged.  hidden_dim 256, 4 heads, T <= 100, M <= 16 (sd_train_layer_fwd_ok).  Weights: planes from
+ * sd_pack_weight_traj (sd_pack_weight_traj_halfs(N, 256) fp16 values; N = 256, or 768 for w_n), repacked after every optimizer step. */
+typedef struct sd_train_layer_fwd_args {
+    int32_t B, T, M, d, heads;
+    const float *h, *qkv;
+    float *a_sa, *lse_sa, *h1, *n2, *q;
+    const float *kv;
+    float *a_ca, *lse_ca, *h2, *nf, *pre, *u, *h3, *nn1, *qkv2;
+    const void *w_o, *w_q, *w_oc, *w_1, *w_2, *w_n;
+    const float *b_o, *b_q, *b_oc, *b_1, *b_2, *b_n;
+    const float *n2_w, *n2_b, *n3_w, *n3_b, *nn_w, *nn_b;
+    float p;
+    uint64_t seed, site_sa_probs, site_sa_out, site_ca_probs, site_ca_out, site_act, site_ffn;
+    uint32_t *amax_a_sa, *amax_n2, *amax_a_ca, *amax_nf, *amax_u, *amax_nn, *amax_out;   /* SD_AMAX_WORDS words each, or NULL */
+} sd_train_layer_fwd_args;
+int sd_train_layer_fwd_ok(int d, int heads, int T, int M);
+int sd_train_layer_fwd(const sd_train_layer_fwd_args *args, void *stream);
+size_t sd_pack_weight_traj_halfs(int N, int K);
+int sd_pack_weight_traj(const float *w, int N, int K, void *planes, void *stream);
+/* n matrices in one launch: matrix i = rows[i] x 256 floats at base + src_offsets[i] (floats; rows multiples of 16) -> planes +
+ * dst_offsets[i] (halfs); the three arrays are DEVICE arrays, max_rows = the largest rows[i]. */
+int sd_pack_weight_traj_multi(const float *base, const int64_t *src_offsets, const int32_t *rows, const int64_t *dst_offsets, int n,
+                              int max_rows, void *planes, void *stream);
+
 /* Several weight gradients dW += dY^T X (and db += column sums of dY, db may be NULL) in one launch, on the fp16 matrix
  * pipe with ONE power-of-two scale per operand tensor: amax_dy / amax_x point at SD_AMAX_WORDS device words whose maximum is
  * the bits of (an upper bound of) max |dY| / max |X| - what sd_train_*_chain leave behind.  dY [R, N] and X [R, K] with row strides ldy / ldx

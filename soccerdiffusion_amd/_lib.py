@@ -63,6 +63,18 @@ class TrainFwdChainArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("amax_a", "amax_n", "amax_u", "amax_nn", "amax_h2")])
 
 
+class TrainLayerFwdArgs(C.Structure):
+    """sd_train_layer_fwd_args (field order = header order)."""
+
+    _fields_ = ([(n, C.c_int32) for n in ("B", "T", "M", "d", "heads")]
+                + [(n, C.c_void_p) for n in ("h", "qkv", "a_sa", "lse_sa", "h1", "n2", "q", "kv", "a_ca", "lse_ca", "h2", "nf", "pre", "u", "h3", "nn1",
+                                             "qkv2", "w_o", "w_q", "w_oc", "w_1", "w_2", "w_n", "b_o", "b_q", "b_oc", "b_1", "b_2", "b_n", "n2_w", "n2_b",
+                                             "n3_w", "n3_b", "nn_w", "nn_b")]
+                + [("p", C.c_float)] + [(n, C.c_uint64) for n in ("seed", "site_sa_probs", "site_sa_out", "site_ca_probs", "site_ca_out", "site_act",
+                                                                  "site_ffn")]
+                + [(n, C.c_void_p) for n in ("amax_a_sa", "amax_n2", "amax_a_ca", "amax_nf", "amax_u", "amax_nn", "amax_out")])
+
+
 class TrainBwdChainArgs(C.Structure):
     """sd_train_bwd_chain_args (field order = header order)."""
 
@@ -134,6 +146,11 @@ SIGNATURES = {
     "sd_adamw_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p, C.c_void_p]),
     "sd_adamw_hyper": (C.c_int, [C.c_double] * 5 + [C.c_long, c_float_p]),
     "sd_set_dropout_epoch": (C.c_int, [C.c_void_p]),
+    "sd_train_layer_fwd_ok": (C.c_int, [C.c_int] * 4),
+    "sd_train_layer_fwd": (C.c_int, [C.POINTER(TrainLayerFwdArgs), C.c_void_p]),
+    "sd_pack_weight_traj_halfs": (C.c_size_t, [C.c_int, C.c_int]),
+    "sd_pack_weight_traj": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sd_pack_weight_traj_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sd_conv3x3_packed_halfs": (C.c_size_t, [C.c_int, C.c_int]),
     "sd_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sd_conv3x3_bn_act": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),

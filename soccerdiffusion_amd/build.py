@@ -15,7 +15,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "sd_kernels.hip"), os.path.join(PKG, "csrc", "sd_train.hip"),
-       os.path.join(PKG, "csrc", "sd_train_chain.hip"), os.path.join(PKG, "csrc", "sd_conv.hip")]
+       os.path.join(PKG, "csrc", "sd_train_chain.hip"), os.path.join(PKG, "csrc", "sd_conv.hip"),
+       os.path.join(PKG, "csrc", "sd_train_traj.hip")]
 HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG, "csrc", "sd_common.h"),
        os.path.join(PKG, "csrc", "sd_panel.h"), os.path.join(PKG, "csrc", "sd_f16x3.h"), os.path.join(PKG, "csrc", "sd_traj.h")]
 # The sampler's translation unit is compiled WITHOUT packed fp32 vector instructions (v_pk_fma/mul/add_f32): they do not overlap with
@@ -40,7 +41,8 @@ def _obj(src: str) -> str:
 
 def _deps(src: str) -> list:
     """sd_f16x3.h and sd_traj.h are included by sd_kernels.hip only, sd_panel.h not by sd_train.hip."""
-    hdr = [h for h in HDR if not ((h.endswith("sd_f16x3.h") or h.endswith("sd_traj.h")) and not src.endswith("sd_kernels.hip"))
+    hdr = [h for h in HDR if not (h.endswith("sd_f16x3.h") and not src.endswith("sd_kernels.hip"))
+           and not (h.endswith("sd_traj.h") and not (src.endswith("sd_kernels.hip") or src.endswith("sd_train_traj.hip")))
            and not (h.endswith("sd_panel.h") and (src.endswith("sd_train.hip") or src.endswith("sd_conv.hip")))]
     return [src] + hdr
 

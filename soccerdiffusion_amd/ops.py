@@ -569,6 +569,42 @@ def train_fwd_chain(R: int, d: int, h_in: Tensor, *, a=None, wo=None, bo=None, h
     check(lib.sd_train_fwd_chain(C.byref(args), _stream()), "sd_train_fwd_chain")
 
 
+def pack_weight_traj(W: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """(N, 256) weight rows -> the split fp16 planes sd_train_layer_fwd streams (16 x 16 x 32 fragment order of csrc/sd_traj.h, scale 2^8)."""
+    lib = _lib.load()
+    _req(W, "W")
+    N, K = W.shape
+    if out is None:
+        out = torch.empty(lib.sd_pack_weight_traj_halfs(N, K), dtype=torch.float16, device=W.device)
+    check(lib.sd_pack_weight_traj(W.data_ptr(), N, K, out.data_ptr(), _stream()), "sd_pack_weight_traj")
+    return out
+
+
+def pack_weight_traj_multi(base: Tensor, src: Tensor, rows: Tensor, dst: Tensor, max_rows: int, planes: Tensor) -> None:
+    """All registered weight slices of a flat parameter buffer -> their trajectory-kernel planes, one launch (device index arrays)."""
+    check(_lib.load().sd_pack_weight_traj_multi(base.data_ptr(), src.data_ptr(), rows.data_ptr(), dst.data_ptr(), src.numel(), int(max_rows),
+                                                planes.data_ptr(), _stream()), "sd_pack_weight_traj_multi")
+
+
+def train_layer_fwd_ok(d: int, heads: int, T: int, M: int) -> bool:
+    return bool(_lib.load().sd_train_layer_fwd_ok(d, heads, T, M))
+
+
+def train_layer_fwd(B: int, T: int, M: int, heads: int, *, tensors: dict, weights: dict, p: float = 0.0, seed: int = 0, sites=(0,) * 6,
+                    amax=(None,) * 7) -> None:
+    """One launch of sd_train_layer_fwd: ``tensors`` / ``weights`` map the field names of sd_train_layer_fwd_args to tensors (weights
+    w_*: ADDRESSES of planes from pack_weight_traj); ``sites`` = dropout sites (self-attention probabilities, its out-projection, cross-
+    attention probabilities, its out-projection, GELU, FFN output); ``amax`` = addresses of the abs-max words of (a_sa, n2, a_ca, nf, u,
+    nn1, h3) or None."""
+    lib = _lib.load()
+    kw = {k: (_addr(v) if isinstance(v, Tensor) else v) for k, v in {**tensors, **weights}.items()}
+    args = _lib.TrainLayerFwdArgs(B=B, T=T, M=M, d=256, heads=heads, p=float(p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                  site_sa_probs=int(sites[0]), site_sa_out=int(sites[1]), site_ca_probs=int(sites[2]), site_ca_out=int(sites[3]),
+                                  site_act=int(sites[4]), site_ffn=int(sites[5]), amax_a_sa=amax[0], amax_n2=amax[1], amax_a_ca=amax[2],
+                                  amax_nf=amax[3], amax_u=amax[4], amax_nn=amax[5], amax_out=amax[6], **kw)
+    check(lib.sd_train_layer_fwd(C.byref(args), _stream()), "sd_train_layer_fwd")
+
+
 def train_bwd_chain(R: int, d: int, dy: Tensor, wt: int, dx: Tensor, *, passes: int = 1, dym=None, pre=None, dpre=None, wt1=None,
                     x=None, ln_w=None, dres=None, dg=None, db=None, p: float = 0.0, seed: int = 0, sites=(0, 0),
                     amax=(None, None)) -> None:

@@ -97,6 +97,22 @@ def _packed_weight(W: Tensor, p: int = 0, transposed: bool = False):
     return opt.flat_wpk.data_ptr() + 2 * (2 * off + (2 * opt._wt_total if transposed else 0))
 
 
+# Planes of whole weight matrices in the 16 x 16 x 32 fragment order of the trajectory kernels (csrc/sd_traj.h), for the layer-forward
+# kernel sd_train_layer_fwd: a second, lazily built set beside flat_wpk.  A matrix registers with its optimizer on first use (in the
+# eager warm-up steps of a graphed loop); from then on FusedAdamW.refresh_transposes repacks every registered matrix in one launch.
+def _packed_weight_traj(W: Tensor, row0: int = 0, rows: Optional[int] = None):
+    """Address of the trajectory-kernel planes of rows [row0, row0 + rows) of W (N x 256, row-major, owned by a FusedAdamW), else None."""
+    d = W.shape[1]
+    if d != 256 or W.stride() != (d, 1):
+        return None
+    ent = _wt_entry(W, 0, d)
+    if ent is None:
+        return None
+    opt = ent[0]
+    rows = W.shape[0] - row0 if rows is None else rows
+    return opt.traj_planes(W, row0, rows)
+
+
 def _linear(A: Tensor, W: Tensor, b, ln=None, res=None, drop=None) -> Tensor:
     """out = [res +] [dropout](LN?(A) W^T + b) on W's split planes when its optimizer keeps them, else on W itself."""
     wpk = _packed_weight(W)
@@ -565,6 +581,28 @@ def _mem_side(device):
     return s
 
 
+TRAJ_LAYERS = [0]   # decoder layers whose forward ran as ONE trajectory-owning launch (tests assert which path ran)
+
+
+def _traj_layer_weights(cfg, P, h: Tensor, memory: Tensor):
+    """The plane addresses sd_train_layer_fwd needs, or None when the layer does not qualify (shape, SD_TRAIN_TRAJ=0, weights that no
+    FusedAdamW keeps planes for): the per-op / row-chain launches run instead."""
+    import os
+
+    if os.environ.get("SD_TRAIN_TRAJ", "1") == "0" or not h.is_cuda or memory is None:
+        return None
+    B, T, d = h.shape
+    if not ops.train_layer_fwd_ok(d, cfg.heads, T, memory.shape[1]):
+        return None
+    (n1w, n1b, Wqkv, bqkv, Wo, bo, n2w, n2b, Wc, bc, Woc, boc, nfw, nfb, W1, b1, W2, b2) = P
+    for _ in range(2):   # a slice that registers on first use re-allocates the plane buffer: resolve the addresses again afterwards
+        w = dict(w_o=_packed_weight_traj(Wo), w_q=_packed_weight_traj(Wc, 0, d), w_oc=_packed_weight_traj(Woc), w_1=_packed_weight_traj(W1),
+                 w_2=_packed_weight_traj(W2), w_n=_packed_weight_traj(cfg.next_w) if cfg.next_w is not None else None)
+    if any(v is None for k, v in w.items() if k != "w_n") or (cfg.next_w is not None and w["w_n"] is None):
+        return None
+    return w
+
+
 class _FusedLayer(Function):
     """One pre-norm transformer layer (nn.TransformerDecoderLayer with memory, nn.TransformerEncoderLayer without) given
     (h, LN1(h), qkv = LN1(h) Wqkv^T + b); returns (h', LN1'(h'), qkv') for the next layer (empty tensors after the last)."""
@@ -592,6 +630,38 @@ class _FusedLayer(Function):
                     ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:], out=kv.view(B * M, 2 * d))
             else:
                 ops.linear_packed(mem2, _packed_weight(Wc, 1), 2 * d, bc[d:], out=kv.view(B * M, 2 * d))
+        tw = _traj_layer_weights(cfg, P, h, memory) if dec else None
+        if tw is not None:
+            # ---- ONE launch for the whole layer forward: a workgroup per trajectory (csrc/sd_train_traj.hip) ----
+            a_sa, h1, q, a_ca, h2, h3 = (_new(B, T, d, like=h) for _ in range(6))
+            n2, nf, pre, u = (_new(R, d, like=h) for _ in range(4))
+            lse_sa, lse_ca = _new(B, heads, T, like=h), _new(B, heads, T, like=h)
+            if cfg.next_w is not None:
+                nn1, qkv2 = _new(R, d, like=h), _new(B, T, 3 * d, like=h)
+            else:
+                nn1, qkv2 = _new(0, like=h), _new(0, like=h)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            TRAJ_LAYERS[0] += 1
+            ops.train_layer_fwd(
+                B, T, M, heads,
+                tensors=dict(h=h, qkv=qkv, a_sa=a_sa, lse_sa=lse_sa, h1=h1, n2=n2, q=q, kv=kv, a_ca=a_ca, lse_ca=lse_ca, h2=h2, nf=nf, pre=pre, u=u,
+                             h3=h3, nn1=nn1 if cfg.next_w is not None else None, qkv2=qkv2 if cfg.next_w is not None else None,
+                             b_o=bo, b_q=bc, b_oc=boc, b_1=b1, b_2=b2, b_n=cfg.next_b, n2_w=n2w, n2_b=n2b, n3_w=nfw, n3_b=nfb,
+                             nn_w=cfg.next_ln[0] if cfg.next_w is not None else None, nn_b=cfg.next_ln[1] if cfg.next_w is not None else None),
+                weights=tw, p=p, seed=seed,
+                sites=(cfg.site(SITE_SA_PROBS), cfg.site(SITE_SA_OUT), cfg.site(SITE_CA_PROBS), cfg.site(SITE_CA_OUT), cfg.site(SITE_FFN_ACT),
+                       cfg.site(SITE_FFN_OUT)),
+                amax=(cfg.ax(_AX_ASA), cfg.ax(_AX_N2), cfg.ax(_AX_ACA), cfg.ax(_AX_NF), cfg.ax(_AX_U),
+                      cfg.ax(_AX_N1, 1) if cfg.next_w is not None else None, cfg.ax(_AX_OUT) if cfg.next_w is None else None))
+            if cfg.next_w is None:
+                _amax_register(h3, cfg.amax, cfg.ax(_AX_OUT), cfg.ax(_AX_SCR))
+            ctx.cfg = cfg
+            ctx.n_c = 6
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(h, n1, qkv, memory, a_sa, lse_sa, h2, nf, pre, u, h1, n2, q, kv, a_ca, lse_ca, *P)
+            ctx.mark_non_differentiable(nn1, qkv2)
+            return h3, nn1, qkv2
         a_sa, lse_sa = ops.attention_lse(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
         saved_c = ()
         if dec:
@@ -860,11 +930,40 @@ class FusedAdamW(torch.optim.Optimizer):
             ops.pack_weight_blocks(self.flat_param, fwd, n, d, self.flat_wpk[half_off:])
             ops.pack_weight_blocks(self.flat_param, fwd, n, d, self.flat_wpk[2 * self._wt_total + half_off:], transposed=True)
         self._wt_versions = [p._version for p in self._wt_params]
+        self._refresh_traj()
         if not getattr(self, "_wt_registered", False):
             owner = weakref.ref(self)
             for key, off, d, pi in self._wt_blocks:
                 _WT_BLOCKS[key] = (owner, off, d, pi)   # no tensor references: a dead optimizer's entries are inert
             self._wt_registered = True
+
+    def traj_planes(self, W: Tensor, row0: int, rows: int):
+        """Address of the trajectory-kernel planes (ops.pack_weight_traj layout) of rows [row0, row0 + rows) of parameter W, which lives
+        in this optimizer's flat buffer; registers the slice on first use and repacks all registered slices."""
+        src = (W.data_ptr() - self.flat_param.data_ptr()) // 4 + row0 * 256
+        if src < 0 or src + rows * 256 > self.flat_param.numel() or rows % 16:
+            return None
+        reg = self.__dict__.setdefault("_traj_reg", {"index": {}, "src": [], "rows": [], "dst": [], "halfs": 0, "planes": None, "dev": None})
+        at = reg["index"].get((src, rows))
+        if at is None:
+            at = reg["halfs"]
+            reg["index"][(src, rows)] = at
+            reg["src"].append(src); reg["rows"].append(rows); reg["dst"].append(at)
+            reg["halfs"] += rows * 256 * 2
+            reg["planes"] = None   # (re)allocated and repacked below
+        if reg["planes"] is None:
+            dev = self.flat_param.device
+            reg["planes"] = torch.empty(reg["halfs"], dtype=torch.float16, device=dev)
+            reg["dev"] = (torch.tensor(reg["src"], dtype=torch.int64, device=dev), torch.tensor(reg["rows"], dtype=torch.int32, device=dev),
+                          torch.tensor(reg["dst"], dtype=torch.int64, device=dev))
+            self._refresh_traj()
+        return reg["planes"].data_ptr() + 2 * at
+
+    def _refresh_traj(self) -> None:
+        reg = self.__dict__.get("_traj_reg")
+        if reg and reg["planes"] is not None:
+            s, r, d = reg["dev"]
+            ops.pack_weight_traj_multi(self.flat_param, s, r, d, max(reg["rows"]), reg["planes"])
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()

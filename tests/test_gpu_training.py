@@ -293,3 +293,40 @@ def test_distillation_step_matches_oracle(fused):
     _, want_loss, want = ref.train_loss_and_grads(sd_s, noisy, torch.zeros(B), want_target, context=[ctx])
     assert abs(float(loss) - float(want_loss)) / float(want_loss) < 1e-4
     _check_grads(student, want)
+
+
+@pytest.mark.parametrize("T,Mc,B,L,p", [(100, 10, 3, 4, 0.0), (100, 10, 5, 2, 0.1), (10, 0, 4, 2, 0.1), (37, 15, 2, 2, 0.1), (64, 3, 2, 3, 0.0), (1, 5, 2, 1, 0.1)])
+def test_trajectory_layer_forward_equals_the_row_chain_path(monkeypatch, T, Mc, B, L, p):
+    """sd_train_layer_fwd (csrc/sd_train_traj.hip: one launch per decoder layer, a workgroup per trajectory) against the four launches it
+    replaces (attention cores + row chains A / B; SD_TRAIN_TRAJ=0): the same prediction, loss and - through the UNCHANGED backward, which
+    reads the tensors and regenerates the dropout masks the forward left behind - the same gradient of every parameter, at fp32 rounding
+    level, with and without dropout, on full, ragged and single-token horizons and 1 .. 16 memory rows."""
+    from soccerdiffusion_amd import training
+    from soccerdiffusion_amd.synthetic import synthetic_state_dict
+
+    d, J = 256, 20
+    sd = synthetic_state_dict(d, J, L, seed=8)
+    g = torch.Generator().manual_seed(T + Mc)
+    x_t, eps = torch.randn(B, T, J, generator=g).cuda(), torch.randn(B, T, J, generator=g).cuda()
+    ctx = [torch.randn(B, Mc, d, generator=g).cuda()] if Mc else []
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    out = {}
+    for traj in ("0", "1"):
+        monkeypatch.setenv("SD_TRAIN_TRAJ", traj)
+        m = _build0(dict(d=d, J=J, L=L, T=T), full=False).cuda()
+        m.load_state_dict(sd)
+        m.train()
+        m.set_dropout(p, seed=99)
+        m._opt = training.FusedAdamW(m.parameters(), lr=1e-3)
+        before = training.TRAJ_LAYERS[0]
+        pred = m.forward_with_context(ctx, x_t, t)
+        assert training.TRAJ_LAYERS[0] - before == (L if traj == "1" else 0)
+        loss = training.mse_loss(pred, eps)
+        loss.backward()
+        out[traj] = (pred.detach().clone(), float(loss), {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
+    assert rel_err(out["1"][0], out["0"][0]) < 2e-6
+    assert abs(out["1"][1] - out["0"][1]) / out["0"][1] < 1e-6
+    scale = max(float(v.norm()) for v in out["0"][2].values())
+    for k, gw in out["0"][2].items():
+        rel = float((out["1"][2][k].double() - gw.double()).norm()) / max(float(gw.norm()), 1e-3 * scale)
+        assert rel < 2e-5, (k, rel)
