@@ -54,6 +54,14 @@ struct L {
     // y = acc * cy + bias -> dropout (site d, logical width 256) -> base + y; rows of this trajectory start at row0.  Stores to `out`.
     static __device__ __forceinline__ void residual_epilogue(const Ctx &c, f32x4 (&H)[2][NTT], const f32x4 (&Y)[2][NTT], const Bias2 &b, float cy,
                                                              const DropoutArgs &d, long row0, const float *base, float *out, float *amax) {
+        if (base) {   // every load of the residual rows first (one round trip, not one per tile)
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+                    H[a2][tt] = *reinterpret_cast<const f32x4 *>(base + (row0 + K::tok_of(c, tt)) * D + 32 * c.w + 16 * a2 + 4 * c.g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             if (!K::tok_ok(c, tt)) continue;
@@ -63,10 +71,9 @@ struct L {
                 const int col = 32 * c.w + 16 * a2 + 4 * c.g;
                 f32x4 y = Y[a2][tt] * cy + b.v[a2];
                 if (d.thresh) y = y * dropout_quad(d, (unsigned long)row * (D / 4) + (unsigned long)(col >> 2));
-                const f32x4 r = base ? *reinterpret_cast<const f32x4 *>(base + row * D + col) : H[a2][tt];
-                const f32x4 v = r + y;
+                const f32x4 v = H[a2][tt] + y;
                 H[a2][tt] = v;
-                *reinterpret_cast<f32x4 *>(out + row * D + col) = v;
+                SD_NT_STORE((f32x4)(v), reinterpret_cast<f32x4 *>(out + row * D + col));
                 if (amax) *amax = fmaxf(*amax, max4(v));
             }
         }
@@ -79,15 +86,31 @@ struct L {
             for (int tt = 0; tt < NTT; ++tt) Y[a2][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // q | k | v of head h of this trajectory (rows of [T][768]) -> Q, K (natural feature order) and V planes in LDS, x ACT
-    static __device__ __forceinline__ void stage_qkv(char *smem, const float *qkv, int h, int T) {
+    // q | k | v of head h of this trajectory (rows of [T][768]) -> Q, K (natural feature order) and V planes in LDS, x ACT.  Two
+    // halves: every load of a head is REQUESTED first (a load - convert - store loop costs one HBM round trip per iteration), for head
+    // h + 1 while head h's attention runs, and written to LDS once that head's buffers are free.
+    static constexpr int QKV_VECS = (TMAX * 16 * 3 + NTHREADS - 1) / NTHREADS;   // 10
+    struct QkvRegs { f32x4 v[QKV_VECS]; };
+    static __device__ __forceinline__ void load_qkv(QkvRegs &r, const float *qkv, int h, int T) {
+#pragma unroll
+        for (int n = 0; n < QKV_VECS; ++n) {
+            const int i = threadIdx.x + n * NTHREADS;
+            const int which = i / (T * 16), rr = i - which * (T * 16);
+            const int tok = rr >> 4, j = rr & 15;
+            r.v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < T * 16 * 3) r.v[n] = *reinterpret_cast<const f32x4 *>(qkv + (long)tok * (3 * D) + which * D + HD * h + 4 * j);
+        }
+    }
+    static __device__ __forceinline__ void store_qkv(const QkvRegs &r, char *smem, int T) {
         char *Qb = smem + LDS_SQ, *Kb = smem + LDS_Q, *Vb = smem + LDS_K;
-        for (int i = threadIdx.x; i < T * 16 * 3; i += NTHREADS) {
-            const int which = i / (T * 16), r = i - which * (T * 16);
-            const int tok = r >> 4, j = r & 15;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(qkv + (long)tok * (3 * D) + which * D + HD * h + 4 * j) * ACT;
+#pragma unroll
+        for (int n = 0; n < QKV_VECS; ++n) {
+            const int i = threadIdx.x + n * NTHREADS;
+            if (i >= T * 16 * 3) continue;
+            const int which = i / (T * 16), rr = i - which * (T * 16);
+            const int tok = rr >> 4, j = rr & 15;
             f16x4 hi, lo;
-            split4(v, hi, lo);
+            split4(r.v[n] * ACT, hi, lo);
             if (which < 2) {
                 char *dst = which == 0 ? Qb : Kb;
                 const int chunk = ((j & 7) >> 1) | ((j >> 3) << 3);
@@ -111,10 +134,14 @@ struct L {
         // =========================== self-attention block ===========================
         zero(Y);
         float am_a = 0.f;
+        QkvRegs qr;
+        load_qkv(qr, a.qkv + row0 * (3 * D), 0, a.T);
 #pragma unroll 1
         for (int h = 0; h < NH; ++h) {
-            stage_qkv(smem, a.qkv + row0 * (3 * D), h, a.T);
+            store_qkv(qr, smem, a.T);
             __syncthreads();   // Q, K, V of head h staged (and every reader of head h-1's O is past its out-projection)
+            if (h + 1 < NH) load_qkv(qr, a.qkv + row0 * (3 * D), h + 1, a.T);   // lands while this head's attention runs
+            __builtin_amdgcn_sched_barrier(0);
             if (c.w < NTT) {
                 const Ctx cl = K::ctx_local(c);
                 const SaW sw{nullptr, nullptr, nullptr, 1.f, a.scale_log2e, nullptr};
@@ -159,7 +186,7 @@ struct L {
 #pragma unroll
                 for (int a2 = 0; a2 < 2; ++a2) {
                     qv[a2] = Y[a2][tt] * cy + bq.v[a2];
-                    if (K::tok_ok(c, tt)) *reinterpret_cast<f32x4 *>(a.q + (row0 + K::tok_of(c, tt)) * D + 32 * c.w + 16 * a2 + 4 * c.g) = qv[a2];
+                    if (K::tok_ok(c, tt)) SD_NT_STORE((f32x4)(qv[a2]), reinterpret_cast<f32x4 *>(a.q + (row0 + K::tok_of(c, tt)) * D + 32 * c.w + 16 * a2 + 4 * c.g));
                 }
                 K::store_x(c, tt, qv[0] * ACT, qv[1] * ACT);
             }
@@ -251,7 +278,7 @@ struct L {
 #pragma unroll
                     for (int ft = 0; ft < 4; ++ft) {
                         const f32x4 o = O[ft] * inv1;
-                        *reinterpret_cast<f32x4 *>(a.a_ca + (row0 + qtok) * D + HD * hh + 16 * ft + 4 * cl.g) = o;
+                        SD_NT_STORE((f32x4)(o), reinterpret_cast<f32x4 *>(a.a_ca + (row0 + qtok) * D + HD * hh + 16 * ft + 4 * cl.g));
                         am_c = fmaxf(am_c, max4(o));
                     }
                 }
@@ -288,8 +315,8 @@ struct L {
                     f32x4 u = {g0[0], g0[1], g1[0], g1[1]};
                     if (a.d_act.thresh) u = u * dropout_quad(a.d_act, (unsigned long)row * (D / 4) + (unsigned long)(col >> 2));
                     if (ok) {
-                        *reinterpret_cast<f32x4 *>(a.pre + row * D + col) = pre;
-                        *reinterpret_cast<f32x4 *>(a.u + row * D + col) = u;
+                        SD_NT_STORE((f32x4)(pre), reinterpret_cast<f32x4 *>(a.pre + row * D + col));
+                        SD_NT_STORE((f32x4)(u), reinterpret_cast<f32x4 *>(a.u + row * D + col));
                         am_u = fmaxf(am_u, max4(u));
                     }
                     uv[a2] = u * ACT;
@@ -321,7 +348,7 @@ struct L {
                     if (!K::tok_ok(c, tt)) continue;
 #pragma unroll
                     for (int a2 = 0; a2 < 2; ++a2)
-                        *reinterpret_cast<f32x4 *>(a.qkv2 + (row0 + K::tok_of(c, tt)) * (3 * D) + p * D + 32 * c.w + 16 * a2 + 4 * c.g) = Y[a2][tt] * cy + bn.v[a2];
+                        SD_NT_STORE((f32x4)(Y[a2][tt] * cy + bn.v[a2]), reinterpret_cast<f32x4 *>(a.qkv2 + (row0 + K::tok_of(c, tt)) * (3 * D) + p * D + 32 * c.w + 16 * a2 + 4 * c.g));
                 }
             }
         }

@@ -607,8 +607,8 @@ static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x
         if (rows_out && tok_ok(c, tt)) {
             const f32x4 u0 = y0 * (1.0f / ACT), u1 = y1 * (1.0f / ACT);
             float *at = rows_out + (long)tok_of(c, tt) * D + 32 * c.w + 4 * c.g;
-            *reinterpret_cast<f32x4 *>(at) = u0;
-            *reinterpret_cast<f32x4 *>(at + 16) = u1;
+            SD_NT_STORE(u0, reinterpret_cast<f32x4 *>(at));
+            SD_NT_STORE(u1, reinterpret_cast<f32x4 *>(at + 16));
             if (amax) {
                 const f32x4 m4 = f32x4{fmaxf(fabsf(u0[0]), fabsf(u1[0])), fmaxf(fabsf(u0[1]), fabsf(u1[1])), fmaxf(fabsf(u0[2]), fabsf(u1[2])), fmaxf(fabsf(u0[3]), fabsf(u1[3]))};
                 *amax = fmaxf(*amax, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
@@ -901,7 +901,7 @@ static __device__ __forceinline__ void att_pv(const Ctx &c, const f32x4 (&S)[NTT
 #pragma unroll
             for (int ft = 0; ft < 4; ++ft) {
                 const f32x4 v = O[ft] * inv1;
-                *reinterpret_cast<f32x4 *>(rows_out + (long)tok * ld + 16 * ft + 4 * g) = v;
+                SD_NT_STORE(v, reinterpret_cast<f32x4 *>(rows_out + (long)tok * ld + 16 * ft + 4 * g));
                 if (amax) *amax = fmaxf(*amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             }
         }

@@ -80,3 +80,25 @@ names = ("a_sa", "n2", "a_ca", "nf", "u", "nn1", "h3")
 for i, k in enumerate(names):
     got = float(amax[i].view(torch.float32).max())
     print(f"amax {k:5s} {got:.6f} want {float(want[k].abs().max()):.6f}")
+
+# ---- timing of the launch alone (B as given; 256 = one workgroup per CU)
+import time  # noqa: E402
+
+
+def launch():
+    ops.train_layer_fwd(B, T, M, heads,
+                        tensors=dict(h=h, qkv=qkv, kv=kv, b_o=b["o"], b_q=b["q"], b_oc=b["oc"], b_1=b["1"], b_2=b["2"], b_n=bn, n2_w=ln["2"][0], n2_b=ln["2"][1],
+                                     n3_w=ln["3"][0], n3_b=ln["3"][1], nn_w=ln["n"][0], nn_b=ln["n"][1], **out),
+                        weights=dict(w_o=planes["o"].data_ptr(), w_q=planes["q"].data_ptr(), w_oc=planes["oc"].data_ptr(), w_1=planes["1"].data_ptr(),
+                                     w_2=planes["2"].data_ptr(), w_n=pn.data_ptr()),
+                        p=p, seed=seed, sites=sites, amax=tuple(amax[i].data_ptr() for i in range(7)))
+
+
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    launch()
+torch.cuda.synchronize()
+print(f"train_layer_fwd: B={B} T={T} M={M} p={p}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us per launch")
