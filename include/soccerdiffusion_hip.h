@@ -357,7 +357,8 @@ int sd_train_bwd_chain(const sd_train_bwd_chain_args *args, void *stream);
  * (rows [B*T, 256]; qkv / qkv2 [B*T, 768]; lse [B, 4, T] as sd_op_attention_lse; kv [B, M, 512] = the memory's K | V projection) and the
  * same abs-max words, with dropout masks at the same (site, row, column) indices, so sd_train_bwd_chain / sd_op_attention_bwd_dropout /
  * sd_gemm_tn_grouped consume them unchanged.  hidden_dim 256, 4 heads, T <= 100, M <= 16 (sd_train_layer_fwd_ok).  Weights: planes from
- * sd_pack_weight_traj (sd_pack_weight_traj_halfs(N, 256) fp16 values; N = 256, or 768 for w_n), repacked after every optimizer step. */
+ * sd_pack_weight_traj (sd_pack_weight_traj_halfs(N, K) fp16 values; K = 256 - or <= 32 for the embedding -, N = 256, or 768 for w_n),
+ * repacked after every optimizer step. */
 typedef struct sd_train_layer_fwd_args {
     int32_t B, T, M, d, heads;
     const float *h, *qkv;
@@ -373,6 +374,11 @@ typedef struct sd_train_layer_fwd_args {
 } sd_train_layer_fwd_args;
 int sd_train_layer_fwd_ok(int d, int heads, int T, int M);
 int sd_train_layer_fwd(const sd_train_layer_fwd_args *args, void *stream);
+/* The entry of the decoder stack in the same geometry: h0 = x Wemb^T + b + pe[:T] (nn.Linear(J -> 256) + PositionalEncoding,
+ * soccer_diffusion/ml/model/decoder.py:48-50), n1 = LN1(h0) of layer 0, qkv = n1 Wqkv^T + b: sd_op_patch_embed (p = 1) + the head launch of
+ * sd_train_fwd_chain in one.  x (B,T,J), J a multiple of 4 up to 32; w_emb / w_qkv: planes from sd_pack_weight_traj ((256, J) and (768, 256)). */
+int sd_train_head_fwd(const float *x, const void *w_emb, const float *b_emb, const float *pe, float *h0, const float *ln_w, const float *ln_b,
+                      float *n1, const void *w_qkv, const float *b_qkv, float *qkv, uint32_t *amax_n1, int B, int T, int J, void *stream);
 size_t sd_pack_weight_traj_halfs(int N, int K);
 int sd_pack_weight_traj(const float *w, int N, int K, void *planes, void *stream);
 /* n matrices in one launch: matrix i = rows[i] x 256 floats at base + src_offsets[i] (floats; rows multiples of 16) -> planes +

@@ -148,6 +148,7 @@ SIGNATURES = {
     "sd_set_dropout_epoch": (C.c_int, [C.c_void_p]),
     "sd_train_layer_fwd_ok": (C.c_int, [C.c_int] * 4),
     "sd_train_layer_fwd": (C.c_int, [C.POINTER(TrainLayerFwdArgs), C.c_void_p]),
+    "sd_train_head_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 3 + [C.c_void_p]),
     "sd_pack_weight_traj_halfs": (C.c_size_t, [C.c_int, C.c_int]),
     "sd_pack_weight_traj": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sd_pack_weight_traj_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

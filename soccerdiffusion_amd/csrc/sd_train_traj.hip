@@ -33,6 +33,10 @@ struct Args {
     unsigned *ax_asa, *ax_n2, *ax_aca, *ax_nf, *ax_u, *ax_nn, *ax_out;
     int T, M, B;
     float scale_log2e;
+    // head of the stack (train_head_fwd_kernel): h0 = x Wemb^T + b + pe -> h3; then the "next" LayerNorm + projection block
+    const float *x_in, *b_emb, *pe;
+    const f16 *w_emb;
+    int J;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -124,6 +128,9 @@ struct L {
         }
     }
 
+    // HEAD: the stack's entry instead of a layer - embedding (nn.Linear(J -> d) + positional rows, decoder.py:48-50) -> h3, then the
+    // LayerNorm 1 + Q | K | V projection of layer 0 (the block every layer runs for its successor)
+    template <bool HEAD>
     static __device__ __forceinline__ void body(const Args &a) {
         extern __shared__ __attribute__((aligned(16))) char smem[];
         Ctx c;
@@ -131,6 +138,53 @@ struct L {
         const long traj = blockIdx.x, row0 = traj * a.T;
         const float cy = 1.0f / (ACT * WSC);
         f32x4 H[2][NTT], Y[2][NTT];
+        float am = 0.f;
+        if constexpr (HEAD) {
+            // x rows -> LDS planes (k = joint, zero-padded to 32), as the sampler's step kernel stages them
+            char *Qb = smem + LDS_Q;
+            const int J = a.J;
+            f16x8 we[2][2];
+            f32x4 be[2], pe4[2][NTT];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f16 *wp = a.w_emb + (long)(2 * c.w + n) * (2 * 512) + c.lane * 8;
+                we[n][0] = *reinterpret_cast<const f16x8 *>(wp);
+                we[n][1] = *reinterpret_cast<const f16x8 *>(wp + 512);
+                const int n0 = 32 * c.w + 16 * n + 4 * c.g;
+                be[n] = *reinterpret_cast<const f32x4 *>(a.b_emb + n0);
+#pragma unroll
+                for (int tt = 0; tt < NTT; ++tt) pe4[n][tt] = *reinterpret_cast<const f32x4 *>(a.pe + (long)K::tok_of(c, tt) * D + n0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float *xr = a.x_in + row0 * J;
+            const int nvec = a.T * J / 4;
+            for (int i = threadIdx.x; i < nvec; i += NTHREADS) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * i);
+                const int tok = (4 * i) / J, j0 = 4 * i - tok * J;
+                const int chunk = j0 >> 3;
+                split_store(Qb + K::q_off(tok, chunk) + 2 * (j0 & 7), Qb + K::q_off(tok, chunk | 4) + 2 * (j0 & 7), v);
+                if (j0 + 4 >= J) {
+                    const f16 z = (f16)0.f;
+                    const f16x4 z4 = {z, z, z, z};
+                    for (int k = J; k < 32; k += 4) {
+                        *reinterpret_cast<f16x4 *>(Qb + K::q_off(tok, k >> 3) + 2 * (k & 7)) = z4;
+                        *reinterpret_cast<f16x4 *>(Qb + K::q_off(tok, (k >> 3) | 4) + 2 * (k & 7)) = z4;
+                    }
+                }
+            }
+            __syncthreads();
+            const float c_e = 1.0f / WSC;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int tt = 0; tt < NTT; ++tt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    mma3<S_EMB>(acc, we[n][0], we[n][1], K::lds16(Qb + K::q_at(c, tt, 0, 0)), K::lds16(Qb + K::q_at(c, tt, 1, 0)));
+                    H[n][tt] = acc * c_e + (be[n] + pe4[n][tt]);
+                    if (K::tok_ok(c, tt))
+                        SD_NT_STORE(H[n][tt], reinterpret_cast<f32x4 *>(a.h3 + (row0 + K::tok_of(c, tt)) * D + 32 * c.w + 16 * n + 4 * c.g));
+                }
+        } else {
         // =========================== self-attention block ===========================
         zero(Y);
         float am_a = 0.f;
@@ -172,7 +226,7 @@ struct L {
             residual_epilogue(c, H, Y, bo, cy, a.d_sao, row0, a.h, a.h1, nullptr);
         }
         // =========================== LayerNorm 2, cross-attention query ===========================
-        float am = 0.f;
+        am = 0.f;
         K::template layer_norm_to_x<false>(c, H, a.n2_w, a.n2_b, a.n2 + row0 * D, &am);
         emit_amax(a.ax_n2, am, c.lane);
         zero(Y);
@@ -333,6 +387,7 @@ struct L {
             residual_epilogue(c, H, Y, b2, cy, a.d_ffn, row0, nullptr, a.h3, a.ax_out ? &am_o : nullptr);
             emit_amax(a.ax_out, am_o, c.lane);
         }
+        }   // !HEAD
         // =========================== the next layer's LayerNorm 1 and Q | K | V projection ===========================
         if (a.w_n) {
             am = 0.f;
@@ -356,7 +411,9 @@ struct L {
 };
 
 template <int NTT>
-__global__ __launch_bounds__(NTHREADS, 2) void train_layer_fwd_kernel(Args a) { L<NTT>::body(a); }
+__global__ __launch_bounds__(NTHREADS, 2) void train_layer_fwd_kernel(Args a) { L<NTT>::template body<false>(a); }
+template <int NTT>
+__global__ __launch_bounds__(NTHREADS, 2) void train_head_fwd_kernel(Args a) { L<NTT>::template body<true>(a); }
 
 // Every weight matrix of a model in ONE launch (after each optimizer step): matrix blockIdx.y = rows[y] x 256 floats at base + src[y]
 // -> planes at dst + dst_off[y] (halfs), the layout of pack_w16_kernel with the fixed scale WSC.
@@ -386,6 +443,18 @@ __global__ void pack_w16_multi_kernel(const float *__restrict__ base, const long
 }
 
 typedef void (*Fn)(Args);
+static Fn head_kernel_for(int ntt) {
+    switch (ntt) {
+        case 1: return train_head_fwd_kernel<1>;
+        case 2: return train_head_fwd_kernel<2>;
+        case 3: return train_head_fwd_kernel<3>;
+        case 4: return train_head_fwd_kernel<4>;
+        case 5: return train_head_fwd_kernel<5>;
+        case 6: return train_head_fwd_kernel<6>;
+        case 7: return train_head_fwd_kernel<7>;
+        default: return nullptr;
+    }
+}
 static Fn kernel_for(int ntt) {
     switch (ntt) {
         case 1: return train_layer_fwd_kernel<1>;
@@ -404,9 +473,9 @@ static Fn kernel_for(int ntt) {
 extern "C" size_t sd_pack_weight_traj_halfs(int N, int K) { return (size_t)((N + 15) / 16 * 16) * ((K + 31) / 32 * 32) * 2; }
 
 extern "C" int sd_pack_weight_traj(const float *w, int N, int K, void *planes, void *stream) {
-    if (!w || !planes || N <= 0 || K != tj::D) return fail(SD_E_BADARG, "sd_pack_weight_traj: weights must be (N, 256)");
-    const int Np = (N + 15) / 16 * 16;
-    SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)Np * (K / 8))), dim3(256), 0, (hipStream_t)stream, w, N, K, Np, K, (const unsigned *)nullptr, tjt::WSC,
+    if (!w || !planes || N <= 0 || !(K == tj::D || (K >= 1 && K <= 32))) return fail(SD_E_BADARG, "sd_pack_weight_traj: weights must be (N, 256) or (N, <= 32)");
+    const int Np = (N + 15) / 16 * 16, Kp = K == tj::D ? K : 32;
+    SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)Np * (Kp / 8))), dim3(256), 0, (hipStream_t)stream, w, N, K, Np, Kp, (const unsigned *)nullptr, tjt::WSC,
               (f16 *)planes, (float *)nullptr);
     SD_CHECK_LAUNCH("pack_w16_kernel");
     return 0;
@@ -461,5 +530,28 @@ extern "C" int sd_train_layer_fwd(const sd_train_layer_fwd_args *p, void *stream
     }
     SD_LAUNCH(fn, dim3((unsigned)p->B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, s, a);
     SD_CHECK_LAUNCH("train_layer_fwd_kernel");
+    return 0;
+}
+
+extern "C" int sd_train_head_fwd(const float *x, const void *w_emb, const float *b_emb, const float *pe, float *h0, const float *ln_w, const float *ln_b,
+                                 float *n1, const void *w_qkv, const float *b_qkv, float *qkv, uint32_t *amax_n1, int B, int T, int J, void *stream) {
+    if (!x || !w_emb || !b_emb || !pe || !h0 || !ln_w || !ln_b || !n1 || !w_qkv || !b_qkv || !qkv || B <= 0) return fail(SD_E_BADARG, "sd_train_head_fwd: null pointer or empty shape");
+    if (T < 1 || T > tj::TMAX || J < 4 || J > 32 || J % 4) return fail(SD_E_BADDIM, "sd_train_head_fwd: T <= 100, J a multiple of 4 up to 32 (hidden_dim 256)");
+    tjt::Args a{};
+    a.x_in = x; a.w_emb = (const f16 *)w_emb; a.b_emb = b_emb; a.pe = pe; a.J = J; a.h3 = h0;
+    a.nn_w = ln_w; a.nn_b = ln_b; a.nn1 = n1; a.w_n = (const f16 *)w_qkv; a.b_n = b_qkv; a.qkv2 = qkv; a.ax_nn = amax_n1;
+    a.T = T; a.B = B; a.M = 1;
+    const int ntt = (T + 15) / 16;
+    const tjt::Fn fn = tjt::head_kernel_for(ntt);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
+    static DevFlag attr_set[8];
+    if (!attr_set[ntt]) {
+        const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
+        if (e != hipSuccess) return fail((int)e, "train_head_fwd_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        attr_set[ntt] = true;
+    }
+    SD_LAUNCH(fn, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, s, a);
+    SD_CHECK_LAUNCH("train_head_fwd_kernel");
     return 0;
 }

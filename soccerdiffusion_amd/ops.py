@@ -586,6 +586,18 @@ def pack_weight_traj_multi(base: Tensor, src: Tensor, rows: Tensor, dst: Tensor,
                                                 planes.data_ptr(), _stream()), "sd_pack_weight_traj_multi")
 
 
+def train_head_fwd(x: Tensor, w_emb: int, b_emb: Tensor, pe: Tensor, ln, w_qkv: int, b_qkv: Tensor, amax_n1: Optional[int]):
+    """One launch of sd_train_head_fwd: (h0, n1, qkv) of the decoder stack's entry; w_emb / w_qkv are ADDRESSES of planes."""
+    _req(x, "x")
+    B, T, J = x.shape
+    h0 = torch.empty(B, T, 256, dtype=torch.float32, device=x.device)
+    n1 = torch.empty(B * T, 256, dtype=torch.float32, device=x.device)
+    qkv = torch.empty(B, T, 768, dtype=torch.float32, device=x.device)
+    check(_lib.load().sd_train_head_fwd(x.data_ptr(), w_emb, _addr(b_emb), _addr(pe), h0.data_ptr(), _addr(ln[0]), _addr(ln[1]), n1.data_ptr(), w_qkv,
+                                        _addr(b_qkv), qkv.data_ptr(), amax_n1, B, T, J, _stream()), "sd_train_head_fwd")
+    return h0, n1, qkv
+
+
 def train_layer_fwd_ok(d: int, heads: int, T: int, M: int) -> bool:
     return bool(_lib.load().sd_train_layer_fwd_ok(d, heads, T, M))
 

@@ -387,6 +387,42 @@ class _PatchEmbed(Function):
         return dx, rW, rb, None
 
 
+class _EmbedHead(Function):
+    """The decoder stack's entry as ONE trajectory-owning launch (sd_train_head_fwd): h0 = Linear(J -> 256)(x) + positional rows, and
+    - not differentiated here, as in _FusedLayer - n1 = LN1(h0), qkv = n1 Wqkv^T + b of layer 0.  The gradient of h0 goes where
+    _PatchEmbed sends it."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pe, n1w, n1b, Wqkv, bqkv, amax_n1: int):
+        ctx.save_for_backward(x, W, b)
+        x = x.contiguous()
+        w_emb = ops.pack_weight_traj(W.detach().contiguous())     # (256, J): a 4-us launch per step
+        h0, n1, qkv = ops.train_head_fwd(x, w_emb.data_ptr(), b.detach(), pe, (n1w.detach(), n1b.detach()), _packed_weight_traj(Wqkv), bqkv.detach(),
+                                         amax_n1)
+        ctx.mark_non_differentiable(n1, qkv)
+        return h0, n1, qkv
+
+    @staticmethod
+    def backward(ctx, dy, _dn, _dqkv):
+        x, W, b = ctx.saved_tensors
+        d = W.shape[0]
+        patches = x.reshape(-1, x.shape[-1])
+        (dW, db), (rW, rb) = _grad_targets(W, b)
+        ent = _amax_lookup(dy) if dy.is_contiguous() else None
+        dy2 = dy.contiguous().view(-1, d)
+        _dw_skinny(dy2, patches, dW.view(d, patches.shape[1]), db, known=dy2, small=patches, ent=ent)
+        return None, rW, rb, None, None, None, None, None, None
+
+
+def _embed_head_ok(gen, x: Tensor, layers) -> bool:
+    import os
+
+    W = gen.embedding.weight
+    J = x.shape[-1]
+    return (os.environ.get("SD_TRAIN_TRAJ", "1") != "0" and x.is_cuda and W.dim() == 2 and W.shape[0] == 256 and J % 4 == 0 and 4 <= J <= 32
+            and x.shape[1] <= 100 and gen.num_heads == 4 and _packed_weight_traj(layers[0].self_attn.in_proj_weight) is not None)
+
+
 class _FcOut(Function):
     """eps = h W^T + b with W (J, d)."""
 
@@ -793,19 +829,30 @@ class _FusedLayer(Function):
 FUSED_STACKS = [0]   # how many layer stacks went through the fused path (tests assert that it is the path that ran)
 
 
-def _fused_stack(layers, h: Tensor, heads: int, memory, dc, decoder: bool, hooks: bool) -> Tensor:
+def _fused_stack(layers, h, heads: int, memory, dc, decoder: bool, hooks: bool, embed=None) -> Tensor:
+    """``embed`` = (x, gen): the stack starts from the raw trajectory - embedding, LayerNorm 1 and the Q | K | V projection of layer 0 in
+    one trajectory-owning launch (_EmbedHead) - instead of from an embedded ``h``."""
     FUSED_STACKS[0] += 1
-    B, T, d = h.shape
-    h = h.contiguous()
     lp0 = layers[0]
-    amax = torch.zeros(len(layers) + 1, _AX_SLOTS, AMAX_WORDS, dtype=torch.int32, device=h.device)
+    dev = embed[0].device if embed is not None else h.device
+    d = lp0.norm1.weight.shape[0]
+    amax = torch.zeros(len(layers) + 1, _AX_SLOTS, AMAX_WORDS, dtype=torch.int32, device=dev)
     if memory is not None and d % 128 == 0:
         ops.absmax(memory.reshape(-1, d), amax.data_ptr() + 4 * AMAX_WORDS * _AX_MEM)
-    with torch.no_grad():
-        n1, qkv = _new(B * T, d, like=h), _new(B, T, 3 * d, like=h)
-        ops.train_fwd_chain(B * T, d, h.detach(), nln=(lp0.norm1.weight, lp0.norm1.bias), nn_out=n1,
-                            wn=_packed_weight(lp0.self_attn.in_proj_weight), bn=lp0.self_attn.in_proj_bias, y_out=qkv, n_next=3,
-                            amax=(None, None, None, amax.data_ptr() + 4 * AMAX_WORDS * _AX_N1))
+    if embed is not None:
+        x, gen = embed
+        pe = gen.positional_encoding.pe[0, : x.shape[1]].contiguous()
+        h, n1, qkv = _EmbedHead.apply(x, gen.embedding.weight, gen.embedding.bias, pe, lp0.norm1.weight, lp0.norm1.bias, lp0.self_attn.in_proj_weight,
+                                      lp0.self_attn.in_proj_bias, amax.data_ptr() + 4 * AMAX_WORDS * _AX_N1)
+        B, T, d = h.shape
+    else:
+        B, T, d = h.shape
+        h = h.contiguous()
+        with torch.no_grad():
+            n1, qkv = _new(B * T, d, like=h), _new(B, T, 3 * d, like=h)
+            ops.train_fwd_chain(B * T, d, h.detach(), nln=(lp0.norm1.weight, lp0.norm1.bias), nn_out=n1,
+                                wn=_packed_weight(lp0.self_attn.in_proj_weight), bn=lp0.self_attn.in_proj_bias, y_out=qkv, n_next=3,
+                                amax=(None, None, None, amax.data_ptr() + 4 * AMAX_WORDS * _AX_N1))
     for li, lp in enumerate(layers):
         if hooks:
             _layer_input_hook(h, li)
@@ -818,10 +865,14 @@ def denoiser_forward_autograd(gen, x: Tensor, memory: Tensor) -> Tensor:
     """Differentiable DiffusionActionGenerator.forward (reference ml/model/decoder.py:38-54)."""
     T = x.shape[1]
     pe = gen.positional_encoding.pe[0, :T].contiguous()
-    h = _PatchEmbed.apply(x, gen.embedding.weight, gen.embedding.bias, pe)
     memory = memory.contiguous()
     dc = gen.dropout.for_call(gen.training)
     layers = list(gen.transformer_decoder.layers)
+    d_model = gen.embedding.weight.shape[0]
+    if _fused_ok(layers, d_model, decoder=True) and _embed_head_ok(gen, x, layers):
+        h = _fused_stack(layers, None, gen.num_heads, memory, dc, decoder=True, hooks=True, embed=(x, gen))
+        return _FcOut.apply(h, gen.fc_out.weight, gen.fc_out.bias)
+    h = _PatchEmbed.apply(x, gen.embedding.weight, gen.embedding.bias, pe)
     if _fused_ok(layers, h.shape[-1], decoder=True):
         h = _fused_stack(layers, h, gen.num_heads, memory, dc, decoder=True, hooks=True)
     else:
