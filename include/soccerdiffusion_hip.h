@@ -379,31 +379,10 @@ int sd_train_layer_fwd(const sd_train_layer_fwd_args *args, void *stream);
  * sd_train_fwd_chain in one.  x (B,T,J), J a multiple of 4 up to 32; w_emb / w_qkv: planes from sd_pack_weight_traj ((256, J) and (768, 256)). */
 int sd_train_head_fwd(const float *x, const void *w_emb, const float *b_emb, const float *pe, float *h0, const float *ln_w, const float *ln_b,
                       float *n1, const void *w_qkv, const float *b_qkv, float *qkv, uint32_t *amax_n1, int B, int T, int J, void *stream);
-/* The backward row chains of a decoder layer in the same geometry, between its two attention-backward launches (sd_train_bwd_chain's
- * semantics, a workgroup per trajectory, every GEMM input with one power-of-two scale per token):
- *   kind 1: g = mask_{site_in}(dy = dh3) -> dym;  t = g W2;  dpre = t o gelu'(pre) o mask_{site_act} -> dpre;  t = dpre W1;
- *           dh2 = LayerNorm-backward(t; x = h2, ln_w) + dres (= dh3) -> dx;  dg / db += (atomics);
- *           dym2 = mask_{site_out2}(dh2) -> dym2;  da = dym2 Woc -> da                           (wt_a, wt_b, wt_c = W2^T, W1^T, Woc^T)
- *   kind 2: t = dy (= dq) Wq;  dh1 = LayerNorm-backward(t; x = h1) + dres (= dh2) -> dx;  dym2 = mask(dh1);  da = dym2 Wo   (wt_a = Wq^T, wt_c = Wo^T)
- *   kind 3: t = sum_p dy[:, p] W_in[p] (dy = dqkv, row stride ld >= 768);  dh = LayerNorm-backward(t; x = h) + dres (= dh1) -> dx
- *           (wt_a, wt_b, wt_c = the q, k, v blocks of W_in, each transposed)
- * dym / dym2 may be NULL when p = 0 (the masked gradient is the gradient).  wt_*: planes of the TRANSPOSED 256 x 256 blocks
- * (sd_pack_weight_traj_multi with a negative row count).  amax_*: SD_AMAX_WORDS words each or NULL (max |masked dy|, |dpre|, |dym2|, |dx|). */
-typedef struct sd_train_layer_bwd_args {
-    int32_t kind, B, T, ld;
-    const float *dy; float *dym; const float *pre; float *dpre;
-    const void *wt_a, *wt_b, *wt_c;
-    const float *x, *ln_w; float *dg, *db; const float *dres; float *dx; float *dym2, *da;
-    float p;
-    uint64_t seed, site_in, site_act, site_out2;
-    uint32_t *amax_dy, *amax_dpre, *amax_dy2, *amax_dx;
-} sd_train_layer_bwd_args;
-int sd_train_layer_bwd(const sd_train_layer_bwd_args *args, void *stream);
 size_t sd_pack_weight_traj_halfs(int N, int K);
 int sd_pack_weight_traj(const float *w, int N, int K, void *planes, void *stream);
 /* n matrices in one launch: matrix i = rows[i] x 256 floats at base + src_offsets[i] (floats; rows multiples of 16) -> planes +
- * dst_offsets[i] (halfs); rows[i] = -256: the TRANSPOSE of that 256 x 256 block; the three arrays are DEVICE arrays, max_rows = the
- * largest |rows[i]|. */
+ * dst_offsets[i] (halfs); the three arrays are DEVICE arrays, max_rows = the largest rows[i]. */
 int sd_pack_weight_traj_multi(const float *base, const int64_t *src_offsets, const int32_t *rows, const int64_t *dst_offsets, int n,
                               int max_rows, void *planes, void *stream);
 

@@ -75,15 +75,6 @@ class TrainLayerFwdArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("amax_a_sa", "amax_n2", "amax_a_ca", "amax_nf", "amax_u", "amax_nn", "amax_out")])
 
 
-class TrainLayerBwdArgs(C.Structure):
-    """sd_train_layer_bwd_args (field order = header order)."""
-
-    _fields_ = ([(n, C.c_int32) for n in ("kind", "B", "T", "ld")]
-                + [(n, C.c_void_p) for n in ("dy", "dym", "pre", "dpre", "wt_a", "wt_b", "wt_c", "x", "ln_w", "dg", "db", "dres", "dx", "dym2", "da")]
-                + [("p", C.c_float)] + [(n, C.c_uint64) for n in ("seed", "site_in", "site_act", "site_out2")]
-                + [(n, C.c_void_p) for n in ("amax_dy", "amax_dpre", "amax_dy2", "amax_dx")])
-
-
 class TrainBwdChainArgs(C.Structure):
     """sd_train_bwd_chain_args (field order = header order)."""
 
@@ -157,7 +148,6 @@ SIGNATURES = {
     "sd_set_dropout_epoch": (C.c_int, [C.c_void_p]),
     "sd_train_layer_fwd_ok": (C.c_int, [C.c_int] * 4),
     "sd_train_layer_fwd": (C.c_int, [C.POINTER(TrainLayerFwdArgs), C.c_void_p]),
-    "sd_train_layer_bwd": (C.c_int, [C.POINTER(TrainLayerBwdArgs), C.c_void_p]),
     "sd_train_head_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 3 + [C.c_void_p]),
     "sd_pack_weight_traj_halfs": (C.c_size_t, [C.c_int, C.c_int]),
     "sd_pack_weight_traj": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -410,292 +410,6 @@ struct L {
     }
 };
 
-// ---------------------------------------------------------------------------------------------------
-// Backward row chains in the same geometry (sd_train_layer_bwd): the dX GEMMs, the GELU / LayerNorm backward and the dropout masks between
-// the two attention-backward launches of a decoder layer, a workgroup per trajectory:
-//   kind 1  [dh3 -> mask -> dym][dym W2][o gelu'(pre) o mask -> dpre][dpre W1][LayerNorm-3 backward + dh3 -> dh2; dgamma, dbeta]
-//           [dh2 -> mask -> dym_c][dym_c Woc -> da_ca]                     (sd_train_bwd_chain: feed-forward chain + cross-attention out-projection chain)
-//   kind 2  [dq Wq][LayerNorm-2 backward + dh2 -> dh1][dh1 -> mask -> dym_s][dym_s Wo -> da_sa]
-//   kind 3  [sum over the three blocks of dqkv W_in][LayerNorm-1 backward + dh1 -> dh]
-// Gradients have no a-priori magnitude: every GEMM input gets ONE power-of-two scale per TOKEN (its abs-max over the 256 features,
-// exchanged over the 8 waves through LDS), un-scaled per accumulator column - the token is the lane.  Weights: planes of the TRANSPOSED
-// blocks (pack_w16_multi_kernel, negative row count).
-// ---------------------------------------------------------------------------------------------------
-struct BArgs {
-    const float *dy;   // [R][ld]: dh3 / dq / dqkv
-    int ld;
-    float *dym;        // kind 1: masked dh3 (NULL: p = 0)
-    const float *pre;
-    float *dpre;
-    const f16 *wt_a, *wt_b, *wt_c;   // kind 1: W2^T, W1^T, Woc^T;  kind 2: Wq^T, -, Wo^T;  kind 3: the q, k, v blocks of W_in, transposed
-    const float *x, *ln_w;           // LayerNorm input rows (h2 / h1 / h), gamma
-    float *dg, *db;
-    const float *dres;               // kind 1: dh3 itself; kind 2: dh2; kind 3: dh1
-    float *dx;                       // dh2 / dh1 / dh
-    float *dym2, *da;                // kind 1: dym_c, da_ca;  kind 2: dym_s, da_sa
-    DropoutArgs d_in, d_act, d_out2;
-    unsigned *ax_dy, *ax_dpre, *ax_dy2, *ax_dx;
-    int T, B;
-};
-
-template <int NTT>
-struct LB {
-    using K = TJ<NTT, true>;
-    using F = L<NTT>;
-
-    static __device__ __forceinline__ void load_rows(const Ctx &c, f32x4 (&Y)[2][NTT], const float *base, int ld) {
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) Y[a2][tt] = *reinterpret_cast<const f32x4 *>(base + (long)K::tok_of(c, tt) * ld + 32 * c.w + 16 * a2 + 4 * c.g);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    static __device__ __forceinline__ void store_rows(const Ctx &c, const f32x4 (&Y)[2][NTT], float *base) {
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            if (!K::tok_ok(c, tt)) continue;
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) SD_NT_STORE(Y[a2][tt], reinterpret_cast<f32x4 *>(base + (long)K::tok_of(c, tt) * D + 32 * c.w + 16 * a2 + 4 * c.g));
-        }
-    }
-    // mask of dropout site d on rows of logical width 256 (the forward's indices)
-    static __device__ __forceinline__ void mask_rows(const Ctx &c, f32x4 (&Y)[2][NTT], const DropoutArgs &d, long row0) {
-        if (!d.thresh) return;
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const unsigned long row = (unsigned long)(row0 + K::tok_of(c, tt));
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) Y[a2][tt] = Y[a2][tt] * dropout_quad(d, row * (D / 4) + (unsigned long)((32 * c.w + 16 * a2 + 4 * c.g) >> 2));
-        }
-    }
-    // one value per (token, wave) through LDS: every lane gets the 8 waves' values of its tokens.  `region`: 100 x 8 floats.
-    template <class Get, class Put>
-    static __device__ __forceinline__ void exchange(const Ctx &c, float *region, Get get, Put put) {
-        if (c.g == 0) {
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt)
-                if (K::tok_ok(c, tt)) region[K::tok_of(c, tt) * 8 + c.w] = get(tt);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const float *sp = region + K::tok_of(c, tt) * 8;
-            put(tt, *reinterpret_cast<const f32x4 *>(sp), *reinterpret_cast<const f32x4 *>(sp + 4));
-        }
-    }
-    // Y -> the X panel as split planes with one power-of-two scale per token; inv[tt] = 1 / scale of this lane's token in tile tt.
-    // Two barriers: the first also fences the panel's previous readers.  amax: running max |Y| over valid tokens.
-    static __device__ __forceinline__ void scaled_to_x(const Ctx &c0, const f32x4 (&Y)[2][NTT], float (&inv)[NTT], float *amax) {
-        const Ctx c = K::ctx_local(c0);
-        float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
-        float m[NTT];
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) m[tt] = rows4_max(fmaxf(max4(Y[0][tt]), max4(Y[1][tt])));
-        float sc[NTT];
-        exchange(c, stat, [&](int tt) __attribute__((always_inline)) { return m[tt]; },
-                 [&](int tt, const f32x4 &p0, const f32x4 &p1) __attribute__((always_inline)) {
-                     const float mm = fmaxf(fmaxf(fmaxf(p0[0], p0[1]), fmaxf(p0[2], p0[3])), fmaxf(fmaxf(p1[0], p1[1]), fmaxf(p1[2], p1[3])));
-                     sc[tt] = f16_scale_from_bits(__builtin_bit_cast(unsigned, mm));
-                     if (amax && K::tok_ok(c, tt)) *amax = fmaxf(*amax, mm);
-                 });
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            inv[tt] = 1.0f / sc[tt];
-            K::store_x(c, tt, Y[0][tt] * sc[tt], Y[1][tt] * sc[tt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-    template <int SITE>
-    static __device__ __forceinline__ void gemm_unscaled(const Ctx &c, f32x4 (&A)[2][NTT], const f16 *wt, const float (&inv)[NTT], bool accumulate) {
-        f32x4 U[2][NTT];
-        F::zero(U);
-        K::template gemm_x2<SITE>(K::ctx_local(c), U, wt);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const float f = inv[tt] * (1.0f / WSC);
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) A[a2][tt] = accumulate ? A[a2][tt] + U[a2][tt] * f : U[a2][tt] * f;
-        }
-    }
-    // Tn (gradient of the LayerNorm output) -> dx = LN-backward(Tn; x, gamma) + dres, in place; dgamma / dbeta of this trajectory's rows
-    // added to dg / db with fp32 atomics (one per feature and workgroup).
-    static __device__ __forceinline__ void ln_bwd(const Ctx &c0, f32x4 (&Tn)[2][NTT], const float *x_rows, const float *ln_w, float *dg, float *db,
-                                                  const float *dres_rows) {
-        const Ctx c = K::ctx_local(c0);
-        float *r1 = reinterpret_cast<float *>(c.smem + LDS_Q), *r2 = r1 + 1024, *r3 = r1 + 2048, *r4 = r1 + 3072;
-        f32x4 X[2][NTT];
-        load_rows(c, X, x_rows, D);
-        f32x4 gam[2];
-#pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2) gam[a2] = *reinterpret_cast<const f32x4 *>(ln_w + 32 * c.w + 16 * a2 + 4 * c.g);
-        float mean[NTT], rstd[NTT];
-        {
-            float s[NTT];
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                const f32x4 t4 = X[0][tt] + X[1][tt];
-                s[tt] = rows4_sum((t4[0] + t4[1]) + (t4[2] + t4[3]));
-            }
-            exchange(c, r1, [&](int tt) __attribute__((always_inline)) { return s[tt]; },
-                     [&](int tt, const f32x4 &p0, const f32x4 &p1) __attribute__((always_inline)) {
-                         mean[tt] = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.0f / D);
-                     });
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) {
-                X[0][tt] = X[0][tt] - mean[tt];
-                X[1][tt] = X[1][tt] - mean[tt];
-                const f32x4 q4 = X[0][tt] * X[0][tt] + X[1][tt] * X[1][tt];
-                s[tt] = rows4_sum((q4[0] + q4[1]) + (q4[2] + q4[3]));
-            }
-            exchange(c, r2, [&](int tt) __attribute__((always_inline)) { return s[tt]; },
-                     [&](int tt, const f32x4 &p0, const f32x4 &p1) __attribute__((always_inline)) {
-                         const float v = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.0f / D);
-                         rstd[tt] = 1.0f / sqrtf(v + SD_LN_EPS);
-                     });
-        }
-        f32x4 dgam[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dbet[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float s1[NTT], s2[NTT];
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-            const bool ok = K::tok_ok(c, tt);
-            f32x4 gsum = {0.f, 0.f, 0.f, 0.f}, gxsum = gsum;
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) {
-                X[a2][tt] = X[a2][tt] * rstd[tt];                       // xhat
-                if (ok) {
-                    dgam[a2] = dgam[a2] + Tn[a2][tt] * X[a2][tt];
-                    dbet[a2] = dbet[a2] + Tn[a2][tt];
-                }
-                Tn[a2][tt] = Tn[a2][tt] * gam[a2];                      // g = dn o gamma
-                gsum = gsum + Tn[a2][tt];
-                gxsum = gxsum + Tn[a2][tt] * X[a2][tt];
-            }
-            s1[tt] = rows4_sum((gsum[0] + gsum[1]) + (gsum[2] + gsum[3]));
-            s2[tt] = rows4_sum((gxsum[0] + gxsum[1]) + (gxsum[2] + gxsum[3]));
-        }
-        float c1[NTT], c2[NTT];
-        exchange(c, r3, [&](int tt) __attribute__((always_inline)) { return s1[tt]; },
-                 [&](int tt, const f32x4 &p0, const f32x4 &p1) __attribute__((always_inline)) {
-                     c1[tt] = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.0f / D);
-                 });
-        exchange(c, r4, [&](int tt) __attribute__((always_inline)) { return s2[tt]; },
-                 [&](int tt, const f32x4 &p0, const f32x4 &p1) __attribute__((always_inline)) {
-                     c2[tt] = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) * (1.0f / D);
-                 });
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) Tn[a2][tt] = (Tn[a2][tt] - c1[tt] - X[a2][tt] * c2[tt]) * rstd[tt];
-        __builtin_amdgcn_sched_barrier(0);
-        if (dres_rows) {   // the residual branch's gradient, into the registers x-hat no longer needs
-            load_rows(c, X, dres_rows, D);
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-                for (int a2 = 0; a2 < 2; ++a2) Tn[a2][tt] = Tn[a2][tt] + X[a2][tt];
-        }
-        // dgamma / dbeta: over the 16 token lanes of a tile row, then one atomic per feature
-#pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float ga = dgam[a2][r], be = dbet[a2][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    ga += __shfl_xor(ga, o, 64);
-                    be += __shfl_xor(be, o, 64);
-                }
-                if (c.t == 0) {
-                    atomicAdd(dg + 32 * c.w + 16 * a2 + 4 * c.g + r, ga);
-                    atomicAdd(db + 32 * c.w + 16 * a2 + 4 * c.g + r, be);
-                }
-            }
-    }
-
-    template <int KIND>
-    static __device__ __forceinline__ void body(const BArgs &a) {
-        extern __shared__ __attribute__((aligned(16))) char smem[];
-        Ctx c;
-        K::ctx_init(c, smem, a.T);
-        const long row0 = (long)blockIdx.x * a.T;
-        f32x4 Y[2][NTT], A[2][NTT];
-        float inv[NTT], am;
-        if constexpr (KIND == 3) {
-#pragma unroll 1
-            for (int p = 0; p < 3; ++p) {
-                load_rows(c, Y, a.dy + row0 * a.ld + p * D, a.ld);
-                am = 0.f;
-                scaled_to_x(c, Y, inv, &am);
-                emit_amax(a.ax_dy, am, c.lane);
-                gemm_unscaled<S_QKV>(c, A, p == 0 ? a.wt_a : p == 1 ? a.wt_b : a.wt_c, inv, p > 0);
-            }
-        } else {
-            load_rows(c, Y, a.dy + row0 * a.ld, a.ld);
-            if constexpr (KIND == 1) {
-                mask_rows(c, Y, a.d_in, row0);
-                if (a.dym) store_rows(c, Y, a.dym + row0 * D);
-            }
-            am = 0.f;
-            scaled_to_x(c, Y, inv, &am);
-            emit_amax(a.ax_dy, am, c.lane);
-            gemm_unscaled<S_W2>(c, A, a.wt_a, inv, false);
-            if constexpr (KIND == 1) {   // back through the GELU: dpre = t o gelu'(pre) o mask, kept for dW1
-                load_rows(c, Y, a.pre + row0 * D, D);
-#pragma unroll
-                for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) A[a2][tt][r] *= gelu_grad_fast(Y[a2][tt][r]);
-                mask_rows(c, A, a.d_act, row0);
-                store_rows(c, A, a.dpre + row0 * D);
-                am = 0.f;
-                scaled_to_x(c, A, inv, &am);
-                emit_amax(a.ax_dpre, am, c.lane);
-                gemm_unscaled<S_W1>(c, A, a.wt_b, inv, false);
-            }
-        }
-        // LayerNorm backward (+ the residual branch's gradient)
-        ln_bwd(c, A, a.x + row0 * D, a.ln_w, a.dg, a.db, a.dres + row0 * D);
-        store_rows(c, A, a.dx + row0 * D);
-        if (a.ax_dx) {
-            am = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < NTT; ++tt)
-                if (K::tok_ok(c, tt)) am = fmaxf(am, fmaxf(max4(A[0][tt]), max4(A[1][tt])));
-            emit_amax(a.ax_dx, am, c.lane);
-        }
-        if constexpr (KIND != 3) {   // the attention's out-projection in front of this block: da = (dx o mask) W
-            mask_rows(c, A, a.d_out2, row0);
-            if (a.dym2) store_rows(c, A, a.dym2 + row0 * D);
-            am = 0.f;
-            scaled_to_x(c, A, inv, &am);
-            emit_amax(a.ax_dy2, am, c.lane);
-            gemm_unscaled<S_OUT>(c, Y, a.wt_c, inv, false);
-            store_rows(c, Y, a.da + row0 * D);
-        }
-    }
-};
-
-template <int NTT, int KIND>
-__global__ __launch_bounds__(NTHREADS, 2) void train_layer_bwd_kernel(BArgs a) { LB<NTT>::template body<KIND>(a); }
-
-typedef void (*BFn)(BArgs);
-template <int KIND>
-static BFn bwd_kernel_for(int ntt) {
-    switch (ntt) {
-        case 1: return train_layer_bwd_kernel<1, KIND>;
-        case 2: return train_layer_bwd_kernel<2, KIND>;
-        case 3: return train_layer_bwd_kernel<3, KIND>;
-        case 4: return train_layer_bwd_kernel<4, KIND>;
-        case 5: return train_layer_bwd_kernel<5, KIND>;
-        case 6: return train_layer_bwd_kernel<6, KIND>;
-        case 7: return train_layer_bwd_kernel<7, KIND>;
-        default: return nullptr;
-    }
-}
-
 template <int NTT>
 __global__ __launch_bounds__(NTHREADS, 2) void train_layer_fwd_kernel(Args a) { L<NTT>::template body<false>(a); }
 template <int NTT>
@@ -705,9 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void train_head_fwd_kernel(Args a) { L
 // -> planes at dst + dst_off[y] (halfs), the layout of pack_w16_kernel with the fixed scale WSC.
 __global__ void pack_w16_multi_kernel(const float *__restrict__ base, const long *__restrict__ src, const int *__restrict__ rows,
                                       const long *__restrict__ dst_off, f16 *__restrict__ dst) {
-    const int y = blockIdx.y;
-    const bool tr = rows[y] < 0;              // a negative row count: the TRANSPOSE of a 256 x 256 block (the dX GEMMs of the backward)
-    const int N = tr ? -rows[y] : rows[y];
+    const int y = blockIdx.y, N = rows[y];
     const float *W = base + src[y];
     f16 *out = dst + dst_off[y];
     const long total = (long)N * (D / 8);
@@ -716,7 +428,7 @@ __global__ void pack_w16_multi_kernel(const float *__restrict__ base, const long
         f16 hh[8], ll[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = (tr ? W[(long)kperm(k8, e) * D + n] : W[(long)n * D + kperm(k8, e)]) * WSC;
+            const float v = W[(long)n * D + kperm(k8, e)] * WSC;
             hh[e] = (f16)v;
             ll[e] = (f16)(v - (float)hh[e]);
         }
@@ -841,39 +553,5 @@ extern "C" int sd_train_head_fwd(const float *x, const void *w_emb, const float 
     }
     SD_LAUNCH(fn, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, s, a);
     SD_CHECK_LAUNCH("train_head_fwd_kernel");
-    return 0;
-}
-
-extern "C" int sd_train_layer_bwd(const sd_train_layer_bwd_args *p, void *stream) {
-    if (!p || p->B <= 0 || p->kind < 1 || p->kind > 3) return fail(SD_E_BADARG, "sd_train_layer_bwd: bad argument");
-    if (p->T < 1 || p->T > tj::TMAX) return fail(SD_E_BADDIM, "sd_train_layer_bwd: T <= 100 (hidden_dim 256)");
-    if (!p->dy || !p->wt_a || !p->x || !p->ln_w || !p->dg || !p->db || !p->dres || !p->dx) return fail(SD_E_BADARG, "sd_train_layer_bwd: null pointer");
-    if (p->kind == 1 && (!p->pre || !p->dpre || !p->wt_b)) return fail(SD_E_BADARG, "sd_train_layer_bwd: kind 1 needs pre, dpre, wt_b");
-    if (p->kind != 3 && (!p->wt_c || !p->da)) return fail(SD_E_BADARG, "sd_train_layer_bwd: kinds 1 and 2 need wt_c, da");
-    if (p->kind == 3 && (!p->wt_b || !p->wt_c)) return fail(SD_E_BADARG, "sd_train_layer_bwd: kind 3 needs the three blocks wt_a, wt_b, wt_c");
-    if (p->ld < tj::D || p->ld % 4 || (p->kind == 3 && p->ld < 3 * tj::D)) return fail(SD_E_BADARG, "sd_train_layer_bwd: bad row stride");
-    if (!(p->p >= 0.f) || !(p->p < 1.f)) return fail(SD_E_BADARG, "sd_train_layer_bwd: p must be in [0, 1)");
-    if (p->p > 0.f && ((p->kind == 1 && !p->dym) || (p->kind != 3 && !p->dym2))) return fail(SD_E_BADARG, "sd_train_layer_bwd: the masked gradients need their buffers when p > 0");
-    tjt::BArgs a;
-    a.dy = p->dy; a.ld = p->ld; a.dym = p->dym; a.pre = p->pre; a.dpre = p->dpre;
-    a.wt_a = (const f16 *)p->wt_a; a.wt_b = (const f16 *)p->wt_b; a.wt_c = (const f16 *)p->wt_c;
-    a.x = p->x; a.ln_w = p->ln_w; a.dg = p->dg; a.db = p->db; a.dres = p->dres; a.dx = p->dx; a.dym2 = p->dym2; a.da = p->da;
-    a.d_in = make_dropout(p->kind == 1 ? p->p : 0.f, p->seed, p->site_in);
-    a.d_act = make_dropout(p->kind == 1 ? p->p : 0.f, p->seed, p->site_act);
-    a.d_out2 = make_dropout(p->kind != 3 ? p->p : 0.f, p->seed, p->site_out2);
-    a.ax_dy = p->amax_dy; a.ax_dpre = p->amax_dpre; a.ax_dy2 = p->amax_dy2; a.ax_dx = p->amax_dx;
-    a.T = p->T; a.B = p->B;
-    const int ntt = (p->T + 15) / 16;
-    const tjt::BFn fn = p->kind == 1 ? tjt::bwd_kernel_for<1>(ntt) : p->kind == 2 ? tjt::bwd_kernel_for<2>(ntt) : tjt::bwd_kernel_for<3>(ntt);
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(SD_KCLASS_LAYER_CHAIN, s);
-    static DevFlag attr_set[4][8];
-    if (!attr_set[p->kind][ntt]) {
-        const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
-        if (e != hipSuccess) return fail((int)e, "train_layer_bwd_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        attr_set[p->kind][ntt] = true;
-    }
-    SD_LAUNCH(fn, dim3((unsigned)p->B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, s, a);
-    SD_CHECK_LAUNCH("train_layer_bwd_kernel");
     return 0;
 }

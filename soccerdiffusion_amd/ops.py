@@ -586,19 +586,6 @@ def pack_weight_traj_multi(base: Tensor, src: Tensor, rows: Tensor, dst: Tensor,
                                                 planes.data_ptr(), _stream()), "sd_pack_weight_traj_multi")
 
 
-def train_layer_bwd(kind: int, B: int, T: int, dy: Tensor, *, wt_a: int, x: Tensor, ln_w: Tensor, dg: Tensor, db: Tensor, dres: Tensor, dx: Tensor,
-                    wt_b=None, wt_c=None, dym=None, pre=None, dpre=None, dym2=None, da=None, p: float = 0.0, seed: int = 0, sites=(0, 0, 0),
-                    amax=(None, None, None, None)) -> None:
-    """One launch of sd_train_layer_bwd (kind 1 / 2 / 3, include/soccerdiffusion_hip.h).  ``dy`` (B*T, 256 or 768) may be a row-strided
-    view; ``wt_*`` are ADDRESSES of the transposed blocks' planes; ``sites`` = (mask of dy, mask after the GELU, mask of dx)."""
-    dyp, ld = _rows(dy, "dy")
-    args = _lib.TrainLayerBwdArgs(kind=kind, B=B, T=T, ld=ld, dy=dyp, dym=_addr(dym), pre=_addr(pre), dpre=_addr(dpre), wt_a=wt_a, wt_b=wt_b, wt_c=wt_c,
-                                  x=_addr(x), ln_w=_addr(ln_w), dg=_addr(dg), db=_addr(db), dres=_addr(dres), dx=_addr(dx), dym2=_addr(dym2), da=_addr(da),
-                                  p=float(p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF, site_in=int(sites[0]), site_act=int(sites[1]), site_out2=int(sites[2]),
-                                  amax_dy=amax[0], amax_dpre=amax[1], amax_dy2=amax[2], amax_dx=amax[3])
-    check(_lib.load().sd_train_layer_bwd(C.byref(args), _stream()), "sd_train_layer_bwd")
-
-
 def train_head_fwd(x: Tensor, w_emb: int, b_emb: Tensor, pe: Tensor, ln, w_qkv: int, b_qkv: Tensor, amax_n1: Optional[int]):
     """One launch of sd_train_head_fwd: (h0, n1, qkv) of the decoder stack's entry; w_emb / w_qkv are ADDRESSES of planes."""
     _req(x, "x")

@@ -100,9 +100,8 @@ def _packed_weight(W: Tensor, p: int = 0, transposed: bool = False):
 # Planes of whole weight matrices in the 16 x 16 x 32 fragment order of the trajectory kernels (csrc/sd_traj.h), for the layer-forward
 # kernel sd_train_layer_fwd: a second, lazily built set beside flat_wpk.  A matrix registers with its optimizer on first use (in the
 # eager warm-up steps of a graphed loop); from then on FusedAdamW.refresh_transposes repacks every registered matrix in one launch.
-def _packed_weight_traj(W: Tensor, row0: int = 0, rows: Optional[int] = None, transposed: bool = False):
-    """Address of the trajectory-kernel planes of rows [row0, row0 + rows) of W (N x 256, row-major, owned by a FusedAdamW) - or, with
-    ``transposed``, of the transpose of that 256 x 256 block (the dX GEMMs of the backward) - else None."""
+def _packed_weight_traj(W: Tensor, row0: int = 0, rows: Optional[int] = None):
+    """Address of the trajectory-kernel planes of rows [row0, row0 + rows) of W (N x 256, row-major, owned by a FusedAdamW), else None."""
     d = W.shape[1]
     if d != 256 or W.stride() != (d, 1):
         return None
@@ -111,7 +110,7 @@ def _packed_weight_traj(W: Tensor, row0: int = 0, rows: Optional[int] = None, tr
         return None
     opt = ent[0]
     rows = W.shape[0] - row0 if rows is None else rows
-    return opt.traj_planes(W, row0, rows, transposed)
+    return opt.traj_planes(W, row0, rows)
 
 
 def _linear(A: Tensor, W: Tensor, b, ln=None, res=None, drop=None) -> Tensor:
@@ -619,7 +618,6 @@ def _mem_side(device):
 
 
 TRAJ_LAYERS = [0]   # decoder layers whose forward ran as ONE trajectory-owning launch (tests assert which path ran)
-TRAJ_BWD_LAYERS = [0]   # ... and whose backward row chains ran as trajectory-owning launches
 
 
 def _traj_layer_weights(cfg, P, h: Tensor, memory: Tensor):
@@ -696,7 +694,6 @@ class _FusedLayer(Function):
                 _amax_register(h3, cfg.amax, cfg.ax(_AX_OUT), cfg.ax(_AX_SCR))
             ctx.cfg = cfg
             ctx.n_c = 6
-            ctx.traj = True
             ctx.set_materialize_grads(False)
             ctx.save_for_backward(h, n1, qkv, memory, a_sa, lse_sa, h2, nf, pre, u, h1, n2, q, kv, a_ca, lse_ca, *P)
             ctx.mark_non_differentiable(nn1, qkv2)
@@ -762,10 +759,6 @@ class _FusedLayer(Function):
         dh3 = dh3.contiguous()
         dh3_2 = dh3.view(R, d)
 
-        if dec and getattr(ctx, "traj", False):
-            tb = _traj_layer_bwd_weights(P)
-            if tb is not None:
-                return _FusedLayer._backward_traj(ctx, cfg, sv, P, g, G, direct, dh3, tb)
         # feed-forward block: dy -> mask -> W2^T -> gelu' o mask -> W1^T -> LayerNorm backward (+ dy)
         dym, dpre, dh2 = (_new(R, d, like=h) if p > 0 else dh3_2), _new(R, d, like=h), _new(B, T, d, like=h)
         ops.train_bwd_chain(R, d, dh3_2, wT(W2), dh2, dym=dym if p > 0 else None, pre=pre, dpre=dpre, wt1=wT(W1), x=h2, ln_w=nfw,
@@ -831,79 +824,6 @@ class _FusedLayer(Function):
             for dY, X, dW, db, _, _ in dws:
                 _dw(dY, X, dW, db)
         return (dh, None, None, dmem, None) + tuple(None if direct else t for t in G)
-
-    @staticmethod
-    def _backward_traj(ctx, cfg, sv, P, g, G, direct, dh3, tb):
-        """The decoder layer's backward with its five row chains as three trajectory-owning launches (sd_train_layer_bwd) around the
-        two attention-backward launches; weight gradients and the memory side as in ``backward``."""
-        heads, p, seed = cfg.heads, cfg.p, cfg.seed
-        h, n1, qkv, memory, a_sa, lse_sa, h2, nf, pre, u = sv[:10]
-        h1, n2, q, kv, a_ca, lse_ca = sv[10:16]
-        (n1w, n1b, Wqkv, bqkv, Wo, bo, n2w, n2b, Wc, bc, Woc, boc, nfw, nfb, W1, b1, W2, b2) = P
-        B, T, d = h.shape
-        R = B * T
-        TRAJ_BWD_LAYERS[0] += 1
-        dh3_2 = dh3.view(R, d)
-        mk = (lambda: _new(R, d, like=h)) if p > 0 else (lambda: None)
-        # kind 1: feed-forward block + the cross-attention's out-projection
-        dym, dpre, dh2, dym_c, da_ca = mk(), _new(R, d, like=h), _new(B, T, d, like=h), mk(), _new(B, T, d, like=h)
-        ops.train_layer_bwd(1, B, T, dh3_2, wt_a=tb["w2"], wt_b=tb["w1"], wt_c=tb["woc"], x=h2, ln_w=nfw, dg=g["norm3.weight"], db=g["norm3.bias"],
-                            dres=dh3, dx=dh2, dym=dym, pre=pre, dpre=dpre, dym2=dym_c, da=da_ca, p=p, seed=seed,
-                            sites=(cfg.site(SITE_FFN_OUT), cfg.site(SITE_FFN_ACT), cfg.site(SITE_CA_OUT)),
-                            amax=(cfg.ax(_AX_DY2), cfg.ax(_AX_DPRE), cfg.ax(_AX_DYC), None))
-        dws = [(dym if p > 0 else dh3_2, u, g["linear2.weight"], g["linear2.bias"], cfg.ax(_AX_DY2), cfg.ax(_AX_U)),
-               (dpre, nf, g["linear1.weight"], g["linear1.bias"], cfg.ax(_AX_DPRE), cfg.ax(_AX_NF)),
-               (dym_c if p > 0 else dh2.view(R, d), a_ca.view(R, d), g["multihead_attn.out_proj.weight"], g["multihead_attn.out_proj.bias"], cfg.ax(_AX_DYC),
-                cfg.ax(_AX_ACA))]
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        ops.attention_bwd(q, kv[..., :d], kv[..., d:], a_ca, da_ca, lse_ca, dq, dkv[..., :d], dkv[..., d:], heads, cfg.drop(SITE_CA_PROBS))
-        M = memory.shape[1]
-        gWc, gbc = g["multihead_attn.in_proj_weight"], g["multihead_attn.in_proj_bias"]
-        dmem = _new(*memory.shape, like=h) if ctx.needs_input_grad[3] else None
-        mside = _mem_side(h.device)
-        if mside is not None:
-            mside.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(mside if mside is not None else torch.cuda.current_stream()):
-            ops.absmax(dkv.view(B * M, 2 * d), cfg.ax(_AX_DKV))
-            dws.append((dkv.view(B * M, 2 * d), memory.reshape(B * M, d), gWc[d:], gbc[d:], cfg.ax(_AX_DKV), cfg.ax_mem))
-            if dmem is not None:
-                ops.train_bwd_chain(B * M, d, dkv.view(B * M, 2 * d), _packed_weight(Wc, 1, transposed=True), dmem.view(B * M, d), passes=2)
-        # kind 2: LayerNorm 2 + query projection, the self-attention's out-projection
-        dh1, dym_s, da_sa = _new(B, T, d, like=h), mk(), _new(B, T, d, like=h)
-        ops.train_layer_bwd(2, B, T, dq.view(R, d), wt_a=tb["wq"], wt_c=tb["wo"], x=h1, ln_w=n2w, dg=g["norm2.weight"], db=g["norm2.bias"], dres=dh2,
-                            dx=dh1, dym2=dym_s, da=da_sa, p=p, seed=seed, sites=(0, 0, cfg.site(SITE_SA_OUT)),
-                            amax=(cfg.ax(_AX_DQ), None, cfg.ax(_AX_DYS), None))
-        dws.append((dq.view(R, d), n2, gWc[:d], gbc[:d], cfg.ax(_AX_DQ), cfg.ax(_AX_N2)))
-        dws.append((dym_s if p > 0 else dh1.view(R, d), a_sa.view(R, d), g["self_attn.out_proj.weight"], g["self_attn.out_proj.bias"], cfg.ax(_AX_DYS),
-                    cfg.ax(_AX_ASA)))
-        dqkv = torch.empty_like(qkv)
-        ops.attention_bwd(qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :], a_sa, da_sa, lse_sa, dqkv[..., :d], dqkv[..., d : 2 * d],
-                          dqkv[..., 2 * d :], heads, cfg.drop(SITE_SA_PROBS))
-        # kind 3: LayerNorm 1 + Q | K | V projection
-        dh = _new(B, T, d, like=h)
-        ops.train_layer_bwd(3, B, T, dqkv.view(R, 3 * d), wt_a=tb["wi"][0], wt_b=tb["wi"][1], wt_c=tb["wi"][2], x=h, ln_w=n1w, dg=g["norm1.weight"],
-                            db=g["norm1.bias"], dres=dh1, dx=dh, amax=(cfg.ax(_AX_DQKV), None, None, cfg.ax(_AX_DX) if cfg.li == 0 else None))
-        if cfg.li == 0:
-            _amax_register(dh, cfg.amax, cfg.ax(_AX_DX), cfg.ax(_AX_SCR2))
-        dws.append((dqkv.view(R, 3 * d), n1, g["self_attn.in_proj_weight"], g["self_attn.in_proj_bias"], cfg.ax(_AX_DQKV), cfg.ax(_AX_N1)))
-        if mside is not None:
-            torch.cuda.current_stream().wait_stream(mside)
-        ops.gemm_tn_grouped(dws)
-        return (dh, None, None, dmem, None) + tuple(None if direct else t for t in G)
-
-
-def _traj_layer_bwd_weights(P):
-    """Plane addresses of the transposed blocks sd_train_layer_bwd multiplies with (None: SD_TRAIN_TRAJ_BWD=0 or no planes)."""
-    if os.environ.get("SD_TRAIN_TRAJ_BWD", "1") == "0":
-        return None
-    (n1w, n1b, Wqkv, bqkv, Wo, bo, n2w, n2b, Wc, bc, Woc, boc, nfw, nfb, W1, b1, W2, b2) = P
-    for _ in range(2):   # (first use re-allocates the plane buffer: resolve again)
-        t = dict(w2=_packed_weight_traj(W2, 0, 256, True), w1=_packed_weight_traj(W1, 0, 256, True), woc=_packed_weight_traj(Woc, 0, 256, True),
-                 wq=_packed_weight_traj(Wc, 0, 256, True), wo=_packed_weight_traj(Wo, 0, 256, True),
-                 wi=[_packed_weight_traj(Wqkv, 256 * i, 256, True) for i in range(3)])
-    if any(v is None for k, v in t.items() if k != "wi") or any(v is None for v in t["wi"]):
-        return None
-    return t
 
 
 FUSED_STACKS = [0]   # how many layer stacks went through the fused path (tests assert that it is the path that ran)
@@ -1068,18 +988,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 _WT_BLOCKS[key] = (owner, off, d, pi)   # no tensor references: a dead optimizer's entries are inert
             self._wt_registered = True
 
-    def traj_planes(self, W: Tensor, row0: int, rows: int, transposed: bool = False):
+    def traj_planes(self, W: Tensor, row0: int, rows: int):
         """Address of the trajectory-kernel planes (ops.pack_weight_traj layout) of rows [row0, row0 + rows) of parameter W, which lives
         in this optimizer's flat buffer; registers the slice on first use and repacks all registered slices."""
         src = (W.data_ptr() - self.flat_param.data_ptr()) // 4 + row0 * 256
-        if src < 0 or src + rows * 256 > self.flat_param.numel() or rows % 16 or (transposed and rows != 256):
+        if src < 0 or src + rows * 256 > self.flat_param.numel() or rows % 16:
             return None
         reg = self.__dict__.setdefault("_traj_reg", {"index": {}, "src": [], "rows": [], "dst": [], "halfs": 0, "planes": None, "dev": None})
-        at = reg["index"].get((src, rows, transposed))
+        at = reg["index"].get((src, rows))
         if at is None:
             at = reg["halfs"]
-            reg["index"][(src, rows, transposed)] = at
-            reg["src"].append(src); reg["rows"].append(-rows if transposed else rows); reg["dst"].append(at)   # (a negative row count = transposed block)
+            reg["index"][(src, rows)] = at
+            reg["src"].append(src); reg["rows"].append(rows); reg["dst"].append(at)
             reg["halfs"] += rows * 256 * 2
             reg["planes"] = None   # (re)allocated and repacked below
         if reg["planes"] is None:
@@ -1094,7 +1014,7 @@ class FusedAdamW(torch.optim.Optimizer):
         reg = self.__dict__.get("_traj_reg")
         if reg and reg["planes"] is not None:
             s, r, d = reg["dev"]
-            ops.pack_weight_traj_multi(self.flat_param, s, r, d, max(abs(v) for v in reg["rows"]), reg["planes"])
+            ops.pack_weight_traj_multi(self.flat_param, s, r, d, max(reg["rows"]), reg["planes"])
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
