@@ -347,10 +347,12 @@ def time_train(leg: TrainLeg, steps: int, warmup: int, dist):
 
 
 def train_chain_roofline(leg: "TrainLeg", step_ms: float, n=4):
-    """Roofline of the training step's dominant kernel class, the fused row chains (sd_train_fwd_chain / sd_train_bwd_chain;
-    47 % of the step in profiles/r02_train_step_kernel_stats.txt): n EAGER steps with a HIP-event pair around every launch
-    (the graphed step cannot be instrumented), their summed time per step against the algorithmic FLOPs they own - the row
-    GEMMs of forward and dX, 2 x 16 T d^2 per layer and trajectory (the weight gradients are the grouped GEMM's)."""
+    """Roofline of the training step's dominant kernel class - the layer chains: since round 4 the trajectory-owning forward launches
+    (sd_train_head_fwd, sd_train_layer_fwd: embedding, both attention cores and every row GEMM of a layer's forward) and the backward
+    row chains (sd_train_bwd_chain; 57 % of the step in profiles/r04_train_kernel_stats_and_traffic.txt): n EAGER steps with a
+    HIP-event pair around every launch (the graphed step cannot be instrumented), their summed time per step against the
+    algorithmic FLOPs they own - the row GEMMs of forward and dX, 2 x 16 T d^2, plus the forward's attention cores, 4 T^2 d + 4 T M d,
+    per layer and trajectory (the weight gradients are the grouped GEMM's, the attention backward its own kernel's)."""
     import ctypes as C
 
     from soccerdiffusion_amd import _lib
@@ -370,13 +372,14 @@ def train_chain_roofline(leg: "TrainLeg", step_ms: float, n=4):
     _lib.check(lib.sd_profile_collect(ms, cnt, k), "sd_profile_collect")
     ch = _lib.KERNEL_CLASSES.index("decoder_layer_kernel")
     chain_ms = ms[ch] / n
-    flops = leg.B * L * 32 * T * D * D
+    flops = leg.B * L * (32 * T * D * D + 4 * T * T * D + 4 * T * M * D)
     ach = flops / max(chain_ms, 1e-9) / 1e9
-    return {"bound": "mfma", "kernel": "fused row chains (train_fwd_chain_kernel / train_bwd_chain_kernel, csrc/sd_train_chain.hip)",
+    return {"bound": "mfma", "kernel": "layer chains (train_head_fwd_kernel / train_layer_fwd_kernel, csrc/sd_train_traj.hip; "
+                                       "train_bwd_chain_kernel, csrc/sd_train_chain.hip)",
             "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4),
             "vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
-            "definition": "algorithmic row-GEMM FLOPs of forward + dX (2 x 16 T d^2 per layer and trajectory) / summed HIP-event time "
-                          "of the chain launches in one eager step",
+            "definition": "algorithmic FLOPs of the forward (16 T d^2 + 4 T^2 d + 4 T M d per layer and trajectory) and of the dX row GEMMs "
+                          "(16 T d^2) / summed HIP-event time of the chain-class launches in one eager step",
             "chain_ms_per_step": round(chain_ms, 4), "chain_launches_per_step": int(cnt[ch] // n),
             "share_of_graphed_step": round(chain_ms / max(step_ms, 1e-9), 4),
             "class_ms_per_eager_step": {nm: round(ms[i] / n, 4) for i, nm in enumerate(_lib.KERNEL_CLASSES) if ms[i] > 0},

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Small-batch rollout latency (the robot's shape: B=1, horizon 10, 30 DDIM steps, d=256, L=4):
-eager launches vs the hipGraph-captured rollout.  The reference's budget is 0.2 s per rollout."""
+"""Small-batch rollout latency (the robot's shape: B = 1, horizon 10, 30 DDIM steps, d = 256, L = 4; reference loop
+soccer_diffusion/ml/inference/ros.py:301-310, budget 0.2 s per rollout) per kernel selection of sd_ddim_sample_ex: the trajectory
+kernel family (modes 3 / 4: any T <= 100 with <= 16 memory rows) against the row-panel / unfused-chain kernels (max_mode 2), for the
+memory sizes of the shipped configs: 31 context rows (falls back: > 16 rows), 10 rows, none (decoder_only.yaml)."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from soccerdiffusion_amd import cli
+from soccerdiffusion_amd import _lib, cli, ops
 
 params = dict(hidden_dim=256, action_context_length=100, trajectory_prediction_length=10, epochs=1, batch_size=1, lr=1e-4,
               train_denoising_timesteps=1000, image_context_length=10, imu_context_length=100, num_imu_encoder_layers=2,
@@ -15,18 +17,33 @@ params = dict(hidden_dim=256, action_context_length=100, trajectory_prediction_l
               distill_teacher_inference_steps=30, use_gamestate=False, encoder_patch_size=10)
 torch.manual_seed(0)
 m = cli.build_model(params).cuda().eval()
-for B in (1, 16):
-    x = torch.randn(B, 10, 20, device="cuda")
-    ctx = [torch.randn(B, 31, 256, device="cuda")]
-    out = {}
-    for name, kw in (("eager", {}), ("hipgraph", {"use_graph": True})):
-        for _ in range(3):
-            m.sample(ctx, x, 30, **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 20
-        for _ in range(n):
-            m.sample(ctx, x, 30, **kw)
-        torch.cuda.synchronize()
-        out[name + "_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
-    print(json.dumps({"B": B, "T": 10, "M": 32, "steps": 30, **out}))
+T, n_steps = 10, 30
+ts = ops.ddim_timesteps(n_steps)
+coef = ops.ddim_coefficients(ts, ops.alphas_cumprod(), n_steps)
+toks = m.step_encoding.table(ts, torch.device("cuda"))
+packed = m.diffusion_action_generator.packed()
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / n * 1e3, 3)
+
+
+for B in (1, 16, 256):
+    for Mc in (31, 10, 0):
+        x = torch.randn(B, T, 20, device="cuda")
+        ctx = torch.randn(B, Mc, 256, device="cuda") if Mc else None
+        rec = {"B": B, "T": T, "memory_rows": Mc + 1, "steps": n_steps, "sd_sampler_mode": _lib.load().sd_sampler_mode(256, 4, T, Mc, 20)}
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for mode in (2, 3, 4):
+            rec[f"eager_max_mode_{mode}_ms"] = timed(lambda: ops.ddim_sample(packed, ctx, toks, coef, x, status=status, max_mode=mode))
+            gs = ops.GraphedSampler(packed, B, T, Mc, toks, coef, max_mode=mode)
+            rec[f"hipgraph_max_mode_{mode}_ms"] = timed(lambda: gs.replay_into(ctx, x))
+            del gs
+        print(json.dumps(rec), flush=True)

@@ -84,7 +84,7 @@ if "FETCH_SIZE" in report and "WRITE_SIZE" in report:
                    if layer else None,
                # sampler mode 3: one launch per DDIM step carries the whole denoiser step
                "traj_step_kernel_bytes_per_launch": per[traj[0]]["hbm_bytes_per_launch"] if traj else None,
-               "round": os.environ.get("SD_PROFILE_ROUND", "r03"),
+               "round": os.environ.get("SD_PROFILE_ROUND", "r04"),
                "per_kernel": per}
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("\n== HBM bytes per launch (2 x FETCH + WRITE):")

@@ -53,7 +53,7 @@ traj = [k for k in summary if "traj_step_kernel" in k]
 if traj:
     k = traj[0]
     json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE (tools/profile_sq.sh); busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
-               "round": os.environ.get("SD_PROFILE_ROUND", "r03"),
+               "round": os.environ.get("SD_PROFILE_ROUND", "r04"),
                "traj_step_kernel_mfma_busy": summary[k]["mfma_busy_frac_of_simd_cycles"],
                "traj_step_kernel_effective_clock_ghz": summary[k]["effective_shader_clock_ghz"],
                "per_kernel": summary}, open(os.path.join(out, "pmc_sq.json"), "w"), indent=1)
