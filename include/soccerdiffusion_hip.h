@@ -221,6 +221,15 @@ int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale
                       const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
                       int relu, void *stream);
 int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream);
+/* The striding convolutions of a ResNet stage entry (conv1 of layers 2 - 4 and their 1 x 1 shortcut): y = act(BatchNorm_eval(conv(x, w; kernel
+ * ksize = 3 with padding 1, or ksize = 1 with padding 0; stride 2))), NHWC fp32, x (N,H,W,Cin) -> y (N,ceil(H/2),ceil(W/2),Cout); Cin a
+ * multiple of 64, Cout of 128; weights (Cout,Cin,ksize,ksize) packed by sd_conv_pack (sd_conv_packed_halfs fp16 values).  Same arithmetic,
+ * scale and abs-max conventions as sd_conv3x3_bn_act. */
+size_t sd_conv_packed_halfs(int Cout, int Cin, int ksize);
+int sd_conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes, float *scale, uint32_t *amax_word, void *stream);
+int sd_conv_s2_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                      const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout, int ksize, int relu,
+                      void *stream);
 
 /* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
 

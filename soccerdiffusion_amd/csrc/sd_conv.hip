@@ -49,26 +49,26 @@ __global__ void zero_words_kernel(unsigned *p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
 }
 
-// W (Cout, Cin, 3, 3) fp32 (torch layout) -> [co tile 32][tap 9][k-step Cin/16][plane][lane][8]: lane = 32 kg + j holds
-// W[32 ct + j][16 ks + 8 kg + e][tap] * scale as hi / lo, e = 0..7.  scale: power of two from the weights' abs-max word.
-__global__ void conv3x3_pack_kernel(const float *__restrict__ W, int Cout, int Cin, const unsigned *maxbits, f16 *__restrict__ dst, float *scale_out) {
+// W (Cout, Cin, KS, KS) fp32 (torch layout; taps = KS^2 = 9 or 1) -> [co tile 32][tap][k-step Cin/16][plane][lane][8]: lane = 32 kg + j
+// holds W[32 ct + j][16 ks + 8 kg + e][tap] * scale as hi / lo, e = 0..7.  scale: power of two from the weights' abs-max word.
+__global__ void conv3x3_pack_kernel(const float *__restrict__ W, int Cout, int Cin, int taps, const unsigned *maxbits, f16 *__restrict__ dst, float *scale_out) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
     const int nks = Cin / 16;
-    const long total = (long)Cout * 9 * (Cin / 8);
+    const long total = (long)Cout * taps * (Cin / 8);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % (Cin / 8));
-        const int tap = (int)((i / (Cin / 8)) % 9);
-        const int co = (int)(i / (Cin / 8) / 9);
+        const int tap = (int)((i / (Cin / 8)) % taps);
+        const int co = (int)(i / (Cin / 8) / taps);
         f16 hh[8], ll[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = W[((long)co * Cin + (c8 * 8 + e)) * 9 + tap] * scale;
+            const float v = W[((long)co * Cin + (c8 * 8 + e)) * taps + tap] * scale;
             hh[e] = (f16)v;
             ll[e] = (f16)(v - (float)hh[e]);
         }
         const int ct = co >> 5, j = co & 31, ks = c8 >> 1, kg = c8 & 1;
-        f16 *o = dst + ((((long)ct * 9 + tap) * nks + ks) * 2) * 512 + (32 * kg + j) * 8;
+        f16 *o = dst + ((((long)ct * taps + tap) * nks + ks) * 2) * 512 + (32 * kg + j) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             o[e] = hh[e];
@@ -186,6 +186,101 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The striding convolutions of a ResNet stage entry: 3 x 3 stride 2 padding 1 (conv1 of layers 2 - 4) and the 1 x 1 stride 2 shortcut,
+// with the inference BatchNorm (+ ReLU) in the epilogue.  Same arithmetic and operand layouts as conv3x3_kernel; the output maps are
+// small (60 x 80 ... 15 x 20), so a workgroup takes a 4 x 8 pixel tile (one 32-row MFMA tile) x 128 output channels, wave w = channel
+// tile w; the 9 x 17 halo (KS = 3) or just the 4 x 8 sampled pixels (KS = 1) of a 64-channel chunk are staged as fp16 hi | lo planes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int S2_TH = 4, S2_TW = 8, S2_COT = 128;
+template <int KS>
+struct S2Cfg {
+    static constexpr int HH = KS == 3 ? (S2_TH - 1) * 2 + 3 : S2_TH, HW = KS == 3 ? (S2_TW - 1) * 2 + 3 : S2_TW;
+    static constexpr int PLANE = HH * HW * PIX, LDS = 2 * PLANE;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
+    using C = S2Cfg<KS>;
+    constexpr int TAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;   // (H + 2 pad - KS) / 2 + 1 for KS = 3 / pad 1 and KS = 1 / pad 0
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int y0 = ty * S2_TH, x0 = tx * S2_TW;        // output tile origin
+    const int co0 = blockIdx.y * S2_COT + w * 32;
+    const float s_in = f16_scale_from_bits(*a.x_amax);
+    const int nks = a.Cin / 16;
+    const f16 *wbase = a.w + (long)(co0 >> 5) * TAPS * nks * 1024 + lane * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // this lane's A row: output pixel (j >> 3, j & 7) of the tile; its halo offset for tap (0, 0)
+    const unsigned abase = KS == 3 ? (unsigned)(((2 * (j >> 3)) * C::HW + 2 * (j & 7)) * PIX + 16 * kg) : (unsigned)(j * PIX + 16 * kg);
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0 > 0) __syncthreads();
+        for (int i = tid; i < C::HH * C::HW * (CK / 4); i += 256) {
+            const int c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            const int hy = p / C::HW, hx = p - hy * C::HW;
+            const int gy = KS == 3 ? 2 * y0 + hy - 1 : 2 * (y0 + hy), gx = KS == 3 ? 2 * x0 + hx - 1 : 2 * (x0 + hx);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+            f16x4 h, l;
+            f16_split4(v, s_in, h, l);
+            char *at = smem + p * PIX + 8 * c4;
+            *reinterpret_cast<f16x4 *>(at) = h;
+            *reinterpret_cast<f16x4 *>(at + C::PLANE) = l;
+        }
+        __syncthreads();
+        const f16 *wp = wbase + (long)(c0 / 16) * 1024;
+        f16x8 bw[2][2], af[2][2];
+        auto load = [&](int s, int st) __attribute__((always_inline)) {
+            const int tap = s >> 2, ks = s & 3;
+            const f16 *q = wp + ((long)tap * nks + ks) * 1024;
+            bw[st][0] = *reinterpret_cast<const f16x8 *>(q);
+            bw[st][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+            const unsigned toff = (unsigned)((KS == 3 ? ((tap / 3) * C::HW + (tap % 3)) * PIX : 0) + 32 * ks);
+            af[st][0] = *reinterpret_cast<const f16x8 *>(smem + abase + toff);
+            af[st][1] = *reinterpret_cast<const f16x8 *>(smem + abase + toff + C::PLANE);
+        };
+        load(0, 0);
+#pragma unroll
+        for (int s = 0; s < TAPS * 4; ++s) {
+            const int st = s & 1;
+            if (s + 1 < TAPS * 4) load(s + 1, st ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma32(af[st][1], bw[st][0], acc);
+            acc = mfma32(af[st][0], bw[st][1], acc);
+            acc = mfma32(af[st][0], bw[st][0], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float un = 1.0f / (s_in * *a.w_scale);
+    const int co = co0 + j;
+    const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        const int gy = y0 + (i >> 3), gx = x0 + (i & 7);
+        if (gy >= Ho || gx >= Wo) continue;
+        const long at = (((long)n * Ho + gy) * Wo + gx) * a.Cout + co;
+        float v = acc[r] * bs + bt;
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[at] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (a.y_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > 0.f) atomicMax(a.y_amax, __builtin_bit_cast(unsigned, mx));
+    }
+}
+
 }   // namespace cv
 
 extern "C" int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream) {
@@ -198,19 +293,29 @@ extern "C" int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *s
 }
 
 extern "C" size_t sd_conv3x3_packed_halfs(int Cout, int Cin) { return (size_t)Cout * Cin * 9 * 2; }
+extern "C" size_t sd_conv_packed_halfs(int Cout, int Cin, int ksize) { return (size_t)Cout * Cin * ksize * ksize * 2; }
 
+static int conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes, float *scale, uint32_t *amax_word, void *stream);
 extern "C" int sd_conv3x3_pack(const float *w, int Cout, int Cin, void *planes, float *scale, uint32_t *amax_word, void *stream) {
+    return conv_pack(w, Cout, Cin, 3, planes, scale, amax_word, stream);
+}
+extern "C" int sd_conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes, float *scale, uint32_t *amax_word, void *stream) {
+    if (ksize != 1 && ksize != 3) return fail(SD_E_BADARG, "sd_conv_pack: kernel size 1 or 3");
+    return conv_pack(w, Cout, Cin, ksize, planes, scale, amax_word, stream);
+}
+static int conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes, float *scale, uint32_t *amax_word, void *stream) {
     if (!w || !planes || !scale || !amax_word || Cout <= 0 || Cin <= 0 || Cout % 64 || Cin % 64)
         return fail(SD_E_BADARG, "sd_conv3x3_pack: channels must be positive multiples of 64");
     hipStream_t st = (hipStream_t)stream;
     SD_LAUNCH(cv::zero_words_kernel, dim3(1), dim3(64), 0, st, amax_word, 1);
     SD_CHECK_LAUNCH("zero_words_kernel");
-    const long n = (long)Cout * Cin * 9;
+    const int taps = ksize * ksize;
+    const long n = (long)Cout * Cin * taps;
     int rc = sd_absmax_word(w, n, amax_word, stream);
     if (rc) return rc;
     long blocks = (n / 8 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    SD_LAUNCH(cv::conv3x3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, amax_word, (f16 *)planes, scale);
+    SD_LAUNCH(cv::conv3x3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, Cout, Cin, taps, amax_word, (f16 *)planes, scale);
     SD_CHECK_LAUNCH("conv3x3_pack_kernel");
     return 0;
 }
@@ -228,5 +333,25 @@ extern "C" int sd_conv3x3_bn_act(const float *x, const void *w_planes, const flo
     if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv3x3_bn_act: too many tiles");
     SD_LAUNCH(cv::conv3x3_kernel, dim3((unsigned)tiles, (unsigned)(Cout / cv::COT)), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv3x3_kernel");
+    return 0;
+}
+
+extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                                 const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout, int ksize, int relu,
+                                 void *stream) {
+    if (!x || !w_planes || !w_scale || !x_amax || !bn_scale || !bn_shift || !y || N <= 0 || H <= 0 || W <= 0)
+        return fail(SD_E_BADARG, "sd_conv_s2_bn_act: null pointer or empty shape");
+    if (ksize != 1 && ksize != 3) return fail(SD_E_BADARG, "sd_conv_s2_bn_act: kernel size 1 or 3");
+    if (Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % cv::S2_COT) return fail(SD_E_BADDIM, "sd_conv_s2_bn_act: Cin a multiple of 64, Cout a multiple of 128");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv_s2_bn_act: x must be 16-byte aligned and distinct from y");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, nullptr, y, y_amax, N, H, W, Cin, Cout, relu,
+                   (Wo + cv::S2_TW - 1) / cv::S2_TW, (Ho + cv::S2_TH - 1) / cv::S2_TH};
+    const long tiles = (long)a.tiles_x * a.tiles_y * N;
+    if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_s2_bn_act: too many tiles");
+    const dim3 grid((unsigned)tiles, (unsigned)(Cout / cv::S2_COT));
+    if (ksize == 3) SD_LAUNCH(cv::conv_s2_kernel<3>, grid, dim3(256), (size_t)cv::S2Cfg<3>::LDS, (hipStream_t)stream, a);
+    else SD_LAUNCH(cv::conv_s2_kernel<1>, grid, dim3(256), (size_t)cv::S2Cfg<1>::LDS, (hipStream_t)stream, a);
+    SD_CHECK_LAUNCH("conv_s2_kernel");
     return 0;
 }

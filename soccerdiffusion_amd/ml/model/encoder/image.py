@@ -75,18 +75,16 @@ class _BasicBlock(nn.Module):
         return pk.refresh(conv.weight)
 
     def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
-        """Inference on the hand-written kernel: h (N, H, W, C) fp32 NHWC with its abs-max word -> (h', its abs-max word).
-        conv2 / bn2 / + identity / relu always; conv1 / bn1 / relu too unless it strides (then it and the 1 x 1 shortcut are
-        torch convolutions on an NCHW copy)."""
+        """Inference on the hand-written kernels: h (N, H, W, C) fp32 NHWC with its abs-max word -> (h', its abs-max word): conv1 / bn1 /
+        relu (stride 1: sd_conv3x3_bn_act; a stage entry: sd_conv_s2_bn_act, as is its 1 x 1 shortcut), conv2 / bn2 / + identity / relu."""
         if self.downsample is None:
             a1 = torch.zeros(1, dtype=torch.int32, device=h.device)
             out = ops.conv3x3_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1)
             idt = h
-        else:
-            x = h.permute(0, 3, 1, 2).contiguous()
-            idt = self.downsample(x).permute(0, 2, 3, 1).contiguous()
-            out = self.relu(self.bn1(self.conv1(x))).permute(0, 2, 3, 1).contiguous()
-            a1 = ops.absmax_word(out)
+        else:   # the stage entry: 3 x 3 stride-2 conv1 and the 1 x 1 stride-2 shortcut (sd_conv_s2_bn_act)
+            a1 = torch.zeros(1, dtype=torch.int32, device=h.device)
+            out = ops.conv_s2_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1)
+            idt = ops.conv_s2_bn_act(h, amax, self._packed("_pkd", self.downsample[0]), *self._bn_fold(self.downsample[1]), relu=False)
         a2 = torch.zeros(1, dtype=torch.int32, device=h.device)
         y = ops.conv3x3_bn_act(out, a1, self._packed("_pk2", self.conv2), *self._bn_fold(self.bn2), res=idt, relu=True, y_amax=a2)
         return y, a2
@@ -138,8 +136,11 @@ class _ResNet(nn.Module):
                 and os.environ.get("SD_CONV", "hip") != "torch")
 
     def forward(self, x):
+        hip = self._hip_inference(x)
+        if hip:   # the whole inference forward in NHWC memory: the stem's library kernels see a channels_last view
+            x = x.contiguous(memory_format=torch.channels_last)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        if self._hip_inference(x):
+        if hip:
             # basic blocks on NHWC tensors through sd_conv3x3_bn_act; back to an NCHW view for the head
             h = x.permute(0, 2, 3, 1).contiguous()
             amax = ops.absmax_word(h)

@@ -888,17 +888,17 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: flo
 
 # ---- image path: ResNet basic-block convolution (csrc/sd_conv.hip) -------------------------------------
 class PackedConv3x3:
-    """A 3 x 3 convolution weight (Cout, Cin, 3, 3) in the fragment order of ``sd_conv3x3_bn_act`` plus the power-of-two scale the
-    fp16 planes carry; repacked when the weight's version counter moves."""
+    """A 3 x 3 (or 1 x 1) convolution weight (Cout, Cin, k, k) in the fragment order of ``sd_conv3x3_bn_act`` / ``sd_conv_s2_bn_act`` plus
+    the power-of-two scale the fp16 planes carry; repacked when the weight's version counter moves."""
 
     def __init__(self, weight: Tensor):
         lib = _lib.load()
         _req(weight, "weight")
         Cout, Cin, kh, kw = weight.shape
-        if (kh, kw) != (3, 3) or Cout % 64 or Cin % 64:
-            raise ValueError("3 x 3 kernels with channel counts that are multiples of 64")
-        self.Cout, self.Cin = Cout, Cin
-        self.planes = torch.empty(lib.sd_conv3x3_packed_halfs(Cout, Cin), dtype=torch.float16, device=weight.device)
+        if kh != kw or kh not in (1, 3) or Cout % 64 or Cin % 64:
+            raise ValueError("3 x 3 or 1 x 1 kernels with channel counts that are multiples of 64")
+        self.Cout, self.Cin, self.ksize = Cout, Cin, kh
+        self.planes = torch.empty(lib.sd_conv_packed_halfs(Cout, Cin, kh), dtype=torch.float16, device=weight.device)
         self.scale = torch.empty(1, dtype=torch.float32, device=weight.device)
         self._word = torch.zeros(1, dtype=torch.int32, device=weight.device)
         self.version = None
@@ -907,8 +907,8 @@ class PackedConv3x3:
     def refresh(self, weight: Tensor) -> "PackedConv3x3":
         if self.version != weight._version:
             w = weight.detach().contiguous()
-            check(_lib.load().sd_conv3x3_pack(w.data_ptr(), self.Cout, self.Cin, self.planes.data_ptr(), self.scale.data_ptr(),
-                                              self._word.data_ptr(), _stream()), "sd_conv3x3_pack")
+            check(_lib.load().sd_conv_pack(w.data_ptr(), self.Cout, self.Cin, self.ksize, self.planes.data_ptr(), self.scale.data_ptr(),
+                                           self._word.data_ptr(), _stream()), "sd_conv_pack")
             self.version = weight._version
         return self
 
@@ -931,8 +931,8 @@ def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
     ``absmax_word`` or the ``y_amax`` of the launch that produced x; ``y_amax`` (zeroed here) receives max |y|."""
     _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
     N, H, W, Cin = x.shape
-    if Cin != w.Cin:
-        raise ValueError("channel mismatch")
+    if Cin != w.Cin or w.ksize != 3:
+        raise ValueError("channel / kernel-size mismatch")
     y = torch.empty(N, H, W, w.Cout, dtype=torch.float32, device=x.device)
     if res is not None:
         _req(res, "res")
@@ -943,4 +943,22 @@ def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
     check(_lib.load().sd_conv3x3_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
                                         bn_shift.data_ptr(), _ptr(res), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, int(relu), _stream()),
           "sd_conv3x3_bn_act")
+    return y
+
+
+def conv_s2_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor, bn_shift: Tensor, relu: bool = True,
+                   y_amax: Optional[Tensor] = None) -> Tensor:
+    """act(conv(x; stride 2) * bn_scale + bn_shift) on NHWC fp32 tensors: the 3 x 3 / padding 1 convolution that opens ResNet layers 2 - 4 or
+    their 1 x 1 shortcut (``w.ksize``), inference BatchNorm folded (reference: torchvision BasicBlock via
+    soccer_diffusion/ml/model/encoder/image.py:55-83).  Same conventions as ``conv3x3_bn_act``."""
+    _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
+    N, H, W, Cin = x.shape
+    if Cin != w.Cin:
+        raise ValueError("channel mismatch")
+    y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, w.Cout, dtype=torch.float32, device=x.device)
+    if y_amax is not None:
+        y_amax.zero_()
+    check(_lib.load().sd_conv_s2_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
+                                        bn_shift.data_ptr(), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, w.ksize, int(relu), _stream()),
+          "sd_conv_s2_bn_act")
     return y

@@ -69,6 +69,34 @@ def test_conv3x3_bn_act_matches_torch_cpu(ops, C_in, C_out, N, H, W, with_res, r
     assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
 
 
+# the stage entries of ResNet-18 on a 480 x 640 frame (3 x 3 stride 2 and the 1 x 1 stride-2 shortcut), odd maps, a ragged tile
+@pytest.mark.parametrize("C_in,C_out,N,H,W", [(64, 128, 2, 120, 160), (128, 256, 2, 60, 80), (256, 512, 2, 30, 40), (64, 128, 1, 15, 21), (128, 128, 1, 7, 9),
+                                             (64, 256, 1, 1, 1)])
+@pytest.mark.parametrize("ksize,relu", [(3, True), (1, False)])
+def test_conv_stride2_bn_act_matches_torch_cpu(ops, C_in, C_out, N, H, W, ksize, relu):
+    g = torch.Generator().manual_seed(C_in + H + ksize)
+    x = torch.randn(N, C_in, H, W, generator=g).abs()
+    w = torch.randn(C_out, C_in, ksize, ksize, generator=g) * (2.0 / (ksize * ksize * C_out)) ** 0.5
+    gamma, beta = 0.5 + torch.rand(C_out, generator=g), 0.2 * torch.randn(C_out, generator=g)
+    mean, var = 0.3 * torch.randn(C_out, generator=g), 0.5 + torch.rand(C_out, generator=g)
+
+    def block(dtype):
+        y = F.conv2d(x.to(dtype), w.to(dtype), stride=2, padding=ksize // 2)
+        y = F.batch_norm(y, mean.to(dtype), var.to(dtype), gamma.to(dtype), beta.to(dtype), training=False, eps=1e-5)
+        return F.relu(y) if relu else y
+
+    want64, want32 = block(torch.float64), block(torch.float32)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    inv = torch.rsqrt(var + 1e-5)
+    ya = torch.zeros(1, dtype=torch.int32, device="cuda")
+    y = ops.conv_s2_bn_act(xh, ops.absmax_word(xh), ops.PackedConv3x3(w.cuda()), (gamma * inv).cuda(), (beta - mean * gamma * inv).cuda(), relu=relu, y_amax=ya)
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert got.shape == want64.shape
+    e, e32 = rel_err(got, want64), rel_err(want32, want64)
+    assert e < 2e-6 and e < 8 * e32 + 2e-7, (e, e32)
+    assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
+
+
 def test_conv3x3_large_and_tiny_activations(ops):
     """One scale per tensor from its abs-max word: activations in the hundreds (an untrained backbone's deep layers) and of 1e-3."""
     for scale in (300.0, 1e-3):
@@ -99,7 +127,7 @@ def test_packed_weight_follows_updates(ops):
 @pytest.mark.parametrize("avgpool,HW", [(True, (96, 128)), (False, (64, 64))])
 def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW):
     """The module-level route (ml/model/encoder/image.py): in eval mode without a tape the basic blocks go through
-    sd_conv3x3_bn_act (13 of the 20 convolutions); tokens equal the same torch.nn modules on the CPU in fp32 (1e-4) and the
+    sd_conv3x3_bn_act (13 of the 20 convolutions) and sd_conv_s2_bn_act (the three stage entries and their shortcuts); tokens equal the same torch.nn modules on the CPU in fp32 (1e-4) and the
     all-MIOpen route on the GPU."""
     import copy
 
@@ -118,15 +146,17 @@ def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW
     with torch.no_grad():
         want = enc(x)
     g = copy.deepcopy(enc).cuda().eval()
-    calls = []
-    orig = o.conv3x3_bn_act
+    calls, calls2 = [], []
+    orig, orig2 = o.conv3x3_bn_act, o.conv_s2_bn_act
     o.conv3x3_bn_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    o.conv_s2_bn_act = lambda *a, **k: (calls2.append(1), orig2(*a, **k))[1]
     try:
         with torch.no_grad():
             got = g(x.cuda())
     finally:
-        o.conv3x3_bn_act = orig
+        o.conv3x3_bn_act, o.conv_s2_bn_act = orig, orig2
     assert len(calls) == 13, len(calls)     # layer1: 4, layers 2-4: 3 each (their first conv strides)
+    assert len(calls2) == 6, len(calls2)    # ... which, with its 1 x 1 shortcut, runs on the stride-2 kernel: only the stem is library code
     assert got.shape == (2, 3, 64)
     assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
     os.environ["SD_CONV"] = "torch"
