@@ -214,7 +214,7 @@ int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const flo
  *   sd_conv3x3_pack: w (Cout,Cin,3,3) fp32 -> sd_conv3x3_packed_halfs(Cout,Cin) fp16 values in fragment order + the power-of-two
  *     scale they carry (device float) - once per weight update; amax_word: one uint32 of device scratch.
  *   x_amax / y_amax: device words holding the bits of max|x| / receiving max|y| (atomic max: zero y_amax before the call; NULL =
- *     not needed).  sd_absmax_word computes such a word for a tensor no convolution produced (n % 4 == 0). */
+ *     not needed).  sd_absmax_word computes such a word for a tensor no convolution produced (x 16-byte aligned). */
 size_t sd_conv3x3_packed_halfs(int Cout, int Cin);
 int sd_conv3x3_pack(const float *w, int Cout, int Cin, void *planes, float *scale, uint32_t *amax_word, void *stream);
 int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
@@ -230,6 +230,14 @@ int sd_conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes, flo
 int sd_conv_s2_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
                       const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout, int ksize, int relu,
                       void *stream);
+/* The ResNet stem in one launch: y = maxpool3x3/s2/p1(relu(BatchNorm_eval(conv7x7/s2/p3(x, w)))) - torchvision ResNet.conv1 / bn1 / relu /
+ * maxpool as the reference instantiates them (soccer_diffusion/ml/model/encoder/image.py:55-83).  x (N,3,H,W) fp32 NCHW frames (the
+ * reference's own layout) -> y (N,Hp,Wp,64) fp32 NHWC with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (likewise W); w (64,3,7,7) packed by
+ * sd_stem_pack (sd_stem_packed_halfs fp16 values).  Same arithmetic, scale and abs-max conventions as sd_conv3x3_bn_act. */
+size_t sd_stem_packed_halfs(void);
+int sd_stem_pack(const float *w, void *planes, float *scale, uint32_t *amax_word, void *stream);
+int sd_stem_conv_bn_relu_pool(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                              const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, void *stream);
 
 /* ---- single-op entry points (unit parity tests and host-side composition) ---------- */
 

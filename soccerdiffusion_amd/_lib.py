@@ -159,6 +159,9 @@ SIGNATURES = {
     "sd_conv_packed_halfs": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sd_conv_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sd_conv_s2_bn_act": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 7 + [C.c_void_p]),
+    "sd_stem_packed_halfs": (C.c_size_t, []),
+    "sd_stem_pack": (C.c_int, [C.c_void_p] * 5),
+    "sd_stem_conv_bn_relu_pool": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_void_p]),
     "sd_profile_enable": (C.c_int, [C.c_int]),
     "sd_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
 }

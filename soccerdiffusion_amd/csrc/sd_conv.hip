@@ -34,8 +34,9 @@ constexpr int COT = 64;                                     // output channels p
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // abs-max of a tensor into ONE word (bits of a non-negative float: unsigned order = float order)
-__global__ void absmax_word_kernel(const float *__restrict__ x, long n4, unsigned *word) {
+__global__ void absmax_word_kernel(const float *__restrict__ x, long n4, long n, unsigned *word) {
     float m = 0.f;
+    if (blockIdx.x == 0 && 4 * n4 + threadIdx.x < n) m = fabsf(x[4 * n4 + threadIdx.x]);   // the tail of an n that is no multiple of 4
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(x + 4 * i);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -43,6 +44,14 @@ __global__ void absmax_word_kernel(const float *__restrict__ x, long n4, unsigne
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __builtin_bit_cast(unsigned, m));
+}
+// max |y| of a wave into the tensor's word.  Read first: after the first few workgroups nearly every wave finds the word at or above
+// its value, and 10^5 .. 10^6 atomics on one address serialise in a single L2 channel (the stem kernel took 2x as long with them).
+__device__ __forceinline__ void publish_amax(unsigned *word, float mx, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const unsigned b = __builtin_bit_cast(unsigned, mx);
+    if (lane == 0 && b > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, b);
 }
 // (a hipMemsetAsync node replays garbage from a captured graph on this stack - DESIGN.md 5.7: zero fills are kernels)
 __global__ void zero_words_kernel(unsigned *p, int n) {
@@ -116,15 +125,25 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0 > 0) __syncthreads();   // every wave has consumed the previous chunk
-        // ---- stage the halo tile of channels c0 .. c0 + 63: 180 pixels x 16 vectors of 4 channels
-        for (int i = tid; i < HH * HW * (CK / 4); i += 256) {
-            const int c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+        // ---- stage the halo tile of channels c0 .. c0 + 63: 180 pixels x 16 vectors of 4 channels.  All 12 loads of a thread are in
+        // flight before the first split / LDS store (one HBM round trip per chunk, not twelve)
+        constexpr int NST = (HH * HW * (CK / 4) + 255) / 256;
+        f32x4 hv[NST];
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
             const int hy = p / HW, hx = p - hy * HW;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+            hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < HH * HW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                hv[q] = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            if (p >= HH * HW) continue;
             f16x4 h, l;
-            f16_split4(v, s_in, h, l);
+            f16_split4(hv[q], s_in, h, l);
             char *at = smem + p * PIX + 8 * c4;
             *reinterpret_cast<f16x4 *>(at) = h;
             *reinterpret_cast<f16x4 *>(at + PLANE) = l;
@@ -179,11 +198,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
             a.y[at] = v;
             mx = fmaxf(mx, fabsf(v));
         }
-    if (a.y_amax) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0 && mx > 0.f) atomicMax(a.y_amax, __builtin_bit_cast(unsigned, mx));
-    }
+    if (a.y_amax) publish_amax(a.y_amax, mx, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -223,14 +238,23 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
     const unsigned abase = KS == 3 ? (unsigned)(((2 * (j >> 3)) * C::HW + 2 * (j & 7)) * PIX + 16 * kg) : (unsigned)(j * PIX + 16 * kg);
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0 > 0) __syncthreads();
-        for (int i = tid; i < C::HH * C::HW * (CK / 4); i += 256) {
-            const int c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+        constexpr int NST = (C::HH * C::HW * (CK / 4) + 255) / 256;   // every load of the chunk in flight before the first LDS store
+        f32x4 hv[NST];
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
             const int hy = p / C::HW, hx = p - hy * C::HW;
             const int gy = KS == 3 ? 2 * y0 + hy - 1 : 2 * (y0 + hy), gx = KS == 3 ? 2 * x0 + hx - 1 : 2 * (x0 + hx);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+            hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < C::HH * C::HW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                hv[q] = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            if (p >= C::HH * C::HW) continue;
             f16x4 h, l;
-            f16_split4(v, s_in, h, l);
+            f16_split4(hv[q], s_in, h, l);
             char *at = smem + p * PIX + 8 * c4;
             *reinterpret_cast<f16x4 *>(at) = h;
             *reinterpret_cast<f16x4 *>(at + C::PLANE) = l;
@@ -274,20 +298,180 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
         a.y[at] = v;
         mx = fmaxf(mx, fabsf(v));
     }
-    if (a.y_amax) {
+    if (a.y_amax) publish_amax(a.y_amax, mx, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The ResNet stem in one launch: conv 7 x 7 stride 2 padding 3 (3 -> 64 channels) + inference BatchNorm + ReLU + max-pool 3 x 3 stride 2
+// padding 1, NCHW frames in, NHWC map out (+ its abs-max word) - four library launches and a 3.1-GB intermediate map at 160 frames of
+// 480 x 640 otherwise.  A workgroup owns a 2 x 8 tile of POOLED pixels: the 5 x 17 convolution outputs under it come from a 15 x 39 x 3
+// input tile (LDS, fp32); their im2col rows (K = 147 -> 160, k = (ky 7 + kx) 3 + ci) are written as fp16 hi | lo planes and multiplied
+// with the packed weights as in the other kernels (6 MFMA tiles of 32 x 32, three products); the 85 x 64 results pass through LDS for
+// the pooling.  71 KB of LDS: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_PH = 2, ST_PW = 8, ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1, ST_IH = 2 * ST_CH + 5, ST_IW = 2 * ST_CW + 5;
+constexpr int ST_NPX = ST_CH * ST_CW;          // 85 convolution pixels per tile
+constexpr int ST_M = 96, ST_K = 160, ST_KREAL = 147;
+constexpr int ST_AROW = ST_K * 2 + 16;         // bytes of an im2col row in one plane (21 sixteen-byte units: odd)
+constexpr int ST_APLANE = ST_M * ST_AROW;
+constexpr int ST_IN_FLOATS = 3 * ST_IH * ST_IW;
+constexpr int ST_LDS = 2 * ST_APLANE + ((ST_IN_FLOATS * 4 + 15) & ~15);
+constexpr int ST_CPITCH = 68;                  // floats per convolution pixel in the pooling buffer (64 + 4: bank spread)
+static_assert(ST_NPX * ST_CPITCH * 4 <= 2 * ST_APLANE, "the pooling buffer reuses the im2col planes");
+
+// W (64, 3, 7, 7) -> [co tile 2][k-step 10][plane][lane][8]: lane = 32 kg + j holds W[32 ct + j][k = 16 ks + 8 kg + e], k = (ky 7 + kx) 3 + ci
+__global__ void stem_pack_kernel(const float *__restrict__ W, const unsigned *maxbits, f16 *__restrict__ dst, float *scale_out) {
+    const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * (ST_K / 8); i += gridDim.x * blockDim.x) {
+        const int co = i / (ST_K / 8), k8 = i % (ST_K / 8);
+        f16 hh[8], ll[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0 && mx > 0.f) atomicMax(a.y_amax, __builtin_bit_cast(unsigned, mx));
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * k8 + e, tap = k / 3, ci = k - 3 * tap;
+            const float v = k < ST_KREAL ? W[(co * 3 + ci) * 49 + tap] * scale : 0.f;
+            hh[e] = (f16)v;
+            ll[e] = (f16)(v - (float)hh[e]);
+        }
+        const int ct = co >> 5, j = co & 31, ks = k8 >> 1, kg = k8 & 1;
+        f16 *o = dst + (((long)ct * (ST_K / 16) + ks) * 2) * 512 + (32 * kg + j) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = hh[e];
+            o[512 + e] = ll[e];
+        }
     }
+}
+
+struct StemArgs {
+    const float *x;           // [N][3][H][W]
+    const f16 *w;
+    const float *w_scale;
+    const unsigned *x_amax;
+    const float *bn_scale, *bn_shift;
+    float *y;                 // [N][Hp][Wp][64]
+    unsigned *y_amax;
+    int N, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
+};
+
+constexpr int ST_THREADS = 512;
+__global__ __launch_bounds__(ST_THREADS, 2) void stem_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Ap = smem;                                                   // im2col planes, later the pooling buffer
+    float *xin = reinterpret_cast<float *>(smem + 2 * ST_APLANE);      // [3][ST_IH][ST_IW]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int py0 = ty * ST_PH, px0 = tx * ST_PW;          // pooled tile origin
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;        // convolution tile origin (the pool's padding row / column)
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;        // input tile origin
+    const float s_in = f16_scale_from_bits(*a.x_amax);
+    // ---- input tile (zeros outside the frame): every load of the thread in flight before the first LDS store
+    constexpr int ST_NLD = (ST_IN_FLOATS + ST_THREADS - 1) / ST_THREADS;
+    float vin[ST_NLD];
+#pragma unroll
+    for (int q = 0; q < ST_NLD; ++q) {
+        const int i = tid + ST_THREADS * q;
+        const int ci = i / (ST_IH * ST_IW), r = i - ci * (ST_IH * ST_IW);
+        const int iy = r / ST_IW, ix = r - iy * ST_IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        vin[q] = 0.f;
+        if (i < ST_IN_FLOATS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) vin[q] = a.x[(((long)n * 3 + ci) * a.H + gy) * a.W + gx];
+    }
+#pragma unroll
+    for (int q = 0; q < ST_NLD; ++q)
+        if (tid + ST_THREADS * q < ST_IN_FLOATS) xin[tid + ST_THREADS * q] = vin[q] * s_in;
+    __syncthreads();
+    // ---- im2col rows as split planes: two k per item (one 4-byte store per plane); rows >= 85 and k >= 147 are zero
+    for (int i = tid; i < ST_M * (ST_K / 2); i += ST_THREADS) {
+        const int r = i / (ST_K / 2), k = 2 * (i - r * (ST_K / 2));
+        float v0 = 0.f, v1 = 0.f;
+        if (r < ST_NPX) {
+            const int cy = r / ST_CW, cx = r - cy * ST_CW;
+            if (k < ST_KREAL) {
+                const int tap = k / 3, ci = k - 3 * tap, ky = tap / 7, kx = tap - 7 * ky;
+                v0 = xin[(ci * ST_IH + 2 * cy + ky) * ST_IW + 2 * cx + kx];
+            }
+            if (k + 1 < ST_KREAL) {
+                const int tap = (k + 1) / 3, ci = k + 1 - 3 * tap, ky = tap / 7, kx = tap - 7 * ky;
+                v1 = xin[(ci * ST_IH + 2 * cy + ky) * ST_IW + 2 * cx + kx];
+            }
+        }
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 h = {(f16)v0, (f16)v1};
+        const f16x2 l = {(f16)(v0 - (float)h[0]), (f16)(v1 - (float)h[1])};
+        *reinterpret_cast<f16x2 *>(Ap + r * ST_AROW + 2 * k) = h;
+        *reinterpret_cast<f16x2 *>(Ap + ST_APLANE + r * ST_AROW + 2 * k) = l;
+    }
+    __syncthreads();
+    // ---- 3 row tiles x 2 column tiles: waves 0 - 5 take one each (tile id = 2 rt + ct); the other two only fill and pool
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    const int ntile = w < 6 ? 1 : 0;
+#pragma unroll
+    for (int m = 0; m < 1; ++m) {
+        if (m >= ntile) break;
+        const int tile = w, rt = tile >> 1, ct = tile & 1;
+        const char *arow = Ap + (32 * rt + j) * ST_AROW + 16 * kg;
+        const f16 *wp = a.w + (long)ct * (ST_K / 16) * 1024 + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < ST_K / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(arow + 32 * ks), al = *reinterpret_cast<const f16x8 *>(arow + ST_APLANE + 32 * ks);
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(wp + ks * 1024), bl = *reinterpret_cast<const f16x8 *>(wp + ks * 1024 + 512);
+            acc[m] = mfma32(al, bh, acc[m]);
+            acc[m] = mfma32(ah, bl, acc[m]);
+            acc[m] = mfma32(ah, bh, acc[m]);
+        }
+    }
+    __syncthreads();   // the im2col planes are consumed: the region becomes the pooling buffer [85 px][ST_CPITCH]
+    float *cbuf = reinterpret_cast<float *>(Ap);
+    const float un = 1.0f / (s_in * *a.w_scale);
+#pragma unroll
+    for (int m = 0; m < 1; ++m) {
+        if (m >= ntile) break;
+        const int tile = w, rt = tile >> 1, ct = tile & 1;
+        const int co = 32 * ct + j;
+        const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row >= ST_NPX) continue;
+            const int cy = row / ST_CW, cx = row - cy * ST_CW;
+            const int gy = cy0 + cy, gx = cx0 + cx;
+            // outside the convolution map = the pool's padding: every window holds its valid centre and ReLU outputs are >= 0, so 0 acts as -inf
+            const bool ok = gy >= 0 && gy < a.Hc && gx >= 0 && gx < a.Wc;
+            cbuf[row * ST_CPITCH + co] = ok ? fmaxf(acc[m][r] * bs + bt, 0.f) : 0.f;
+        }
+    }
+    __syncthreads();
+    float mx = 0.f;
+    for (int i = tid; i < ST_PH * ST_PW * 64; i += ST_THREADS) {
+        const int co = i & 63, pp = i >> 6, ppy = pp / ST_PW, ppx = pp - ppy * ST_PW;
+        const int gy = py0 + ppy, gx = px0 + ppx;
+        if (gy >= a.Hp || gx >= a.Wp) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v = fmaxf(v, cbuf[((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_CPITCH + co]);
+        a.y[(((long)n * a.Hp + gy) * a.Wp + gx) * 64 + co] = v;
+        mx = fmaxf(mx, v);
+    }
+    if (a.y_amax) publish_amax(a.y_amax, mx, lane);
 }
 
 }   // namespace cv
 
 extern "C" int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream) {
-    if (!x || !word || n <= 0 || n % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(SD_E_BADARG, "sd_absmax_word: x must be 16-byte aligned, n a multiple of 4");
+    if (!x || !word || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(SD_E_BADARG, "sd_absmax_word: x must be 16-byte aligned, n > 0");
     long blocks = (n / 4 + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
-    SD_LAUNCH(cv::absmax_word_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), word);
+    if (blocks < 1) blocks = 1;
+    SD_LAUNCH(cv::absmax_word_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 4), (long)n, word);
     SD_CHECK_LAUNCH("absmax_word_kernel");
     return 0;
 }
@@ -353,5 +537,42 @@ extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const flo
     if (ksize == 3) SD_LAUNCH(cv::conv_s2_kernel<3>, grid, dim3(256), (size_t)cv::S2Cfg<3>::LDS, (hipStream_t)stream, a);
     else SD_LAUNCH(cv::conv_s2_kernel<1>, grid, dim3(256), (size_t)cv::S2Cfg<1>::LDS, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv_s2_kernel");
+    return 0;
+}
+
+extern "C" size_t sd_stem_packed_halfs(void) { return (size_t)64 * cv::ST_K * 2; }
+
+extern "C" int sd_stem_pack(const float *w, void *planes, float *scale, uint32_t *amax_word, void *stream) {
+    if (!w || !planes || !scale || !amax_word) return fail(SD_E_BADARG, "sd_stem_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    SD_LAUNCH(cv::zero_words_kernel, dim3(1), dim3(64), 0, st, amax_word, 1);
+    SD_CHECK_LAUNCH("zero_words_kernel");
+    int rc = sd_absmax_word(w, 64 * 3 * 49, amax_word, stream);
+    if (rc) return rc;
+    SD_LAUNCH(cv::stem_pack_kernel, dim3(5), dim3(256), 0, st, w, amax_word, (f16 *)planes, scale);
+    SD_CHECK_LAUNCH("stem_pack_kernel");
+    return 0;
+}
+
+extern "C" int sd_stem_conv_bn_relu_pool(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                                         const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, void *stream) {
+    if (!x || !w_planes || !w_scale || !x_amax || !bn_scale || !bn_shift || !y || N <= 0 || H <= 0 || W <= 0)
+        return fail(SD_E_BADARG, "sd_stem_conv_bn_relu_pool: null pointer or empty shape");
+    cv::StemArgs a;
+    a.x = x; a.w = (const f16 *)w_planes; a.w_scale = w_scale; a.x_amax = x_amax; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y = y; a.y_amax = y_amax;
+    a.N = N; a.H = H; a.W = W;
+    a.Hc = (H - 1) / 2 + 1; a.Wc = (W - 1) / 2 + 1;          // conv 7 x 7, stride 2, padding 3
+    a.Hp = (a.Hc - 1) / 2 + 1; a.Wp = (a.Wc - 1) / 2 + 1;    // max-pool 3 x 3, stride 2, padding 1
+    a.tiles_x = (a.Wp + cv::ST_PW - 1) / cv::ST_PW; a.tiles_y = (a.Hp + cv::ST_PH - 1) / cv::ST_PH;
+    const long tiles = (long)a.tiles_x * a.tiles_y * N;
+    if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_stem_conv_bn_relu_pool: too many tiles");
+    static DevFlag attr_set;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void *)cv::stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cv::ST_LDS);
+        if (e != hipSuccess) return fail((int)e, "stem_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        attr_set = true;
+    }
+    SD_LAUNCH(cv::stem_kernel, dim3((unsigned)tiles), dim3(cv::ST_THREADS), (size_t)cv::ST_LDS, (hipStream_t)stream, a);
+    SD_CHECK_LAUNCH("stem_kernel");
     return 0;
 }

@@ -136,20 +136,21 @@ class _ResNet(nn.Module):
                 and os.environ.get("SD_CONV", "hip") != "torch")
 
     def forward(self, x):
-        hip = self._hip_inference(x)
-        if hip:   # the whole inference forward in NHWC memory: the stem's library kernels see a channels_last view
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        if hip:
-            # basic blocks on NHWC tensors through sd_conv3x3_bn_act; back to an NCHW view for the head
-            h = x.permute(0, 2, 3, 1).contiguous()
-            amax = ops.absmax_word(h)
+        if self._hip_inference(x):
+            # the whole inference forward on the hand-written kernels: the stem (conv1 / bn1 / relu / maxpool) in one launch from the NCHW
+            # frames to an NHWC map, the basic blocks on NHWC tensors, back to an NCHW view for the head
+            x = x.contiguous()
+            pk = self.__dict__.get("_pk_stem")
+            if pk is None or pk.planes.device != x.device:
+                pk = self.__dict__["_pk_stem"] = ops.PackedStem(self.conv1.weight)
+            amax = torch.zeros(1, dtype=torch.int32, device=x.device)
+            h = ops.stem_conv_bn_relu_pool(x, ops.absmax_word(x), pk.refresh(self.conv1.weight), *_BasicBlock._bn_fold(self.bn1), y_amax=amax)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:
                     h, amax = blk.forward_nhwc(h, amax)
-            x = h.permute(0, 3, 1, 2).contiguous()
+            x = h.permute(0, 3, 1, 2)
         else:
-            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x))))))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 

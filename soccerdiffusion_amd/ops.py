@@ -962,3 +962,44 @@ def conv_s2_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
                                         bn_shift.data_ptr(), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, w.ksize, int(relu), _stream()),
           "sd_conv_s2_bn_act")
     return y
+
+
+class PackedStem:
+    """ResNet's first convolution (64, 3, 7, 7) in the fragment order of ``sd_stem_conv_bn_relu_pool``; repacked when the weight moves."""
+
+    def __init__(self, weight: Tensor):
+        lib = _lib.load()
+        _req(weight, "weight")
+        if tuple(weight.shape) != (64, 3, 7, 7):
+            raise ValueError("the ResNet stem convolution is (64, 3, 7, 7)")
+        self.planes = torch.empty(lib.sd_stem_packed_halfs(), dtype=torch.float16, device=weight.device)
+        self.scale = torch.empty(1, dtype=torch.float32, device=weight.device)
+        self._word = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        self.version = None
+        self.refresh(weight)
+
+    def refresh(self, weight: Tensor) -> "PackedStem":
+        if self.version != weight._version:
+            w = weight.detach().contiguous()
+            check(_lib.load().sd_stem_pack(w.data_ptr(), self.planes.data_ptr(), self.scale.data_ptr(), self._word.data_ptr(), _stream()),
+                  "sd_stem_pack")
+            self.version = weight._version
+        return self
+
+
+def stem_conv_bn_relu_pool(x: Tensor, x_amax: Tensor, w: PackedStem, bn_scale: Tensor, bn_shift: Tensor,
+                           y_amax: Optional[Tensor] = None) -> Tensor:
+    """maxpool3x3/s2/p1(relu(conv7x7/s2/p3(x) * bn_scale + bn_shift)): NCHW frames (N, 3, H, W) -> NHWC map (N, Hp, Wp, 64) in one
+    launch - torchvision ResNet's conv1 / bn1 / relu / maxpool in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83)."""
+    _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
+    N, C3, H, W = x.shape
+    if C3 != 3:
+        raise ValueError("the stem takes 3-channel frames")
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, 64, dtype=torch.float32, device=x.device)
+    if y_amax is not None:
+        y_amax.zero_()
+    check(_lib.load().sd_stem_conv_bn_relu_pool(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
+                                                bn_shift.data_ptr(), y.data_ptr(), _ptr(y_amax), N, H, W, _stream()),
+          "sd_stem_conv_bn_relu_pool")
+    return y

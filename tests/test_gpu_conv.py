@@ -127,7 +127,8 @@ def test_packed_weight_follows_updates(ops):
 @pytest.mark.parametrize("avgpool,HW", [(True, (96, 128)), (False, (64, 64))])
 def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW):
     """The module-level route (ml/model/encoder/image.py): in eval mode without a tape the basic blocks go through
-    sd_conv3x3_bn_act (13 of the 20 convolutions) and sd_conv_s2_bn_act (the three stage entries and their shortcuts); tokens equal the same torch.nn modules on the CPU in fp32 (1e-4) and the
+    sd_conv3x3_bn_act (13 of the 20 convolutions) and sd_conv_s2_bn_act (the three stage entries and their shortcuts), the stem through
+    sd_stem_conv_bn_relu_pool; tokens equal the same torch.nn modules on the CPU in fp32 (1e-4) and the
     all-MIOpen route on the GPU."""
     import copy
 
@@ -146,17 +147,19 @@ def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW
     with torch.no_grad():
         want = enc(x)
     g = copy.deepcopy(enc).cuda().eval()
-    calls, calls2 = [], []
-    orig, orig2 = o.conv3x3_bn_act, o.conv_s2_bn_act
+    calls, calls2, calls3 = [], [], []
+    orig, orig2, orig3 = o.conv3x3_bn_act, o.conv_s2_bn_act, o.stem_conv_bn_relu_pool
+    o.stem_conv_bn_relu_pool = lambda *a, **k: (calls3.append(1), orig3(*a, **k))[1]
     o.conv3x3_bn_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     o.conv_s2_bn_act = lambda *a, **k: (calls2.append(1), orig2(*a, **k))[1]
     try:
         with torch.no_grad():
             got = g(x.cuda())
     finally:
-        o.conv3x3_bn_act, o.conv_s2_bn_act = orig, orig2
+        o.conv3x3_bn_act, o.conv_s2_bn_act, o.stem_conv_bn_relu_pool = orig, orig2, orig3
+    assert len(calls3) == 1                 # conv1 / bn1 / relu / maxpool: one launch
     assert len(calls) == 13, len(calls)     # layer1: 4, layers 2-4: 3 each (their first conv strides)
-    assert len(calls2) == 6, len(calls2)    # ... which, with its 1 x 1 shortcut, runs on the stride-2 kernel: only the stem is library code
+    assert len(calls2) == 6, len(calls2)    # ... which, with its 1 x 1 shortcut, runs on the stride-2 kernel: no library convolution is left
     assert got.shape == (2, 3, 64)
     assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
     os.environ["SD_CONV"] = "torch"
@@ -170,3 +173,31 @@ def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW
     xg = x.cuda().requires_grad_(True)
     g(xg).square().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+# the stem on a 480 x 640 frame, small / odd / ragged frames (conv and pool borders inside one tile), a single pixel
+@pytest.mark.parametrize("N,H,W", [(2, 480, 640), (3, 96, 128), (1, 37, 53), (2, 64, 64), (1, 7, 9), (1, 1, 1), (1, 30, 200)])
+def test_stem_conv_bn_relu_pool_matches_torch_cpu(ops, N, H, W):
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(N, 3, H, W, generator=g) * 2.0 - 0.7                     # normalised frames: both signs
+    w = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / (49 * 64)) ** 0.5
+    gamma, beta = 0.5 + torch.rand(64, generator=g), 0.2 * torch.randn(64, generator=g)
+    mean, var = 0.3 * torch.randn(64, generator=g), 0.5 + torch.rand(64, generator=g)
+
+    def stem(dtype):
+        y = F.conv2d(x.to(dtype), w.to(dtype), stride=2, padding=3)
+        y = F.batch_norm(y, mean.to(dtype), var.to(dtype), gamma.to(dtype), beta.to(dtype), training=False, eps=1e-5)
+        return F.max_pool2d(F.relu(y), 3, 2, 1)
+
+    want64, want32 = stem(torch.float64), stem(torch.float32)
+    xd = x.cuda()
+    inv = torch.rsqrt(var + 1e-5)
+    ya = torch.zeros(1, dtype=torch.int32, device="cuda")
+    xa = ops.absmax_word(xd)
+    assert xa.view(torch.float32).item() == float(x.abs().max())
+    y = ops.stem_conv_bn_relu_pool(xd, xa, ops.PackedStem(w.cuda()), (gamma * inv).cuda(), (beta - mean * gamma * inv).cuda(), y_amax=ya)
+    got = y.permute(0, 3, 1, 2).cpu()
+    assert got.shape == want64.shape
+    e, e32 = rel_err(got, want64), rel_err(want32, want64)
+    assert e < 2e-6 and e < 8 * e32 + 2e-7, (e, e32)
+    assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
