@@ -30,7 +30,13 @@ constexpr int PIX = 2 * CK + 16;                            // bytes of a halo p
 constexpr int PLANE = HH * HW * PIX;                        // the lo plane follows the hi plane
 constexpr int LDS_BYTES = 2 * PLANE;                        // 51 840
 constexpr int COT = 64;                                     // output channels per workgroup
+#ifndef SD_CONV_WD
+#define SD_CONV_WD 4
+#endif
+constexpr int WD = SD_CONV_WD;                              // register stages of the weight-fragment ring (lookahead WD - 1 k-steps)
 
+// row (0 / 1) of MFMA row i = 0..31 inside its 2 x 16 pixel block: columns 4 - 11 of the two rows swap lanes (see conv3x3_kernel)
+__device__ __forceinline__ int row32(int i) { return (i >> 4) ^ ((((i & 15) + 4) >> 3) & 1); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // abs-max of a tensor into ONE word (bits of a non-negative float: unsigned order = float order)
@@ -118,10 +124,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    // this lane's A rows: pixel (row 4 ph + 2 m + (j >> 4), column j & 15) of the tile, as a halo offset for tap (0, 0)
+    // this lane's A rows: pixel (row 4 ph + 2 m + row32(j), column j & 15) of the tile, as a halo offset for tap (0, 0).  row32 puts
+    // the 16 lanes of each ds_read_b128 group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) on the 16 consecutive pixels of ONE halo
+    // row (144-byte pitch: 16 distinct 16-byte slots); with row = j >> 4 a group straddled two rows and lost two of its slots (46 % of
+    // the LDS cycles were conflicts)
     unsigned abase[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) abase[m] = (unsigned)(((4 * ph + 2 * m + (j >> 4)) * HW + (j & 15)) * PIX + 16 * kg);
+    for (int m = 0; m < 2; ++m) abase[m] = (unsigned)(((4 * ph + 2 * m + row32(j)) * HW + (j & 15)) * PIX + 16 * kg);
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0 > 0) __syncthreads();   // every wave has consumed the previous chunk
@@ -151,12 +160,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
         __syncthreads();
         // ---- 9 taps x 4 k-steps: weight fragments (global / L2) and halo fragments (LDS) one step ahead
         const f16 *wp = wbase + (long)(c0 / 16) * 1024;
-        f16x8 bw[2][2], af[2][2][2];   // [stage][plane], [stage][tile][plane]
-        auto load = [&](int s, int st) __attribute__((always_inline)) {
+        // a step is 6 MFMAs = 192 cycles of the pipe and a SIMD holds three waves: one step of lookahead is ~600 cycles against an L2
+        // round trip of ~1 500 under load, so the weight fragments run WD - 1 steps ahead (a ring of WD register stages)
+        f16x8 bw[WD][2], af[2][2][2];   // [ring stage][plane], [stage][tile][plane]
+        auto load_w = [&](int s) __attribute__((always_inline)) {
             const int tap = s >> 2, ks = s & 3;
             const f16 *q = wp + ((long)tap * nks + ks) * 1024;
-            bw[st][0] = *reinterpret_cast<const f16x8 *>(q);
-            bw[st][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+            bw[s % WD][0] = *reinterpret_cast<const f16x8 *>(q);
+            bw[s % WD][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+        };
+        auto load_a = [&](int s, int st) __attribute__((always_inline)) {
+            const int tap = s >> 2, ks = s & 3;
             const unsigned toff = (unsigned)(((tap / 3) * HW + (tap % 3)) * PIX + 32 * ks);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -164,17 +178,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
                 af[st][m][1] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff + PLANE);
             }
         };
-        load(0, 0);
+#pragma unroll
+        for (int s = 0; s < WD - 1; ++s) load_w(s);
+        load_a(0, 0);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             const int st = s & 1;
-            if (s + 1 < 36) load(s + 1, st ^ 1);
+            if (s + WD - 1 < 36) load_w(s + WD - 1);
+            if (s + 1 < 36) load_a(s + 1, st ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                acc[m] = mfma32(af[st][m][1], bw[st][0], acc[m]);   // lo . hi
-                acc[m] = mfma32(af[st][m][0], bw[st][1], acc[m]);   // hi . lo
-                acc[m] = mfma32(af[st][m][0], bw[st][0], acc[m]);   // hi . hi
+                acc[m] = mfma32(af[st][m][1], bw[s % WD][0], acc[m]);   // lo . hi
+                acc[m] = mfma32(af[st][m][0], bw[s % WD][1], acc[m]);   // hi . lo
+                acc[m] = mfma32(af[st][m][0], bw[s % WD][0], acc[m]);   // hi . hi
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;           // accumulator row = A row
-            const int gy = y0 + 4 * ph + 2 * m + (i >> 4), gx = x0 + (i & 15);
+            const int gy = y0 + 4 * ph + 2 * m + row32(i), gx = x0 + (i & 15);
             if (gy >= a.H || gx >= a.W) continue;
             const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co;
             float v = acc[m][r] * bs + bt;
@@ -261,25 +278,32 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
         }
         __syncthreads();
         const f16 *wp = wbase + (long)(c0 / 16) * 1024;
-        f16x8 bw[2][2], af[2][2];
-        auto load = [&](int s, int st) __attribute__((always_inline)) {
+        constexpr int SD = KS == 3 ? 2 * WD : 4;   // a step is 3 MFMAs here: twice the lookahead (KS = 1: all 4 steps at once)
+        f16x8 bw[SD][2], af[2][2];
+        auto load_w = [&](int s) __attribute__((always_inline)) {
             const int tap = s >> 2, ks = s & 3;
             const f16 *q = wp + ((long)tap * nks + ks) * 1024;
-            bw[st][0] = *reinterpret_cast<const f16x8 *>(q);
-            bw[st][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+            bw[s % SD][0] = *reinterpret_cast<const f16x8 *>(q);
+            bw[s % SD][1] = *reinterpret_cast<const f16x8 *>(q + 512);
+        };
+        auto load_a = [&](int s, int st) __attribute__((always_inline)) {
+            const int tap = s >> 2, ks = s & 3;
             const unsigned toff = (unsigned)((KS == 3 ? ((tap / 3) * C::HW + (tap % 3)) * PIX : 0) + 32 * ks);
             af[st][0] = *reinterpret_cast<const f16x8 *>(smem + abase + toff);
             af[st][1] = *reinterpret_cast<const f16x8 *>(smem + abase + toff + C::PLANE);
         };
-        load(0, 0);
+#pragma unroll
+        for (int s = 0; s < SD - 1 && s < TAPS * 4; ++s) load_w(s);
+        load_a(0, 0);
 #pragma unroll
         for (int s = 0; s < TAPS * 4; ++s) {
             const int st = s & 1;
-            if (s + 1 < TAPS * 4) load(s + 1, st ^ 1);
+            if (s + SD - 1 < TAPS * 4) load_w(s + SD - 1);
+            if (s + 1 < TAPS * 4) load_a(s + 1, st ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc = mfma32(af[st][1], bw[st][0], acc);
-            acc = mfma32(af[st][0], bw[st][1], acc);
-            acc = mfma32(af[st][0], bw[st][0], acc);
+            acc = mfma32(af[st][1], bw[s % SD][0], acc);
+            acc = mfma32(af[st][0], bw[s % SD][1], acc);
+            acc = mfma32(af[st][0], bw[s % SD][0], acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -304,37 +328,48 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // The ResNet stem in one launch: conv 7 x 7 stride 2 padding 3 (3 -> 64 channels) + inference BatchNorm + ReLU + max-pool 3 x 3 stride 2
 // padding 1, NCHW frames in, NHWC map out (+ its abs-max word) - four library launches and a 3.1-GB intermediate map at 160 frames of
-// 480 x 640 otherwise.  A workgroup owns a 2 x 8 tile of POOLED pixels: the 5 x 17 convolution outputs under it come from a 15 x 39 x 3
-// input tile (LDS, fp32); their im2col rows (K = 147 -> 160, k = (ky 7 + kx) 3 + ci) are written as fp16 hi | lo planes and multiplied
-// with the packed weights as in the other kernels (6 MFMA tiles of 32 x 32, three products); the 85 x 64 results pass through LDS for
-// the pooling.  71 KB of LDS: two workgroups per CU.
+// 480 x 640 otherwise.  A workgroup (5 waves) owns a 4 x 8 tile of POOLED pixels: the 9 x 17 convolution outputs under it come from a
+// 23 x 39 x 3 input tile, which is staged channel-interleaved as fp16 hi | lo planes.  No im2col: for a kernel row ky the 7 x 3 values
+// (kx, ci) of an output pixel are 21 CONSECUTIVE halfs of an input row (from half 6 cx on), so K is ordered (ky, kx, ci) with each
+// kernel row padded to 24 = three 8-half lane chunks (21 chunks + 1 of zero weights = 11 k-steps of 16) and an A fragment is one
+// ds_read_b128 of the input row.  Its byte offset 12 cx + 16 q is 16-byte aligned only for cx = 0 mod 4, hence FOUR copies of the tile,
+// copy s = cx mod 4 shifted by 4 s bytes; the copies start 12 sixteen-byte slots apart (mod 16) so that 16 consecutive cx read 16
+// distinct slots.  (The first version wrote explicit im2col rows: 4.3 ms at 160 frames, its fill loop 3/4 of that.)
+// Wave w = convolution pixels 32 w .. 32 w + 31 (row-major in the 9 x 17 tile; 153 of 160 rows real) x all 64 channels.  The results
+// (BatchNorm, ReLU) pass through LDS (over the dead input planes) for the pooling.  50 KB of LDS: three workgroups per CU.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ST_PH = 2, ST_PW = 8, ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1, ST_IH = 2 * ST_CH + 5, ST_IW = 2 * ST_CW + 5;
-constexpr int ST_NPX = ST_CH * ST_CW;          // 85 convolution pixels per tile
-constexpr int ST_M = 96, ST_K = 160, ST_KREAL = 147;
-constexpr int ST_AROW = ST_K * 2 + 16;         // bytes of an im2col row in one plane (21 sixteen-byte units: odd)
-constexpr int ST_APLANE = ST_M * ST_AROW;
-constexpr int ST_IN_FLOATS = 3 * ST_IH * ST_IW;
-constexpr int ST_LDS = 2 * ST_APLANE + ((ST_IN_FLOATS * 4 + 15) & ~15);
-constexpr int ST_CPITCH = 68;                  // floats per convolution pixel in the pooling buffer (64 + 4: bank spread)
-static_assert(ST_NPX * ST_CPITCH * 4 <= 2 * ST_APLANE, "the pooling buffer reuses the im2col planes");
+constexpr int ST_PH = 4, ST_PW = 8, ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1, ST_IH = 2 * ST_CH + 5, ST_IW = 2 * ST_CW + 5;
+constexpr int ST_NPX = ST_CH * ST_CW;           // 153 convolution pixels per tile
+constexpr int ST_WAVES = 5, ST_THREADS = 64 * ST_WAVES;
+constexpr int ST_NKS = 11;                      // k-steps of 16: 7 kernel rows x 24 halfs = 21 chunks of 8 (+ 1 of zero weights)
+constexpr int ST_ROWH = 3 * ST_IW;              // 117 halfs of an input row
+constexpr int ST_RP = 272;                      // bytes of a copy's row: 12 (shift) + 234, and 17 slots (odd: kernel rows spread over the banks)
+constexpr int ST_RD = ST_RP / 4;                // ... in dwords
+constexpr int ST_CS = ((ST_IH * ST_RP / 16 + 15) / 16 * 16 + 12) * 16;   // copy stride: = 12 slots mod 16, >= the copy
+constexpr int ST_PLANE = 4 * ST_CS;
+constexpr int ST_CPITCH = 68;                   // floats per convolution pixel in the pooling buffer (64 + 4: bank spread)
+constexpr int ST_LDS = 2 * ST_PLANE;
+static_assert(ST_CS >= ST_IH * ST_RP && ST_NPX * ST_CPITCH * 4 <= ST_LDS, "copies fit their stride; the pooling buffer reuses the planes");
+static_assert(12 + 12 * (ST_CW - 1) + 32 + 16 <= ST_RP && ST_NPX <= 32 * ST_WAVES, "fragment reads stay inside a row");
 
-// W (64, 3, 7, 7) -> [co tile 2][k-step 10][plane][lane][8]: lane = 32 kg + j holds W[32 ct + j][k = 16 ks + 8 kg + e], k = (ky 7 + kx) 3 + ci
+// W (64, 3, 7, 7) -> [co tile 2][k-step 11][plane][lane][8]: lane = 32 kg + j holds, for chunk c = 2 ks + kg (kernel row ky = c / 3,
+// third q = c % 3), W[32 ct + j][ci][ky][kx] at e = 0..7 with 8 q + e = 3 kx + ci < 21; zero elsewhere (and for c = 21)
 __global__ void stem_pack_kernel(const float *__restrict__ W, const unsigned *maxbits, f16 *__restrict__ dst, float *scale_out) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * (ST_K / 8); i += gridDim.x * blockDim.x) {
-        const int co = i / (ST_K / 8), k8 = i % (ST_K / 8);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 2 * ST_NKS; i += gridDim.x * blockDim.x) {
+        const int co = i / (2 * ST_NKS), c = i % (2 * ST_NKS);
+        const int ky = c / 3, q = c - 3 * ky;
         f16 hh[8], ll[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = 8 * k8 + e, tap = k / 3, ci = k - 3 * tap;
-            const float v = k < ST_KREAL ? W[(co * 3 + ci) * 49 + tap] * scale : 0.f;
+            const int kk = 8 * q + e, kx = kk / 3, ci = kk - 3 * kx;
+            const float v = (c < 21 && kk < 21) ? W[((co * 3 + ci) * 7 + ky) * 7 + kx] * scale : 0.f;
             hh[e] = (f16)v;
             ll[e] = (f16)(v - (float)hh[e]);
         }
-        const int ct = co >> 5, j = co & 31, ks = k8 >> 1, kg = k8 & 1;
-        f16 *o = dst + (((long)ct * (ST_K / 16) + ks) * 2) * 512 + (32 * kg + j) * 8;
+        const int ct = co >> 5, j = co & 31, ks = c >> 1, kg = c & 1;
+        f16 *o = dst + (((long)ct * ST_NKS + ks) * 2) * 512 + (32 * kg + j) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             o[e] = hh[e];
@@ -354,11 +389,8 @@ struct StemArgs {
     int N, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
 };
 
-constexpr int ST_THREADS = 512;
-__global__ __launch_bounds__(ST_THREADS, 2) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(ST_THREADS) void stem_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Ap = smem;                                                   // im2col planes, later the pooling buffer
-    float *xin = reinterpret_cast<float *>(smem + 2 * ST_APLANE);      // [3][ST_IH][ST_IW]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kg = lane >> 5;
     int t = blockIdx.x;
@@ -369,76 +401,80 @@ __global__ __launch_bounds__(ST_THREADS, 2) void stem_kernel(StemArgs a) {
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;        // convolution tile origin (the pool's padding row / column)
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;        // input tile origin
     const float s_in = f16_scale_from_bits(*a.x_amax);
-    // ---- input tile (zeros outside the frame): every load of the thread in flight before the first LDS store
-    constexpr int ST_NLD = (ST_IN_FLOATS + ST_THREADS - 1) / ST_THREADS;
-    float vin[ST_NLD];
+    // ---- input tile -> four shifted copies of its hi | lo planes.  An item is a dword of a copy's row: the half pair (2 p, 2 p + 1) of
+    // the row (zeros outside the frame, left of the row (p < 0: the copies' shifts) and right of it) goes to dword p + s of copy s
+    constexpr int ST_PAIRS = ST_RD + 3;                     // p = -3 .. ST_RD - 1
+    constexpr int ST_ITEMS = ST_IH * ST_PAIRS, ST_NIT = (ST_ITEMS + ST_THREADS - 1) / ST_THREADS;
+    float v0[ST_NIT], v1[ST_NIT];
 #pragma unroll
-    for (int q = 0; q < ST_NLD; ++q) {
-        const int i = tid + ST_THREADS * q;
-        const int ci = i / (ST_IH * ST_IW), r = i - ci * (ST_IH * ST_IW);
-        const int iy = r / ST_IW, ix = r - iy * ST_IW;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        vin[q] = 0.f;
-        if (i < ST_IN_FLOATS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) vin[q] = a.x[(((long)n * 3 + ci) * a.H + gy) * a.W + gx];
+    for (int q = 0; q < ST_NIT; ++q) {
+        const int i = tid + ST_THREADS * q, iy = i / ST_PAIRS, p = i - iy * ST_PAIRS - 3;
+        const int gy = iy0 + iy;
+        v0[q] = v1[q] = 0.f;
+        if (i < ST_ITEMS && p >= 0 && gy >= 0 && gy < a.H) {
+            const int e0 = 2 * p, e1 = 2 * p + 1;
+            const int x0 = e0 / 3, c0 = e0 - 3 * x0, x1 = e1 / 3, c1 = e1 - 3 * x1;
+            const float *row = a.x + ((long)n * 3 * a.H + gy) * a.W;
+            const long cstride = (long)a.H * a.W;
+            if (e0 < ST_ROWH && ix0 + x0 >= 0 && ix0 + x0 < a.W) v0[q] = row[c0 * cstride + ix0 + x0];
+            if (e1 < ST_ROWH && ix0 + x1 >= 0 && ix0 + x1 < a.W) v1[q] = row[c1 * cstride + ix0 + x1];
+        }
     }
 #pragma unroll
-    for (int q = 0; q < ST_NLD; ++q)
-        if (tid + ST_THREADS * q < ST_IN_FLOATS) xin[tid + ST_THREADS * q] = vin[q] * s_in;
-    __syncthreads();
-    // ---- im2col rows as split planes: two k per item (one 4-byte store per plane); rows >= 85 and k >= 147 are zero
-    for (int i = tid; i < ST_M * (ST_K / 2); i += ST_THREADS) {
-        const int r = i / (ST_K / 2), k = 2 * (i - r * (ST_K / 2));
-        float v0 = 0.f, v1 = 0.f;
-        if (r < ST_NPX) {
-            const int cy = r / ST_CW, cx = r - cy * ST_CW;
-            if (k < ST_KREAL) {
-                const int tap = k / 3, ci = k - 3 * tap, ky = tap / 7, kx = tap - 7 * ky;
-                v0 = xin[(ci * ST_IH + 2 * cy + ky) * ST_IW + 2 * cx + kx];
-            }
-            if (k + 1 < ST_KREAL) {
-                const int tap = (k + 1) / 3, ci = k + 1 - 3 * tap, ky = tap / 7, kx = tap - 7 * ky;
-                v1 = xin[(ci * ST_IH + 2 * cy + ky) * ST_IW + 2 * cx + kx];
-            }
-        }
+    for (int q = 0; q < ST_NIT; ++q) {
+        const int i = tid + ST_THREADS * q, iy = i / ST_PAIRS, p = i - iy * ST_PAIRS - 3;
+        if (i >= ST_ITEMS) continue;
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        const f16x2 h = {(f16)v0, (f16)v1};
-        const f16x2 l = {(f16)(v0 - (float)h[0]), (f16)(v1 - (float)h[1])};
-        *reinterpret_cast<f16x2 *>(Ap + r * ST_AROW + 2 * k) = h;
-        *reinterpret_cast<f16x2 *>(Ap + ST_APLANE + r * ST_AROW + 2 * k) = l;
-    }
-    __syncthreads();
-    // ---- 3 row tiles x 2 column tiles: waves 0 - 5 take one each (tile id = 2 rt + ct); the other two only fill and pool
-    f32x16 acc[1];
+        const float s0 = v0[q] * s_in, s1 = v1[q] * s_in;
+        const f16x2 h = {(f16)s0, (f16)s1};
+        const f16x2 l = {(f16)(s0 - (float)h[0]), (f16)(s1 - (float)h[1])};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-    const int ntile = w < 6 ? 1 : 0;
-#pragma unroll
-    for (int m = 0; m < 1; ++m) {
-        if (m >= ntile) break;
-        const int tile = w, rt = tile >> 1, ct = tile & 1;
-        const char *arow = Ap + (32 * rt + j) * ST_AROW + 16 * kg;
-        const f16 *wp = a.w + (long)ct * (ST_K / 16) * 1024 + lane * 8;
-#pragma unroll
-        for (int ks = 0; ks < ST_K / 16; ++ks) {
-            const f16x8 ah = *reinterpret_cast<const f16x8 *>(arow + 32 * ks), al = *reinterpret_cast<const f16x8 *>(arow + ST_APLANE + 32 * ks);
-            const f16x8 bh = *reinterpret_cast<const f16x8 *>(wp + ks * 1024), bl = *reinterpret_cast<const f16x8 *>(wp + ks * 1024 + 512);
-            acc[m] = mfma32(al, bh, acc[m]);
-            acc[m] = mfma32(ah, bl, acc[m]);
-            acc[m] = mfma32(ah, bh, acc[m]);
+        for (int s = 0; s < 4; ++s) {
+            const int d = p + s;
+            if (d < 0 || d >= ST_RD) continue;
+            char *at = smem + s * ST_CS + iy * ST_RP + 4 * d;
+            *reinterpret_cast<f16x2 *>(at) = h;
+            *reinterpret_cast<f16x2 *>(at + ST_PLANE) = l;
         }
     }
-    __syncthreads();   // the im2col planes are consumed: the region becomes the pooling buffer [85 px][ST_CPITCH]
-    float *cbuf = reinterpret_cast<float *>(Ap);
+    __syncthreads();
+    // ---- this wave's 32 convolution pixels x 64 channels: 11 k-steps x (2 channel tiles x 3 products)
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    {
+        const int r0 = min(32 * w + j, ST_NPX - 1);          // rows past the tile repeat its last pixel; they are never stored
+        const int cy = r0 / ST_CW, cx = r0 - cy * ST_CW;
+        const char *arow = smem + (cx & 3) * ST_CS + 2 * cy * ST_RP + 4 * (cx & 3) + 12 * cx;
+        const f16 *wp = a.w + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < ST_NKS; ++ks) {
+            // chunk c = 2 ks + kg: kernel row c / 3, third c % 3; c = 21 has zero weights: it reads chunk 20 again
+            const int ca = 2 * ks, cb = 2 * ks + 1 < 21 ? 2 * ks + 1 : 20;
+            const int off = kg ? (cb / 3) * ST_RP + 16 * (cb % 3) : (ca / 3) * ST_RP + 16 * (ca % 3);
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(arow + off), al = *reinterpret_cast<const f16x8 *>(arow + off + ST_PLANE);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f16 *q = wp + ((long)(m * ST_NKS + ks) * 2) * 512;
+                const f16x8 bh = *reinterpret_cast<const f16x8 *>(q), bl = *reinterpret_cast<const f16x8 *>(q + 512);
+                acc[m] = mfma32(al, bh, acc[m]);
+                acc[m] = mfma32(ah, bl, acc[m]);
+                acc[m] = mfma32(ah, bh, acc[m]);
+            }
+        }
+    }
+    __syncthreads();   // the input planes are consumed: the region becomes the pooling buffer [153 px][ST_CPITCH]
+    float *cbuf = reinterpret_cast<float *>(smem);
     const float un = 1.0f / (s_in * *a.w_scale);
 #pragma unroll
-    for (int m = 0; m < 1; ++m) {
-        if (m >= ntile) break;
-        const int tile = w, rt = tile >> 1, ct = tile & 1;
-        const int co = 32 * ct + j;
+    for (int m = 0; m < 2; ++m) {
+        const int co = 32 * m + j;
         const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (row >= ST_NPX) continue;
             const int cy = row / ST_CW, cx = row - cy * ST_CW;
             const int gy = cy0 + cy, gx = cx0 + cx;
@@ -540,7 +576,7 @@ extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const flo
     return 0;
 }
 
-extern "C" size_t sd_stem_packed_halfs(void) { return (size_t)64 * cv::ST_K * 2; }
+extern "C" size_t sd_stem_packed_halfs(void) { return (size_t)64 * cv::ST_NKS * 16 * 2; }
 
 extern "C" int sd_stem_pack(const float *w, void *planes, float *scale, uint32_t *amax_word, void *stream) {
     if (!w || !planes || !scale || !amax_word) return fail(SD_E_BADARG, "sd_stem_pack: null pointer");
@@ -549,7 +585,7 @@ extern "C" int sd_stem_pack(const float *w, void *planes, float *scale, uint32_t
     SD_CHECK_LAUNCH("zero_words_kernel");
     int rc = sd_absmax_word(w, 64 * 3 * 49, amax_word, stream);
     if (rc) return rc;
-    SD_LAUNCH(cv::stem_pack_kernel, dim3(5), dim3(256), 0, st, w, amax_word, (f16 *)planes, scale);
+    SD_LAUNCH(cv::stem_pack_kernel, dim3(6), dim3(256), 0, st, w, amax_word, (f16 *)planes, scale);
     SD_CHECK_LAUNCH("stem_pack_kernel");
     return 0;
 }
