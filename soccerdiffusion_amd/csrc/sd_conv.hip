@@ -37,6 +37,23 @@ constexpr int WD = SD_CONV_WD;                              // register stages o
 
 // row (0 / 1) of MFMA row i = 0..31 inside its 2 x 16 pixel block: columns 4 - 11 of the two rows swap lanes (see conv3x3_kernel)
 __device__ __forceinline__ int row32(int i) { return (i >> 4) ^ ((((i & 15) + 4) >> 3) & 1); }
+// XCD-aware work order of a 1-D grid over (tile, output-channel block): workgroup ids go round-robin over the 8 XCDs (id % 8), each
+// with its own 4-MB L2.  The channel blocks of one tile read the same halo, so `g` of them (a divisor of yb whose packed weights fit
+// half an L2 together: y_group) take CONSECUTIVE slots of ONE XCD's sequence: they run together and all but the first find the halo
+// in that L2.  With the channel block as the grid's slow dimension every block fetched its input from HBM again (measured, 160 frames:
+// layer 2 1.31 -> 0.79 GB per launch, layer 3 1.17 -> 0.51 GB; with all 8 blocks of layer 4 together their 9.4 MB of weights thrash
+// the L2 instead: 1.17 -> 1.64 GB, hence the cap).  Time is unchanged either way: the kernels are not HBM-bound.  tile >= ntiles: idle.
+__device__ __forceinline__ void xcd_tile(int yb, int g, int ntiles, int &tile, int &yblk) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, t8 = (ntiles + 7) >> 3;
+    const int inner = k % g, rest = k / g;
+    yblk = (rest / t8) * g + inner;
+    tile = (rest % t8) * 8 + xcd;
+}
+inline int y_group(int yb, long weight_bytes_per_block) {
+    int g = 1;
+    while (g * 2 <= yb && yb % (g * 2) == 0 && (long)(g * 2) * weight_bytes_per_block <= (2L << 20)) g *= 2;
+    return g;
+}
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // abs-max of a tensor into ONE word (bits of a non-negative float: unsigned order = float order)
@@ -102,6 +119,7 @@ struct ConvArgs {
     float *y;                // [N][H][W][Cout]
     unsigned *y_amax;        // abs-max word of y, or NULL
     int N, H, W, Cin, Cout, relu, tiles_x, tiles_y;
+    int ygroup;              // output-channel blocks that share a halo in one XCD's L2 (xcd_tile)
 };
 
 __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
@@ -109,12 +127,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kg = lane >> 5;
     const int ph = w & 1, ch = w >> 1;                 // pixel half, output-channel half of this wave
-    int t = blockIdx.x;
+    int t, yblk;
+    xcd_tile(a.Cout / COT, a.ygroup, a.tiles_x * a.tiles_y * a.N, t, yblk);
+    if (t >= a.tiles_x * a.tiles_y * a.N) return;
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int co0 = blockIdx.y * COT + ch * 32;        // this wave's 32 output channels
+    const int co0 = yblk * COT + ch * 32;              // this wave's 32 output channels
     const float s_in = f16_scale_from_bits(*a.x_amax);
     const int nks = a.Cin / 16;
     const f16 *wbase = a.w + (long)(co0 >> 5) * 9 * nks * 1024 + lane * 8;   // [tap][ks][plane]: 1024 halfs per (tap, ks)
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
             if (gy >= a.H || gx >= a.W) continue;
             const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co;
             float v = acc[m][r] * bs + bt;
-            if (a.res) v += a.res[at];
+            if (a.res) v += __builtin_nontemporal_load(a.res + at);
             if (a.relu) v = fmaxf(v, 0.f);
             a.y[at] = v;
             mx = fmaxf(mx, fabsf(v));
@@ -239,12 +259,14 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kg = lane >> 5;
     const int Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;   // (H + 2 pad - KS) / 2 + 1 for KS = 3 / pad 1 and KS = 1 / pad 0
-    int t = blockIdx.x;
+    int t, yblk;
+    xcd_tile(a.Cout / S2_COT, a.ygroup, a.tiles_x * a.tiles_y * a.N, t, yblk);
+    if (t >= a.tiles_x * a.tiles_y * a.N) return;
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int y0 = ty * S2_TH, x0 = tx * S2_TW;        // output tile origin
-    const int co0 = blockIdx.y * S2_COT + w * 32;
+    const int co0 = yblk * S2_COT + w * 32;
     const float s_in = f16_scale_from_bits(*a.x_amax);
     const int nks = a.Cin / 16;
     const f16 *wbase = a.w + (long)(co0 >> 5) * TAPS * nks * 1024 + lane * 8;
@@ -548,10 +570,11 @@ extern "C" int sd_conv3x3_bn_act(const float *x, const void *w_planes, const flo
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv3x3_bn_act: channels must be positive multiples of 64");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv3x3_bn_act: x must be 16-byte aligned and distinct from y");
     cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu,
-                   (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH};
+                   (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH, cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * 9 * 4)};
     const long tiles = (long)a.tiles_x * a.tiles_y * N;
-    if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv3x3_bn_act: too many tiles");
-    SD_LAUNCH(cv::conv3x3_kernel, dim3((unsigned)tiles, (unsigned)(Cout / cv::COT)), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
+    const long wgs = (tiles + 7) / 8 * 8 * (Cout / cv::COT);   // cv::xcd_tile's order
+    if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv3x3_bn_act: too many tiles");
+    SD_LAUNCH(cv::conv3x3_kernel, dim3((unsigned)wgs), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv3x3_kernel");
     return 0;
 }
@@ -566,10 +589,12 @@ extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const flo
     if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv_s2_bn_act: x must be 16-byte aligned and distinct from y");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, nullptr, y, y_amax, N, H, W, Cin, Cout, relu,
-                   (Wo + cv::S2_TW - 1) / cv::S2_TW, (Ho + cv::S2_TH - 1) / cv::S2_TH};
+                   (Wo + cv::S2_TW - 1) / cv::S2_TW, (Ho + cv::S2_TH - 1) / cv::S2_TH,
+                   cv::y_group(Cout / cv::S2_COT, (long)cv::S2_COT * Cin * ksize * ksize * 4)};
     const long tiles = (long)a.tiles_x * a.tiles_y * N;
-    if (tiles > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_s2_bn_act: too many tiles");
-    const dim3 grid((unsigned)tiles, (unsigned)(Cout / cv::S2_COT));
+    const long wgs = (tiles + 7) / 8 * 8 * (Cout / cv::S2_COT);   // cv::xcd_tile's order
+    if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_s2_bn_act: too many tiles");
+    const dim3 grid((unsigned)wgs);
     if (ksize == 3) SD_LAUNCH(cv::conv_s2_kernel<3>, grid, dim3(256), (size_t)cv::S2Cfg<3>::LDS, (hipStream_t)stream, a);
     else SD_LAUNCH(cv::conv_s2_kernel<1>, grid, dim3(256), (size_t)cv::S2Cfg<1>::LDS, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv_s2_kernel");

@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT && python tools/rocprof_db_stats.py gpurun_out/$out 4 | cut 
 python - <<PY
 import sqlite3, glob
 c = sqlite3.connect(glob.glob('gpurun_out/$out/*_results.db')[0])
-for r in c.execute("select name, grid_x, grid_y, count(*), avg(end-start)/1e3 from kernels where name like 'cv::conv3x3%' or name like '%conv_s2%' or name like 'cv::stem_k%' group by name, grid_x, grid_y order by 1,2 desc"):
+for r in c.execute("select name, grid_x, grid_y, count(*), avg(end-start)/1e3 from kernels where name like '%conv3x3_k%' or name like '%conv_s2%' or name like '%stem_k%' group by name, grid_x, grid_y order by 1,2 desc"):
     print(r)
 PY
 head -9 gpurun_out/$out.txt; tail -1 gpurun_out/$out.txt
