@@ -64,9 +64,17 @@ class _BasicBlock(nn.Module):
 
     @staticmethod
     def _bn_fold(bn: nn.BatchNorm2d):
-        """Inference BatchNorm as y = x * s + t per channel."""
+        """Inference BatchNorm as y = x * s + t per channel; cached on the module until one of its four tensors changes (four tiny
+        launches per convolution otherwise - a third of the robot's 10-frame forward)."""
+        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device, bn.weight.data_ptr())
+        hit = bn.__dict__.get("_sd_fold")
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
         s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
-        return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous()
+        t = (bn.bias.detach() - bn.running_mean * s).contiguous()
+        s = s.contiguous()
+        bn.__dict__["_sd_fold"] = (key, s, t)
+        return s, t
 
     def _packed(self, name: str, conv: nn.Conv2d) -> "ops.PackedConv3x3":
         pk = self.__dict__.get(name)
@@ -74,19 +82,18 @@ class _BasicBlock(nn.Module):
             pk = self.__dict__[name] = ops.PackedConv3x3(conv.weight)
         return pk.refresh(conv.weight)
 
-    def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
+    def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor, words: torch.Tensor):
         """Inference on the hand-written kernels: h (N, H, W, C) fp32 NHWC with its abs-max word -> (h', its abs-max word): conv1 / bn1 /
-        relu (stride 1: sd_conv3x3_bn_act; a stage entry: sd_conv_s2_bn_act, as is its 1 x 1 shortcut), conv2 / bn2 / + identity / relu."""
+        relu (stride 1: sd_conv3x3_bn_act; a stage entry: sd_conv_s2_bn_act, as is its 1 x 1 shortcut), conv2 / bn2 / + identity / relu.
+        ``words``: two zeroed int32 words for the abs-max of conv1's and conv2's outputs."""
+        a1, a2 = words[0:1], words[1:2]
         if self.downsample is None:
-            a1 = torch.zeros(1, dtype=torch.int32, device=h.device)
-            out = ops.conv3x3_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1)
+            out = ops.conv3x3_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1, zero_amax=False)
             idt = h
         else:   # the stage entry: 3 x 3 stride-2 conv1 and the 1 x 1 stride-2 shortcut (sd_conv_s2_bn_act)
-            a1 = torch.zeros(1, dtype=torch.int32, device=h.device)
-            out = ops.conv_s2_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1)
+            out = ops.conv_s2_bn_act(h, amax, self._packed("_pk1", self.conv1), *self._bn_fold(self.bn1), relu=True, y_amax=a1, zero_amax=False)
             idt = ops.conv_s2_bn_act(h, amax, self._packed("_pkd", self.downsample[0]), *self._bn_fold(self.downsample[1]), relu=False)
-        a2 = torch.zeros(1, dtype=torch.int32, device=h.device)
-        y = ops.conv3x3_bn_act(out, a1, self._packed("_pk2", self.conv2), *self._bn_fold(self.bn2), res=idt, relu=True, y_amax=a2)
+        y = ops.conv3x3_bn_act(out, a1, self._packed("_pk2", self.conv2), *self._bn_fold(self.bn2), res=idt, relu=True, y_amax=a2, zero_amax=False)
         return y, a2
 
 
@@ -143,11 +150,19 @@ class _ResNet(nn.Module):
             pk = self.__dict__.get("_pk_stem")
             if pk is None or pk.planes.device != x.device:
                 pk = self.__dict__["_pk_stem"] = ops.PackedStem(self.conv1.weight)
-            amax = torch.zeros(1, dtype=torch.int32, device=x.device)
-            h = ops.stem_conv_bn_relu_pool(x, ops.absmax_word(x), pk.refresh(self.conv1.weight), *_BasicBlock._bn_fold(self.bn1), y_amax=amax)
+            # the abs-max words of the forward's 18 activation tensors (frames, stem, two per block): one fill
+            words = self.__dict__.get("_amax_words")
+            if words is None or words.device != x.device:
+                words = self.__dict__["_amax_words"] = torch.zeros(32, dtype=torch.int32, device=x.device)
+            words.zero_()
+            amax = words[1:2]
+            h = ops.stem_conv_bn_relu_pool(x, ops.absmax_word(x, words[0:1], zero=False), pk.refresh(self.conv1.weight), *_BasicBlock._bn_fold(self.bn1),
+                                           y_amax=amax, zero_amax=False)
+            at = 2
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:
-                    h, amax = blk.forward_nhwc(h, amax)
+                    h, amax = blk.forward_nhwc(h, amax, words[at:at + 2])
+                    at += 2
             x = h.permute(0, 3, 1, 2)
         else:
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x))))))))

@@ -913,22 +913,23 @@ class PackedConv3x3:
         return self
 
 
-def absmax_word(x: Tensor, word: Optional[Tensor] = None) -> Tensor:
+def absmax_word(x: Tensor, word: Optional[Tensor] = None, zero: bool = True) -> Tensor:
     """The bits of max |x| in one int32 device word (the activation scale ``conv3x3_bn_act`` derives for its fp16 planes)."""
     _req(x, "x")
     if word is None:
         word = torch.zeros(1, dtype=torch.int32, device=x.device)
-    else:
+    elif zero:
         word.zero_()
     check(_lib.load().sd_absmax_word(x.data_ptr(), x.numel(), word.data_ptr(), _stream()), "sd_absmax_word")
     return word
 
 
 def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor, bn_shift: Tensor, res: Optional[Tensor] = None,
-                   relu: bool = True, y_amax: Optional[Tensor] = None) -> Tensor:
+                   relu: bool = True, y_amax: Optional[Tensor] = None, zero_amax: bool = True) -> Tensor:
     """relu(conv3x3(x) * bn_scale + bn_shift (+ res)) on NHWC fp32 tensors (stride 1, padding 1) - torchvision BasicBlock's
     conv / bn / relu in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83).  ``x_amax``: word from
-    ``absmax_word`` or the ``y_amax`` of the launch that produced x; ``y_amax`` (zeroed here) receives max |y|."""
+    ``absmax_word`` or the ``y_amax`` of the launch that produced x; ``y_amax`` (zeroed here unless ``zero_amax`` is False: the caller
+    zeroed it, e.g. all words of a forward in one fill) receives max |y|."""
     _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
     N, H, W, Cin = x.shape
     if Cin != w.Cin or w.ksize != 3:
@@ -938,7 +939,7 @@ def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
         _req(res, "res")
         if res.shape != y.shape:
             raise ValueError("residual shape mismatch")
-    if y_amax is not None:
+    if y_amax is not None and zero_amax:
         y_amax.zero_()
     check(_lib.load().sd_conv3x3_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
                                         bn_shift.data_ptr(), _ptr(res), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, int(relu), _stream()),
@@ -947,7 +948,7 @@ def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
 
 
 def conv_s2_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor, bn_shift: Tensor, relu: bool = True,
-                   y_amax: Optional[Tensor] = None) -> Tensor:
+                   y_amax: Optional[Tensor] = None, zero_amax: bool = True) -> Tensor:
     """act(conv(x; stride 2) * bn_scale + bn_shift) on NHWC fp32 tensors: the 3 x 3 / padding 1 convolution that opens ResNet layers 2 - 4 or
     their 1 x 1 shortcut (``w.ksize``), inference BatchNorm folded (reference: torchvision BasicBlock via
     soccer_diffusion/ml/model/encoder/image.py:55-83).  Same conventions as ``conv3x3_bn_act``."""
@@ -956,7 +957,7 @@ def conv_s2_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
     if Cin != w.Cin:
         raise ValueError("channel mismatch")
     y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, w.Cout, dtype=torch.float32, device=x.device)
-    if y_amax is not None:
+    if y_amax is not None and zero_amax:
         y_amax.zero_()
     check(_lib.load().sd_conv_s2_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
                                         bn_shift.data_ptr(), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, w.ksize, int(relu), _stream()),
@@ -988,7 +989,7 @@ class PackedStem:
 
 
 def stem_conv_bn_relu_pool(x: Tensor, x_amax: Tensor, w: PackedStem, bn_scale: Tensor, bn_shift: Tensor,
-                           y_amax: Optional[Tensor] = None) -> Tensor:
+                           y_amax: Optional[Tensor] = None, zero_amax: bool = True) -> Tensor:
     """maxpool3x3/s2/p1(relu(conv7x7/s2/p3(x) * bn_scale + bn_shift)): NCHW frames (N, 3, H, W) -> NHWC map (N, Hp, Wp, 64) in one
     launch - torchvision ResNet's conv1 / bn1 / relu / maxpool in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83)."""
     _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
@@ -997,7 +998,7 @@ def stem_conv_bn_relu_pool(x: Tensor, x_amax: Tensor, w: PackedStem, bn_scale: T
         raise ValueError("the stem takes 3-channel frames")
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(N, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, 64, dtype=torch.float32, device=x.device)
-    if y_amax is not None:
+    if y_amax is not None and zero_amax:
         y_amax.zero_()
     check(_lib.load().sd_stem_conv_bn_relu_pool(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
                                                 bn_shift.data_ptr(), y.data_ptr(), _ptr(y_amax), N, H, W, _stream()),

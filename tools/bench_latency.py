@@ -47,3 +47,22 @@ for B in (1, 16, 256):
             rec[f"hipgraph_max_mode_{mode}_ms"] = timed(lambda: gs.replay_into(ctx, x))
             del gs
         print(json.dumps(rec), flush=True)
+
+# ---- the robot's image-conditioned rollout (reference default.yaml: 10 frames of 224 x 224, ResNet-18 without the final avgpool, one
+# sequence-encoder layer; B = 1, T = 10, 30 steps): encode_input_data + sample, hand-written backbone kernels vs the library route
+del m, packed
+img = dict(params, use_images=True, image_resolution=224, image_use_final_avgpool=False)
+torch.manual_seed(0)
+m = cli.build_model(img).cuda().eval()
+for B in (1, 16):
+    data = {"image_data": torch.rand(B, 10, 3, 224, 224, device="cuda")}
+    x = torch.randn(B, T, 20, device="cuda")
+    rec = {"B": B, "T": T, "steps": n_steps, "frames": 10, "frame_size": [224, 224], "case": "image-conditioned rollout (encode + sample)"}
+    with torch.no_grad():
+        for route in ("hip", "torch"):
+            if route == "torch":
+                os.environ["SD_CONV"] = "torch"
+            rec[f"encode_{route}_backbone_ms"] = timed(lambda: m.encode_input_data(data))
+            rec[f"encode_and_sample_{route}_backbone_ms"] = timed(lambda: m.sample(m.encode_input_data(data), x, n_steps))
+            os.environ.pop("SD_CONV", None)
+    print(json.dumps(rec), flush=True)
