@@ -108,15 +108,18 @@ size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
  *   3 = ONE launch per step: a workgroup owns a trajectory (embedding, every layer with its self-attention, fc_out, DDIM
  *       update; q | k | v and the residual stream never leave the CU; soccerdiffusion_amd/csrc/sd_traj.h).  Mode 2's
  *       arithmetic: three fp16 MFMAs per product on hi + lo operands at EVERY site.  hidden_dim 256, 4 heads, T <= 100 (one
- *       instantiation per ceil(T / 16) token tiles), Mc + 1 <= 16, J <= 32, J % 4 == 0; the layer count (<= 8) is checked
- *       at the call - a deeper model runs mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
+ *       instantiation per ceil(T / 16) token tiles), Mc + 1 <= 64 memory rows (up to 16: one key tile in the folded
+ *       cross-attention; 17 .. 64: the wide instantiation with 2 .. 4 key tiles - the reference's full-context configs, e.g.
+ *       sim_scratch.yaml's 51 rows), J <= 32, J % 4 == 0; the layer count (<= 8) is checked at the call - a deeper model runs
+ *       mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
  *   4 = mode 3 with ONE exception: the Q | K | V projection of the self-attention reads a single fp16 plane of LayerNorm
  *       1's output (two MFMAs per product there, 11-bit activation operand), which frees the LDS that lets the four images
  *       of a head live side by side (two barriers per head instead of five; ~ 1.15 x mode 3).  The error this leaves in a
  *       logit grows with the logit: measured noise-prediction error against fp64 ~ 1e-5 x max |logit| (1.6e-5 on freshly
  *       initialised weights, 1e-4 at |logit| ~ 9, 1e-3 at 25; mode 3: 1e-6 throughout - tools/exp/eps_stress.py,
  *       profiles/r04_eps_stress.txt), so the kernel reports SD_STATUS_SHARP_LOGITS (below) when a logit leaves
- *       SD_SHARP_LOGIT_LIMIT and the caller repeats the rollout on mode 3.
+ *       SD_SHARP_LOGIT_LIMIT and the caller repeats the rollout on mode 3.  Up to 16 memory rows; with more, max_mode = 4
+ *       runs mode 3's wide instantiation.
  * Returns the mode an automatic call (max_mode = -1) runs: 3 where the trajectory kernel applies - mode 4 is opt-in. */
 int sd_sampler_mode(int d, int heads, int T, int Mc, int J);
 

@@ -2342,7 +2342,8 @@ __global__ void kv_place_kernel(const float *__restrict__ src, long src_layer_st
 //     G  = K_h[r] Wq_h          (D floats)   K_h = kv[r][h*HD .. +HD),  Wq_h = rows h*HD.. of Wq (D x D)
 //     V' = V_h[r] Wo[:, h]^T    (D floats)   V_h = kv[r][D + h*HD ..),  Wo[:, h] = columns h*HD.. of Wo
 //     c  = bq_h . K_h[r]
-// written to row item*item_rows + h*head_rows + key0 + m of gv ([rows][2D]) / cb ([rows]).
+// written to row item*item_rows + ((key0 + m) / head_rows) * 4 head_rows + h*head_rows + (key0 + m) % head_rows of gv ([rows][2D]) /
+// cb ([rows]): an item's keys in tiles of head_rows slots, [tile][head][slot] (one tile when keys_per_item <= head_rows).
 // VALU kernel (0.5 % of a rollout's flops): a block owns FOLD_RB memory rows in LDS, thread = column.
 constexpr int FOLD_RB = 16;
 
@@ -2367,13 +2368,15 @@ __global__ __launch_bounds__(256) void xattn_fold_kernel(const float *__restrict
 #pragma unroll
     for (int r = 0; r < FOLD_RB; ++r) {
         const long row = r0 + r, item = row / keys_per_item;
-        dst[r] = item * item_rows + (long)h * head_rows + key0 + (row - item * keys_per_item);
+        const int key = key0 + (int)(row - item * keys_per_item);   // key tile key / head_rows, slot key % head_rows
+        dst[r] = item * item_rows + (long)(key / head_rows) * (4 * head_rows) + (long)h * head_rows + key % head_rows;
     }
     if (threadIdx.x < FOLD_RB && r0 + threadIdx.x < n_rows) {
         float c = 0.f;
         for (int j = 0; j < HD; ++j) c += bq[h * HD + j] * Ks[threadIdx.x * HD + j];
         const long row = r0 + threadIdx.x, item = row / keys_per_item;
-        cb[item * item_rows + (long)h * head_rows + key0 + (row - item * keys_per_item)] = c;
+        const int key = key0 + (int)(row - item * keys_per_item);
+        cb[item * item_rows + (long)(key / head_rows) * (4 * head_rows) + (long)h * head_rows + key % head_rows] = c;
     }
     for (int n = threadIdx.x; n < D; n += 256) {
         float acc[FOLD_RB];
@@ -2537,6 +2540,7 @@ static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long B = 0) {
     Scratch s;
     size_t off = 0;
+    const size_t kt = B > 0 ? (size_t)((RM / B + 15) / 16) : 1;   // key tiles of the folded blocks (memory rows per trajectory / 16)
     s.h = ws + off; off += align64((size_t)((R + 63) / 64 * 64) * d);   // whole panels (accumulator-order layout)
     s.qkv = ws + off; off += align64((size_t)R * 3 * d);
     s.a = ws + off; off += align64((size_t)R * d);
@@ -2546,8 +2550,8 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
     s.kvtmp = ws + off; off += align64((size_t)L * RM * 2 * d);
     s.gv = s.cb = s.gvstep = s.cstep = nullptr;
     if (n_steps > 0) {
-        s.gv = ws + off; off += align64((size_t)L * B * 64 * 2 * d);
-        s.cb = ws + off; off += align64((size_t)L * B * 64);
+        s.gv = ws + off; off += align64((size_t)L * B * kt * 64 * 2 * d);
+        s.cb = ws + off; off += align64((size_t)L * B * kt * 64);
         s.gvstep = ws + off; off += align64((size_t)L * n_steps * 4 * 2 * d);
         s.cstep = ws + off; off += align64((size_t)L * n_steps * 4);
     }
@@ -2556,8 +2560,8 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
     s.maxbits = nullptr;
     if (n_steps > 0 && d == 256) {   // sizes in floats (2 halfs each)
         s.wf = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * 6 * d * d);
-        s.g16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * 4 * 16 * d);
-        s.v16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * 4 * 16 * d);
+        s.g16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * kt * 4 * 16 * d);
+        s.v16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * B * kt * 4 * 16 * d);
         s.gstep16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * n_steps * 4 * 16 * d);
         s.vstep16 = reinterpret_cast<f16 *>(ws + off); off += align64((size_t)L * n_steps * 16 * d);
         s.scales = ws + off; off += align64((size_t)(L + 1) * 8);
@@ -2578,13 +2582,14 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
 extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps) {
     // M memory rows per trajectory (+1: the sampler adds the step row to the context rows)
     const size_t R = (size_t)B * T, RM = (size_t)B * ((M > 0 ? M : 0) + 1);
+    const size_t kt = (size_t)(((M > 0 ? M : 0) + 1 + 15) / 16);   // as carve()
     size_t n = align64(R * d) * 2 + align64((R + 63) / 64 * 64 * d) + align64(R * 3 * d) + 2 * align64((size_t)L * RM * 2 * d) +
                align64((size_t)L * (n_steps > 0 ? n_steps : 1) * 2 * d) + 1024;
     if (n_steps > 0)   // folded cross-attention blocks of the sampler: 64 rows of 2d (+ 1 bias) per trajectory and layer
-        n += align64((size_t)L * B * 64 * 2 * d) + align64((size_t)L * B * 64) + align64((size_t)L * n_steps * 4 * 2 * d) +
+        n += align64((size_t)L * B * kt * 64 * 2 * d) + align64((size_t)L * B * kt * 64) + align64((size_t)L * n_steps * 4 * 2 * d) +
              align64((size_t)L * n_steps * 4);
     if (n_steps > 0 && d == 256)   // fp16x3 operands (sd_f16x3.h)
-        n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
+        n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * kt * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
              align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8) + align64((size_t)2 * 32 * d);
     if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
     return n;
@@ -2842,11 +2847,25 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
 static bool traj_ok(int d, int heads, int T, int Mk, int J, int L) {
     static const char *env = getenv("SD_SAMPLER_TRAJ");
     if (env && strcmp(env, "0") == 0) return false;
-    return d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 16 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+    return d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 64 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
 }
+// key tiles of 16 memory slots in the folded blocks: 1 for the trajectory kernels proper, 2 .. 4 for traj_step_wide_kernel (17 .. 64 rows)
+static int key_tiles(int Mk) { return Mk <= 16 ? 1 : (Mk + 15) / 16; }
 
 // the instantiation for ceil(T / 16) token tiles; precise = three fp16 products at the Q | K | V site too (sampler mode 3), else two (mode 4)
 typedef void (*TrajStepFn)(tj::StepArgs);
+static TrajStepFn traj_step_wide_fn(int ntt) {
+    switch (ntt) {
+        case 1: return tj::traj_step_wide_kernel<1>;
+        case 2: return tj::traj_step_wide_kernel<2>;
+        case 3: return tj::traj_step_wide_kernel<3>;
+        case 4: return tj::traj_step_wide_kernel<4>;
+        case 5: return tj::traj_step_wide_kernel<5>;
+        case 6: return tj::traj_step_wide_kernel<6>;
+        case 7: return tj::traj_step_wide_kernel<7>;
+        default: return nullptr;
+    }
+}
 template <bool PRECISE>
 static TrajStepFn traj_step_fn(int ntt) {
     switch (ntt) {
@@ -2862,8 +2881,8 @@ static TrajStepFn traj_step_fn(int ntt) {
 }
 
 static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
-    const int d = w->d, L = w->L;
-    const size_t gvstride = (size_t)B * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
+    const int d = w->d, L = w->L, nkt = key_tiles(Mc + 1);
+    const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
     // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' in words 4 and 5 of every layer
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
@@ -2896,11 +2915,11 @@ static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, i
             SD_CHECK_LAUNCH("pack_w16_kernel");
         }
         const size_t blk = (size_t)32 * d;   // halfs per (trajectory, head)
-        SD_LAUNCH(tj::pack_g16_kernel, dim3(grid_for((long)B * 4 * 16 * d / 8)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, Mc, mb + 4,
-                  s.g16 + (size_t)l * B * 4 * blk, sc + 4);
+        SD_LAUNCH(tj::pack_g16_kernel, dim3(grid_for((long)B * nkt * 4 * 16 * d / 8)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * nkt, Mc, mb + 4,
+                  s.g16 + (size_t)l * B * nkt * 4 * blk, sc + 4, nkt);
         SD_CHECK_LAUNCH("pack_g16_kernel");
-        SD_LAUNCH(tj::pack_v16_kernel, dim3(grid_for((long)B * 16 * 2 * 64)), dim3(256), 0, st, s.gv + l * gvstride, (long)B, Mc, mb + 5,
-                  s.v16 + (size_t)l * B * 4 * blk, sc + 5);
+        SD_LAUNCH(tj::pack_v16_kernel, dim3(grid_for((long)B * nkt * 16 * 2 * 64)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * nkt, Mc, mb + 5,
+                  s.v16 + (size_t)l * B * nkt * 4 * blk, sc + 5, nkt);
         SD_CHECK_LAUNCH("pack_v16_kernel");
         SD_LAUNCH(tj::pack_gstep16_kernel, dim3(grid_for((long)n_steps * 4 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_steps,
                   mb + 4, s.gstep16 + (size_t)l * n_steps * 4 * blk, (float *)nullptr);
@@ -2915,9 +2934,10 @@ static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, i
 // one denoiser step + DDIM update in ONE launch (step index i selects the step-token blocks)
 static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
                              const float *coef, hipStream_t st, bool precise, float *eps = nullptr, int32_t *status = nullptr) {
-    const int d = w->d, L = w->L;
-    const size_t blk = (size_t)32 * d, cbstride = (size_t)B * 64;
+    const int d = w->d, L = w->L, nkt = key_tiles(Mc + 1);
+    const size_t blk = (size_t)32 * d, cbstride = (size_t)B * nkt * 64;
     tj::StepArgs a{};
+    a.nkt = nkt;
     a.status = status;
     a.x = x;
     a.eps_out = eps;
@@ -2939,8 +2959,8 @@ static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scrat
         q.w_o = f16_wf(s, l, d, 0); q.w_1 = f16_wf(s, l, d, 1); q.w_2 = f16_wf(s, l, d, 2); q.w_in = f16_wf(s, l, d, 3);
         q.b_in = lw.sa_in_b; q.b_o = lw.sa_out_b; q.b_1 = lw.lin1_b; q.b_2 = lw.lin2_b; q.b_oc = lw.ca_out_b;
         q.sc = s.scales + l * 8;
-        q.g16 = s.g16 + (size_t)l * B * 4 * blk;
-        q.v16 = s.v16 + (size_t)l * B * 4 * blk;
+        q.g16 = s.g16 + (size_t)l * B * nkt * 4 * blk;
+        q.v16 = s.v16 + (size_t)l * B * nkt * 4 * blk;
         q.cb = s.cb + l * cbstride;
         // per-layer regions as carved for mode 2 (n_steps * 4 * blk / n_steps * blk halfs), the step blocks packed densely inside
         q.gstep = s.gstep16 + (size_t)l * n_steps * 4 * blk + (size_t)i * (4 * 8 * 2 * 32);
@@ -2950,14 +2970,16 @@ static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scrat
         q.nln_b = l + 1 < L ? w->layers[l + 1].n1_b : nullptr;
     }
     const int ntt = (T + 15) / 16;
-    const TrajStepFn fn = precise ? traj_step_fn<true>(ntt) : traj_step_fn<false>(ntt);
+    // more than 16 memory rows: the wide instantiation (three products everywhere, whatever the mode asked for)
+    const int variant = nkt > 1 ? 2 : (precise ? 1 : 0);
+    const TrajStepFn fn = variant == 2 ? traj_step_wide_fn(ntt) : (precise ? traj_step_fn<true>(ntt) : traj_step_fn<false>(ntt));
     if (!fn) return fail(SD_E_BADARG, "traj_step_kernel: horizon out of range");
     ProfScope prof(SD_KCLASS_TRAJ_STEP, st);
-    static DevFlag attr_set[2][8];
-    if (!attr_set[precise ? 1 : 0][ntt]) {
+    static DevFlag attr_set[3][8];
+    if (!attr_set[variant][ntt]) {
         const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "traj_step_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        attr_set[precise ? 1 : 0][ntt] = true;
+        attr_set[variant][ntt] = true;
     }
     SD_LAUNCH(fn, dim3((unsigned)B), dim3(tj::NTHREADS), (size_t)tj::LDS_BYTES, st, a);
     SD_CHECK_LAUNCH("traj_step_kernel");
@@ -3080,7 +3102,8 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
     // the trajectory kernel (modes 3 / 4) takes any horizon <= 100: it needs the folded blocks, not the row-panel kernels' T >= 64
     const bool traj = max_mode >= 3 && small && f16_ok(d, w->J) && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wf != nullptr && s.wio != nullptr;
     const bool fold = traj || (max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && small);
-    const size_t gvstride = (size_t)B * 64 * 2 * d, cbstride = (size_t)B * 64;
+    const int nkt = traj ? key_tiles(Mk) : 1;   // (the row-panel fold: Mk <= 16)
+    const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, cbstride = (size_t)B * nkt * 64;
     const size_t gvsstride = (size_t)n_steps * 4 * 2 * d, cssstride = (size_t)n_steps * 4;
     const bool f16 = traj || (max_mode >= 2 && fold && f16_ok(d, w->J) && s.wf != nullptr);
     const bool chain16 = max_mode >= 2 && !fold && chain16_ok(d, w->J) && s.wfc != nullptr && !fused_layer_ok(d, w->heads, T, Mk);
@@ -3113,7 +3136,7 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
                 const long rows = (long)B * Mc;
                 SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((rows + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st,
                           s.kvtmp + (size_t)l * B * Mc * 2 * d, rows, Mc, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w,
-                          s.gv + l * gvstride, s.cb + l * cbstride, 64L, 16, 0, d, hd, f16 ? s.maxbits + l * 8 + 4 : (unsigned *)nullptr,
+                          s.gv + l * gvstride, s.cb + l * cbstride, 64L * nkt, 16, 0, d, hd, f16 ? s.maxbits + l * 8 + 4 : (unsigned *)nullptr,
                           f16 ? s.maxbits + l * 8 + 5 : (unsigned *)nullptr);
                 SD_CHECK_LAUNCH("xattn_fold_kernel");
             }

@@ -1,4 +1,4 @@
-// Trajectory-owning decoder kernels of the sampler (hidden_dim 256, 4 heads, 96 < horizon <= 100, <= 16 memory rows): ONE
+// Trajectory-owning decoder kernels of the sampler (hidden_dim 256, 4 heads, horizon <= 100, <= 64 memory rows): ONE
 // workgroup of 8 waves carries ONE trajectory through a whole denoiser step - embedding, every decoder layer with its
 // self-attention (reference: nn.TransformerDecoderLayer as built by soccer_diffusion/ml/model/decoder.py:26-35, norm_first;
 // forward of decoder.py:38-54), fc_out and the DDIM update - so the residual stream, q | k | v and the attention output
@@ -182,8 +182,9 @@ static __global__ void pack_w16_kernel(const float *__restrict__ W, int N, int K
 
 // Folded keys of the context rows: gv rows [(item * 4 + head) * 16 + slot][2 D] (G in the first D columns) ->
 // per (item, head) blocks [ks 8][plane][lane = 16 g + slot][8], k = 32 ks + 8 g + e.  Slots >= n_slots are zero.
+// items = trajectories x key tiles (tile kt of a trajectory = item % nkt; its slot s is memory row 16 kt + s, valid below n_slots)
 static __global__ void pack_g16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
-                                float *scale_out) {
+                                float *scale_out, int nkt = 1) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
     const long total = items * 4 * 16 * (D / 8);
@@ -191,7 +192,7 @@ static __global__ void pack_g16_kernel(const float *__restrict__ gv, long items,
         const int k8 = (int)(i % (D / 8)), slot = (int)((i / (D / 8)) % 16);
         const long ih = i / (D / 8) / 16;
         f16x4 h0 = {0, 0, 0, 0}, l0 = h0, h1 = h0, l1 = h0;
-        if (slot < n_slots) {
+        if (16 * (int)((ih >> 2) % nkt) + slot < n_slots) {
             const float *row = gv + (ih * 16 + slot) * 2 * D + kperm(k8, 0);   // features .. + 3 and + 16 .. + 19 (kperm)
             f16_split4(*reinterpret_cast<const f32x4 *>(row), scale, h0, l0);
             f16_split4(*reinterpret_cast<const f32x4 *>(row + 16), scale, h1, l1);
@@ -226,7 +227,7 @@ static __global__ void pack_gstep16_kernel(const float *__restrict__ gvstep, lon
 // Folded values of the context rows -> per item [n-tile 16][kk 2][plane][lane = 16 g + i][8]: V'^T[n = 16 nt + i][k = 32 kk + 8 g + e],
 // k = head * 16 + slot
 static __global__ void pack_v16_kernel(const float *__restrict__ gv, long items, int n_slots, const unsigned *maxbits, f16 *__restrict__ dst,
-                                float *scale_out) {
+                                float *scale_out, int nkt = 1) {
     const float scale = f16_scale_from_bits(*maxbits);
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
     const long total = items * 16 * 2 * 64;
@@ -238,7 +239,7 @@ static __global__ void pack_v16_kernel(const float *__restrict__ gv, long items,
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 32 * kk + 8 * g + e, head = k >> 4, slot = k & 15;
-            const float v = slot < n_slots ? gv[((item * 4 + head) * 16 + slot) * 2 * D + D + n] * scale : 0.f;
+            const float v = 16 * (int)(item % nkt) + slot < n_slots ? gv[((item * 4 + head) * 16 + slot) * 2 * D + D + n] * scale : 0.f;
             hh[e] = (f16)v;
             ll[e] = (f16)(v - (float)hh[e]);
         }
@@ -420,6 +421,7 @@ struct StepArgs {
     float c0, c1, c2, c3;          // DDIM coefficients of this step (sqrt a_t, sqrt(1 - a_t), sqrt a_prev, sqrt(1 - a_prev))
     float scale_log2e;
     int T, B, J, L, Mk, update_x;
+    int nkt;                       // key tiles of 16 memory slots (1; 2 .. 4 only for the WIDE instantiations: 17 .. 64 memory rows)
     int *status;                   // range-guard word (SD_STATUS_SHARP_LOGITS) or NULL
     LayerW layer[MAX_L];
 };
@@ -1052,7 +1054,163 @@ static __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
 
 
 
-static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e, int *status) {
+// ---- folded cross-attention over 17 .. 64 memory rows (WIDE): the folded blocks of a trajectory are nkt = ceil(Mk / 16) key tiles
+// laid out as nkt consecutive 16-slot blocks (block traj * nkt + kt of g16 / v16 / cb: the same fragment layouts as one tile); the
+// step token is slot (Mk - 1) & 15 of the LAST tile.  Scores of all tiles stay in registers (4 x 4 accumulators), the softmax runs
+// over them, then one round per tile: write P (the same 96-column panel), barrier, h += V'^T P^T.  Written for the robot's shapes
+// (reference sim_scratch.yaml: 51 memory rows, B = 1): nothing is prefetched across phases, two barriers per extra tile.
+static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, int nkt, float scale_log2e) {
+    const Ctx c = ctx_local(c0);
+    constexpr int KT = 4;
+    const int hh = c.w >> 1, Mc = Mk - 1, klast = nkt - 1, mcs = Mc & 15;
+    const bool odd = c.w & 1;
+    const int tt1 = odd ? NH0 : 0, n1 = odd ? NTT - NH0 : NH0;
+    char *Pb = c.smem + LDS_P;
+    const char *X = c.smem + LDS_X;
+    f32x4 S[KT][NH0];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) S[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt >= nkt) break;
+        // folded keys of (head, key tile): lanes of the step token's slot read the shared step block instead
+        f16x8 gfr[8][2];
+        const bool stepl = kt == klast && c.t == mcs;
+        const f16 *gp = stepl ? L.gstep + (long)hh * (8 * 2 * 32) + c.g * 8 : L.g16 + ((traj * nkt + kt) * 4 + hh) * (8 * 2 * 512) + c.lane * 8;
+        const int gstride = stepl ? 32 : 512;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) gfr[ks][pl] = *reinterpret_cast<const f16x8 *>(gp + (ks * 2 + pl) * gstride);
+        auto scores = [&](auto odd_c) __attribute__((always_inline)) {
+            constexpr bool OD = decltype(odd_c)::value;
+            constexpr int N1 = OD ? NTT - NH0 : NH0, T1 = OD ? NH0 : 0;
+            constexpr int N1D = N1 > 0 ? N1 : 1;
+            f16x8 xb[3][2];
+            ring_pipe<8 * N1, 3>(
+                [&](int s) __attribute__((always_inline)) {
+                    xb[s % 3][0] = lds16(X + x_at(c, T1 + s % N1D, 0, s / N1D));
+                    xb[s % 3][1] = lds16(X + x_at(c, T1 + s % N1D, 1, s / N1D));
+                },
+                [&](int s) __attribute__((always_inline)) { mma3<S_XSC>(S[kt][s % N1D], gfr[s / N1D][0], gfr[s / N1D][1], xb[s % 3][0], xb[s % 3][1]); });
+        };
+        if (odd) scores(std::true_type{});
+        else scores(std::false_type{});
+    }
+    // ---- softmax over all key slots of all tiles (accumulator rows 4 g + r of tile kt = memory row 16 kt + 4 g + r)
+    const float c_g = 1.0f / (ACT * L.sc[4]);
+    const float cs = L.cstep[hh];
+    f32x4 cbv[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        cbv[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < nkt) cbv[kt] = *reinterpret_cast<const f32x4 *>(L.cb + (traj * nkt + kt) * 64 + hh * 16 + 4 * c.g);
+        if (kt == klast) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * c.g + r == mcs) cbv[kt][r] = cs;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NH0; ++i) {
+        if (i >= n1) continue;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 v = S[kt][i] * c_g + cbv[kt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * kt + 4 * c.g + r >= Mk) v[r] = -INFINITY;
+            S[kt][i] = v;
+            m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        }
+        m = rows4_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const f32x4 e = (S[kt][i] - m) * scale_log2e;
+            const f32x4 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+            S[kt][i] = p;
+            sum += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+        sum = rows4_sum(sum);
+        const float f = PSC / sum;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) S[kt][i] = S[kt][i] * f;
+    }
+    // ---- h += sum over tiles of V'_kt^T P_kt^T + boc
+    const float up = PSC * L.sc[5];
+    const Bias2 boc = bias_load(c, L.b_oc);
+    scale_h(H, up);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt >= nkt) break;
+        TJ_SYNC(4);   // the previous readers of this region (out-projection / the previous tile's P V') are done: P may be written
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            if (i >= n1) continue;
+            const f32x4 p = S[kt][i];
+            const int tt = tt1 + i, tok = tt < NTT - 1 ? 16 * tt + c.t : c.tok6;
+            if (tt == NTT - 1 && !c.ok6) continue;
+            const int chunk = (2 * (hh & 1) + (c.g >> 1)) | ((hh >> 1) << 3);
+            split_store(Pb + p_off(tok, chunk) + 8 * (c.g & 1), Pb + p_off(tok, chunk | 4) + 8 * (c.g & 1), p);
+            if (kt == klast && c.g == (mcs >> 2)) {   // the step token's probability again at k = 64 + 8 hh (its V' comes from the shared step block)
+                const float pv = p[mcs & 3];
+                const f16 ph = (f16)pv, pl = (f16)(pv - (float)ph);
+                const f16x8 z8h = {ph, 0, 0, 0, 0, 0, 0, 0}, z8l = {pl, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | (2 << 3))) = z8h;
+                *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | 4 | (2 << 3))) = z8l;
+            }
+        }
+        // folded values of this tile (and, for the last one, the step token's value columns)
+        f16x8 av[2][3][2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f16 *vp = L.v16 + (((traj * nkt + kt) * 16 + 2 * c.w + n) * 2) * (2 * 512) + c.lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];
+                av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        TJ_SYNC(5);   // P complete
+        f16x8 pb[3][2];
+        if (kt == klast) {
+            ring_pipe<3 * NTT, 3>(
+                [&](int s) __attribute__((always_inline)) {
+                    pb[s % 3][0] = lds16(Pb + p_at(c, s / 3, 0, s % 3));
+                    pb[s % 3][1] = lds16(Pb + p_at(c, s / 3, 1, s % 3));
+                },
+                [&](int s) __attribute__((always_inline)) {
+                    const int tt = s / 3, kk = s % 3;
+                    mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], pb[s % 3][0], pb[s % 3][1]);
+                    mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], pb[s % 3][0], pb[s % 3][1]);
+                });
+        } else {
+            ring_pipe<2 * NTT, 3>(
+                [&](int s) __attribute__((always_inline)) {
+                    pb[s % 3][0] = lds16(Pb + p_at(c, s / 2, 0, s % 2));
+                    pb[s % 3][1] = lds16(Pb + p_at(c, s / 2, 1, s % 2));
+                },
+                [&](int s) __attribute__((always_inline)) {
+                    const int tt = s / 2, kk = s % 2;
+                    mma3<S_XPV>(H[0][tt], av[0][kk][0], av[0][kk][1], pb[s % 3][0], pb[s % 3][1]);
+                    mma3<S_XPV>(H[1][tt], av[1][kk][0], av[1][kk][1], pb[s % 3][0], pb[s % 3][1]);
+                });
+        }
+    }
+    unscale_h(H, 1.0f / up, boc);
+}
+
+template <bool WIDE = false>
+static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e, int *status,
+                                                     int nkt = 1) {
     // ---- self-attention block: h += Wo . SA(LN1(h)) + bo
     {
         const Ctx &c = c0;
@@ -1071,7 +1229,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
     LnAffine aff2;
     ln_affine_load(c0, L.n2_w, L.n2_b, aff2);
     f16x8 gfr[8][2];
-    {
+    if constexpr (!WIDE) {
         const int hh = c0.w >> 1, Mc = Mk - 1;
         const f16 *gp = c0.t == Mc ? L.gstep + (long)hh * (8 * 2 * 32) + c0.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c0.lane * 8;
         const int gstride = c0.t == Mc ? 32 : 512;
@@ -1085,7 +1243,9 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
     layer_norm_to_x(c0, H, aff2);
     TJ_STAMP(32);
     // ---- folded cross-attention: wave w scores head w >> 1 for token tiles tt1 .. (half w & 1)
-    {
+    if constexpr (WIDE) {
+        cross_wide(c0, L, H, traj, Mk, nkt, scale_log2e);
+    } else {
         const Ctx c = ctx_local(c0);
         const int hh = c.w >> 1, Mc = Mk - 1;
         const bool odd = c.w & 1;
@@ -1257,6 +1417,7 @@ static __device__ __forceinline__ void sa_body(const SaArgs &a) {
     TJ_STAMP(32);
 }
 
+template <bool WIDE = false>
 static __device__ __forceinline__ void step_body(const StepArgs &a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx c;
@@ -1320,7 +1481,7 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
     layer_norm_to_x<!PRECISE>(c, H, a.n1_w, a.n1_b);
     TJ_STAMP(2);
 #pragma unroll 1
-    for (int l = 0; l < a.L; ++l) decoder_layer(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status);
+    for (int l = 0; l < a.L; ++l) decoder_layer<WIDE>(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status, a.nkt);
     // ---- fc_out + DDIM: eps^T = Wout . h^T + b.  h has no a-priori bound: one power-of-two scale per token
     {
         float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
@@ -1406,6 +1567,9 @@ static __global__ __launch_bounds__(NTHREADS, 2) void traj_sa_kernel(SaArgs a) {
 // sampler mode 3: NTT token tiles; PRECISE = three fp16 products at the Q | K | V site too
 template <int NTT, bool PRECISE>
 __global__ __launch_bounds__(NTHREADS, 2) void traj_step_kernel(StepArgs a) { TJ<NTT, PRECISE>::step_body(a); }
+// ... with 17 .. 64 memory rows (2 .. 4 key tiles in the folded cross-attention: cross_wide); three products everywhere
+template <int NTT>
+__global__ __launch_bounds__(NTHREADS, 2) void traj_step_wide_kernel(StepArgs a) { TJ<NTT, true>::template step_body<true>(a); }
 
 
 }   // namespace tj

@@ -278,13 +278,18 @@ assert err < 1e-4, err
                                        # trajectory_prediction_length 10, BASELINE configs[0]'s 16, tile edges, one token
                                        (10, 0, 20, 4, 3), (10, 15, 20, 2, 2), (16, 10, 20, 2, 2), (17, 3, 8, 2, 3), (1, 2, 4, 1, 2), (32, 10, 20, 2, 2),
                                        (33, 0, 12, 3, 2), (48, 15, 32, 2, 3), (49, 5, 20, 2, 2), (64, 10, 20, 4, 2), (65, 1, 20, 2, 3), (80, 7, 28, 2, 2),
-                                       (81, 10, 20, 2, 2), (96, 10, 20, 2, 3)])
+                                       (81, 10, 20, 2, 2), (96, 10, 20, 2, 3),
+                                       # 17 .. 64 memory rows (2 .. 4 key tiles, traj_step_wide_kernel): tile edges, the reference's
+                                       # sim_scratch.yaml (20 + 20 + 10 context rows, 6 layers, horizon 10), the full-context robot shape 31
+                                       (10, 16, 20, 2, 2), (10, 17, 20, 2, 3), (10, 31, 20, 4, 2), (10, 32, 20, 2, 2), (10, 50, 20, 6, 2), (16, 47, 8, 2, 2),
+                                       (100, 48, 20, 2, 2), (100, 63, 20, 4, 2), (33, 40, 12, 2, 3), (97, 16, 32, 2, 2), (1, 63, 4, 1, 2)])
 def test_trajectory_step_kernel_every_step(ops, T, Mc, J, L, B):
     """Sampler modes 3 / 4 (csrc/sd_traj.h; reference blocks decoder.py:26-54 under the DDIM loop of plot.py:122-131): x after EVERY
     step against the fp32 oracle, at the edges of what the kernel takes - every token-tile count 1 .. 7 with full and ragged last
     tiles (T = 1 .. 100, incl. the reference's shipped trajectory_prediction_length 10, ml/training/config/*.yaml), no context
-    rows / a full set of 16 key slots, the smallest and largest joint counts, 1 and 8 layers - and equal to the kernels of
-    mode 2 (or, for T < 64, of the unfused chains) at fp32 rounding level."""
+    rows / a full set of 16 key slots / 17 .. 64 memory rows (the wide instantiation's 2 .. 4 key tiles), the smallest and largest joint
+    counts, 1 and 8 layers - and equal to the kernels of mode 2 (or, for T < 64 or more than 16 memory rows, of the unfused chains) at
+    fp32 rounding level."""
     from soccerdiffusion_amd import _lib
 
     d, n_steps = 256, 5

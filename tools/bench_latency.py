@@ -2,7 +2,8 @@
 """Small-batch rollout latency (the robot's shape: B = 1, horizon 10, 30 DDIM steps, d = 256, L = 4; reference loop
 soccer_diffusion/ml/inference/ros.py:301-310, budget 0.2 s per rollout) per kernel selection of sd_ddim_sample_ex: the trajectory
 kernel family (modes 3 / 4: any T <= 100 with <= 16 memory rows) against the row-panel / unfused-chain kernels (max_mode 2), for the
-memory sizes of the shipped configs: 31 context rows (falls back: > 16 rows), 10 rows, none (decoder_only.yaml)."""
+memory sizes of the shipped configs: 50 context rows (sim_scratch.yaml: 20 + 20 + 10) and 31 (three 100-sample modalities at patch 10) - the
+wide instantiation, 2 .. 4 key tiles -, 10 rows, none (decoder_only.yaml)."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,7 +37,7 @@ def timed(fn, n=20):
 
 
 for B in (1, 16, 256):
-    for Mc in (31, 10, 0):
+    for Mc in (50, 31, 10, 0):
         x = torch.randn(B, T, 20, device="cuda")
         ctx = torch.randn(B, Mc, 256, device="cuda") if Mc else None
         rec = {"B": B, "T": T, "memory_rows": Mc + 1, "steps": n_steps, "sd_sampler_mode": _lib.load().sd_sampler_mode(256, 4, T, Mc, 20)}
