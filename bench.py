@@ -904,6 +904,31 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
         out["train"]["workload"] = "BASELINE.json configs[1]: C2 training step, B=256, d=256 L=4 T=100 J=20 M=11 (bench.py --mode train)"
     except Exception as e:  # noqa: BLE001
         out["train"] = {"error": repr(e)[:300]}
+    # (d) SURVEY 8 row f2: the image backbone's inference forward on this repository's convolution kernels (csrc/sd_conv.hip) at
+    # BASELINE configs[4]'s per-GPU share - 16 trajectories x 10 frames of 480 x 640 (the MIOpen route beside it: tools/bench_conv.py)
+    try:
+        from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+        torch.manual_seed(0)
+        enc = image_encoder_factory(ImageEncoderType.RESNET18, 256, True, 480).to(dev).eval()
+        frames = torch.rand(16, 10, 3, 480, 640, device=dev)
+        with torch.no_grad():
+            enc(frames)
+            torch.cuda.synchronize()
+            n = 5
+            t0 = time.perf_counter()
+            for _ in range(n):
+                enc(frames)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        flops = 2 * 1.814e9 * 480 * 640 / (224 * 224)   # ResNet-18: 1.814 GMAC per 224 x 224 frame, convolutions only
+        out["image_backbone"] = {"workload": "BASELINE.json configs[4] per-GPU share, inference: ResNet-18 on 16 x 10 frames of 480 x 640 (all 20 convolutions hand-written: sd_stem_conv_bn_relu_pool, sd_conv3x3_bn_act, sd_conv_s2_bn_act)",
+                                 "ms_per_forward": round(dt * 1e3, 3), "value": round(160 / dt, 1), "unit": "frames/s",
+                                 "algorithmic_tflops": round(160 * flops / dt / 1e12, 1),
+                                 "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; 2e-6 vs torch's CPU operators)"}
+        del enc, frames
+    except Exception as e:  # noqa: BLE001
+        out["image_backbone"] = {"error": repr(e)[:300]}
     return out
 
 
