@@ -227,3 +227,20 @@ def test_grouped_weight_gradient_partition_terminates_and_covers():
             cs += cs & 1
             want += ((N_ + 127) // 128) * ((K_ + 127) // 128) * ((slabs + cs - 1) // cs)
         assert tot == want
+
+
+def test_workspace_grows_with_the_key_tiles_of_the_memory():
+    """sd_workspace_floats: the folded cross-attention blocks of the sampler are laid out per (trajectory, key tile of 16 memory rows)
+    - one tile up to 16 rows (context + the step token), then one more per 16 (traj_step_wide_kernel, up to 64 rows)."""
+    from soccerdiffusion_amd import _lib
+
+    lib = _lib.load()
+    B, T, d, L, n = 8, 10, 256, 4, 30
+    w = [lib.sd_workspace_floats(B, T, M, d, L, n) for M in (0, 15, 16, 31, 32, 63)]
+    assert w[0] < w[1] < w[2] < w[3] < w[4] < w[5]
+    per_tile = 2 * L * B * 64 * 2 * d          # fp32 blocks + their fp16 hi | lo planes (2 halfs per float), per key tile
+    rows = lambda M: 2 * L * B * (M + 1) * 2 * d   # kv + kvtmp
+    assert w[2] - w[1] >= per_tile + rows(16) - rows(15)          # 16 -> 17 rows: a second tile
+    assert abs((w[1] - w[0]) - (rows(15) - rows(0))) <= 64 * 8    # within one tile only the K/V rows grow (64-float alignment)
+    assert lib.sd_sampler_mode(256, 4, 10, 50, 20) == 3 and lib.sd_sampler_mode(256, 4, 100, 63, 20) == 3   # 51 / 64 memory rows
+    assert lib.sd_sampler_mode(256, 4, 10, 64, 20) != 3                                                         # 65: not the trajectory kernel

@@ -66,6 +66,29 @@ def test_b4096_trajectories_match_oracle_and_small_batch(ops, mode):
     assert float(norms.min()) > 0.0 and float(norms.max()) < 1e4
 
 
+def test_wide_memory_rollout_at_batch_size(ops):
+    """17 .. 64 memory rows at a batch that fills the chip four times (B = 1024, horizon 100, 51 memory rows = the reference's
+    sim_scratch.yaml context, 4 key tiles): the folded blocks of (trajectory, key tile) pairs are addressed per workgroup - picked
+    trajectories against the fp32 CPU oracle on that trajectory alone and against the same trajectories sampled in a batch of 6."""
+    B, Mc, n_steps, L_ = 1024, 50, 10, 2
+    sd = ref.synthetic_state_dict(D, J, L_, seed=17)
+    acp, ts, toks, coef = _setup(ops, sd, n_steps)
+    x_T = torch.randn(B, T, J, generator=torch.Generator().manual_seed(21))
+    ctx = torch.randn(B, Mc, D, generator=torch.Generator().manual_seed(22))
+    packed = ops.pack_denoiser(sd, "cuda", max_len=T)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got = ops.ddim_sample(packed, ctx.cuda(), toks, coef, x_T.cuda(), status=status)
+    assert int(status.item()) == 0 and torch.isfinite(got).all()
+    picks = [0, 1, 255, 256, 700, 1023]
+    xs, cs = x_T[picks].contiguous(), ctx[picks].contiguous()
+    n = len(picks)
+    want = ddim_ref.sample(lambda x, t: ref.forward_with_context(sd, [cs], x, torch.full((n,), t, dtype=torch.int64)), xs, n_steps, acp)[-1]
+    errs = [rel_err(got[b], want[i]) for i, b in enumerate(picks)]
+    assert all(e < 1e-5 for e in errs), errs
+    small = ops.ddim_sample(packed, cs.cuda(), toks, coef, xs.cuda())
+    assert all(rel_err(got[b], small[i]) < 1e-5 for i, b in enumerate(picks))
+
+
 @pytest.mark.parametrize("d,L_,T_,Mc,B,n_steps", [(256, 2, 100, 10, 37, 8), (256, 2, 10, 31, 3, 6), (64, 2, 16, 10, 2, 10)])
 def test_graphed_sampler_replay_is_bit_identical_to_eager(ops, d, L_, T_, Mc, B, n_steps):
     """ops.GraphedSampler (hipGraph-captured rollout, BASELINE configs[2]): replays equal the eager call bit for bit,

@@ -125,3 +125,51 @@ def test_backbone_on_gpu_matches_the_same_modules_on_cpu_fp32():
         assert got.shape == (2, 3, 64)
         assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
         assert float((xg.grad.cpu() - xc.grad).norm() / xc.grad.norm()) < 1e-3
+
+
+def test_image_conditioned_rollout_at_the_shipped_frame_size_on_both_backbone_routes():
+    """The robot's image-conditioned rollout at the reference's shipped frame size (sim_scratch.yaml: 10 frames of 224 x 224, ResNet-18
+    without the final avgpool, one sequence-encoder layer, action history + IMU at patch 5: 20 + 20 + 10 context rows, horizon 10,
+    d = 256): encode_input_data + sample with the backbone on this repository's convolution kernels (csrc/sd_conv.hip) equals the same
+    call with the backbone on torch.nn / MIOpen (SD_CONV=torch) - tokens at 1e-5, the denoised trajectory at 1e-4 - and the rollout
+    itself runs the wide trajectory kernel (51 memory rows)."""
+    import os
+
+    from soccerdiffusion_amd import _lib
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, SequenceEncoderType
+    from soccerdiffusion_amd.ml.model.model import End2EndDiffusionTransformer
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = End2EndDiffusionTransformer(
+        num_joints=20, hidden_dim=256, use_action_history=True, num_action_history_encoder_layers=2,
+        max_action_context_length=100, use_imu=True, imu_orientation_embedding_method="five_dim",
+        num_imu_encoder_layers=2, imu_context_length=100, use_joint_states=False, joint_state_encoder_layers=1,
+        joint_state_context_length=100, use_images=True, image_encoder_type=ImageEncoderType.RESNET18,
+        image_sequence_encoder_type=SequenceEncoderType("transformer"), num_image_sequence_encoder_layers=1,
+        image_context_length=10, image_use_final_avgpool=False, image_resolution=224, use_gamestate=False,
+        num_decoder_layers=3, trajectory_prediction_length=10, encoder_patch_size=5).to(dev)
+    # non-trivial BatchNorm statistics
+    m.train()
+    with torch.no_grad():
+        m.image_sequence_encoder.image_encoder(torch.rand(2, 2, 3, 224, 224, device=dev))
+    m.eval()
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    data = {"joint_command_history": torch.randn(B, 100, 20, generator=g).to(dev), "rotation": torch.randn(B, 100, 5, generator=g).to(dev),
+            "image_data": torch.rand(B, 10, 3, 224, 224, generator=g).to(dev)}
+    x_T = torch.randn(B, 10, 20, generator=g).to(dev)
+    with torch.no_grad():
+        ctx = m.encode_input_data(data)
+        assert [tuple(c.shape) for c in ctx] == [(B, 20, 256), (B, 20, 256), (B, 10, 256)]
+        assert _lib.load().sd_sampler_mode(256, 4, 10, 50, 20) == 3
+        x = m.sample(ctx, x_T, 30)
+        os.environ["SD_CONV"] = "torch"
+        try:
+            ctx_lib = m.encode_input_data(data)
+            x_lib = m.sample(ctx_lib, x_T, 30)
+        finally:
+            del os.environ["SD_CONV"]
+    assert torch.isfinite(x).all()
+    assert float((ctx[2] - ctx_lib[2]).norm() / ctx_lib[2].norm()) < 1e-5
+    assert float((x - x_lib).norm() / x_lib.norm()) < 1e-4
