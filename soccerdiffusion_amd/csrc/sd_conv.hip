@@ -245,11 +245,32 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
 // tile w; the 9 x 17 halo (KS = 3) or just the 4 x 8 sampled pixels (KS = 1) of a 64-channel chunk are staged as fp16 hi | lo planes.
 // ---------------------------------------------------------------------------------------------------
 constexpr int S2_TH = 4, S2_TW = 8, S2_COT = 128;
+// KS = 3: the 9 x 17 halo is stored de-interleaved by column parity (a tap reads columns 2 ox + dx: one parity, consecutive indices),
+// sub-plane [parity][row][9 pixels of 144 bytes, row pitch 84 slots].  With the lane map s2_pixel a 16-lane ds_read_b128 group covers
+// two output rows x 8 columns: slots 9 ox + {0, 8} (the rows are 2 x 84 = 8 (mod 16) slots apart): 16 distinct.  (Reading columns
+// 2 ox of ONE plane puts every lane on an even slot: 60 % of the LDS cycles were conflicts.)
 template <int KS>
 struct S2Cfg {
     static constexpr int HH = KS == 3 ? (S2_TH - 1) * 2 + 3 : S2_TH, HW = KS == 3 ? (S2_TW - 1) * 2 + 3 : S2_TW;
-    static constexpr int PLANE = HH * HW * PIX, LDS = 2 * PLANE;
+    static constexpr int RP = KS == 3 ? 84 * 16 : S2_TW * PIX;          // bytes of a sub-plane row
+    static constexpr int SUB = HH * RP;                                  // bytes of a parity sub-plane (KS = 1: the plane)
+    static constexpr int PLANE = KS == 3 ? 2 * SUB : SUB, LDS = 2 * PLANE;
+    // byte offset of halo pixel (hy, hx) in a plane
+    static __device__ __forceinline__ int at(int hy, int hx) { return KS == 3 ? (hx & 1) * SUB + hy * RP + (hx >> 1) * PIX : (hy * S2_TW + hx) * PIX; }
 };
+// MFMA row i = 0 .. 31 -> output pixel (oy, ox) of the 4 x 8 tile.  KS = 3: rows {0, 1} on lanes {0-3, 12-15, 20-27}, rows {2, 3} on
+// {4-11, 16-19, 28-31} - the lane groups of ds_read_b128; KS = 1: row-major.
+template <int KS>
+__device__ __forceinline__ void s2_pixel(int i, int &oy, int &ox) {
+    if (KS == 3) {
+        const int q = i >> 2;
+        oy = (0xD728 >> (2 * q)) & 3;                    // q = 0 .. 7 -> 0 2 2 0 3 1 1 3
+        ox = i - 4 * ((065542110 >> (3 * q)) & 7);      // ... minus 0 4 4 8 16 20 20 24
+    } else {
+        oy = i >> 3;
+        ox = i & 7;
+    }
+}
 
 template <int KS>
 __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
@@ -273,8 +294,10 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // this lane's A row: output pixel (j >> 3, j & 7) of the tile; its halo offset for tap (0, 0)
-    const unsigned abase = KS == 3 ? (unsigned)(((2 * (j >> 3)) * C::HW + 2 * (j & 7)) * PIX + 16 * kg) : (unsigned)(j * PIX + 16 * kg);
+    // this lane's A row: output pixel s2_pixel(j) of the tile; its halo offset for tap (0, 0)
+    int oyj, oxj;
+    s2_pixel<KS>(j, oyj, oxj);
+    const unsigned abase = (unsigned)((KS == 3 ? C::at(2 * oyj, 2 * oxj) : C::at(oyj, oxj)) + 16 * kg);
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0 > 0) __syncthreads();
         constexpr int NST = (C::HH * C::HW * (CK / 4) + 255) / 256;   // every load of the chunk in flight before the first LDS store
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
             if (p >= C::HH * C::HW) continue;
             f16x4 h, l;
             f16_split4(hv[q], s_in, h, l);
-            char *at = smem + p * PIX + 8 * c4;
+            char *at = smem + C::at(p / C::HW, p % C::HW) + 8 * c4;
             *reinterpret_cast<f16x4 *>(at) = h;
             *reinterpret_cast<f16x4 *>(at + C::PLANE) = l;
         }
@@ -310,7 +333,8 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
         };
         auto load_a = [&](int s, int st) __attribute__((always_inline)) {
             const int tap = s >> 2, ks = s & 3;
-            const unsigned toff = (unsigned)((KS == 3 ? ((tap / 3) * C::HW + (tap % 3)) * PIX : 0) + 32 * ks);
+            // tap (dy, dx): halo pixel (2 oy + dy, 2 ox + dx) = parity dx & 1, row + dy, index + (dx >> 1)
+            const unsigned toff = (unsigned)((KS == 3 ? ((tap % 3) & 1) * C::SUB + (tap / 3) * C::RP + ((tap % 3) >> 1) * PIX : 0) + 32 * ks);
             af[st][0] = *reinterpret_cast<const f16x8 *>(smem + abase + toff);
             af[st][1] = *reinterpret_cast<const f16x8 *>(smem + abase + toff + C::PLANE);
         };
@@ -336,7 +360,9 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const int gy = y0 + (i >> 3), gx = x0 + (i & 7);
+        int oy, ox;
+        s2_pixel<KS>(i, oy, ox);
+        const int gy = y0 + oy, gx = x0 + ox;
         if (gy >= Ho || gx >= Wo) continue;
         const long at = (((long)n * Ho + gy) * Wo + gx) * a.Cout + co;
         float v = acc[r] * bs + bt;
