@@ -224,6 +224,12 @@ int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale
                       const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
                       int relu, void *stream);
 int sd_absmax_word(const float *x, int64_t n, uint32_t *word, void *stream);
+/* The same launch for a 1 x 1 stride-1 convolution (torchvision Bottleneck's conv1 / conv3 and the stride-1 shortcut of ResNet-50's
+ * layer 1, reference option image_encoder_type "resnet50": soccer_diffusion/ml/model/encoder/image.py:62-66): weights (Cout,Cin,1,1)
+ * packed by sd_conv_pack(ksize = 1); same tensors, epilogue (BatchNorm, residual, ReLU) and conventions as sd_conv3x3_bn_act. */
+int sd_conv1x1_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                      const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
+                      int relu, void *stream);
 /* The striding convolutions of a ResNet stage entry (conv1 of layers 2 - 4 and their 1 x 1 shortcut): y = act(BatchNorm_eval(conv(x, w; kernel
  * ksize = 3 with padding 1, or ksize = 1 with padding 0; stride 2))), NHWC fp32, x (N,H,W,Cin) -> y (N,ceil(H/2),ceil(W/2),Cout); Cin a
  * multiple of 64, Cout of 128; weights (Cout,Cin,ksize,ksize) packed by sd_conv_pack (sd_conv_packed_halfs fp16 values).  Same arithmetic,

@@ -155,6 +155,7 @@ SIGNATURES = {
     "sd_conv3x3_packed_halfs": (C.c_size_t, [C.c_int, C.c_int]),
     "sd_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sd_conv3x3_bn_act": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
+    "sd_conv1x1_bn_act": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p]),
     "sd_absmax_word": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sd_conv_packed_halfs": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sd_conv_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -122,7 +122,11 @@ struct ConvArgs {
     int ygroup;              // output-channel blocks that share a halo in one XCD's L2 (xcd_tile)
 };
 
+// KS = 3: the 3 x 3 / padding-1 convolution described above.  KS = 1: the same tile, epilogue and pipelines for a 1 x 1 convolution (ResNet-50's
+// bottleneck projections): no halo, one tap, 4 k-steps per 64-channel chunk.
+template <int KS>
 __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
+    constexpr int HH = TH + KS - 1, HW = TW + KS - 1, PAD = KS / 2, TAPS = KS * KS, NSTEP = TAPS * 4, PLANE = HH * HW * PIX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kg = lane >> 5;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
     const int co0 = yblk * COT + ch * 32;              // this wave's 32 output channels
     const float s_in = f16_scale_from_bits(*a.x_amax);
     const int nks = a.Cin / 16;
-    const f16 *wbase = a.w + (long)(co0 >> 5) * 9 * nks * 1024 + lane * 8;   // [tap][ks][plane]: 1024 halfs per (tap, ks)
+    const f16 *wbase = a.w + (long)(co0 >> 5) * TAPS * nks * 1024 + lane * 8;   // [tap][ks][plane]: 1024 halfs per (tap, ks)
 
     f32x16 acc[2];
 #pragma unroll
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
         for (int q = 0; q < NST; ++q) {
             const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
             const int hy = p / HW, hx = p - hy * HW;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
             hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p < HH * HW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                 hv[q] = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * a.H + gy) * a.W + gx) * a.Cin + c0 + 4 * c4);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
         };
         auto load_a = [&](int s, int st) __attribute__((always_inline)) {
             const int tap = s >> 2, ks = s & 3;
-            const unsigned toff = (unsigned)(((tap / 3) * HW + (tap % 3)) * PIX + 32 * ks);
+            const unsigned toff = (unsigned)(((tap / KS) * HW + (tap % KS)) * PIX + 32 * ks);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 af[st][m][0] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff);
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
         for (int s = 0; s < WD - 1; ++s) load_w(s);
         load_a(0, 0);
 #pragma unroll
-        for (int s = 0; s < 36; ++s) {
+        for (int s = 0; s < NSTEP; ++s) {
             const int st = s & 1;
-            if (s + WD - 1 < 36) load_w(s + WD - 1);
-            if (s + 1 < 36) load_a(s + 1, st ^ 1);
+            if (s + WD - 1 < NSTEP) load_w(s + WD - 1);
+            if (s + 1 < NSTEP) load_a(s + 1, st ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -588,19 +592,33 @@ static int conv_pack(const float *w, int Cout, int Cin, int ksize, void *planes,
     return 0;
 }
 
+static int conv_s1_bn_act(int ksize, const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                          const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout, int relu,
+                          void *stream);
 extern "C" int sd_conv3x3_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
                                  const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
                                  int relu, void *stream) {
+    return conv_s1_bn_act(3, x, w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu, stream);
+}
+extern "C" int sd_conv1x1_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                                 const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout,
+                                 int relu, void *stream) {
+    return conv_s1_bn_act(1, x, w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu, stream);
+}
+static int conv_s1_bn_act(int ksize, const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                          const float *bn_shift, const float *res, float *y, uint32_t *y_amax, int N, int H, int W, int Cin, int Cout, int relu,
+                          void *stream) {
     if (!x || !w_planes || !w_scale || !x_amax || !bn_scale || !bn_shift || !y || N <= 0 || H <= 0 || W <= 0)
         return fail(SD_E_BADARG, "sd_conv3x3_bn_act: null pointer or empty shape");
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv3x3_bn_act: channels must be positive multiples of 64");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv3x3_bn_act: x must be 16-byte aligned and distinct from y");
     cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu,
-                   (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH, cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * 9 * 4)};
+                   (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH, cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * ksize * ksize * 4)};
     const long tiles = (long)a.tiles_x * a.tiles_y * N;
     const long wgs = (tiles + 7) / 8 * 8 * (Cout / cv::COT);   // cv::xcd_tile's order
     if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv3x3_bn_act: too many tiles");
-    SD_LAUNCH(cv::conv3x3_kernel, dim3((unsigned)wgs), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
+    if (ksize == 3) SD_LAUNCH(cv::conv3x3_kernel<3>, dim3((unsigned)wgs), dim3(256), (size_t)cv::LDS_BYTES, (hipStream_t)stream, a);
+    else SD_LAUNCH(cv::conv3x3_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)(2 * cv::TH * cv::TW * cv::PIX), (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv3x3_kernel");
     return 0;
 }

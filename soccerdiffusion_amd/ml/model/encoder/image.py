@@ -116,6 +116,27 @@ class _Bottleneck(nn.Module):
         out = self.relu(self.bn2(self.conv2(out)))
         return self.relu(self.bn3(self.conv3(out)) + idt)
 
+    _packed = _BasicBlock._packed
+
+    def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor, words: torch.Tensor):
+        """Inference on the hand-written kernels (as _BasicBlock.forward_nhwc): conv1 1 x 1 / bn1 / relu, conv2 3 x 3 with the block's stride /
+        bn2 / relu, conv3 1 x 1 / bn3 / + identity (a 1 x 1 shortcut with the stride where the shapes differ) / relu.  ``words``: three
+        zeroed int32 words for the abs-max of the three outputs."""
+        fold = _BasicBlock._bn_fold
+        a1, a2, a3 = words[0:1], words[1:2], words[2:3]
+        out = ops.conv3x3_bn_act(h, amax, self._packed("_pk1", self.conv1), *fold(self.bn1), relu=True, y_amax=a1, zero_amax=False)
+        stride = self.conv2.stride[0]
+        conv2 = ops.conv3x3_bn_act if stride == 1 else ops.conv_s2_bn_act
+        out = conv2(out, a1, self._packed("_pk2", self.conv2), *fold(self.bn2), relu=True, y_amax=a2, zero_amax=False)
+        if self.downsample is None:
+            idt = h
+        elif stride == 1:
+            idt = ops.conv3x3_bn_act(h, amax, self._packed("_pkd", self.downsample[0]), *fold(self.downsample[1]), relu=False)
+        else:
+            idt = ops.conv_s2_bn_act(h, amax, self._packed("_pkd", self.downsample[0]), *fold(self.downsample[1]), relu=False)
+        y = ops.conv3x3_bn_act(out, a2, self._packed("_pk3", self.conv3), *fold(self.bn3), res=idt, relu=True, y_amax=a3, zero_amax=False)
+        return y, a3
+
 
 class _ResNet(nn.Module):
     """torchvision.models.resnet.ResNet, attribute for attribute (conv1, bn1, layer1-4, avgpool, fc)."""
@@ -139,8 +160,7 @@ class _ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def _hip_inference(self, x: torch.Tensor) -> bool:
-        return (x.is_cuda and not self.training and not torch.is_grad_enabled() and isinstance(self.layer1[0], _BasicBlock)
-                and os.environ.get("SD_CONV", "hip") != "torch")
+        return x.is_cuda and not self.training and not torch.is_grad_enabled() and os.environ.get("SD_CONV", "hip") != "torch"
 
     def forward(self, x):
         if self._hip_inference(x):
@@ -150,10 +170,10 @@ class _ResNet(nn.Module):
             pk = self.__dict__.get("_pk_stem")
             if pk is None or pk.planes.device != x.device:
                 pk = self.__dict__["_pk_stem"] = ops.PackedStem(self.conv1.weight)
-            # the abs-max words of the forward's 18 activation tensors (frames, stem, two per block): one fill
+            # the abs-max words of the forward's activation tensors (frames, stem, up to three per block): one fill
             words = self.__dict__.get("_amax_words")
             if words is None or words.device != x.device:
-                words = self.__dict__["_amax_words"] = torch.zeros(32, dtype=torch.int32, device=x.device)
+                words = self.__dict__["_amax_words"] = torch.zeros(64, dtype=torch.int32, device=x.device)
             words.zero_()
             amax = words[1:2]
             h = ops.stem_conv_bn_relu_pool(x, ops.absmax_word(x, words[0:1], zero=False), pk.refresh(self.conv1.weight), *_BasicBlock._bn_fold(self.bn1),
@@ -161,8 +181,8 @@ class _ResNet(nn.Module):
             at = 2
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:
-                    h, amax = blk.forward_nhwc(h, amax, words[at:at + 2])
-                    at += 2
+                    h, amax = blk.forward_nhwc(h, amax, words[at:at + 3])
+                    at += 3
             x = h.permute(0, 3, 1, 2)
         else:
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.maxpool(self.relu(self.bn1(self.conv1(x))))))))

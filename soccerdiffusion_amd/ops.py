@@ -926,14 +926,14 @@ def absmax_word(x: Tensor, word: Optional[Tensor] = None, zero: bool = True) -> 
 
 def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor, bn_shift: Tensor, res: Optional[Tensor] = None,
                    relu: bool = True, y_amax: Optional[Tensor] = None, zero_amax: bool = True) -> Tensor:
-    """relu(conv3x3(x) * bn_scale + bn_shift (+ res)) on NHWC fp32 tensors (stride 1, padding 1) - torchvision BasicBlock's
-    conv / bn / relu in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83).  ``x_amax``: word from
+    """relu(conv(x) * bn_scale + bn_shift (+ res)) on NHWC fp32 tensors, stride 1: 3 x 3 / padding 1 or 1 x 1 (``w.ksize``) - torchvision
+    BasicBlock's / Bottleneck's conv / bn / relu in inference mode (reference: soccer_diffusion/ml/model/encoder/image.py:55-83).  ``x_amax``: word from
     ``absmax_word`` or the ``y_amax`` of the launch that produced x; ``y_amax`` (zeroed here unless ``zero_amax`` is False: the caller
     zeroed it, e.g. all words of a forward in one fill) receives max |y|."""
     _req(x, "x"); _req(bn_scale, "bn_scale"); _req(bn_shift, "bn_shift")
     N, H, W, Cin = x.shape
-    if Cin != w.Cin or w.ksize != 3:
-        raise ValueError("channel / kernel-size mismatch")
+    if Cin != w.Cin:
+        raise ValueError("channel mismatch")
     y = torch.empty(N, H, W, w.Cout, dtype=torch.float32, device=x.device)
     if res is not None:
         _req(res, "res")
@@ -941,9 +941,10 @@ def conv3x3_bn_act(x: Tensor, x_amax: Tensor, w: PackedConv3x3, bn_scale: Tensor
             raise ValueError("residual shape mismatch")
     if y_amax is not None and zero_amax:
         y_amax.zero_()
-    check(_lib.load().sd_conv3x3_bn_act(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
-                                        bn_shift.data_ptr(), _ptr(res), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, int(relu), _stream()),
-          "sd_conv3x3_bn_act")
+    fn = _lib.load().sd_conv3x3_bn_act if w.ksize == 3 else _lib.load().sd_conv1x1_bn_act   # (a 1 x 1 weight: Bottleneck projections)
+    check(fn(x.data_ptr(), w.planes.data_ptr(), w.scale.data_ptr(), x_amax.data_ptr(), bn_scale.data_ptr(),
+             bn_shift.data_ptr(), _ptr(res), y.data_ptr(), _ptr(y_amax), N, H, W, Cin, w.Cout, int(relu), _stream()),
+          "sd_conv3x3_bn_act" if w.ksize == 3 else "sd_conv1x1_bn_act")
     return y
 
 

@@ -201,3 +201,75 @@ def test_stem_conv_bn_relu_pool_matches_torch_cpu(ops, N, H, W):
     e, e32 = rel_err(got, want64), rel_err(want32, want64)
     assert e < 2e-6 and e < 8 * e32 + 2e-7, (e, e32)
     assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
+
+
+# ResNet-50's bottleneck projections on a 480 x 640 frame (64 -> 256 at 120 x 160 ... 2048 -> 512 at 15 x 20), ragged maps, one pixel
+@pytest.mark.parametrize("C_in,C_out,N,H,W", [(64, 256, 2, 120, 160), (256, 64, 2, 120, 160), (512, 128, 2, 60, 80), (1024, 256, 2, 30, 40),
+                                             (2048, 512, 2, 15, 20), (512, 2048, 1, 15, 20), (64, 64, 1, 13, 23), (128, 192, 1, 1, 1)])
+@pytest.mark.parametrize("with_res,relu", [(True, True), (False, False)])
+def test_conv1x1_bn_act_matches_torch_cpu(ops, C_in, C_out, N, H, W, with_res, relu):
+    g = torch.Generator().manual_seed(C_in + C_out + H)
+    x = torch.randn(N, C_in, H, W, generator=g).abs()
+    w = torch.randn(C_out, C_in, 1, 1, generator=g) * (2.0 / C_out) ** 0.5
+    gamma, beta = 0.5 + torch.rand(C_out, generator=g), 0.2 * torch.randn(C_out, generator=g)
+    mean, var = 0.3 * torch.randn(C_out, generator=g), 0.5 + torch.rand(C_out, generator=g)
+    res = torch.randn(N, C_out, H, W, generator=g).abs()
+
+    def block(dtype):
+        y = F.batch_norm(F.conv2d(x.to(dtype), w.to(dtype)), mean.to(dtype), var.to(dtype), gamma.to(dtype), beta.to(dtype), training=False, eps=1e-5)
+        if with_res:
+            y = y + res.to(dtype)
+        return F.relu(y) if relu else y
+
+    want64, want32 = block(torch.float64), block(torch.float32)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    inv = torch.rsqrt(var + 1e-5)
+    ya = torch.zeros(1, dtype=torch.int32, device="cuda")
+    y = ops.conv3x3_bn_act(xh, ops.absmax_word(xh), ops.PackedConv3x3(w.cuda()), (gamma * inv).cuda(), (beta - mean * gamma * inv).cuda(),
+                           res=res.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None, relu=relu, y_amax=ya)
+    got = y.permute(0, 3, 1, 2).cpu()
+    e, e32 = rel_err(got, want64), rel_err(want32, want64)
+    assert e < 2e-6 and e < 8 * e32 + 2e-7, (e, e32)
+    assert abs(ya.view(torch.float32).item() - float(got.abs().max())) <= 1e-6 * float(got.abs().max())
+
+
+def test_resnet50_inference_runs_the_hip_kernels_and_matches_cpu_fp32():
+    """The reference's other ResNet option (image_encoder_type "resnet50", ml/model/encoder/image.py:62-66): torchvision Bottleneck blocks
+    (1 x 1, 3 x 3 with the stride, 1 x 1 x 4; 1 x 1 shortcuts) on sd_conv3x3_bn_act / sd_conv1x1_bn_act / sd_conv_s2_bn_act - 52 convolutions
+    + the stem, none on the library - against the same modules on the CPU in fp32 and the all-MIOpen route."""
+    import copy
+
+    from soccerdiffusion_amd import ops as o
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+    torch.manual_seed(0)
+    enc = image_encoder_factory(ImageEncoderType.RESNET50, 64, True, 64)
+    enc.train()
+    with torch.no_grad():
+        enc(torch.rand(2, 2, 3, 64, 96))
+    enc.eval()
+    x = torch.rand(2, 2, 3, 64, 96, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = enc(x)
+    g = copy.deepcopy(enc).cuda().eval()
+    calls = {"s1": 0, "s2": 0, "stem": 0}
+    orig = (o.conv3x3_bn_act, o.conv_s2_bn_act, o.stem_conv_bn_relu_pool)
+    o.conv3x3_bn_act = lambda *a, **k: (calls.__setitem__("s1", calls["s1"] + 1), orig[0](*a, **k))[1]
+    o.conv_s2_bn_act = lambda *a, **k: (calls.__setitem__("s2", calls["s2"] + 1), orig[1](*a, **k))[1]
+    o.stem_conv_bn_relu_pool = lambda *a, **k: (calls.__setitem__("stem", calls["stem"] + 1), orig[2](*a, **k))[1]
+    try:
+        with torch.no_grad():
+            got = g(x.cuda())
+    finally:
+        o.conv3x3_bn_act, o.conv_s2_bn_act, o.stem_conv_bn_relu_pool = orig
+    # 16 blocks x 3 convolutions + 4 shortcuts = 52: stride 2 in conv2 and the shortcut of layers 2 - 4's first blocks (6)
+    assert calls == {"s1": 46, "s2": 6, "stem": 1}, calls
+    assert got.shape == (2, 2, 64)
+    assert float((got.cpu() - want).abs().max() / want.abs().max()) < 1e-4
+    os.environ["SD_CONV"] = "torch"
+    try:
+        with torch.no_grad():
+            lib = g(x.cuda())
+    finally:
+        del os.environ["SD_CONV"]
+    assert float((got - lib).abs().max() / lib.abs().max()) < 1e-4

@@ -95,4 +95,18 @@ with torch.no_grad():
 out["backbone_forward"] = {"frames": N, "hip_ms": round(t_hip * 1e3, 1), "all_miopen_ms": round(t_lib * 1e3, 1),
                            "frames_per_s_hip": round(N / t_hip, 1), "frames_per_s_miopen": round(N / t_lib, 1),
                            "max_rel_diff_of_tokens": float((a - b).abs().max() / b.abs().max())}
+# the reference's other ResNet option (Bottleneck blocks: 1 x 1 / 3 x 3 / 1 x 1 on sd_conv1x1_bn_act, sd_conv3x3_bn_act, sd_conv_s2_bn_act)
+del enc, a, b
+torch.manual_seed(0)
+enc = image_encoder_factory(ImageEncoderType.RESNET50, 256, True, 480).to(dev).eval()
+with torch.no_grad():
+    t_hip = timed(lambda: enc(frames), 3)
+    a = enc(frames)
+    os.environ["SD_CONV"] = "torch"
+    t_lib = timed(lambda: enc(frames), 3)
+    b = enc(frames)
+    del os.environ["SD_CONV"]
+out["resnet50_forward"] = {"frames": N, "hip_ms": round(t_hip * 1e3, 1), "all_miopen_ms": round(t_lib * 1e3, 1),
+                           "frames_per_s_hip": round(N / t_hip, 1), "frames_per_s_miopen": round(N / t_lib, 1),
+                           "max_rel_diff_of_tokens": float((a - b).abs().max() / b.abs().max())}
 print(json.dumps(out, indent=1))
