@@ -213,32 +213,43 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                acc[m] = mfma32(af[st][m][1], bw[s % WD][0], acc[m]);   // lo . hi
-                acc[m] = mfma32(af[st][m][0], bw[s % WD][1], acc[m]);   // hi . lo
-                acc[m] = mfma32(af[st][m][0], bw[s % WD][0], acc[m]);   // hi . hi
+                // weights as the A operand: the accumulator is the TRANSPOSED tile - lane = pixel, registers = output channels, four
+                // consecutive channels in four consecutive registers, so the epilogue moves 16 bytes per lane
+                acc[m] = mfma32(bw[s % WD][0], af[st][m][1], acc[m]);   // hi . lo
+                acc[m] = mfma32(bw[s % WD][1], af[st][m][0], acc[m]);   // lo . hi
+                acc[m] = mfma32(bw[s % WD][0], af[st][m][0], acc[m]);   // hi . hi
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- epilogue: un-scale, BatchNorm (inference: y = conv * s + t), residual, ReLU, NHWC store, abs-max
+    // ---- epilogue: un-scale, BatchNorm (inference: y = conv * s + t), residual, ReLU, NHWC store, abs-max.  Lane (j, kg) holds pixel
+    // (row32(j), j & 15) of its 2 x 16 block; register r = channel (r & 3) + 8 (r >> 2) + 4 kg of the wave's 32: 16-byte accesses (with
+    // pixels as the A operand a lane held ONE channel of 16 pixels: 4-byte accesses, and layer 1 took 1.07 instead of 0.89 ms; a 4 x 4
+    // lane-quad transpose on top, which makes every access a whole 128-byte line, costs more in shuffles than it saves: 0.91 ms average)
     const float un = 1.0f / (s_in * *a.w_scale);
-    const int co = co0 + j;
-    const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
+    f32x4 bs[4], bt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bs[q] = *reinterpret_cast<const f32x4 *>(a.bn_scale + co0 + 8 * q + 4 * kg) * un;
+        bt[q] = *reinterpret_cast<const f32x4 *>(a.bn_shift + co0 + 8 * q + 4 * kg);
+    }
     float mx = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + 4 * ph + 2 * m + row32(j), gx = x0 + (j & 15);
+        if (gy >= a.H || gx >= a.W) continue;
+        const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * kg;
+        f32x4 rv[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;           // accumulator row = A row
-            const int gy = y0 + 4 * ph + 2 * m + row32(i), gx = x0 + (i & 15);
-            if (gy >= a.H || gx >= a.W) continue;
-            const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co;
-            float v = acc[m][r] * bs + bt;
-            if (a.res) v += __builtin_nontemporal_load(a.res + at);
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.y[at] = v;
-            mx = fmaxf(mx, fabsf(v));
+        for (int q = 0; q < 4; ++q) rv[q] = a.res ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.res + at + 8 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = f32x4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]} * bs[q] + bt[q] + rv[q];
+            if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            *reinterpret_cast<f32x4 *>(a.y + at + 8 * q) = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
+    }
     if (a.y_amax) publish_amax(a.y_amax, mx, lane);
 }
 
@@ -351,28 +362,28 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(ConvArgs a) {
             if (s + SD - 1 < TAPS * 4) load_w(s + SD - 1);
             if (s + 1 < TAPS * 4) load_a(s + 1, st ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc = mfma32(af[st][1], bw[s % SD][0], acc);
-            acc = mfma32(af[st][0], bw[s % SD][1], acc);
-            acc = mfma32(af[st][0], bw[s % SD][0], acc);
+            acc = mfma32(bw[s % SD][0], af[st][1], acc);   // weights as A: the transposed tile (lane = pixel), 16-byte epilogue accesses
+            acc = mfma32(bw[s % SD][1], af[st][0], acc);
+            acc = mfma32(bw[s % SD][0], af[st][0], acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const float un = 1.0f / (s_in * *a.w_scale);
-    const int co = co0 + j;
-    const float bs = a.bn_scale[co] * un, bt = a.bn_shift[co];
     float mx = 0.f;
+    {   // lane (j, kg): output pixel s2_pixel(j); register r = channel (r & 3) + 8 (r >> 2) + 4 kg of the wave's 32
+        const int gy = y0 + oyj, gx = x0 + oxj;
+        if (gy < Ho && gx < Wo) {
+            const long at = (((long)n * Ho + gy) * Wo + gx) * a.Cout + co0 + 4 * kg;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        int oy, ox;
-        s2_pixel<KS>(i, oy, ox);
-        const int gy = y0 + oy, gx = x0 + ox;
-        if (gy >= Ho || gx >= Wo) continue;
-        const long at = (((long)n * Ho + gy) * Wo + gx) * a.Cout + co;
-        float v = acc[r] * bs + bt;
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.y[at] = v;
-        mx = fmaxf(mx, fabsf(v));
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bs = *reinterpret_cast<const f32x4 *>(a.bn_scale + co0 + 8 * q + 4 * kg) * un;
+                const f32x4 bt = *reinterpret_cast<const f32x4 *>(a.bn_shift + co0 + 8 * q + 4 * kg);
+                f32x4 v = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]} * bs + bt;
+                if (a.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<f32x4 *>(a.y + at + 8 * q) = v;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+        }
     }
     if (a.y_amax) publish_amax(a.y_amax, mx, lane);
 }
