@@ -211,7 +211,8 @@ int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const flo
 /* ---- image path: ResNet basic-block convolution -------------------------------------------------------
  * y = act(BatchNorm_eval(conv3x3(x, w; stride 1, padding 1)) [+ res]) - torchvision BasicBlock's conv1/bn1/relu and
  * conv2/bn2 (+ identity) / relu as the reference configures them (soccer_diffusion/ml/model/encoder/image.py:55-83), inference mode.
- * Tensors are NHWC fp32: x (N,H,W,Cin), res / y (N,H,W,Cout); Cin, Cout multiples of 64.  bn_scale = gamma / sqrt(var + eps),
+ * Tensors are NHWC fp32: x (N,H,W,Cin), res / y (N,H,W,Cout); Cin, Cout multiples of 64; x, y, res, bn_scale and bn_shift 16-byte aligned
+ * (SD_E_BADARG otherwise: the kernels use 16-byte accesses).  bn_scale = gamma / sqrt(var + eps),
  * bn_shift = beta - mean * bn_scale (per output channel).  Implicit GEMM with three fp16 MFMAs per product on hi + lo operands,
  * fp32 accumulate (fp32-grade results; soccerdiffusion_amd/csrc/sd_conv.hip).
  *   sd_conv3x3_pack: w (Cout,Cin,3,3) fp32 -> sd_conv3x3_packed_halfs(Cout,Cin) fp16 values in fragment order + the power-of-two

@@ -623,6 +623,9 @@ static int conv_s1_bn_act(int ksize, const float *x, const void *w_planes, const
         return fail(SD_E_BADARG, "sd_conv3x3_bn_act: null pointer or empty shape");
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv3x3_bn_act: channels must be positive multiples of 64");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv3x3_bn_act: x must be 16-byte aligned and distinct from y");
+    // the epilogue moves 16 bytes per lane: four consecutive output channels of y / res / the BatchNorm vectors
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+        return fail(SD_E_BADARG, "sd_conv3x3_bn_act / sd_conv1x1_bn_act: y, res, bn_scale and bn_shift must be 16-byte aligned");
     cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, res, y, y_amax, N, H, W, Cin, Cout, relu,
                    (W + cv::TW - 1) / cv::TW, (H + cv::TH - 1) / cv::TH, cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * ksize * ksize * 4)};
     const long tiles = (long)a.tiles_x * a.tiles_y * N;
@@ -642,6 +645,8 @@ extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const flo
     if (ksize != 1 && ksize != 3) return fail(SD_E_BADARG, "sd_conv_s2_bn_act: kernel size 1 or 3");
     if (Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % cv::S2_COT) return fail(SD_E_BADDIM, "sd_conv_s2_bn_act: Cin a multiple of 64, Cout a multiple of 128");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || x == y) return fail(SD_E_BADARG, "sd_conv_s2_bn_act: x must be 16-byte aligned and distinct from y");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+        return fail(SD_E_BADARG, "sd_conv_s2_bn_act: y, bn_scale and bn_shift must be 16-byte aligned");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     cv::ConvArgs a{x, (const f16 *)w_planes, w_scale, x_amax, bn_scale, bn_shift, nullptr, y, y_amax, N, H, W, Cin, Cout, relu,
                    (Wo + cv::S2_TW - 1) / cv::S2_TW, (Ho + cv::S2_TH - 1) / cv::S2_TH,

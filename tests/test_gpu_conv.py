@@ -273,3 +273,17 @@ def test_resnet50_inference_runs_the_hip_kernels_and_matches_cpu_fp32():
     finally:
         del os.environ["SD_CONV"]
     assert float((got - lib).abs().max() / lib.abs().max()) < 1e-4
+
+
+def test_misaligned_vectors_are_refused_not_dereferenced(ops):
+    """The epilogues use 16-byte accesses on y / res / the BatchNorm vectors: a misaligned pointer must come back as SD_E_BADARG from the
+    C ABI, not reach the kernel."""
+    x = torch.rand(1, 4, 4, 64, device="cuda")
+    pk = ops.PackedConv3x3(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    buf = torch.ones(65, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_bn_act(x, ops.absmax_word(x), pk, buf[1:], torch.zeros(64, device="cuda"))
+    pk2 = ops.PackedConv3x3(torch.randn(128, 64, 3, 3, device="cuda") * 0.05)
+    buf2 = torch.ones(129, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv_s2_bn_act(x, ops.absmax_word(x), pk2, torch.ones(128, device="cuda"), buf2[1:])
