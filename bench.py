@@ -424,10 +424,11 @@ def main():
     ap.add_argument("--mode", choices=("sample", "train"), default="sample")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU per step (default 4096 sample / 256 train)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode: dropout probability (reference: 0.1)")
-    ap.add_argument("--sampler-mode", type=int, choices=(0, 1, 2, 3, 4), default=4,
-                    help="sample mode: cap of sd_ddim_sample_ex's kernel selection.  4 (default) = what End2EndDiffusionTransformer.sample runs: "
-                         "the trajectory kernel with the two-product Q|K|V site, its SD_STATUS_SHARP_LOGITS guard read after the timed region; "
-                         "3 = three fp16 products at every site (valid for any weights)")
+    ap.add_argument("--sampler-mode", type=int, choices=(0, 1, 2, 3, 4), default=3,
+                    help="sample mode: cap of sd_ddim_sample_ex's kernel selection.  3 (default) = what End2EndDiffusionTransformer.sample and "
+                         "an automatic sd_ddim_sample call run: the trajectory kernel with three fp16 products at every site (valid for any "
+                         "weights); 4 = the opt-in two-product Q|K|V site (max_mode=4 / SD_SAMPLER_MODE=4), its SD_STATUS_SHARP_LOGITS guard "
+                         "read after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="train mode: issue the step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -462,6 +463,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks (this one {dist.get_rank()}) for --gpus {args.gpus}")
     try:
         if args.mode == "train":
             run_train(args, rank, world, dev, dist)
@@ -471,6 +474,23 @@ def main():
         if dist:
             dist.barrier()
             dist.destroy_process_group()
+
+
+def rank_inventory(dev, rank, world, dist, share):
+    """Self-verification of an N > 1 run (`world` in the JSON line): every rank's device - name, PCI address, uuid - gathered on all
+    ranks, so the line itself shows N distinct GPUs (or, in the one-GPU rehearsal, that the ranks shared one), plus the backend."""
+    import torch
+
+    p = torch.cuda.get_device_properties(dev)
+    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    mine = {"rank": rank, "device_index": dev.index, "name": torch.cuda.get_device_name(dev), "pci": pci, "uuid": str(getattr(p, "uuid", "")),
+            "pid": os.getpid()}
+    ranks = [mine]
+    if dist:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    return {"size": world, "backend": (dist.get_backend() if dist else None), "ranks": ranks,
+            "distinct_devices": len({(r["pci"], r["uuid"]) for r in ranks}), "shared_gpu_rehearsal": bool(share)}
 
 
 def run_train(args, rank, world, dev, dist):
@@ -488,10 +508,13 @@ def run_train(args, rank, world, dev, dist):
         except Exception as e:  # noqa: BLE001 - a sub-record must not take the line down
             chain = {"error": repr(e)[:300]}
     leg.close()
+    inventory = rank_inventory(dev, rank, world, dist, os.environ.get("SD_BENCH_SHARE_GPU") == "1")   # (a collective: every rank calls it)
     if rank != 0:
         return
     rec = train_record(elapsed, steps, world, B, loss, ar, leg.dropout, leg.opt.flat_param.numel())
     rec["allreduce_exposed_ms"] = round(ar_exposed, 4)
+    if world > 1 and ar > 0:   # bus bandwidth of the flat-gradient exchange as RCCL's tests define it: bytes x 2 (N - 1) / N / time
+        rec["allreduce_busbw_gbs"] = round(rec["allreduce_bytes"] * 2 * (world - 1) / world / (ar * 1e-3) / 1e9, 2)
     if world > 1:
         rec["allreduce_form"] = ("per-layer buckets started from gradient hooks and overlapped with the rest of the backward (training.BucketedAllReduce; "
                                  "the step is issued eagerly at N > 1, the same step cli train runs); allreduce_ms = the flat exchange alone, "
@@ -517,6 +540,7 @@ def run_train(args, rank, world, dev, dist):
         "whole_step": {"achieved": rec["algorithmic_tflops_per_gpu"], "unit": "TFLOP/s", "frac_of_f16_mfma_peak": rec["frac_of_f16_mfma_peak"],
                        "definition": "3 x F_step (SURVEY 8(d)) x trajectories / wall time, per GPU"},
         "train": rec,
+        "world": inventory,
         "cpu_baseline": None,
     }
     if not args.no_cpu_baseline and world == 1:
@@ -549,7 +573,8 @@ def run_sample(args, rank, world, dev, dist):
     x = torch.empty_like(x_T)
     guard = torch.zeros(1, dtype=torch.int32, device=dev)   # range-guard word of sd_ddim_sample_ex, read after the timed region
 
-    # the kernels this call runs: sd_sampler_mode (3 where the trajectory kernel applies) capped by --sampler-mode; 4 is opt-in
+    # the kernels this call runs: sd_sampler_mode (3 where the trajectory kernel applies) capped by --sampler-mode (default 3 = the
+    # product default, ops.default_sampler_cap()); 4 is opt-in
     auto_mode = lib.sd_sampler_mode(D, HEADS, T, MC, J)
     mode = args.sampler_mode if (auto_mode == 3 and args.sampler_mode >= 3) else min(auto_mode, args.sampler_mode)
 
@@ -590,6 +615,7 @@ def run_sample(args, rank, world, dev, dist):
         _lib.check(lib.sd_profile_collect(ms, cnt, n), "sd_profile_collect")
         roofline = sample_roofline(ms, cnt, steps, B, elapsed, mode)
 
+    inventory = rank_inventory(dev, rank, world, dist, os.environ.get("SD_BENCH_SHARE_GPU") == "1")   # (a collective: every rank calls it)
     if rank != 0:
         return
     extras = {}
@@ -620,6 +646,7 @@ def run_sample(args, rank, world, dev, dist):
             "decoder_layers": L, "memory_tokens": M, "parallelism": f"dp{world} (independent rollouts, no collective)",
         },
         "roofline": roofline,
+        "world": inventory,
         **extras,
         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd),
     }
@@ -637,8 +664,8 @@ DTYPE_BY_MODE = {
     4: "f32 (operands split into fp16 hi+lo, fp32 accumulate; 3 fp16 MFMAs per product EXCEPT the self-attention's Q|K|V projection, "
        "which reads ONE fp16 plane of LayerNorm 1's output: 2 MFMAs per product, 11-bit activation operand at that site.  Error of a "
        "noise prediction vs the fp64 oracle ~ 1e-5 x max|attention logit|: 1.7e-5 on these weights (max |logit| 1.6; 50-step rollout "
-       "5.1e-6), 1e-4 at |logit| ~ 9.  The kernel sets SD_STATUS_SHARP_LOGITS beyond |logit| 5 - checked == 0 after this timed region - "
-       "and ops.ddim_sample_guarded then repeats on mode 3; `other_traj_mode` is mode 3's rate for the same rollout)",
+       "5.1e-6), 1e-4 at |logit| ~ 9.  OPT-IN (max_mode=4 / SD_SAMPLER_MODE=4): the kernel sets SD_STATUS_SHARP_LOGITS beyond |logit| 5 "
+       "- checked == 0 after the timed region - and ops.ddim_sample_guarded then repeats on mode 3, the default)",
 }
 
 
@@ -740,7 +767,7 @@ def traj_roofline(ms, cnt, steps, B, elapsed, mode=4):
     # (per trajectory), the split weights once
     design_bytes = B * (2 * T * J * 4 + L * (2 * 4 * 16 * D * 2 * 2 + 64 * 4)) + L * 6 * D * D * 4 + 2 * 32 * D * 4
     fused_alg_bytes_per_step = B * FUSED_BYTES_PER_TRAJ_STEP + 10.59e6
-    prof = profiles_record()
+    prof = profiles_record(mode)
     traffic = prof.get("traj_step_kernel_bytes_per_launch") if prof else None
     hbm = {"algorithmic_bytes_per_launch_this_design": design_bytes, "achieved": round(design_bytes / avg_s / 1e9, 1), "peak": PEAK_HBM_GBS,
            "unit": "GB/s", "frac": round(design_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
@@ -781,11 +808,13 @@ def traj_roofline(ms, cnt, steps, B, elapsed, mode=4):
     }
 
 
-def profiles_record():
+def profiles_record(mode=None):
     """Counter-derived figures read from the committed profile summaries (profiles/*.json): measured by rocprofv3 on
-    ANOTHER box and run than this line, so they are evidence with provenance, not live measurements."""
+    ANOTHER box and run than this line, so they are evidence with provenance, not live measurements.  Sampler mode 3
+    (traj_step_kernel<7, true>) has passes of its own (pmc_*_mode3.json); the plain files are mode 4's (and the older modes')."""
     out = {}
-    p = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    sfx = "_mode3" if mode == 3 else ""
+    p = os.path.join(REPO, "profiles", f"pmc_traffic{sfx}.json")
     if os.path.exists(p):
         with open(p) as fh:
             t = json.load(fh)
@@ -798,7 +827,8 @@ def profiles_record():
                     out["attention_kernel_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
         out["traffic_source"] = t.get("source")
         out["traffic_round"] = t.get("round", "r01")
-    p = os.path.join(REPO, "profiles", "pmc_sq.json")
+        out["traffic_kernel"] = t.get("dominant_kernel")
+    p = os.path.join(REPO, "profiles", f"pmc_sq{sfx}.json")
     if os.path.exists(p):
         with open(p) as fh:
             s = json.load(fh)
@@ -815,6 +845,47 @@ def profiles_record():
     return out or None
 
 
+def loop_form_record(sd, x_T, ctx, dev, x_native=None):
+    """50 x (End2EndDiffusionTransformer.forward_with_context + DDIMScheduler.step) as a Python loop, at B = 256 and at the headline batch."""
+    import torch
+
+    from soccerdiffusion_amd import cli
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+
+    model = cli.build_model(C2_PARAMS).to(dev).eval()
+    model.load_state_dict(sd)
+    sched = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+    sched.config["num_train_timesteps"] = 1000
+    sched.set_timesteps(N_DDIM)
+    rec = {"workload": "the reference's loop form (plot.py:122-131): 50 x [model.forward_with_context(ctx, x, t) -> one traj_step_kernel launch "
+                       "through sd_sampler_eps + the step token's K/V and fold; scheduler.step -> sd_ddim_step], eager, sampler mode 3; context "
+                       "folded once per loop (ops.LoopSampler)"}
+    for Bs in sorted({256, x_T.shape[0]}):
+        xs, cs = x_T[:Bs].contiguous(), [ctx[:Bs].contiguous()]
+
+        def loop():
+            traj = xs
+            with torch.no_grad():
+                for t in sched.timesteps:
+                    eps = model.forward_with_context(cs, traj, torch.full((Bs,), int(t), device=dev))
+                    traj = sched.step(eps, t, traj).prev_sample
+            return traj
+
+        y = loop()
+        torch.cuda.synchronize()
+        n = 3 if Bs > 1024 else 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            y = loop()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        r = {"ms_per_rollout": round(dt * 1e3, 3), "value": round(Bs / dt, 2), "unit": "trajectories/s", "rollouts_timed": n}
+        if x_native is not None and Bs == x_native.shape[0]:
+            r["max_rel_diff_to_headline"] = float(((y - x_native).flatten(1).norm(dim=1) / x_native.flatten(1).norm(dim=1)).max())
+        rec[f"b{Bs}"] = r
+    return rec
+
+
 def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=None):
     """After the headline region, N = 1: (a) the same rollout replayed from a hipGraph (BASELINE configs[2] names a
     hipGraph-captured step), checked bit for bit against the eager result; (b) north_star's B = 256 sampling shape;
@@ -826,21 +897,29 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
     # (0) the same rollout in the OTHER trajectory-kernel mode (3: three products everywhere / 4: two at the Q|K|V projection)
     if mode >= 3:
         try:
+            from soccerdiffusion_amd import _lib
+
+            lib = _lib.load()
             other = 7 - mode
             y = torch.empty_like(x)
             st = torch.zeros(1, dtype=torch.int32, device=dev)
             for i in range(3):
                 if i == 1:
                     torch.cuda.synchronize()
+                    lib.sd_profile_enable(1)   # a HIP-event pair around every launch of the two timed rollouts: this mode's own roofline
                     t0 = time.perf_counter()
                 y.copy_(x_T)
                 ops.ddim_sample(packed, ctx, toks, coef, y, inplace=True, status=st, max_mode=other)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 2
+            lib.sd_profile_enable(0)
+            nk = len(_lib.KERNEL_CLASSES)
+            kms, kcnt = (C.c_double * nk)(), (C.c_long * nk)()
+            _lib.check(lib.sd_profile_collect(kms, kcnt, nk), "sd_profile_collect")
             out["other_traj_mode"] = {"sampler_mode": other, "ms_per_rollout": round(dt * 1e3, 3), "value": round(B / dt, 2),
                                       "unit": "trajectories/s", "status_word": int(st.item()),
                                       "max_rel_diff_to_headline": float(((y - x).flatten(1).norm(dim=1) / x.flatten(1).norm(dim=1)).max()),
-                                      "dtype": DTYPE_BY_MODE[other]}
+                                      "dtype": DTYPE_BY_MODE[other], "roofline": traj_roofline(kms, kcnt, 2, B, 2 * dt, other)}
         except Exception as e:  # noqa: BLE001
             out["other_traj_mode"] = {"error": repr(e)[:300]}
     # (a) hipGraph replay at the headline batch
@@ -887,6 +966,13 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
         del gs
     except Exception as e:  # noqa: BLE001
         out["b256"] = {"error": repr(e)[:300]}
+    # (b2) the reference's OWN loop form - for t in scheduler.timesteps: eps = model.forward_with_context(ctx, x, t); x = scheduler.step(eps,
+    # t, x).prev_sample (plot.py:122-131, distill.py:179-189) - through the boundary class: every call reaches traj_step_kernel through
+    # ops.LoopSampler (weights split and context folded once per loop), the DDIM update is its own launch
+    try:
+        out["loop_form"] = loop_form_record(sd, x_T, ctx, dev, x if B == 4096 else None)
+    except Exception as e:  # noqa: BLE001
+        out["loop_form"] = {"error": repr(e)[:300]}
     # (c) C2 training step on this GPU
     try:
         leg = TrainLeg(dev, 0, 1, TRAIN_B, 40)

@@ -39,6 +39,7 @@ extern "C" {
 #define SD_E_BADARG (-1)   /* null pointer / non-positive size                       */
 #define SD_E_BADDIM (-2)   /* hidden_dim not in {64,128,256,512} or not /heads        */
 #define SD_E_TOOBIG (-3)   /* sequence longer than the kernels support               */
+#define SD_E_UNSUPPORTED (-4) /* sd_sampler_prepare / sd_sampler_eps: this shape does not take the trajectory kernels */
 
 /* One pre-norm transformer layer (torch nn.TransformerDecoderLayer / EncoderLayer with
  * norm_first=True, activation="gelu", dim_feedforward=d — reference
@@ -110,8 +111,9 @@ size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
  *       arithmetic: three fp16 MFMAs per product on hi + lo operands at EVERY site.  hidden_dim 256, 4 heads, T <= 100 (one
  *       instantiation per ceil(T / 16) token tiles), Mc + 1 <= 64 memory rows (up to 16: one key tile in the folded
  *       cross-attention; 17 .. 64: the wide instantiation with 2 .. 4 key tiles - the reference's full-context configs, e.g.
- *       sim_scratch.yaml's 51 rows), J <= 32, J % 4 == 0; the layer count (<= 8) is checked at the call - a deeper model runs
- *       mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
+ *       sim_scratch.yaml's 51 rows), any J <= 32 (the embedding's K and fc_out's N are zero-padded in the packed planes; the
+ *       reference's database has 22 joints, soccer_diffusion/dataset/models.py:222-247); the layer count (<= 8) is checked at the
+ *       call - a deeper model runs mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
  *   4 = mode 3 with ONE exception: the Q | K | V projection of the self-attention reads a single fp16 plane of LayerNorm
  *       1's output (two MFMAs per product there, 11-bit activation operand), which frees the LDS that lets the four images
  *       of a head live side by side (two barriers per head instead of five; ~ 1.15 x mode 3).  The error this leaves in a
@@ -207,6 +209,26 @@ int sd_ddim_sample_ex(const sd_denoiser_weights *w, const float *ctx, const floa
 int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx, const float *step_tokens,
                        const float *coef, float *x, float *trace, float *eps_trace, float *workspace,
                        int B, int T, int Mc, int n_steps, int32_t *status, int max_mode, void *stream);
+
+/* The denoiser evaluated ONE step at a time on the trajectory kernels of sampler modes 3 / 4 - the reference's own loop form,
+ *   for t in scheduler.timesteps: eps = model.forward_with_context(ctx, x, t); x = scheduler.step(eps, t, x).prev_sample
+ * (soccer_diffusion/ml/inference/plot.py:122-131, ml/training/distill.py:179-189, ml/inference/ros.py:301-310), whose
+ * forward_with_context (ml/model/model.py:159-179) cannot know that it is inside a loop: what does not depend on x or the step is
+ * prepared once into the caller's workspace and reused by every evaluation.
+ *   sd_sampler_prepare: `what` = SD_PREPARE_WEIGHTS (abs-max + split fp16 planes of every matrix: once per weight update) |
+ *     SD_PREPARE_CONTEXT (K / V of the context rows, folded with Wq / Woc as sd_ddim_sample does: once per context).
+ *   sd_sampler_eps: eps (B,T,J) = denoiser(x, [ctx rows | step token]); step_tokens (n_tok,d) with n_tok = 1 (one step for the
+ *     whole batch) or n_tok = B (row b = sample b's StepToken); x is only read.  status / max_mode as sd_ddim_sample_ex (3 or -1:
+ *     three products everywhere, no status needed; 4: the guarded two-product Q | K | V site).
+ * Both calls must see the same (w, workspace, B, T, Mc, n_tok, max_mode); workspace = sd_workspace_floats(B, T, max(Mc, 1), d, L,
+ * n_tok) floats, owned by the caller and left alone between the calls.  Return SD_E_UNSUPPORTED (nothing launched) where the shape
+ * does not take the trajectory kernels (sd_sampler_mode < 3): the caller then uses sd_denoiser_forward. */
+#define SD_PREPARE_WEIGHTS 1
+#define SD_PREPARE_CONTEXT 2
+int sd_sampler_prepare(const sd_denoiser_weights *w, const float *ctx, float *workspace, int B, int T, int Mc, int n_tok,
+                       int what, int max_mode, void *stream);
+int sd_sampler_eps(const sd_denoiser_weights *w, const float *step_tokens, const float *x, float *eps, float *workspace,
+                   int B, int T, int Mc, int n_tok, int32_t *status, int max_mode, void *stream);
 
 /* ---- image path: ResNet basic-block convolution -------------------------------------------------------
  * y = act(BatchNorm_eval(conv3x3(x, w; stride 1, padding 1)) [+ res]) - torchvision BasicBlock's conv1/bn1/relu and

@@ -107,6 +107,8 @@ SIGNATURES = {
     "sd_ddim_sample": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_ddim_sample_ex": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "sd_ddim_sample_eps": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "sd_sampler_prepare": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sd_sampler_eps": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "sd_op_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_op_patch_embed": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),

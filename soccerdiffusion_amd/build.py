@@ -63,6 +63,33 @@ def _run(cmd: list, what: str, verbose: bool) -> None:
         sys.stderr.write(res.stderr)
 
 
+def packed_fp32_in_traj_kernels(obj: str = None) -> dict:
+    """{kernel symbol: number of v_pk_{fma,mul,add}_f32 instructions} for every trajectory step kernel (traj_step_kernel / traj_step_wide_kernel /
+    the generic family) in the sampler's object file.  EXTRA_FLAGS removes the packed fp32 operations from that translation unit's target
+    features; the flag goes through -Xclang and a toolchain update could drop it silently, so build() checks its effect on the code."""
+    import re
+    import tempfile
+
+    obj = obj or _obj(SRC[0])
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}",
+                        f"--output={co}", "--unbundle"], check=True, capture_output=True)
+        asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+    counts, cur = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+        if m:
+            cur = m.group(1) if "traj_step" in m.group(1) else None
+            if cur:
+                counts[cur] = 0
+        elif cur and re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+            counts[cur] += 1
+    return counts
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """One object per translation unit (recompiled only when it or a header it includes changed; the two compile in
     parallel), then one link.  The units share host functions only - no relocatable device code is needed."""
@@ -86,6 +113,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         os.replace(_obj(src) + ".tmp", _obj(src))
         if verbose:
             sys.stderr.write(err)
+        if os.path.basename(src) == "sd_kernels.hip":
+            counts = packed_fp32_in_traj_kernels(_obj(src))
+            bad = {k: v for k, v in counts.items() if v}
+            if not counts or bad:
+                os.remove(_obj(src))
+                raise RuntimeError(f"packed fp32 instructions in the trajectory step kernels (or none of them found): {bad or counts}; "
+                                   "EXTRA_FLAGS['sd_kernels.hip'] no longer takes effect")
     _run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *[_obj(s) for s in SRC], "-o", LIB + ".tmp"], "linking " + LIB, verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -2526,11 +2526,11 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
 
 // the fp16x3 kernels are instantiated for hidden_dim 256 (the folded fp32 kernels serve the other sizes);
 // SD_SAMPLER_GEMM=f32 keeps the fp32-MFMA kernels (A/B runs)
-static bool f16_ok(int d, int J) {
+static bool f16_env_ok() {
     static const char *env = getenv("SD_SAMPLER_GEMM");
-    if (env && strcmp(env, "f32") == 0) return false;
-    return d == 256 && J % 4 == 0;
+    return !(env && strcmp(env, "f32") == 0);
 }
+static bool f16_ok(int d, int J) { return f16_env_ok() && d == 256 && J % 4 == 0; }
 
 // folded cross-attention applies: fused layer kernel, <= 16 key slots per head, <= 2 trajectories per panel
 static bool fold_ok(int d, int heads, int T, int Mk) { return heads == 4 && d >= 128 && Mk <= 16 && T >= 64; }
@@ -2847,7 +2847,9 @@ static int decoder_stack_f16(const sd_denoiser_weights *w, float *x, const Scrat
 static bool traj_ok(int d, int heads, int T, int Mk, int J, int L) {
     static const char *env = getenv("SD_SAMPLER_TRAJ");
     if (env && strcmp(env, "0") == 0) return false;
-    return d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 64 && J % 4 == 0 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+    // any joint count up to 32 (the embedding's K and fc_out's N are zero-padded to 32 in the packed planes; the reference's database
+    // has 22 joints: soccer_diffusion/dataset/models.py:222-247)
+    return f16_env_ok() && d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 64 && J >= 1 && J <= 32 && L >= 1 && L <= tj::MAX_L;
 }
 // key tiles of 16 memory slots in the folded blocks: 1 for the trajectory kernels proper, 2 .. 4 for traj_step_wide_kernel (17 .. 64 rows)
 static int key_tiles(int Mk) { return Mk <= 16 ? 1 : (Mk + 15) / 16; }
@@ -2880,10 +2882,28 @@ static TrajStepFn traj_step_fn(int ntt) {
     }
 }
 
-static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, int Mc, int n_steps, hipStream_t st) {
-    const int d = w->d, L = w->L, nkt = key_tiles(Mc + 1);
-    const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, gvsstride = (size_t)n_steps * 4 * 2 * d;
-    // maxbits were zeroed before the fold kernels, which left the abs-max of G and V' in words 4 and 5 of every layer
+// zeroes words [col0, col0 + ncols) of every 8-word row of the abs-max table
+__global__ void zero_word_cols_kernel(unsigned *mb, int rows, int col0, int ncols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * ncols) mb[(i / ncols) * 8 + col0 + i % ncols] = 0u;
+}
+static int zero_word_cols(unsigned *mb, int rows, int col0, int ncols, hipStream_t st) {
+    SD_LAUNCH(zero_word_cols_kernel, dim3((unsigned)((rows * ncols + 63) / 64)), dim3(64), 0, st, mb, rows, col0, ncols);
+    SD_CHECK_LAUNCH("zero_word_cols_kernel");
+    return 0;
+}
+
+// The trajectory path prepares its operands in three independent stages (sd_ddim_sample_eps runs all three per call;
+// sd_sampler_prepare / sd_sampler_eps let a caller that evaluates the denoiser step by step - the reference's own loop,
+// soccer_diffusion/ml/inference/plot.py:122-131 - keep the first two across calls):
+//   weights: abs-max + split planes of every matrix (words 0 .. 3 of a layer's row of the abs-max table, 6 / 7 of row L)
+//   context: K / V of the context rows, the fold, its split blocks g16 / v16 (words 4 / 5, scales sc[4] / sc[5])
+//   steps:   K / V of the n_tok step tokens, their fold, the split step blocks (words 6 / 7, scales sc[6] / sc[7])
+static int traj_prepare_weights(const sd_denoiser_weights *w, const Scratch &s, hipStream_t st) {
+    const int d = w->d, L = w->L;
+    int rc = zero_word_cols(s.maxbits, L, 0, 4, st);
+    if (!rc) rc = zero_word_cols(s.maxbits + L * 8, 1, 6, 2, st);
+    if (rc) return rc;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
@@ -2907,33 +2927,88 @@ static int traj_prepare(const sd_denoiser_weights *w, const Scratch &s, int B, i
         const sd_layer_weights &lw = w->layers[l];
         const float *mats[4] = {lw.sa_out_w, lw.lin1_w, lw.lin2_w, lw.sa_in_w};
         const int rows[4] = {d, d, d, 3 * d};
-        unsigned *mb = s.maxbits + l * 8;
-        float *sc = s.scales + l * 8;
         for (int m = 0; m < 4; ++m) {
-            SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)rows[m] * d / 8)), dim3(256), 0, st, mats[m], rows[m], d, rows[m], d, mb + m, 0.f,
-                      f16_wf(s, l, d, m), sc + m);
+            SD_LAUNCH(tj::pack_w16_kernel, dim3(grid_for((long)rows[m] * d / 8)), dim3(256), 0, st, mats[m], rows[m], d, rows[m], d, s.maxbits + l * 8 + m, 0.f,
+                      f16_wf(s, l, d, m), s.scales + l * 8 + m);
             SD_CHECK_LAUNCH("pack_w16_kernel");
         }
-        const size_t blk = (size_t)32 * d;   // halfs per (trajectory, head)
+    }
+    return 0;
+}
+
+static int traj_prepare_ctx(const sd_denoiser_weights *w, const Scratch &s, const float *ctx, int B, int Mc, hipStream_t st) {
+    const int d = w->d, L = w->L, hd = d / 4, nkt = key_tiles(Mc + 1);
+    const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, cbstride = (size_t)B * nkt * 64;
+    const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
+    int rc = zero_async(s.gv, L * gvstride * sizeof(float), st);   // unused key slots must be finite
+    if (!rc) rc = zero_async(s.cb, L * cbstride * sizeof(float), st);
+    if (!rc) rc = zero_word_cols(s.maxbits, L, 4, 2, st);
+    if (rc) return rc;
+    const size_t blk = (size_t)32 * d;   // halfs per (trajectory, head)
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        unsigned *mb = s.maxbits + l * 8;
+        if (Mc > 0) {
+            const long rows = (long)B * Mc;
+            float *kvl = s.kvtmp + (size_t)l * B * Mc * 2 * d;
+            rc = linear(ctx, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, kvl, B * Mc, 2 * d, d, 0, st, 0);
+            if (rc) return rc;
+            SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((rows + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st, kvl, rows, Mc, lw.ca_in_w, lw.ca_in_b,
+                      lw.ca_out_w, s.gv + l * gvstride, s.cb + l * cbstride, 64L * nkt, 16, 0, d, hd, mb + 4, mb + 5);
+            SD_CHECK_LAUNCH("xattn_fold_kernel");
+        }
         SD_LAUNCH(tj::pack_g16_kernel, dim3(grid_for((long)B * nkt * 4 * 16 * d / 8)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * nkt, Mc, mb + 4,
-                  s.g16 + (size_t)l * B * nkt * 4 * blk, sc + 4, nkt);
+                  s.g16 + (size_t)l * B * nkt * 4 * blk, s.scales + l * 8 + 4, nkt);
         SD_CHECK_LAUNCH("pack_g16_kernel");
         SD_LAUNCH(tj::pack_v16_kernel, dim3(grid_for((long)B * nkt * 16 * 2 * 64)), dim3(256), 0, st, s.gv + l * gvstride, (long)B * nkt, Mc, mb + 5,
-                  s.v16 + (size_t)l * B * nkt * 4 * blk, sc + 5, nkt);
+                  s.v16 + (size_t)l * B * nkt * 4 * blk, s.scales + l * 8 + 5, nkt);
         SD_CHECK_LAUNCH("pack_v16_kernel");
-        SD_LAUNCH(tj::pack_gstep16_kernel, dim3(grid_for((long)n_steps * 4 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_steps,
-                  mb + 4, s.gstep16 + (size_t)l * n_steps * 4 * blk, (float *)nullptr);
+    }
+    return 0;
+}
+
+// n_tok step tokens (rows of `tokens`): one per DDIM step of a rollout, or one per trajectory of a single evaluation
+static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, const float *tokens, int n_tok, int Mc, hipStream_t st) {
+    const int d = w->d, L = w->L, hd = d / 4;
+    const size_t kvsstride = (size_t)n_tok * 2 * d, gvsstride = (size_t)n_tok * 4 * 2 * d, cssstride = (size_t)n_tok * 4;
+    const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
+    const size_t blk = (size_t)32 * d;
+    int rc = zero_word_cols(s.maxbits, L, 6, 2, st);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) {
+        const sd_layer_weights &lw = w->layers[l];
+        unsigned *mb = s.maxbits + l * 8;
+        float *sc = s.scales + l * 8;
+        rc = linear(tokens, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_tok, 2 * d, d, 0,
+                    st, 0);
+        if (rc) return rc;
+        SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((n_tok + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st, s.kvstep + (size_t)l * kvsstride,
+                  (long)n_tok, 1, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w, s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd, mb + 6, mb + 7);
+        SD_CHECK_LAUNCH("xattn_fold_kernel");
+        // per-layer regions as carved for mode 2 (n_tok * 4 * blk / n_tok * blk halfs), the step blocks packed densely inside
+        SD_LAUNCH(tj::pack_gstep16_kernel, dim3(grid_for((long)n_tok * 4 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_tok, mb + 6,
+                  s.gstep16 + (size_t)l * n_tok * 4 * blk, sc + 6);
         SD_CHECK_LAUNCH("pack_gstep16_kernel");
-        SD_LAUNCH(tj::pack_vstep16_kernel, dim3(grid_for((long)n_steps * 4 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_steps, mb + 5,
-                  s.vstep16 + (size_t)l * n_steps * blk);
+        SD_LAUNCH(tj::pack_vstep16_kernel, dim3(grid_for((long)n_tok * 4 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_tok, mb + 7,
+                  s.vstep16 + (size_t)l * n_tok * blk, sc + 7);
         SD_CHECK_LAUNCH("pack_vstep16_kernel");
+        if (Mc == 0) {
+            // no context rows: the (all-zero) context blocks carry no scale of their own - they take the step blocks' (a scale of 1
+            // from an abs-max of 0 would drag the common value scale of tj::step_scale down to 1)
+            SD_LAUNCH(tj::pack_g16_kernel, dim3(1), dim3(64), 0, st, s.gv, 0L, 0, mb + 6, s.g16, sc + 4, 1);
+            SD_CHECK_LAUNCH("pack_g16_kernel");
+            SD_LAUNCH(tj::pack_v16_kernel, dim3(1), dim3(64), 0, st, s.gv, 0L, 0, mb + 7, s.v16, sc + 5, 1);
+            SD_CHECK_LAUNCH("pack_v16_kernel");
+        }
     }
     return 0;
 }
 
 // one denoiser step + DDIM update in ONE launch (step index i selects the step-token blocks)
+// coef NULL: no DDIM update (x is only read); per_traj: trajectory b reads step block b of the n_steps prepared ones (i = 0)
 static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scratch &s, int B, int T, int Mc, int i, int n_steps,
-                             const float *coef, hipStream_t st, bool precise, float *eps = nullptr, int32_t *status = nullptr) {
+                             const float *coef, hipStream_t st, bool precise, float *eps = nullptr, int32_t *status = nullptr,
+                             bool per_traj = false) {
     const int d = w->d, L = w->L, nkt = key_tiles(Mc + 1);
     const size_t blk = (size_t)32 * d, cbstride = (size_t)B * nkt * 64;
     tj::StepArgs a{};
@@ -2949,9 +3024,10 @@ static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scrat
     a.w_out = s.wio + (size_t)2 * 32 * d;
     a.b_out = w->out_b;
     a.sc_io = s.scales + L * 8 + 6;
-    a.c0 = coef[0]; a.c1 = coef[1]; a.c2 = coef[2]; a.c3 = coef[3];
+    if (coef) { a.c0 = coef[0]; a.c1 = coef[1]; a.c2 = coef[2]; a.c3 = coef[3]; }
     a.scale_log2e = (1.0f / sqrtf((float)(d / w->heads))) * 1.44269504088896340736f;
-    a.T = T; a.B = B; a.J = w->J; a.L = L; a.Mk = Mc + 1; a.update_x = 1;
+    a.T = T; a.B = B; a.J = w->J; a.L = L; a.Mk = Mc + 1; a.update_x = coef ? 1 : 0;
+    a.step_per_traj = per_traj ? 1 : 0;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         tj::LayerW &q = a.layer[l];
@@ -3060,7 +3136,7 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
 
 extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
     const int Mk = Mc + 1;
-    if (f16_ok(d, J) && traj_ok(d, heads, T, Mk, J, 1)) return 3;   // (the layer count is checked at the call: <= 8; mode 4 is opt-in)
+    if (traj_ok(d, heads, T, Mk, J, 1)) return 3;   // (the layer count is checked at the call: <= 8; mode 4 is opt-in)
     if (!(fold_ok(d, heads, T, Mk) && fused_layer_ok(d, heads, T, Mk))) return 0;
     if (!f16_ok(d, J)) return 1;
     return 2;
@@ -3100,7 +3176,7 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
     const size_t kvstride = (size_t)B * Mk * 2 * d, kvsstride = (size_t)n_steps * 2 * d;
     const bool small = (long)B * Mk * 2 * d < (1L << 30);
     // the trajectory kernel (modes 3 / 4) takes any horizon <= 100: it needs the folded blocks, not the row-panel kernels' T >= 64
-    const bool traj = max_mode >= 3 && small && f16_ok(d, w->J) && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wf != nullptr && s.wio != nullptr;
+    const bool traj = max_mode >= 3 && small && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wf != nullptr && s.wio != nullptr;
     const bool fold = traj || (max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && small);
     const int nkt = traj ? key_tiles(Mk) : 1;   // (the row-panel fold: Mk <= 16)
     const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, cbstride = (size_t)B * nkt * 64;
@@ -3110,7 +3186,12 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
     if (status) {
         if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
     }
-    for (int l = 0; l < L; ++l) {
+    if (traj) {
+        if ((rc = traj_prepare_weights(w, s, st))) return rc;
+        if ((rc = traj_prepare_ctx(w, s, ctx, B, Mc, st))) return rc;
+        if ((rc = traj_prepare_steps(w, s, step_tokens, n_steps, Mc, st))) return rc;
+    }
+    for (int l = 0; l < L && !traj; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         const float *wkv = lw.ca_in_w + (size_t)d * d, *bkv = lw.ca_in_b + d;
         auto lin = max_mode >= 2 ? linear : linear32;
@@ -3122,7 +3203,8 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
         if (rc) return rc;
     }
     if (chain16 && (rc = f16_prepare_chain(w, s, st))) return rc;
-    if (fold) {
+    if (traj) {
+    } else if (fold) {
         // the memory is fixed over the rollout: fold Wq into its keys and Woc into its values once
         const int hd = d / 4;
         const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
@@ -3146,9 +3228,7 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
                       f16 ? s.maxbits + l * 8 + 5 : (unsigned *)nullptr);
             SD_CHECK_LAUNCH("xattn_fold_kernel");
         }
-        if (traj) {
-            if ((rc = traj_prepare(w, s, B, Mc, n_steps, st))) return rc;
-        } else if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
+        if (f16 && (rc = f16_prepare(w, s, B, Mc, n_steps, st))) return rc;
     } else if (Mc > 0) {
         SD_LAUNCH(kv_place_kernel, dim3(grid_for((long)B * Mc * 2 * d), L), dim3(256), 0, st, s.kvtmp, (long)B * Mc * 2 * d, s.kv,
                   (long)kvstride, B, Mc, Mk, 2 * d, 0);
@@ -3192,6 +3272,54 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
         SD_CHECK_LAUNCH("finite_check_kernel");
     }
     return 0;
+}
+
+// ---- the denoiser evaluated step by step on the trajectory kernels (the reference's own loop form) --------------------------
+static int sampler_eval_args(const sd_denoiser_weights *w, float *workspace, int B, int T, int Mc, int n_tok, int max_mode, const char *who,
+                             Scratch *out, bool *precise) {
+    int rc = check_denoiser(w);
+    if (rc) return rc;
+    if (!workspace || B <= 0 || T <= 0 || Mc < 0 || (n_tok != 1 && n_tok != B)) return fail(SD_E_BADARG, who);
+    if (max_mode < -1 || max_mode > 4) return fail(SD_E_BADARG, who);
+    if (T > w->T_max) return fail(SD_E_TOOBIG, who);
+    if (max_mode < 0) max_mode = 3;
+    const int d = w->d, Mk = Mc + 1;
+    *out = carve(workspace, (long)B * T, (long)B * Mk, d, w->L, n_tok, B);
+    const bool small = (long)B * Mk * 2 * d < (1L << 30);
+    if (!(max_mode >= 3 && small && traj_ok(d, w->heads, T, Mk, w->J, w->L) && out->wf && out->wio)) return SD_E_UNSUPPORTED;
+    *precise = max_mode == 3;
+    return 0;
+}
+
+extern "C" int sd_sampler_prepare(const sd_denoiser_weights *w, const float *ctx, float *workspace, int B, int T, int Mc, int n_tok,
+                                  int what, int max_mode, void *stream) {
+    Scratch s;
+    bool precise;
+    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_prepare: bad argument", &s, &precise);
+    if (rc) return rc;
+    if ((what & ~(SD_PREPARE_WEIGHTS | SD_PREPARE_CONTEXT)) || (Mc > 0 && (what & SD_PREPARE_CONTEXT) && !ctx))
+        return fail(SD_E_BADARG, "sd_sampler_prepare: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if ((what & SD_PREPARE_WEIGHTS) && (rc = traj_prepare_weights(w, s, st))) return rc;
+    if ((what & SD_PREPARE_CONTEXT) && (rc = traj_prepare_ctx(w, s, ctx, B, Mc, st))) return rc;
+    return 0;
+}
+
+extern "C" int sd_sampler_eps(const sd_denoiser_weights *w, const float *step_tokens, const float *x, float *eps, float *workspace,
+                              int B, int T, int Mc, int n_tok, int32_t *status, int max_mode, void *stream) {
+    Scratch s;
+    bool precise;
+    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_eps: bad argument", &s, &precise);
+    if (rc) return rc;
+    if (!step_tokens || !x || !eps) return fail(SD_E_BADARG, "sd_sampler_eps: null pointer");
+    if (!precise && !status) return fail(SD_E_BADARG, "sd_sampler_eps: max_mode 4 needs a status word (SD_STATUS_SHARP_LOGITS)");
+    hipStream_t st = (hipStream_t)stream;
+    if (status) {
+        if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
+    }
+    if ((rc = traj_prepare_steps(w, s, step_tokens, n_tok, Mc, st))) return rc;
+    // x is only read (no DDIM coefficients: no update)
+    return decoder_step_traj(w, const_cast<float *>(x), s, B, T, Mc, 0, n_tok, nullptr, st, precise, eps, precise ? nullptr : status, n_tok > 1);
 }
 
 // ======================================================================================

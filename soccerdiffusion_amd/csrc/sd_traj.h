@@ -252,8 +252,10 @@ static __global__ void pack_v16_kernel(const float *__restrict__ gv, long items,
     }
 }
 // Folded values of the step tokens -> [item][plane][head][n]
-static __global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst) {
+static __global__ void pack_vstep16_kernel(const float *__restrict__ gvstep, long items, const unsigned *maxbits, f16 *__restrict__ dst,
+                                           float *scale_out = nullptr) {
     const float scale = f16_scale_from_bits(*maxbits);
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
     const long total = items * 4 * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i % D), head = (int)((i / D) & 3);
@@ -381,13 +383,28 @@ struct LayerW {
     const float *n2_w, *n2_b, *n3_w, *n3_b;
     const f16 *w_in, *w_o, *w_1, *w_2;            // fragment-major planes
     const float *b_in, *b_o, *b_1, *b_2, *b_oc;
-    const float *sc;                              // [0] Wo, [1] W1, [2] W2, [3] in_proj, [4] G, [5] V'
+    const float *sc;                              // [0] Wo, [1] W1, [2] W2, [3] in_proj, [4] G, [5] V', [6] G of the step token, [7] its V'
     const f16 *g16, *v16;                         // folded context blocks of this layer, all trajectories
     const float *cb;                              // [B][64] score biases
-    const f16 *gstep, *vstep;                     // this layer and step
+    const f16 *gstep, *vstep;                     // this layer and step (trajectory 0's block when the step tokens are per trajectory)
     const float *cstep;                           // 4 score biases of the step token
     const float *nln_w, *nln_b;                   // LayerNorm that follows (next layer's norm1), or NULL
 };
+
+// halfs of one step token's folded blocks (per layer): G [head 4][ks 8][plane 2][g 4][8], V' [plane 2][head 4][D]
+constexpr long STEP_G_HALFS = 4 * 8 * 2 * 32, STEP_V_HALFS = 2 * 4 * D;
+
+// The step token's folded blocks carry scales of their own (sc[6], sc[7]): the context blocks are packed once per context, before the
+// step tokens of later calls are known (sd_sampler_prepare / sd_sampler_eps).  Scores: the accumulator row of the step token's slot is
+// multiplied by c_gs instead of 1 / (ACT sc[4]).  Values: H accumulates at the scale PSC s_v with s_v = min(sc[5], sc[7]); the
+// probabilities of the context slots are multiplied by m_c = s_v / sc[5], the step token's by m_s = s_v / sc[7] - powers of two <= 1, one of
+// them 1: the kind with the larger values is exact, the other loses only what is below the larger kind's resolution.
+struct StepScale { float c_gs, s_v, m_c, m_s; };
+__device__ __forceinline__ StepScale step_scale(const LayerW &L) {
+    const float s5 = L.sc[5], s7 = L.sc[7];
+    const float sv = fminf(s5, s7);
+    return StepScale{1.0f / (ACT * L.sc[6]), sv, sv / s5, sv / s7};
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Stage-A experiment kernel (tools/exp/traj_layer.hip): h' = h + SelfAttention(LN1(h)), h in fragment order
@@ -422,6 +439,8 @@ struct StepArgs {
     float scale_log2e;
     int T, B, J, L, Mk, update_x;
     int nkt;                       // key tiles of 16 memory slots (1; 2 .. 4 only for the WIDE instantiations: 17 .. 64 memory rows)
+    int step_per_traj;             // 0: one step token for the whole batch (the sampler's loop); 1: trajectory b reads block b of gstep / vstep /
+                                   // cstep (forward_with_context with a step per sample: sd_sampler_eps)
     int *status;                   // range-guard word (SD_STATUS_SHARP_LOGITS) or NULL
     LayerW layer[MAX_L];
 };
@@ -1059,8 +1078,9 @@ static __device__ __forceinline__ void scale_h(f32x4 (&H)[2][NTT], float f) {
 // step token is slot (Mk - 1) & 15 of the LAST tile.  Scores of all tiles stay in registers (4 x 4 accumulators), the softmax runs
 // over them, then one round per tile: write P (the same 96-column panel), barrier, h += V'^T P^T.  Written for the robot's shapes
 // (reference sim_scratch.yaml: 51 memory rows, B = 1): nothing is prefetched across phases, two barriers per extra tile.
-static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, int nkt, float scale_log2e) {
+static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, int nkt, float scale_log2e, long sblk) {
     const Ctx c = ctx_local(c0);
+    const f16 *gstep = L.gstep + sblk * STEP_G_HALFS, *vstep = L.vstep + sblk * STEP_V_HALFS;
     constexpr int KT = 4;
     const int hh = c.w >> 1, Mc = Mk - 1, klast = nkt - 1, mcs = Mc & 15;
     const bool odd = c.w & 1;
@@ -1078,7 +1098,7 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
         // folded keys of (head, key tile): lanes of the step token's slot read the shared step block instead
         f16x8 gfr[8][2];
         const bool stepl = kt == klast && c.t == mcs;
-        const f16 *gp = stepl ? L.gstep + (long)hh * (8 * 2 * 32) + c.g * 8 : L.g16 + ((traj * nkt + kt) * 4 + hh) * (8 * 2 * 512) + c.lane * 8;
+        const f16 *gp = stepl ? gstep + (long)hh * (8 * 2 * 32) + c.g * 8 : L.g16 + ((traj * nkt + kt) * 4 + hh) * (8 * 2 * 512) + c.lane * 8;
         const int gstride = stepl ? 32 : 512;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -1101,8 +1121,9 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
     }
     // ---- softmax over all key slots of all tiles (accumulator rows 4 g + r of tile kt = memory row 16 kt + 4 g + r)
     const float c_g = 1.0f / (ACT * L.sc[4]);
-    const float cs = L.cstep[hh];
-    f32x4 cbv[KT];
+    const float cs = L.cstep[sblk * 4 + hh];
+    const StepScale ss = step_scale(L);
+    f32x4 cbv[KT], cgl = f32x4{c_g, c_g, c_g, c_g};   // cgl: the last tile's multipliers (the step token's slot carries its own scale)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         cbv[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1110,7 +1131,10 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
         if (kt == klast) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * c.g + r == mcs) cbv[kt][r] = cs;
+                if (4 * c.g + r == mcs) {
+                    cbv[kt][r] = cs;
+                    cgl[r] = ss.c_gs;
+                }
         }
     }
 #pragma unroll
@@ -1119,7 +1143,7 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            f32x4 v = S[kt][i] * c_g + cbv[kt];
+            f32x4 v = S[kt][i] * (kt == klast ? cgl : f32x4{c_g, c_g, c_g, c_g}) + cbv[kt];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (16 * kt + 4 * c.g + r >= Mk) v[r] = -INFINITY;
@@ -1141,7 +1165,7 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
         for (int kt = 0; kt < KT; ++kt) S[kt][i] = S[kt][i] * f;
     }
     // ---- h += sum over tiles of V'_kt^T P_kt^T + boc
-    const float up = PSC * L.sc[5];
+    const float up = PSC * ss.s_v;
     const Bias2 boc = bias_load(c, L.b_oc);
     scale_h(H, up);
 #pragma unroll
@@ -1155,9 +1179,9 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
             const int tt = tt1 + i, tok = tt < NTT - 1 ? 16 * tt + c.t : c.tok6;
             if (tt == NTT - 1 && !c.ok6) continue;
             const int chunk = (2 * (hh & 1) + (c.g >> 1)) | ((hh >> 1) << 3);
-            split_store(Pb + p_off(tok, chunk) + 8 * (c.g & 1), Pb + p_off(tok, chunk | 4) + 8 * (c.g & 1), p);
-            if (kt == klast && c.g == (mcs >> 2)) {   // the step token's probability again at k = 64 + 8 hh (its V' comes from the shared step block)
-                const float pv = p[mcs & 3];
+            split_store(Pb + p_off(tok, chunk) + 8 * (c.g & 1), Pb + p_off(tok, chunk | 4) + 8 * (c.g & 1), p * ss.m_c);
+            if (kt == klast && c.g == (mcs >> 2)) {   // the step token's probability again at k = 64 + 8 hh (its V' comes from the step block)
+                const float pv = p[mcs & 3] * ss.m_s;
                 const f16 ph = (f16)pv, pl = (f16)(pv - (float)ph);
                 const f16x8 z8h = {ph, 0, 0, 0, 0, 0, 0, 0}, z8l = {pl, 0, 0, 0, 0, 0, 0, 0};
                 *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | (2 << 3))) = z8h;
@@ -1175,7 +1199,7 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
                 for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                const f16 sv = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];
+                const f16 sv = vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];
                 av[n][2][pl] = f16x8{sv, 0, 0, 0, 0, 0, 0, 0};
             }
         }
@@ -1210,7 +1234,8 @@ static __device__ __forceinline__ void cross_wide(const Ctx &c0, const LayerW &L
 
 template <bool WIDE = false>
 static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[2][NTT], long traj, int Mk, float scale_log2e, int *status,
-                                                     int nkt = 1) {
+                                                     int nkt = 1, long sblk = 0) {
+    const f16 *gstep = L.gstep + sblk * STEP_G_HALFS, *vstep = L.vstep + sblk * STEP_V_HALFS;
     // ---- self-attention block: h += Wo . SA(LN1(h)) + bo
     {
         const Ctx &c = c0;
@@ -1231,7 +1256,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
     f16x8 gfr[8][2];
     if constexpr (!WIDE) {
         const int hh = c0.w >> 1, Mc = Mk - 1;
-        const f16 *gp = c0.t == Mc ? L.gstep + (long)hh * (8 * 2 * 32) + c0.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c0.lane * 8;
+        const f16 *gp = c0.t == Mc ? gstep + (long)hh * (8 * 2 * 32) + c0.g * 8 : L.g16 + (traj * 4 + hh) * (8 * 2 * 512) + c0.lane * 8;
         const int gstride = c0.t == Mc ? 32 : 512;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1244,7 +1269,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
     TJ_STAMP(32);
     // ---- folded cross-attention: wave w scores head w >> 1 for token tiles tt1 .. (half w & 1)
     if constexpr (WIDE) {
-        cross_wide(c0, L, H, traj, Mk, nkt, scale_log2e);
+        cross_wide(c0, L, H, traj, Mk, nkt, scale_log2e, sblk);
     } else {
         const Ctx c = ctx_local(c0);
         const int hh = c.w >> 1, Mc = Mk - 1;
@@ -1259,7 +1284,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
         // the score GEMM: an HBM round trip under load is longer than the softmax, and a load consumed before an older one has returned
         // waits for that one too (loads return in order).
         f32x4 cbv = *reinterpret_cast<const f32x4 *>(L.cb + traj * 64 + hh * 16 + 4 * c.g);
-        const float cs = L.cstep[hh];
+        const float cs = L.cstep[sblk * 4 + hh];
         __builtin_amdgcn_sched_barrier(0);
         f16x8 av[2][3][2];
         f16 svv[2][2];
@@ -1271,7 +1296,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) av[n][kk][pl] = *reinterpret_cast<const f16x8 *>(vp + (kk * 2 + pl) * 512);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) svv[n][pl] = L.vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
+            for (int pl = 0; pl < 2; ++pl) svv[n][pl] = vstep[(pl * 4 + c.g) * D + 16 * (2 * c.w + n) + c.t];   // k = 64 + 8 g: head g
         }
         __builtin_amdgcn_sched_barrier(0);
         // (8 k-steps x 4 or 3 token tiles) steps of three MFMAs, the panel fragments two steps ahead; once per parity: the tile
@@ -1295,15 +1320,22 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) av[n][2][pl] = f16x8{svv[n][pl], 0, 0, 0, 0, 0, 0, 0};
         // softmax over the Mk key slots (accumulator rows 4 g + r) of each token (lane column)
+        // the step token's slot carries the scales of the step blocks (sc[6], sc[7]): a score multiplier of its own, and both kinds of
+        // probability are brought to the common value scale s_v = min(sc[5], sc[7]) (step_scale)
         const float c_g = 1.0f / (ACT * L.sc[4]);
+        const StepScale ss = step_scale(L);
+        f32x4 cg4 = {c_g, c_g, c_g, c_g};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * c.g + r == Mc) cbv[r] = cs;
+            if (4 * c.g + r == Mc) {
+                cbv[r] = cs;
+                cg4[r] = ss.c_gs;
+            }
         TJ_SYNC(4);   // the previous readers of Q / K (out-projection, PV) are done: P may be written
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             if (i >= n1) continue;
-            f32x4 v = S[i] * c_g + cbv;
+            f32x4 v = S[i] * cg4 + cbv;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (4 * c.g + r >= Mk) v[r] = -INFINITY;
@@ -1311,7 +1343,9 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
             const f32x4 e = (v - m) * scale_log2e;
             f32x4 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
             const float sum = rows4_sum((p[0] + p[1]) + (p[2] + p[3]));
-            p = p * (PSC / sum);
+            const float f = PSC / sum;
+            const float pstep = p[Mc & 3] * (f * ss.m_s);
+            p = p * (f * ss.m_c);
             const int tt = tt1 + i, tok = tt < NTT - 1 ? 16 * tt + c.t : c.tok6;
             if (tt == NTT - 1 && !c.ok6) continue;
             // k = 16 hh + 4 g + r: k-step hh >> 1, 8-group 2 (hh & 1) + g / 2
@@ -1319,7 +1353,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
             split_store(Pb + p_off(tok, chunk) + 8 * (c.g & 1), Pb + p_off(tok, chunk | 4) + 8 * (c.g & 1), p);
             // the step token's probability again at k = 64 + 8 hh (its V' comes from the shared step block): a whole chunk
             if (c.g == (Mc >> 2)) {
-                const float pv = p[Mc & 3];
+                const float pv = pstep;
                 const f16 ph = (f16)pv, pl = (f16)(pv - (float)ph);
                 const f16x8 z8h = {ph, 0, 0, 0, 0, 0, 0, 0}, z8l = {pl, 0, 0, 0, 0, 0, 0, 0};
                 *reinterpret_cast<f16x8 *>(Pb + p_off(tok, hh | (2 << 3))) = z8h;
@@ -1329,7 +1363,7 @@ static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW
         TJ_SYNC(5);   // P complete
         TJ_STAMP(33);
         // h += V'^T P^T + boc: K = 64 (context slots of 4 heads) + 32 (step columns)
-        const float up = PSC * L.sc[5];
+        const float up = PSC * ss.s_v;
         const Bias2 boc = bias_load(c, L.b_oc);
         scale_h(H, up);
         f16x8 pb[3][2];
@@ -1450,7 +1484,24 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         const float *xr = a.x + traj * (long)a.T * J;
-        const int nvec = a.T * J / 4;            // J % 4 == 0
+        if (J & 3) {
+            // any joint count <= 32 (the reference's database has 22: soccer_diffusion/dataset/models.py:222-247): one thread per (token,
+            // 8-joint chunk), scalar loads (rows are not 16-byte aligned), joints >= J zero
+            for (int i = threadIdx.x; i < a.T * 4; i += NTHREADS) {
+                const int tok = i >> 2, chunk = i & 3;
+                f16x8 h8, l8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = 8 * chunk + e;
+                    const float v = j < J ? xr[tok * J + j] * XSC : 0.f;
+                    h8[e] = (f16)v;
+                    l8[e] = (f16)(v - (float)h8[e]);
+                }
+                *reinterpret_cast<f16x8 *>(Qb + q_off(tok, chunk)) = h8;
+                *reinterpret_cast<f16x8 *>(Qb + q_off(tok, chunk | 4)) = l8;
+            }
+        }
+        const int nvec = (J & 3) ? 0 : a.T * J / 4;
         for (int i = threadIdx.x; i < nvec; i += NTHREADS) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * i) * XSC;
             const int tok = (4 * i) / J, j0 = 4 * i - tok * J;     // 4 consecutive joints of one token
@@ -1481,7 +1532,7 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
     layer_norm_to_x<!PRECISE>(c, H, a.n1_w, a.n1_b);
     TJ_STAMP(2);
 #pragma unroll 1
-    for (int l = 0; l < a.L; ++l) decoder_layer<WIDE>(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status, a.nkt);
+    for (int l = 0; l < a.L; ++l) decoder_layer<WIDE>(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status, a.nkt, a.step_per_traj ? traj : 0L);
     // ---- fc_out + DDIM: eps^T = Wout . h^T + b.  h has no a-priori bound: one power-of-two scale per token
     {
         float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);
@@ -1542,8 +1593,21 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
             for (int n = 0; n < 2; ++n) {
                 const int j0 = 16 * n + 4 * c.g;
                 if (!ok || j0 >= J) continue;
-                const f32x4 e = E[n] * c_o + *reinterpret_cast<const f32x4 *>(a.b_out + j0);
                 const long at = (traj * a.T + tok) * J + j0;
+                if (J & 3) {   // rows of J floats are not 16-byte aligned, the last group of four is ragged: element by element
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (j0 + r >= J) continue;
+                        const float e = E[n][r] * c_o + a.b_out[j0 + r];
+                        if (a.eps_out) a.eps_out[at + r] = e;
+                        if (a.update_x) {
+                            const float x0 = (a.x[at + r] - a.c1 * e) / a.c0;
+                            a.x[at + r] = a.c2 * x0 + a.c3 * e;
+                        }
+                    }
+                    continue;
+                }
+                const f32x4 e = E[n] * c_o + *reinterpret_cast<const f32x4 *>(a.b_out + j0);
                 if (a.eps_out) *reinterpret_cast<f32x4 *>(a.eps_out + at) = e;
                 if (a.update_x) {
                     const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.x + at);

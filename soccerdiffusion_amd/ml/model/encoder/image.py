@@ -2,18 +2,19 @@
 
 Per frame a ResNet-18/50 turns an image into one token; a BaseEncoder with 8 heads
 (image.py:116) lets the frames' tokens talk to each other.  The sequence transformer runs
-on this package's HIP kernels.  The ResNet backbone is SURVEY §8 f2 "next" scope: it is the
-torchvision architecture (absent offline, so restated here layer for layer with torchvision's
-``state_dict`` keys).  In INFERENCE (eval mode, no autograd tape, CUDA) the 3 x 3 stride-1
-convolutions of ResNet-18's basic blocks - 13 of its 20 convolutions, ~80 % of its FLOPs -
-run on the hand-written implicit-GEMM kernel ``sd_conv3x3_bn_act`` (csrc/sd_conv.hip) with
-the folded BatchNorm, the residual and the ReLU in its epilogue, on NHWC tensors; everything
-else of the backbone (the 7 x 7 stem, the three stride-2 convolutions and 1 x 1 shortcuts, and
-the whole training path) is ``torch.nn``, i.e. MIOpen convolutions through PyTorch-ROCm
-(``SD_CONV=torch`` in the environment keeps the inference path on them too).  Pretrained ImageNet weights cannot be fetched offline
-(``weights=...DEFAULT`` in the reference): load them from a reference checkpoint.
-The Swin-T/S encoders are restated the same way (shifted-window attention with torch ops).
-Parity of the backbones is unpinned (no torchvision here, no reference fixture).
+on this package's HIP kernels.  The ResNet backbone is the torchvision
+architecture - absent offline, so restated here layer for layer with torchvision's
+``state_dict`` keys; architecture parity is unpinned (no torchvision, no reference fixture).
+INFERENCE (eval mode, no autograd tape, fp32 CUDA tensors): the whole forward runs on the
+hand-written kernels of csrc/sd_conv.hip on NHWC tensors - the stem (conv 7 x 7 / BatchNorm /
+ReLU / max-pool in one launch, ``sd_stem_conv_bn_relu_pool``), every 3 x 3 stride-1 block
+convolution (``sd_conv3x3_bn_act``), the stride-2 stage entries and 1 x 1 shortcuts
+(``sd_conv_s2_bn_act`` / ``sd_conv1x1_bn_act``), BatchNorm folded, residual and ReLU in the
+epilogues (``SD_CONV=torch`` in the environment keeps ``torch.nn``).
+TRAINING (a tape, or ``train()`` mode): see ``_ResNet.forward``.
+Pretrained ImageNet weights cannot be fetched offline (``weights=...DEFAULT`` in the
+reference): load them from a reference checkpoint.  The Swin-T/S encoders are restated with
+torch ops (shifted-window attention); every shipped YAML uses resnet18.
 """
 
 from __future__ import annotations
@@ -21,6 +22,7 @@ from __future__ import annotations
 from enum import Enum
 
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -39,6 +41,18 @@ class ImageEncoderType(Enum):
 class SequenceEncoderType(Enum):
     TRANSFORMER = "transformer"
     NONE = "none"
+
+
+# Derived tensors of a module (packed weight planes, folded BatchNorm vectors) live OUTSIDE the module - keyed weakly by it - so that
+# ``copy.deepcopy`` / pickling of a model neither carries nor shares them.
+_DERIVED: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _derived(mod: nn.Module) -> dict:
+    d = _DERIVED.get(mod)
+    if d is None:
+        d = _DERIVED[mod] = {}
+    return d
 
 
 def _conv(cin, cout, k, stride=1, pad=0):
@@ -66,20 +80,23 @@ class _BasicBlock(nn.Module):
     def _bn_fold(bn: nn.BatchNorm2d):
         """Inference BatchNorm as y = x * s + t per channel; cached on the module until one of its four tensors changes (four tiny
         launches per convolution otherwise - a third of the robot's 10-frame forward)."""
-        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device, bn.weight.data_ptr())
-        hit = bn.__dict__.get("_sd_fold")
+        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device, bn.weight.data_ptr(),
+               ops.weights_generation())
+        store = _derived(bn)
+        hit = store.get("fold")
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
         s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         t = (bn.bias.detach() - bn.running_mean * s).contiguous()
         s = s.contiguous()
-        bn.__dict__["_sd_fold"] = (key, s, t)
+        store["fold"] = (key, s, t)
         return s, t
 
     def _packed(self, name: str, conv: nn.Conv2d) -> "ops.PackedConv3x3":
-        pk = self.__dict__.get(name)
+        store = _derived(conv)
+        pk = store.get("planes")
         if pk is None or pk.planes.device != conv.weight.device:
-            pk = self.__dict__[name] = ops.PackedConv3x3(conv.weight)
+            pk = store["planes"] = ops.PackedConv3x3(conv.weight)
         return pk.refresh(conv.weight)
 
     def forward_nhwc(self, h: torch.Tensor, amax: torch.Tensor, words: torch.Tensor):
@@ -160,21 +177,22 @@ class _ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def _hip_inference(self, x: torch.Tensor) -> bool:
-        return x.is_cuda and not self.training and not torch.is_grad_enabled() and os.environ.get("SD_CONV", "hip") != "torch"
+        # fp32 only (a half / bf16 model or an autocast input keeps the torch.nn route)
+        return (x.is_cuda and x.dtype == torch.float32 and self.conv1.weight.dtype == torch.float32 and not self.training
+                and not torch.is_grad_enabled() and os.environ.get("SD_CONV", "hip") != "torch")
 
     def forward(self, x):
         if self._hip_inference(x):
             # the whole inference forward on the hand-written kernels: the stem (conv1 / bn1 / relu / maxpool) in one launch from the NCHW
             # frames to an NHWC map, the basic blocks on NHWC tensors, back to an NCHW view for the head
             x = x.contiguous()
-            pk = self.__dict__.get("_pk_stem")
+            store = _derived(self.conv1)
+            pk = store.get("planes")
             if pk is None or pk.planes.device != x.device:
-                pk = self.__dict__["_pk_stem"] = ops.PackedStem(self.conv1.weight)
-            # the abs-max words of the forward's activation tensors (frames, stem, up to three per block): one fill
-            words = self.__dict__.get("_amax_words")
-            if words is None or words.device != x.device:
-                words = self.__dict__["_amax_words"] = torch.zeros(64, dtype=torch.int32, device=x.device)
-            words.zero_()
+                pk = store["planes"] = ops.PackedStem(self.conv1.weight)
+            # the abs-max words of the forward's activation tensors (frames, stem, up to three per block): one fill, allocated per call
+            # (forwards on different streams / threads must not share them; the caching allocator hands the same block back)
+            words = torch.zeros(64, dtype=torch.int32, device=x.device)
             amax = words[1:2]
             h = ops.stem_conv_bn_relu_pool(x, ops.absmax_word(x, words[0:1], zero=False), pk.refresh(self.conv1.weight), *_BasicBlock._bn_fold(self.bn1),
                                            y_amax=amax, zero_amax=False)

@@ -7,6 +7,7 @@ reference class): ``sample`` runs the whole DDIM loop natively."""
 
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -19,6 +20,17 @@ from .encoder.image import ImageEncoderType, SequenceEncoderType, image_sequence
 from .misc import StepToken
 
 NUM_HEADS = 4  # fixed by the reference (model.py:57,71,85,115)
+
+# per-model caches (captured rollout graphs, the loop form's prepared workspaces): outside the module, keyed weakly by it, so that
+# copy.deepcopy / pickling of a model neither carries nor shares them
+_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _model_cache(model: nn.Module, name: str) -> dict:
+    per = _CACHES.get(model)
+    if per is None:
+        per = _CACHES[model] = {}
+    return per.setdefault(name, {})
 
 
 class End2EndDiffusionTransformer(nn.Module):
@@ -98,13 +110,52 @@ class End2EndDiffusionTransformer(nn.Module):
         B = x.shape[0]
         if step.dim() == 0:
             step = step.reshape(1)
-        if step.shape[0] != B:
-            if step.shape[0] != 1:
-                raise RuntimeError(f"step has {step.shape[0]} entries for a batch of {B}")  # torch.cat would fail too
-            step = step.expand(B)
+        if step.shape[0] != B and step.shape[0] != 1:
+            raise RuntimeError(f"step has {step.shape[0]} entries for a batch of {B}")  # torch.cat would fail too
         step = step.to(x.device)
+        eps = self._loop_form_eps(context, x, step)
+        if eps is not None:
+            return eps
+        if step.shape[0] != B:
+            step = step.expand(B)
         memory = self._assemble_memory(context, step, B, x.device)
         return self.diffusion_action_generator(x, memory)
+
+    def _loop_form_eps(self, context, x: torch.Tensor, step: torch.Tensor) -> Optional[torch.Tensor]:
+        """Inference calls (no tape, no live dropout) on shapes the trajectory kernels take run ``ops.LoopSampler``: the reference's
+        loops call this method once per DDIM step with the same context (plot.py:122-131, distill.py:179-189, ros.py:301-310), so the
+        weights' split planes and the context's folded K / V are prepared on the first call and reused by the following ones.
+        Returns None where that route does not apply (training, a differentiable input, CPU tensors, other shapes)."""
+        import os
+
+        dag = self.diffusion_action_generator
+        if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or (self.training and dag.dropout.p > 0.0)
+                or os.environ.get("SD_LOOP_FORM", "1") == "0"):
+            return None
+        if torch.is_grad_enabled() and (x.requires_grad or any(c.requires_grad for c in context)
+                                        or any(p.requires_grad for p in dag.parameters()) or self.step_encoding.token.requires_grad):
+            return None
+        if any((not c.is_cuda) or c.dtype != torch.float32 or c.dim() != 3 or c.shape[0] != x.shape[0] for c in context):
+            return None
+        B, T, _ = x.shape
+        Mc = sum(int(c.shape[1]) for c in context)
+        n_tok = 1 if step.shape[0] == 1 else B
+        packed = dag.packed()
+        cap = min(ops.sampler_cap(packed), 3)   # (mode 4 needs its status word read back: a host synchronisation per call)
+        key = (B, T, Mc, n_tok, x.device, cap)
+        cache = _model_cache(self, "loop")
+        ls = cache.get(key)
+        if ls is None:
+            if len(cache) >= 4:
+                cache.clear()   # a prepared workspace is pinned memory: a handful of shapes at a time
+            ls = cache[key] = ops.LoopSampler(packed, B, T, Mc, n_tok, x.device, max_mode=cap)
+        if not ls.supported:
+            return None
+        if step.dtype not in (torch.int64, torch.float32):
+            step = step.to(torch.float32 if step.is_floating_point() else torch.int64)
+        tokens = ops.step_token(step.contiguous(), self.step_encoding._freq, self.step_encoding.token.detach()).view(n_tok, self.hidden_dim)
+        wkey = (dag._signature(), tuple(p._version for p in dag.parameters()), ops.weights_generation())
+        return ls.eps(packed, list(context), tokens, x.contiguous(), wkey)
 
     # ---- extras ------------------------------------------------------------------------
     def dropout_stacks(self):
@@ -156,10 +207,12 @@ class End2EndDiffusionTransformer(nn.Module):
     @torch.no_grad()
     def sample(self, context: Sequence[torch.Tensor], x_T: torch.Tensor, num_inference_steps: int,
                return_trace: bool = False, alphas_cumprod: Optional[torch.Tensor] = None, use_graph: bool = False,
-               with_dropout: bool = False):
+               with_dropout: bool = False, max_mode: Optional[int] = None):
         """The reference's denoising loop (plot.py:122-131 / distill.py:179-189 / ros.py:301-310)
         as one native call: n x (denoiser forward + DDIM update) with the context K/V cached.
         ``use_graph`` replays the rollout from a hipGraph captured for this (B, T, M, n) shape.
+        ``max_mode``: the highest sampler mode (``sd_sampler_mode``) the call may run; None = ``ops.default_sampler_cap()`` = 3 (three fp16
+        products at every site: valid for any weights); 4 opts in to the guarded two-product Q | K | V site (falls back to 3 by itself).
         The native rollout has no dropout (inference).  ``with_dropout=True`` on a model in ``train()`` mode instead
         steps through ``forward_with_context`` + the scheduler update like the reference's loop does, dropout live in
         every call - what distill.py's teacher, which is never put into eval mode, actually computes (distill.py:127-189)."""
@@ -183,16 +236,19 @@ class End2EndDiffusionTransformer(nn.Module):
         if use_graph and not return_trace:
             B, T, _ = x_T.shape
             Mc = 0 if ctx is None else ctx.shape[1]
-            cap = getattr(packed, "sampler_cap", 4)   # as ops.ddim_sample_guarded: mode 4 until its guard tripped on these weights
+            cap = ops.sampler_cap(packed, max_mode)   # as ops.ddim_sample_guarded
             key = (B, T, Mc, num_inference_steps, x_T.device, self.diffusion_action_generator._signature(),
                    self.step_encoding.token._version, cap)
-            cache = self.__dict__.setdefault("_graphs", {})
+            cache = _model_cache(self, "graphs")
             if key not in cache:
                 cache.clear()  # one shape at a time: a graph pins its workspace
                 cache[key] = ops.GraphedSampler(packed, B, T, Mc, self.step_encoding.table(ts, x_T.device), coef, max_mode=cap)
             out = cache[key](ctx, x_T)
-            if int(cache[key].status.item()) == 0:
+            word = int(cache[key].status.item())
+            if word == 0:
                 return out
+            if word & ops.STATUS_SHARP_LOGITS:
+                packed.sampler_cap = 3   # pinned before the eager rerun: it starts on mode 3, not on mode 4 again
             # range guard tripped (ops.ddim_sample_guarded): fall through to the guarded eager path
         tokens = self.step_encoding.table(ts, x_T.device)
-        return ops.ddim_sample_guarded(packed, ctx, tokens, coef, x_T.contiguous(), trace=return_trace)
+        return ops.ddim_sample_guarded(packed, ctx, tokens, coef, x_T.contiguous(), trace=return_trace, max_mode=max_mode)

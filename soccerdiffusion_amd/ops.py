@@ -192,6 +192,21 @@ def pack_encoder(sd: Mapping[str, Tensor], device, prefix: str, heads: int = 4, 
 
 _ws_cache: dict = {}
 
+# Derived copies of the weights (split fp16 planes, folded BatchNorm vectors, the loop-form sampler's prepared workspace) are keyed on
+# the tensors' version counters - which do NOT move when FusedAdamW updates its flat buffer through a native kernel on raw pointers
+# (training.py) or when a captured training graph is replayed.  Every such update bumps this counter, and every cache key includes it.
+_weights_generation = 0
+
+
+def weights_generation() -> int:
+    return _weights_generation
+
+
+def bump_weights_generation() -> None:
+    global _weights_generation
+    _weights_generation += 1
+
+
 
 def workspace(n_floats: int, device) -> Tensor:
     """Grow-only scratch buffer per (device, stream)."""
@@ -297,7 +312,7 @@ def ddim_step(eps: Tensor, x: Tensor, coef4) -> Tensor:
 
 
 STATUS_NONFINITE = 1  # SD_STATUS_NONFINITE
-STATUS_SHARP_LOGITS = 2  # SD_STATUS_SHARP_LOGITS (sampler mode 3: a self-attention logit beyond the validated range)
+STATUS_SHARP_LOGITS = 2  # SD_STATUS_SHARP_LOGITS (sampler mode 4: a self-attention logit beyond the validated range)
 
 
 class GraphedSampler:
@@ -385,30 +400,50 @@ def ddim_sample(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coe
     return out if len(out) > 1 else x
 
 
+def default_sampler_cap() -> int:
+    """The highest sampler mode a call runs unless told otherwise: 3 - three fp16 products at every site, valid for any weights.
+    Mode 4 (two products at the Q | K | V projection, guarded by SD_STATUS_SHARP_LOGITS) is opt-in: ``max_mode=4`` at the call
+    (``End2EndDiffusionTransformer.sample(..., max_mode=4)``) or ``SD_SAMPLER_MODE=4`` in the environment."""
+    import os
+
+    try:
+        cap = int(os.environ.get("SD_SAMPLER_MODE", "3"))
+    except ValueError:
+        cap = 3
+    return cap if 0 <= cap <= 4 else 3
+
+
+def sampler_cap(packed: _Packed, max_mode: Optional[int] = None) -> int:
+    """``max_mode`` of a call: the caller's (or the default), lowered to 3 once these weights tripped mode 4's guard."""
+    cap = default_sampler_cap() if max_mode is None else int(max_mode)
+    return min(cap, getattr(packed, "sampler_cap", 4))
+
+
 def ddim_sample_guarded(packed: _Packed, ctx: Optional[Tensor], step_tokens: Tensor, coef: np.ndarray, x_T: Tensor,
-                        trace: bool = False):
+                        trace: bool = False, max_mode: Optional[int] = None):
     """``ddim_sample`` with the range guard read back (one host synchronisation): when the split-fp16 kernels of
     sampler modes 2 .. 4 were driven out of their operand range (|8 v| >= 65520 for a LayerNorm / attention / GELU output -
     e.g. a checkpoint with LayerNorm weights in the thousands), the rollout is repeated on the exact-fp32 MFMA kernels
     (``max_mode`` 1), which have no such limit.  Raises if that result is not finite either (non-finite inputs).
-    Mode 4's own guard (SD_STATUS_SHARP_LOGITS: a self-attention logit beyond the range its two-product Q | K | V site is
-    validated on) repeats the rollout on mode 3 and pins ``packed.sampler_cap`` there."""
+    ``max_mode``: None = ``default_sampler_cap()`` (3).  With 4, mode 4's own guard (SD_STATUS_SHARP_LOGITS: a self-attention logit
+    beyond the range its two-product Q | K | V site is validated on) repeats the rollout on mode 3 and pins ``packed.sampler_cap`` there."""
     import warnings
 
     status = torch.zeros(1, dtype=torch.int32, device=x_T.device)
-    cap = getattr(packed, "sampler_cap", 4)   # mode 4 (opt-in, guarded by the status word) until these weights tripped its guard
+    cap = sampler_cap(packed, max_mode)
     out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=cap)
     word = int(status.item())
     if word == 0:
         return out
-    if word == STATUS_SHARP_LOGITS:
+    if word & STATUS_SHARP_LOGITS:
         # sampler mode 4 met a self-attention logit beyond the range its two-product Q | K | V projection is validated on
         # (SD_SHARP_LOGIT_LIMIT): the same rollout with three fp16 products at every site (mode 3).  Sharpness is a property
         # of the checkpoint, so later calls with these weights start there.
         packed.sampler_cap = 3
-        out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=3)
-        if int(status.item()) == 0:
-            return out
+        if not word & STATUS_NONFINITE:
+            out = ddim_sample(packed, ctx, step_tokens, coef, x_T, trace=trace, status=status, max_mode=3)
+            if int(status.item()) == 0:
+                return out
     mode = _lib.load().sd_sampler_mode(packed.d, packed.heads, x_T.shape[1], 0 if ctx is None else ctx.shape[1], packed.J)
     if mode < 2 and _chain16_possible(packed):
         mode = 2   # the unfused row chains run on the split-fp16 pipe as well
@@ -419,6 +454,68 @@ def ddim_sample_guarded(packed: _Packed, ctx: Optional[Tensor], step_tokens: Ten
         if int(status.item()) == 0:
             return out
     raise FloatingPointError("sd_ddim_sample produced non-finite values on the fp32 kernels too: the inputs or the weights are not finite")
+
+
+PREPARE_WEIGHTS, PREPARE_CONTEXT = 1, 2   # SD_PREPARE_*
+E_UNSUPPORTED = -4   # SD_E_UNSUPPORTED
+
+
+class LoopSampler:
+    """``forward_with_context`` inside the reference's own denoising loop (soccer_diffusion/ml/inference/plot.py:122-131,
+    ml/training/distill.py:179-189, ml/inference/ros.py:301-310) on the trajectory kernels of sampler mode 3: one launch of
+    ``traj_step_kernel`` per call (plus the step tokens' K / V and fold).  What does not depend on x or the step - the split
+    weight planes, the context's K / V folded with Wq / Woc - is prepared into a workspace this object owns and reused until the
+    weights (``weights_key``) or the context tensors (identity and version counters; held here so that their addresses cannot be
+    recycled under the cache) change.  ``supported`` is False where the shape does not take these kernels."""
+
+    def __init__(self, packed: _Packed, B: int, T: int, Mc: int, n_tok: int, device, max_mode: int = 3):
+        lib = _lib.load()
+        self.shape = (B, T, Mc, n_tok)
+        self.max_mode = int(max_mode)
+        self.supported = (lib.sd_sampler_mode(packed.d, packed.heads, T, Mc, packed.J) >= 3 and packed.L <= 8
+                          and B * (Mc + 1) * 2 * packed.d < (1 << 30))
+        self.ws = (torch.empty(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, n_tok), dtype=torch.float32, device=device)
+                   if self.supported else None)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device) if self.supported and self.max_mode == 4 else None
+        self.weights_key = None
+        self.context: list = []
+        self.versions: tuple = ()
+        self.prepares = 0   # (tests: how many times the context was folded)
+
+    def _context_hit(self, context) -> bool:
+        return (len(context) == len(self.context) and all(a is b for a, b in zip(context, self.context))
+                and tuple(c._version for c in context) == self.versions)
+
+    def eps(self, packed: _Packed, context, tokens: Tensor, x: Tensor, weights_key) -> Optional[Tensor]:
+        """Noise prediction (B, T, J) or None when the library declines the shape (the caller falls back)."""
+        lib = _lib.load()
+        B, T, Mc, n_tok = self.shape
+        _req(x, "x"); _req(tokens, "step tokens")
+        what = 0
+        if weights_key != self.weights_key:
+            what = PREPARE_WEIGHTS | PREPARE_CONTEXT   # the fold multiplies the context's K / V with Wq / Woc
+        elif not self._context_hit(context):
+            what = PREPARE_CONTEXT
+        if what:
+            ctx = None
+            if Mc > 0:
+                ctx = (context[0] if len(context) == 1 else torch.cat(list(context), dim=1)).contiguous()
+                _req(ctx, "context")
+            rc = lib.sd_sampler_prepare(C.byref(packed.struct), _ptr(ctx), self.ws.data_ptr(), B, T, Mc, n_tok, what, self.max_mode, _stream())
+            if rc == E_UNSUPPORTED:
+                self.supported = False
+                return None
+            check(rc, "sd_sampler_prepare")
+            self.weights_key, self.context, self.versions = weights_key, list(context), tuple(c._version for c in context)
+            self.prepares += 1
+        eps = torch.empty_like(x)
+        rc = lib.sd_sampler_eps(C.byref(packed.struct), tokens.data_ptr(), x.data_ptr(), eps.data_ptr(), self.ws.data_ptr(), B, T, Mc, n_tok,
+                                _ptr(self.status), self.max_mode, _stream())
+        if rc == E_UNSUPPORTED:
+            self.supported = False
+            return None
+        check(rc, "sd_sampler_eps")
+        return eps
 
 
 def _chain16_possible(packed: _Packed) -> bool:
@@ -905,11 +1002,11 @@ class PackedConv3x3:
         self.refresh(weight)
 
     def refresh(self, weight: Tensor) -> "PackedConv3x3":
-        if self.version != weight._version:
+        if self.version != (weight._version, _weights_generation):
             w = weight.detach().contiguous()
             check(_lib.load().sd_conv_pack(w.data_ptr(), self.Cout, self.Cin, self.ksize, self.planes.data_ptr(), self.scale.data_ptr(),
                                            self._word.data_ptr(), _stream()), "sd_conv_pack")
-            self.version = weight._version
+            self.version = (weight._version, _weights_generation)
         return self
 
 
@@ -981,11 +1078,11 @@ class PackedStem:
         self.refresh(weight)
 
     def refresh(self, weight: Tensor) -> "PackedStem":
-        if self.version != weight._version:
+        if self.version != (weight._version, _weights_generation):
             w = weight.detach().contiguous()
             check(_lib.load().sd_stem_pack(w.data_ptr(), self.planes.data_ptr(), self.scale.data_ptr(), self._word.data_ptr(), _stream()),
                   "sd_stem_pack")
-            self.version = weight._version
+            self.version = (weight._version, _weights_generation)
         return self
 
 

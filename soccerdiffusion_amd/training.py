@@ -404,6 +404,8 @@ class _EmbedHead(Function):
 
     @staticmethod
     def backward(ctx, dy, _dn, _dqkv):
+        if ctx.needs_input_grad[0]:   # (_embed_head_ok sends a differentiable x to _PatchEmbed, which raises as well)
+            raise NotImplementedError("the denoiser's embedding has no gradient with respect to the noisy trajectory")
         x, W, b = ctx.saved_tensors
         d = W.shape[0]
         patches = x.reshape(-1, x.shape[-1])
@@ -419,7 +421,7 @@ def _embed_head_ok(gen, x: Tensor, layers) -> bool:
 
     W = gen.embedding.weight
     J = x.shape[-1]
-    return (os.environ.get("SD_TRAIN_TRAJ", "1") != "0" and x.is_cuda and W.dim() == 2 and W.shape[0] == 256 and J % 4 == 0 and 4 <= J <= 32
+    return (os.environ.get("SD_TRAIN_TRAJ", "1") != "0" and x.is_cuda and not x.requires_grad and W.dim() == 2 and W.shape[0] == 256 and J % 4 == 0 and 4 <= J <= 32
             and x.shape[1] <= 100 and gen.num_heads == 4 and _packed_weight_traj(layers[0].self_attn.in_proj_weight) is not None)
 
 
@@ -972,6 +974,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """The per-step derived copies of the weights: the split planes of every d x d block and of its transpose (two
         launches per block width; the transposition happens inside the pack kernel), or - without planes - an fp32 gather
         of the transposed blocks (one kernel; see _WT_BLOCKS)."""
+        ops.bump_weights_generation()   # every path that rewrites flat_param ends here (step, step_from_device_hyper, broadcast)
         if not self._wt_blocks or not self.flat_param.is_cuda:
             return
         import weakref
@@ -1324,6 +1327,7 @@ class GraphedTrainStep:
                 self._loss = self._body()
         self._upload_hyper()
         self.graph.replay()
+        ops.bump_weights_generation()   # the replayed update rewrote the flat parameter buffer without any Python-side hook
         if self.split:
             allreduce_gradients(self.opt, self.world)
             self.opt.step_from_device_hyper(self.hyper[:7])

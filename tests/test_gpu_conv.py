@@ -175,6 +175,38 @@ def test_resnet18_inference_runs_the_hip_blocks_and_matches_cpu_fp32(avgpool, HW
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
 
 
+def test_eval_forward_sees_fused_adamw_updates():
+    """FusedAdamW re-points every parameter into one flat buffer and updates it with a native kernel on raw pointers: no tensor version
+    counter moves.  The packed planes / folded BatchNorm vectors of the inference route are keyed on ops.weights_generation()
+    as well, so an eval forward after an optimizer step encodes frames with the UPDATED weights - equal to the torch.nn route."""
+    import copy
+
+    from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+    from soccerdiffusion_amd.training import FusedAdamW
+
+    torch.manual_seed(3)
+    enc = image_encoder_factory(ImageEncoderType.RESNET18, 64, True, 64).cuda()
+    x = torch.rand(1, 2, 3, 64, 64, device="cuda")
+    enc.eval()
+    with torch.no_grad():
+        before = enc(x)
+    assert copy.deepcopy(enc) is not None   # (the derived planes live outside the modules: nothing un-copyable inside)
+    opt = FusedAdamW(enc.parameters(), lr=5e-2)
+    for p in enc.parameters():
+        p.grad.normal_()
+    opt.step()
+    with torch.no_grad():
+        after = enc(x)
+    os.environ["SD_CONV"] = "torch"
+    try:
+        with torch.no_grad():
+            lib = enc(x)
+    finally:
+        del os.environ["SD_CONV"]
+    assert float((after - before).abs().max()) > 1e-3            # the update is visible ...
+    assert float((after - lib).abs().max() / lib.abs().max()) < 1e-4   # ... and it is the updated weights' result
+
+
 # the stem on a 480 x 640 frame, small / odd / ragged frames (conv and pool borders inside one tile), a single pixel
 @pytest.mark.parametrize("N,H,W", [(2, 480, 640), (3, 96, 128), (1, 37, 53), (2, 64, 64), (1, 7, 9), (1, 1, 1), (1, 30, 200)])
 def test_stem_conv_bn_relu_pool_matches_torch_cpu(ops, N, H, W):

@@ -228,10 +228,16 @@ def test_guarded_sampler_leaves_mode4_on_sharp_attention(ops):
     toks = ops.step_token(torch.tensor(ts).cuda(), ops.step_frequencies(d).cuda(), sd["step_encoding.token"].cuda()).reshape(n, d)
     coef = ops.ddim_coefficients(ts, acp, n)
     assert not hasattr(packed, "sampler_cap")
-    got = ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, x_T.cuda())
+    # the default is mode 3 (ops.default_sampler_cap): valid for any weights, no guard to trip, nothing pinned
+    assert ops.default_sampler_cap() == 3
+    plain = ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, x_T.cuda())
+    assert not hasattr(packed, "sampler_cap")
+    assert float((plain.double().cpu() - want).norm() / want.norm()) < 1e-5
+    # opting in to mode 4 on these weights trips its guard: rerun on mode 3, pinned there
+    got = ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, x_T.cuda(), max_mode=4)
     assert packed.sampler_cap == 3
-    assert float((got.double().cpu() - want).norm() / want.norm()) < 1e-5
-    again = ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, x_T.cuda())
+    assert torch.equal(got, plain)
+    again = ops.ddim_sample_guarded(packed, ctx.cuda(), toks, coef, x_T.cuda(), max_mode=4)
     assert torch.equal(got, again)
     # and without a status word mode 4 is refused rather than run unguarded
     with pytest.raises(Exception):
@@ -282,7 +288,10 @@ assert err < 1e-4, err
                                        # 17 .. 64 memory rows (2 .. 4 key tiles, traj_step_wide_kernel): tile edges, the reference's
                                        # sim_scratch.yaml (20 + 20 + 10 context rows, 6 layers, horizon 10), the full-context robot shape 31
                                        (10, 16, 20, 2, 2), (10, 17, 20, 2, 3), (10, 31, 20, 4, 2), (10, 32, 20, 2, 2), (10, 50, 20, 6, 2), (16, 47, 8, 2, 2),
-                                       (100, 48, 20, 2, 2), (100, 63, 20, 4, 2), (33, 40, 12, 2, 3), (97, 16, 32, 2, 2), (1, 63, 4, 1, 2)])
+                                       (100, 48, 20, 2, 2), (100, 63, 20, 4, 2), (33, 40, 12, 2, 3), (97, 16, 32, 2, 2), (1, 63, 4, 1, 2),
+                                       # joint counts that are not multiples of four: the real database's 22 (reference dataset/models.py:222-247), odd
+                                       # counts, one joint, 31
+                                       (100, 10, 22, 4, 3), (10, 30, 22, 2, 2), (33, 5, 21, 2, 2), (10, 0, 1, 1, 2), (100, 15, 31, 2, 2), (10, 50, 22, 6, 1)])
 def test_trajectory_step_kernel_every_step(ops, T, Mc, J, L, B):
     """Sampler modes 3 / 4 (csrc/sd_traj.h; reference blocks decoder.py:26-54 under the DDIM loop of plot.py:122-131): x after EVERY
     step against the fp32 oracle, at the edges of what the kernel takes - every token-tile count 1 .. 7 with full and ragged last

@@ -143,8 +143,15 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(mode):
     per_gpu = 64 if mode == "sample" else 16
     assert abs(d["value"] - 2 * per_gpu * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
     assert d["cpu_baseline"] is None
+    # the line verifies its own world: size, backend, one entry per rank with the device it ran on (here both ranks on one GPU)
+    w = d["world"]
+    assert w["size"] == 2 and w["backend"] == "gloo" and w["shared_gpu_rehearsal"] is True
+    assert [r["rank"] for r in w["ranks"]] == [0, 1] and len({r["pid"] for r in w["ranks"]}) == 2
+    assert all("MI3" in r["name"] or "AMD" in r["name"] for r in w["ranks"]) and w["distinct_devices"] == 1
     if mode == "train":
         assert d["train"]["allreduce_bytes"] > 10_000_000 and d["train"]["allreduce_ms"] > 0
+        t = d["train"]
+        assert abs(t["allreduce_busbw_gbs"] - t["allreduce_bytes"] * 2 * (2 - 1) / 2 / (t["allreduce_ms"] * 1e-3) / 1e9) / t["allreduce_busbw_gbs"] < 0.02
         assert "all-reduce" in d["config"]["parallelism"]
         # the step the N-rank benchmark times is the one cli train runs: eager, per-layer buckets overlapped with the backward;
         # the exchange is reported alone and as what it still costs on the critical path
