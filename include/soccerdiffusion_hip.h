@@ -114,6 +114,11 @@ size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_steps);
  *       sim_scratch.yaml's 51 rows), any J <= 32 (the embedding's K and fc_out's N are zero-padded in the packed planes; the
  *       reference's database has 22 joints, soccer_diffusion/dataset/models.py:222-247); the layer count (<= 8) is checked at the
  *       call - a deeper model runs mode 2; SD_SAMPLER_TRAJ=0 in the environment selects mode 2.
+ *       Every OTHER hidden_dim 128 / 256 / 512 shape - the reference's default.yaml (hidden_dim 128, 312 memory rows) and
+ *       larger_model.yaml (hidden_dim 512, 8 layers, 312 memory rows), hidden_dim 256 with more than 64 memory rows - runs the GENERIC
+ *       trajectory kernels (soccerdiffusion_amd/csrc/sd_trajg.hip): same ownership and arithmetic, geometry as a template parameter,
+ *       the cross-attention un-folded with the memory's projected K / V streamed from HBM (any number of rows), T <= 100 (hidden_dim
+ *       512: T <= 48 - a longer panel does not fit the CU's LDS; such a shape runs mode 2's unfused chains), 4 heads, J <= 32, <= 8 layers.
  *   4 = mode 3 with ONE exception: the Q | K | V projection of the self-attention reads a single fp16 plane of LayerNorm
  *       1's output (two MFMAs per product there, 11-bit activation operand), which frees the LDS that lets the four images
  *       of a head live side by side (two barriers per head instead of five; ~ 1.15 x mode 3).  The error this leaves in a

@@ -1294,6 +1294,7 @@ static int chain_b(const ChainBArgs &g, int d, hipStream_t s) {
 
 #include "sd_f16x3.h"
 #include "sd_traj.h"
+#include "sd_trajg.h"
 
 template <int D>
 static int launch_panel16(const float *A, int lda, const float *W, const float *bias, const float *ln_w, const float *ln_b,
@@ -2522,6 +2523,7 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
     f16 *wfc;
     float *scc;
     unsigned *mbc;
+    float *gws;   // region of the generic trajectory kernels (sd_trajg.hip: hidden_dim 128 / 256 / 512, any memory length), or NULL
 };
 
 // the fp16x3 kernels are instantiated for hidden_dim 256 (the folded fp32 kernels serve the other sizes);
@@ -2576,6 +2578,8 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.scc = ws + off; off += align64((size_t)L * 8);
         s.mbc = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)L * 8);
     }
+    s.gws = nullptr;
+    if (n_steps > 0 && B > 0 && (d == 128 || d == 256 || d == 512)) s.gws = ws + off;   // trajg_workspace_floats(B, Mc, d, L, n_steps) floats
     return s;
 }
 
@@ -2592,6 +2596,7 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
         n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * kt * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
              align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8) + align64((size_t)2 * 32 * d);
     if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
+    if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += trajg_workspace_floats(B, M > 0 ? M : 0, d, L, n_steps);
     return n;
 }
 
@@ -3136,7 +3141,7 @@ extern "C" int sd_encoder_forward(const sd_encoder_weights *w, const float *x, f
 
 extern "C" int sd_sampler_mode(int d, int heads, int T, int Mc, int J) {
     const int Mk = Mc + 1;
-    if (traj_ok(d, heads, T, Mk, J, 1)) return 3;   // (the layer count is checked at the call: <= 8; mode 4 is opt-in)
+    if (traj_ok(d, heads, T, Mk, J, 1) || trajg_ok(d, heads, T, Mk, J, 1)) return 3;   // (the layer count is checked at the call: <= 8; mode 4 is opt-in)
     if (!(fold_ok(d, heads, T, Mk) && fused_layer_ok(d, heads, T, Mk))) return 0;
     if (!f16_ok(d, J)) return 1;
     return 2;
@@ -3177,6 +3182,31 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
     const bool small = (long)B * Mk * 2 * d < (1L << 30);
     // the trajectory kernel (modes 3 / 4) takes any horizon <= 100: it needs the folded blocks, not the row-panel kernels' T >= 64
     const bool traj = max_mode >= 3 && small && traj_ok(d, w->heads, T, Mk, w->J, L) && s.wf != nullptr && s.wio != nullptr;
+    // ... and the generic trajectory kernels (sd_trajg.hip) every other hidden_dim 128 / 256 / 512 shape, whatever its memory length
+    const bool trajg = !traj && max_mode >= 3 && trajg_ok(d, w->heads, T, Mk, w->J, L) && s.gws != nullptr;
+    if (trajg) {
+        if (status) {
+            if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
+        }
+        if ((rc = trajg_prepare_weights(w, s.gws, B, Mc, n_steps, st))) return rc;
+        if ((rc = trajg_prepare_ctx(w, s.gws, ctx, s.kvtmp, B, Mc, n_steps, st))) return rc;
+        if ((rc = trajg_prepare_steps(w, s.gws, step_tokens, s.kvstep, B, Mc, n_steps, st))) return rc;
+        for (int i = 0; i < n_steps; ++i) {
+            float *eps_i = eps_trace ? eps_trace + (size_t)i * R * w->J : nullptr;
+            if ((rc = trajg_step(w, s.gws, x, eps_i, B, T, Mc, i, n_steps, coef + 4 * i, false, st))) return rc;
+            if (trace) {
+                const long n = (long)R * w->J;
+                SD_LAUNCH(copy_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, trace + (size_t)i * n, n, 1L, (int)n);
+                SD_CHECK_LAUNCH("copy_rows_kernel");
+            }
+        }
+        if (status) {
+            const long n = (long)R * w->J;
+            SD_LAUNCH(finite_check_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, status, SD_STATUS_NONFINITE);
+            SD_CHECK_LAUNCH("finite_check_kernel");
+        }
+        return 0;
+    }
     const bool fold = traj || (max_mode >= 1 && fold_ok(d, w->heads, T, Mk) && fused_layer_ok(d, w->heads, T, Mk) && small);
     const int nkt = traj ? key_tiles(Mk) : 1;   // (the row-panel fold: Mk <= 16)
     const size_t gvstride = (size_t)B * nkt * 64 * 2 * d, cbstride = (size_t)B * nkt * 64;
@@ -3275,8 +3305,9 @@ extern "C" int sd_ddim_sample_eps(const sd_denoiser_weights *w, const float *ctx
 }
 
 // ---- the denoiser evaluated step by step on the trajectory kernels (the reference's own loop form) --------------------------
+// *generic: the shape runs on the generic trajectory kernels (sd_trajg.hip) instead of sd_traj.h's
 static int sampler_eval_args(const sd_denoiser_weights *w, float *workspace, int B, int T, int Mc, int n_tok, int max_mode, const char *who,
-                             Scratch *out, bool *precise) {
+                             Scratch *out, bool *precise, bool *generic) {
     int rc = check_denoiser(w);
     if (rc) return rc;
     if (!workspace || B <= 0 || T <= 0 || Mc < 0 || (n_tok != 1 && n_tok != B)) return fail(SD_E_BADARG, who);
@@ -3286,20 +3317,29 @@ static int sampler_eval_args(const sd_denoiser_weights *w, float *workspace, int
     const int d = w->d, Mk = Mc + 1;
     *out = carve(workspace, (long)B * T, (long)B * Mk, d, w->L, n_tok, B);
     const bool small = (long)B * Mk * 2 * d < (1L << 30);
-    if (!(max_mode >= 3 && small && traj_ok(d, w->heads, T, Mk, w->J, w->L) && out->wf && out->wio)) return SD_E_UNSUPPORTED;
-    *precise = max_mode == 3;
+    *generic = false;
+    if (!(max_mode >= 3 && small && traj_ok(d, w->heads, T, Mk, w->J, w->L) && out->wf && out->wio)) {
+        if (!(max_mode >= 3 && trajg_ok(d, w->heads, T, Mk, w->J, w->L) && out->gws)) return SD_E_UNSUPPORTED;
+        *generic = true;
+    }
+    *precise = max_mode == 3 || *generic;
     return 0;
 }
 
 extern "C" int sd_sampler_prepare(const sd_denoiser_weights *w, const float *ctx, float *workspace, int B, int T, int Mc, int n_tok,
                                   int what, int max_mode, void *stream) {
     Scratch s;
-    bool precise;
-    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_prepare: bad argument", &s, &precise);
+    bool precise, generic;
+    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_prepare: bad argument", &s, &precise, &generic);
     if (rc) return rc;
     if ((what & ~(SD_PREPARE_WEIGHTS | SD_PREPARE_CONTEXT)) || (Mc > 0 && (what & SD_PREPARE_CONTEXT) && !ctx))
         return fail(SD_E_BADARG, "sd_sampler_prepare: bad argument");
     hipStream_t st = (hipStream_t)stream;
+    if (generic) {
+        if ((what & SD_PREPARE_WEIGHTS) && (rc = trajg_prepare_weights(w, s.gws, B, Mc, n_tok, st))) return rc;
+        if ((what & SD_PREPARE_CONTEXT) && (rc = trajg_prepare_ctx(w, s.gws, ctx, s.kvtmp, B, Mc, n_tok, st))) return rc;
+        return 0;
+    }
     if ((what & SD_PREPARE_WEIGHTS) && (rc = traj_prepare_weights(w, s, st))) return rc;
     if ((what & SD_PREPARE_CONTEXT) && (rc = traj_prepare_ctx(w, s, ctx, B, Mc, st))) return rc;
     return 0;
@@ -3308,14 +3348,18 @@ extern "C" int sd_sampler_prepare(const sd_denoiser_weights *w, const float *ctx
 extern "C" int sd_sampler_eps(const sd_denoiser_weights *w, const float *step_tokens, const float *x, float *eps, float *workspace,
                               int B, int T, int Mc, int n_tok, int32_t *status, int max_mode, void *stream) {
     Scratch s;
-    bool precise;
-    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_eps: bad argument", &s, &precise);
+    bool precise, generic;
+    int rc = sampler_eval_args(w, workspace, B, T, Mc, n_tok, max_mode, "sd_sampler_eps: bad argument", &s, &precise, &generic);
     if (rc) return rc;
     if (!step_tokens || !x || !eps) return fail(SD_E_BADARG, "sd_sampler_eps: null pointer");
     if (!precise && !status) return fail(SD_E_BADARG, "sd_sampler_eps: max_mode 4 needs a status word (SD_STATUS_SHARP_LOGITS)");
     hipStream_t st = (hipStream_t)stream;
     if (status) {
         if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
+    }
+    if (generic) {
+        if ((rc = trajg_prepare_steps(w, s.gws, step_tokens, s.kvstep, B, Mc, n_tok, st))) return rc;
+        return trajg_step(w, s.gws, const_cast<float *>(x), eps, B, T, Mc, 0, n_tok, nullptr, n_tok > 1, st);
     }
     if ((rc = traj_prepare_steps(w, s, step_tokens, n_tok, Mc, st))) return rc;
     // x is only read (no DDIM coefficients: no update)

@@ -472,8 +472,7 @@ class LoopSampler:
         lib = _lib.load()
         self.shape = (B, T, Mc, n_tok)
         self.max_mode = int(max_mode)
-        self.supported = (lib.sd_sampler_mode(packed.d, packed.heads, T, Mc, packed.J) >= 3 and packed.L <= 8
-                          and B * (Mc + 1) * 2 * packed.d < (1 << 30))
+        self.supported = lib.sd_sampler_mode(packed.d, packed.heads, T, Mc, packed.J) >= 3 and packed.L <= 8
         self.ws = (torch.empty(lib.sd_workspace_floats(B, T, max(Mc, 1), packed.d, packed.L, n_tok), dtype=torch.float32, device=device)
                    if self.supported else None)
         self.status = torch.zeros(1, dtype=torch.int32, device=device) if self.supported and self.max_mode == 4 else None

@@ -241,6 +241,10 @@ def test_workspace_grows_with_the_key_tiles_of_the_memory():
     per_tile = 2 * L * B * 64 * 2 * d          # fp32 blocks + their fp16 hi | lo planes (2 halfs per float), per key tile
     rows = lambda M: 2 * L * B * (M + 1) * 2 * d   # kv + kvtmp
     assert w[2] - w[1] >= per_tile + rows(16) - rows(15)          # 16 -> 17 rows: a second tile
-    assert abs((w[1] - w[0]) - (rows(15) - rows(0))) <= 64 * 8    # within one tile only the K/V rows grow (64-float alignment)
+    # within one tile the K/V rows grow - and the generic trajectory kernels' K / V^T planes (csrc/sd_trajg.hip), one pair of 32 rows at a time
+    pair = lambda M: 2 * L * B * ((M + 31) // 32) * 32 * d
+    assert abs((w[1] - w[0]) - (rows(15) - rows(0)) - (pair(15) - pair(0))) <= 64 * 12
     assert lib.sd_sampler_mode(256, 4, 10, 50, 20) == 3 and lib.sd_sampler_mode(256, 4, 100, 63, 20) == 3   # 51 / 64 memory rows
-    assert lib.sd_sampler_mode(256, 4, 10, 64, 20) != 3                                                         # 65: not the trajectory kernel
+    # 65 rows and more, hidden_dim 128 / 512, 22 joints: the generic trajectory kernels - every shipped YAML's shape is mode 3
+    assert lib.sd_sampler_mode(256, 4, 10, 64, 20) == 3 and lib.sd_sampler_mode(128, 4, 10, 311, 22) == 3 and lib.sd_sampler_mode(512, 4, 10, 311, 20) == 3
+    assert lib.sd_sampler_mode(512, 4, 100, 10, 20) != 3 and lib.sd_sampler_mode(64, 4, 16, 10, 20) != 3     # a 100-token panel at 512 does not fit the LDS
