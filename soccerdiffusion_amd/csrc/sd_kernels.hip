@@ -2972,40 +2972,129 @@ static int traj_prepare_ctx(const sd_denoiser_weights *w, const Scratch &s, cons
     return 0;
 }
 
+// ---- the step tokens' part of the preparation, all layers in one launch each (a forward_with_context call of the reference's loop pays
+// it once per call: four launches instead of four per layer)
+struct StepFoldArgs { const float *wkv[tj::MAX_L], *bkv[tj::MAX_L], *wq[tj::MAX_L], *bq[tj::MAX_L], *woc[tj::MAX_L]; };
+// grid (n_tok, L), 256 threads, hidden_dim 256: K | V = Wkv tok + bkv (memory rows are not layer-normed), then the fold of
+// xattn_fold_kernel for this one row: G_h = Wq_h^T K_h, V'_h = Woc_h V_h, c_h = bq_h . K_h -> gvstep rows [tok * 4 + h][2 D], cstep
+// [tok * 4 + h]; abs-max of G / V' -> words 6 / 7 of the layer's row
+__global__ __launch_bounds__(256) void step_fold_all_kernel(StepFoldArgs a, const float *__restrict__ tokens, float *__restrict__ gvstep,
+                                                            long gv_layer_stride, float *__restrict__ cstep, long c_layer_stride,
+                                                            unsigned *maxbits) {
+    constexpr int D = tj::D, HD = tj::HD;
+    __shared__ __attribute__((aligned(16))) float st[D], skv[2 * D];
+    const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long tok = blockIdx.x;
+    st[threadIdx.x] = tokens[tok * D + threadIdx.x];
+    __syncthreads();
+    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(st + 4 * lane);
+    const float *wkv = a.wkv[l], *bkv = a.bkv[l];
+    for (int o = wv; o < 2 * D; o += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wkv + (long)o * D + 4 * lane);
+        const float s = wave_sum((w4[0] * t4[0] + w4[1] * t4[1]) + (w4[2] * t4[2] + w4[3] * t4[3]));
+        if (lane == 0) skv[o] = s + bkv[o];
+    }
+    __syncthreads();
+    {   // wave h: the score bias of head h
+        const float c = wave_sum(a.bq[l][wv * HD + lane] * skv[wv * HD + lane]);
+        if (lane == 0) cstep[l * c_layer_stride + tok * 4 + wv] = c;
+    }
+    const int n = threadIdx.x;
+    const float *wq = a.wq[l], *woc = a.woc[l] + (long)n * D;
+    float *out = gvstep + l * gv_layer_stride + tok * 4 * 2 * D;
+    float mg = 0.f, mv = 0.f;
+#pragma unroll 1
+    for (int h = 0; h < 4; ++h) {
+        float g = 0.f, v = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < HD; ++j) g += wq[(long)(h * HD + j) * D + n] * skv[h * HD + j];
+#pragma unroll 4
+        for (int j = 0; j < HD; j += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(woc + h * HD + j), v4 = *reinterpret_cast<const f32x4 *>(skv + D + h * HD + j);
+            v += (w4[0] * v4[0] + w4[1] * v4[1]) + (w4[2] * v4[2] + w4[3] * v4[3]);
+        }
+        out[(long)h * 2 * D + n] = g;
+        out[(long)h * 2 * D + D + n] = v;
+        mg = fmaxf(mg, fabsf(g));
+        mv = fmaxf(mv, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+        mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+    }
+    if (lane == 0) {
+        const unsigned bg = __builtin_bit_cast(unsigned, mg), bv = __builtin_bit_cast(unsigned, mv);
+        if (bg > __atomic_load_n(maxbits + l * 8 + 6, __ATOMIC_RELAXED)) atomicMax(maxbits + l * 8 + 6, bg);
+        if (bv > __atomic_load_n(maxbits + l * 8 + 7, __ATOMIC_RELAXED)) atomicMax(maxbits + l * 8 + 7, bv);
+    }
+}
+// grid (blocks, L): tj::pack_gstep16_kernel + tj::pack_vstep16_kernel of every layer (scales from words 6 / 7 -> sc[6], sc[7]); with
+// no_ctx also sc[4] = sc[6], sc[5] = sc[7] (no context rows: the all-zero context blocks carry no scale of their own - a scale of 1 from an
+// abs-max of 0 would drag the common value scale of tj::step_scale down to 1)
+__global__ void pack_step16_all_kernel(const float *__restrict__ gvstep, long gv_layer_stride, long n_tok, const unsigned *maxbits,
+                                       f16 *__restrict__ gdst, long g_layer_stride, f16 *__restrict__ vdst, long v_layer_stride, float *scales,
+                                       int no_ctx) {
+    constexpr int D = tj::D;
+    const int l = blockIdx.y;
+    const float sg = f16_scale_from_bits(maxbits[l * 8 + 6]), sv = f16_scale_from_bits(maxbits[l * 8 + 7]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scales[l * 8 + 6] = sg;
+        scales[l * 8 + 7] = sv;
+        if (no_ctx) {
+            scales[l * 8 + 4] = sg;
+            scales[l * 8 + 5] = sv;
+        }
+    }
+    const float *src = gvstep + l * gv_layer_stride;
+    f16 *gd = gdst + l * g_layer_stride, *vd = vdst + l * v_layer_stride;
+    const long ng = n_tok * 4 * (D / 8), nv = n_tok * 4 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ng + nv; i += (long)gridDim.x * blockDim.x) {
+        if (i < ng) {
+            const int k8 = (int)(i % (D / 8));
+            const long ih = i / (D / 8);
+            f16x4 h0, l0, h1, l1;
+            const float *row = src + ih * 2 * D + tj::kperm(k8, 0);
+            f16_split4(*reinterpret_cast<const f32x4 *>(row), sg, h0, l0);
+            f16_split4(*reinterpret_cast<const f32x4 *>(row + 16), sg, h1, l1);
+            f16 *o = gd + ih * (8 * 2 * 32) + ((k8 >> 2) * 2) * 32 + (k8 & 3) * 8;
+            *reinterpret_cast<f16x4 *>(o) = h0;
+            *reinterpret_cast<f16x4 *>(o + 4) = h1;
+            *reinterpret_cast<f16x4 *>(o + 32) = l0;
+            *reinterpret_cast<f16x4 *>(o + 36) = l1;
+        } else {
+            const long j = i - ng;
+            const int n = (int)(j % D), head = (int)((j / D) & 3);
+            const long item = j / D / 4;
+            const float v = src[(item * 4 + head) * 2 * D + D + n] * sv;
+            const f16 h = (f16)v;
+            vd[(item * 2 + 0) * 4 * D + head * D + n] = h;
+            vd[(item * 2 + 1) * 4 * D + head * D + n] = (f16)(v - (float)h);
+        }
+    }
+}
+
 // n_tok step tokens (rows of `tokens`): one per DDIM step of a rollout, or one per trajectory of a single evaluation
 static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, const float *tokens, int n_tok, int Mc, hipStream_t st) {
-    const int d = w->d, L = w->L, hd = d / 4;
-    const size_t kvsstride = (size_t)n_tok * 2 * d, gvsstride = (size_t)n_tok * 4 * 2 * d, cssstride = (size_t)n_tok * 4;
-    const size_t lds = 2 * (size_t)FOLD_RB * hd * sizeof(float);
+    const int d = w->d, L = w->L;
+    const size_t gvsstride = (size_t)n_tok * 4 * 2 * d, cssstride = (size_t)n_tok * 4;
     const size_t blk = (size_t)32 * d;
     int rc = zero_word_cols(s.maxbits, L, 6, 2, st);
     if (rc) return rc;
+    StepFoldArgs fa{};
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
-        unsigned *mb = s.maxbits + l * 8;
-        float *sc = s.scales + l * 8;
-        rc = linear(tokens, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, s.kvstep + (size_t)l * kvsstride, n_tok, 2 * d, d, 0,
-                    st, 0);
-        if (rc) return rc;
-        SD_LAUNCH(xattn_fold_kernel, dim3((unsigned)((n_tok + FOLD_RB - 1) / FOLD_RB), 4), dim3(256), lds, st, s.kvstep + (size_t)l * kvsstride,
-                  (long)n_tok, 1, lw.ca_in_w, lw.ca_in_b, lw.ca_out_w, s.gvstep + l * gvsstride, s.cstep + l * cssstride, 4L, 1, 0, d, hd, mb + 6, mb + 7);
-        SD_CHECK_LAUNCH("xattn_fold_kernel");
-        // per-layer regions as carved for mode 2 (n_tok * 4 * blk / n_tok * blk halfs), the step blocks packed densely inside
-        SD_LAUNCH(tj::pack_gstep16_kernel, dim3(grid_for((long)n_tok * 4 * d / 8)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_tok, mb + 6,
-                  s.gstep16 + (size_t)l * n_tok * 4 * blk, sc + 6);
-        SD_CHECK_LAUNCH("pack_gstep16_kernel");
-        SD_LAUNCH(tj::pack_vstep16_kernel, dim3(grid_for((long)n_tok * 4 * d)), dim3(256), 0, st, s.gvstep + l * gvsstride, (long)n_tok, mb + 7,
-                  s.vstep16 + (size_t)l * n_tok * blk, sc + 7);
-        SD_CHECK_LAUNCH("pack_vstep16_kernel");
-        if (Mc == 0) {
-            // no context rows: the (all-zero) context blocks carry no scale of their own - they take the step blocks' (a scale of 1
-            // from an abs-max of 0 would drag the common value scale of tj::step_scale down to 1)
-            SD_LAUNCH(tj::pack_g16_kernel, dim3(1), dim3(64), 0, st, s.gv, 0L, 0, mb + 6, s.g16, sc + 4, 1);
-            SD_CHECK_LAUNCH("pack_g16_kernel");
-            SD_LAUNCH(tj::pack_v16_kernel, dim3(1), dim3(64), 0, st, s.gv, 0L, 0, mb + 7, s.v16, sc + 5, 1);
-            SD_CHECK_LAUNCH("pack_v16_kernel");
-        }
+        fa.wkv[l] = lw.ca_in_w + (size_t)d * d; fa.bkv[l] = lw.ca_in_b + d;
+        fa.wq[l] = lw.ca_in_w; fa.bq[l] = lw.ca_in_b; fa.woc[l] = lw.ca_out_w;
     }
+    SD_LAUNCH(step_fold_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, fa, tokens, s.gvstep, (long)gvsstride, s.cstep, (long)cssstride,
+              s.maxbits);
+    SD_CHECK_LAUNCH("step_fold_all_kernel");
+    // per-layer regions as carved for mode 2 (n_tok * 4 * blk / n_tok * blk halfs), the step blocks packed densely inside
+    unsigned gx = grid_for((long)n_tok * 4 * (d / 8 + d));
+    SD_LAUNCH(pack_step16_all_kernel, dim3(gx, (unsigned)L), dim3(256), 0, st, s.gvstep, (long)gvsstride, (long)n_tok, s.maxbits, s.gstep16,
+              (long)((size_t)n_tok * 4 * blk), s.vstep16, (long)((size_t)n_tok * blk), s.scales, Mc == 0 ? 1 : 0);
+    SD_CHECK_LAUNCH("pack_step16_all_kernel");
     return 0;
 }
 

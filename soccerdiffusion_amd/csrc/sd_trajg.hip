@@ -74,6 +74,9 @@ __device__ __forceinline__ f16x8 zero8() { return f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 // ---------------------------------------------------------------------------------------------------
 // once-per-call packing
 // ---------------------------------------------------------------------------------------------------
+// scale slots of a layer's 16-float row
+enum { SC_IN = 0, SC_O = 1, SC_Q = 2, SC_OC = 3, SC_1 = 4, SC_2 = 5, SC_K = 6, SC_V = 7, SC_KS = 8, SC_VS = 9, SC_EMB = 10, SC_OUT = 11 };
+
 __global__ void absmax_kernel(const float *__restrict__ x, long n, unsigned *word) {
     float m = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
@@ -173,22 +176,62 @@ __global__ void pack_vt_kernel(const float *__restrict__ kv, long items, int row
         }
     }
 }
-// The step tokens' K | V rows kvstep [n_tok][2 D] -> compact split rows [n_tok][4][D]: K hi, K lo, V hi, V lo
-__global__ void pack_step_kernel(const float *__restrict__ kvstep, long n_tok, int D, const unsigned *maxK, const unsigned *maxV,
-                                 f16 *__restrict__ dst, float *scaleK, float *scaleV) {
-    const float sk = f16_scale_from_bits(*maxK), sv = f16_scale_from_bits(*maxV);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *scaleK = sk;
-        *scaleV = sv;
+// The step tokens, all layers in one launch (a forward_with_context call of the reference's loop pays this once per call).  grid (n_tok, L),
+// 256 threads: K | V = Wkv tok + bkv -> kvstep [l][tok][2 D] (fp32), abs-max of the K and of the V columns -> words SC_KS / SC_VS of row l
+struct StepKvArgs { const float *wkv[MAX_L], *bkv[MAX_L]; };
+__global__ __launch_bounds__(256) void step_kv_all_kernel(StepKvArgs a, const float *__restrict__ tokens, int D, float *__restrict__ kvstep,
+                                                          long layer_stride, unsigned *maxbits) {
+    __shared__ __attribute__((aligned(16))) float st[512];
+    const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long tok = blockIdx.x;
+    for (int k = threadIdx.x; k < D; k += 256) st[k] = tokens[tok * D + k];
+    __syncthreads();
+    const float *wkv = a.wkv[l], *bkv = a.bkv[l];
+    float *out = kvstep + l * layer_stride + tok * 2 * D;
+    float mk = 0.f, mv = 0.f;
+    for (int o = wv; o < 2 * D; o += 4) {
+        float p = 0.f;
+        for (int k = 4 * lane; k < D; k += 256) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wkv + (long)o * D + k), t4 = *reinterpret_cast<const f32x4 *>(st + k);
+            p += (w4[0] * t4[0] + w4[1] * t4[1]) + (w4[2] * t4[2] + w4[3] * t4[3]);
+        }
+        const float v = wave_sum(p) + bkv[o];
+        if (lane == 0) out[o] = v;
+        if (o < D) mk = fmaxf(mk, fabsf(v));
+        else mv = fmaxf(mv, fabsf(v));
     }
+    if (lane == 0) {
+        unsigned *wk = maxbits + l * 16 + SC_KS, *wv2 = maxbits + l * 16 + SC_VS;
+        const unsigned bk = __builtin_bit_cast(unsigned, mk), bv = __builtin_bit_cast(unsigned, mv);
+        if (bk > __atomic_load_n(wk, __ATOMIC_RELAXED)) atomicMax(wk, bk);
+        if (bv > __atomic_load_n(wv2, __ATOMIC_RELAXED)) atomicMax(wv2, bv);
+    }
+}
+// grid (blocks, L): kvstep [l][n_tok][2 D] -> compact split rows [l][n_tok][4][D]: K hi, K lo, V hi, V lo; scales from words SC_KS / SC_VS ->
+// the layer's scale row (with no_ctx also into SC_K / SC_V: no context rows - their unused planes take the step rows' scales, a scale of 1
+// would drag the common value scale down)
+__global__ void pack_step_all_kernel(const float *__restrict__ kvstep, long src_layer_stride, long n_tok, int D, const unsigned *maxbits,
+                                     f16 *__restrict__ dst, long dst_layer_stride, float *scales, int no_ctx) {
+    const int l = blockIdx.y;
+    const float sk = f16_scale_from_bits(maxbits[l * 16 + SC_KS]), sv = f16_scale_from_bits(maxbits[l * 16 + SC_VS]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scales[l * 16 + SC_KS] = sk;
+        scales[l * 16 + SC_VS] = sv;
+        if (no_ctx) {
+            scales[l * 16 + SC_K] = sk;
+            scales[l * 16 + SC_V] = sv;
+        }
+    }
+    const float *src = kvstep + l * src_layer_stride;
+    f16 *d = dst + l * dst_layer_stride;
     const long total = n_tok * 2 * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long tok = i / (2 * D);
         const int c = (int)(i - tok * 2 * D), isv = c >= D, f = isv ? c - D : c;
-        const float v = kvstep[i] * (isv ? sv : sk);
+        const float v = src[i] * (isv ? sv : sk);
         const f16 h = (f16)v;
-        dst[(tok * 4 + 2 * isv) * D + f] = h;
-        dst[(tok * 4 + 2 * isv + 1) * D + f] = (f16)(v - (float)h);
+        d[(tok * 4 + 2 * isv) * D + f] = h;
+        d[(tok * 4 + 2 * isv + 1) * D + f] = (f16)(v - (float)h);
     }
 }
 // abs-max of the K columns and of the V columns of kv [rows][2 D], separately
@@ -214,21 +257,14 @@ __global__ void zero_words_kernel(unsigned *p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
-// sc[dst] = sc[src] for two pairs of every layer's 16-float row (no context rows: the context planes take the step planes' scales)
-__global__ void copy_scales_kernel(float *sc, int rows, int d0, int s0, int d1, int s1) {
+// zeroes words [col0, col0 + ncols) of every 16-word row
+__global__ void zero_word_cols16_kernel(unsigned *mb, int rows, int col0, int ncols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) {
-        sc[i * 16 + d0] = sc[i * 16 + s0];
-        sc[i * 16 + d1] = sc[i * 16 + s1];
-    }
+    if (i < rows * ncols) mb[(i / ncols) * 16 + col0 + i % ncols] = 0u;
 }
-
 // ---------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------
-// scale slots of a layer's 16-float row
-enum { SC_IN = 0, SC_O = 1, SC_Q = 2, SC_OC = 3, SC_1 = 4, SC_2 = 5, SC_K = 6, SC_V = 7, SC_KS = 8, SC_VS = 9, SC_EMB = 10, SC_OUT = 11 };
-
 struct LayerW {
     const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b;
     const f16 *w_in, *w_o, *w_q, *w_oc, *w_1, *w_2;      // fragment-major planes
@@ -286,6 +322,18 @@ struct TG {
         c.oK = c.oQ + (unsigned)(T * QROW);
         c.oS = c.oK + (unsigned)(T * VROW);
     }
+    // A copy of the context whose per-lane values the compiler must treat as new (sd_traj.h: ctx_local): every LDS address derived from
+    // them is then computed inside the phase that uses it.  Without this hipcc hoists the loop-invariant addresses of ALL phases out of the
+    // head and layer loops, keeps hundreds of them live and spills as many registers.
+    static __device__ __forceinline__ Ctx ctx_local(const Ctx &c) {
+        Ctx d = c;
+        asm volatile("" : "+v"(d.lane));
+        d.g = d.lane >> 4;
+        d.t = d.lane & 15;
+        d.okl = LAST0 + d.t < d.T;
+        d.tokl = d.okl ? LAST0 + d.t : d.T - 1;
+        return d;
+    }
     static __device__ __forceinline__ bool tok_ok(const Ctx &c, int tt) { return tt < NTT - 1 || c.okl; }
     static __device__ __forceinline__ int tok_of(const Ctx &c, int tt) { return tt < NTT - 1 ? 16 * tt + c.t : c.tokl; }
     // panel: row tok, 16-byte chunk (plane * XCH + k / 8), XOR-swizzled by the token (reads of 16 lanes = 16 tokens hit 16 different chunks)
@@ -304,7 +352,8 @@ struct TG {
     // ---- LayerNorm over the D features of H -> panel (scaled by ACT).  Per wave: mean and centred sum of squares of its 16 NA
     // features per token, exchanged through LDS, combined by Chan's formula in every lane (two barriers: the first also fences the
     // panel's previous readers)
-    static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c, const f32x4 (&H)[NA][NTT], const float *ln_w, const float *ln_b) {
+    static __device__ __forceinline__ void layer_norm_to_x(const Ctx &c0, const f32x4 (&H)[NA][NTT], const float *ln_w, const float *ln_b) {
+        const Ctx c = ctx_local(c0);
         constexpr float FW = 16.0f * NA;
         float *stat = reinterpret_cast<float *>(c.smem + c.oS);
         f32x4 gw[NA], gb[NA];
@@ -389,7 +438,8 @@ struct TG {
         }
     }
     // acc[a][tt] += W[n-tiles NA w + a] . X^T
-    static __device__ __forceinline__ void gemm_own(const Ctx &c, f32x4 (&acc)[NA][NTT], const f16 *wmat) {
+    static __device__ __forceinline__ void gemm_own(const Ctx &c0, f32x4 (&acc)[NA][NTT], const f16 *wmat) {
+        const Ctx c = ctx_local(c0);
         const f16 *pa[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) pa[a] = wmat + (long)(NA * c.w + a) * (KS * 2 * 512);
@@ -414,9 +464,11 @@ struct TG {
 
     // ---- self-attention of head h on the residual accumulators (pre-scaled by ACT * s_o): H += Wo[:, head] . O_head^T.
     // Q (later O) in the Q buffer, K (later V) in the K buffer; five barriers
-    static __device__ __forceinline__ void sa_head(const Ctx &c, const LayerW &L, int h, f32x4 (&H)[NA][NTT], float scale_log2e) {
+    static __device__ __forceinline__ void sa_head(const Ctx &c0, const LayerW &L, int h, f32x4 (&H)[NA][NTT], float scale_log2e) {
+        Ctx c = ctx_local(c0);
         char *Qb = c.smem + c.oQ, *Kb = c.smem + c.oK;
-        const int w = c.w, g = c.g, t = c.t;
+        const int w = c.w;
+        int g = c.g, t = c.t;
         // jobs of this wave: n-tiles w, w + 8, ... of the head's [Q | K | V] block (3 NQ n-tiles)
         f32x4 acc[NJOB][NTT];
 #pragma unroll
@@ -429,11 +481,20 @@ struct TG {
             const int job = min(w + 8 * j, 3 * NQ - 1), which = job / NQ, tile = job % NQ;
             pa[j] = L.w_in + (long)(which * (D / 16) + h * NQ + tile) * (KS * 2 * 512);
         }
-        gemm_panel<NJOB>(c, pa, [&](int j, int tt, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) __attribute__((always_inline)) {
-            if (w + 8 * j < 3 * NQ) mma3(acc[j][tt], ah, al, bh, bl);
-        });
+        // (a wave has NJOB or NJOB - 1 jobs: the choice is made once, outside the pipeline - a wave-uniform branch inside every one of its
+        // unrolled steps made hipcc keep the whole prefetch state live across all of them: 277 spilled registers at hidden_dim 128, T = 100)
+        auto body = [&](int j, int tt, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) __attribute__((always_inline)) { mma3(acc[j][tt], ah, al, bh, bl); };
+        if (w + 8 * (NJOB - 1) < 3 * NQ) {
+            gemm_panel<NJOB>(c, pa, body);
+        } else if constexpr (NJOB > 1) {
+            const f16 *pb[NJOB - 1];
+#pragma unroll
+            for (int j = 0; j < NJOB - 1; ++j) pb[j] = pa[j];
+            gemm_panel<NJOB - 1>(c, pb, body);
+        }
         const float c_in = 1.0f / L.sc[SC_IN];   // accumulator -> ACT * value
         __syncthreads();   // B1: the previous head's readers of Q / O and K / V are done
+        c = ctx_local(c0); g = c.g; t = c.t;
 #pragma unroll
         for (int j = 0; j < NJOB; ++j) {
             const int job = w + 8 * j, which = job / NQ, tile = job % NQ;
@@ -449,9 +510,15 @@ struct TG {
             }
         }
         __syncthreads();   // B2: Q, K complete
+        c = ctx_local(c0); g = c.g; t = c.t;
         f32x4 S[NTT];
         float psum = 1.f;
+#if defined(TG_ABL) && (TG_ABL & 8)
+        for (int kt = 0; kt < NTT; ++kt) S[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (false) {
+#else
         if (w < NTT) {
+#endif
             // scores S^T[key][query] = K Q^T of query tile w
             f16x8 qf[KH][2];
             const int qtok = min(16 * w + t, c.T - 1);
@@ -486,6 +553,7 @@ struct TG {
             psum = rows4_sum((ps[0] + ps[1]) + (ps[2] + ps[3]));
         }
         __syncthreads();   // B3: K is dead
+        c = ctx_local(c0); g = c.g; t = c.t;
 #pragma unroll
         for (int j = 0; j < NJOB; ++j) {
             const int job = w + 8 * j, tile = job % NQ;
@@ -499,7 +567,12 @@ struct TG {
             }
         }
         __syncthreads();   // B4: V complete (every wave has read its Q fragments: O may overwrite Q)
+        c = ctx_local(c0); g = c.g; t = c.t;
+#if defined(TG_ABL) && (TG_ABL & 16)
+        if (false) {
+#else
         if (w < NTT) {
+#endif
             // O^T = V^T P^T: P^T straight from the score accumulators (key order 16 (e >> 2) + 4 g + (e & 3) inside a pair of key tiles),
             // V^T through transposing LDS reads
             constexpr int NKP = (NTT + 1) / 2;
@@ -539,7 +612,11 @@ struct TG {
             }
         }
         __syncthreads();   // B5: O complete
+        c = ctx_local(c0); g = c.g; t = c.t;
         // out-projection of this head: K = HD
+#if defined(TG_ABL) && (TG_ABL & 64)
+        if (false)
+#endif
 #pragma unroll
         for (int kk = 0; kk < KH; ++kk) {
             f16x8 wo[NA][2];
@@ -560,9 +637,11 @@ struct TG {
 
     // ---- cross-attention over the projected memory (Mc context rows streamed from HBM + the step token); on entry the panel holds
     // LN2(h), on exit H has the block's output added
-    static __device__ __forceinline__ void cross_block(const Ctx &c, const LayerW &L, f32x4 (&H)[NA][NTT], long traj, const StepArgs &a, long sblk) {
+    static __device__ __forceinline__ void cross_block(const Ctx &c0, const LayerW &L, f32x4 (&H)[NA][NTT], long traj, const StepArgs &a, long sblk) {
+        Ctx c = ctx_local(c0);
         char *X = c.smem;
-        const int w = c.w, g = c.g, t = c.t;
+        const int w = c.w;
+        int g = c.g, t = c.t;
         // Q_c = Wq LN2(h) + bq -> the panel (ACT * q as split planes), in place
         {
             f32x4 U[NA][NTT];
@@ -590,6 +669,7 @@ struct TG {
         for (int ui = 0; ui < NUNIT; ++ui) {
             const int u = w + 8 * ui;
             if (u >= 4 * NTT) break;
+            c = ctx_local(c0); g = c.g; t = c.t;
             const int hh = u / NTT, qt = u - hh * NTT;
             const int qtok = qt < NTT - 1 ? 16 * qt + t : c.tokl;
             f16x8 qf[KH][2];
@@ -712,18 +792,24 @@ struct TG {
         unscale_h(c, H, 1.0f / up, L.b_oc);
     }
 
-    static __device__ __forceinline__ void decoder_layer(const Ctx &c, const LayerW &L, f32x4 (&H)[NA][NTT], long traj, const StepArgs &a, long sblk) {
+    static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[NA][NTT], long traj, const StepArgs &a, long sblk) {
+        const Ctx &c = c0;
         // ---- self-attention block: h += Wo . SA(LN1(h)) + bo   (the panel holds LN1(h))
         {
             const float up = ACT * L.sc[SC_O];
             scale_h(H, up);
+#if !(defined(TG_ABL) && (TG_ABL & 1))
 #pragma unroll 1
             for (int h = 0; h < 4; ++h) sa_head(c, L, h, H, a.scale_log2e);
+#endif
             unscale_h(c, H, 1.0f / up, L.b_o);
         }
         layer_norm_to_x(c, H, L.n2_w, L.n2_b);
+#if !(defined(TG_ABL) && (TG_ABL & 2))
         cross_block(c, L, H, traj, a, sblk);
+#endif
         layer_norm_to_x(c, H, L.n3_w, L.n3_b);
+#if !(defined(TG_ABL) && (TG_ABL & 4))
         // ---- feed-forward: h += W2 gelu(W1 LN3(h) + b1) + b2
         {
             f32x4 U[NA][NTT];
@@ -731,9 +817,10 @@ struct TG {
             for (int aa = 0; aa < NA; ++aa)
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) U[aa][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_own(c, U, L.w_1);
+            gemm_own(c0, U, L.w_1);
             const float c1 = 1.0f / (ACT * L.sc[SC_1]);
             __syncthreads();   // every wave has read LN3(h): the panel receives gelu(u)
+            const Ctx c = ctx_local(c0);
 #pragma unroll
             for (int aa = 0; aa < NA; ++aa) {
                 const f32x4 b1 = *reinterpret_cast<const f32x4 *>(L.b_1 + 16 * (NA * c.w + aa) + 4 * c.g);
@@ -747,9 +834,10 @@ struct TG {
             __syncthreads();
             const float up = ACT * L.sc[SC_2];
             scale_h(H, up);
-            gemm_own(c, H, L.w_2);
-            unscale_h(c, H, 1.0f / up, L.b_2);
+            gemm_own(c0, H, L.w_2);
+            unscale_h(c0, H, 1.0f / up, L.b_2);
         }
+#endif
     }
 
     static __device__ __forceinline__ void step_body(const StepArgs &a) {
@@ -874,6 +962,7 @@ __global__ __launch_bounds__(NTHREADS) void traj_step_generic_kernel(StepArgs a)
 
 }   // namespace tg
 
+#ifndef TG_NO_HOST   // (register-pressure experiments compile single instantiations of the kernel without the dispatch below)
 // ======================================================================================
 // host side
 // ======================================================================================
@@ -1001,8 +1090,8 @@ int trajg_prepare_ctx(const sd_denoiser_weights *w, float *gws, const float *ctx
     const GScratch s = gcarve(gws, B, Mc, d, L, n_tok);
     if (Mc == 0) return 0;   // no planes; the context scales are set from the step tokens' (trajg_prepare_steps)
     int rc;
-    for (int l = 0; l < L; ++l)
-        if ((rc = zero_words(s.maxbits + l * 16 + tg::SC_K, 2, st))) return rc;
+    SD_LAUNCH(tg::zero_word_cols16_kernel, dim3(1), dim3(64), 0, st, s.maxbits, L, (int)tg::SC_K, 2);
+    SD_CHECK_LAUNCH("zero_word_cols16_kernel");
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         float *kvl = kvtmp + (size_t)l * B * Mc * 2 * d;
@@ -1024,24 +1113,18 @@ int trajg_prepare_ctx(const sd_denoiser_weights *w, float *gws, const float *ctx
 int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *tokens, float *kvstep, int B, int Mc, int n_tok, hipStream_t st) {
     const int d = w->d, L = w->L;
     const GScratch s = gcarve(gws, B, Mc, d, L, n_tok);
-    int rc;
-    for (int l = 0; l < L; ++l)
-        if ((rc = zero_words(s.maxbits + l * 16 + tg::SC_KS, 2, st))) return rc;
+    SD_LAUNCH(tg::zero_word_cols16_kernel, dim3(1), dim3(64), 0, st, s.maxbits, L, (int)tg::SC_KS, 2);
+    SD_CHECK_LAUNCH("zero_word_cols16_kernel");
+    tg::StepKvArgs ka{};
     for (int l = 0; l < L; ++l) {
-        const sd_layer_weights &lw = w->layers[l];
-        float *kvl = kvstep + (size_t)l * n_tok * 2 * d;
-        if ((rc = linear(tokens, lw.ca_in_w + (size_t)d * d, lw.ca_in_b + d, nullptr, nullptr, nullptr, kvl, n_tok, 2 * d, d, 0, st, 0))) return rc;
-        unsigned *mb = s.maxbits + l * 16;
-        SD_LAUNCH(tg::absmax_kv_kernel, dim3(grid_for((long)n_tok * 2 * d)), dim3(256), 0, st, kvl, (long)n_tok, d, mb + tg::SC_KS, mb + tg::SC_VS);
-        SD_CHECK_LAUNCH("absmax_kv_kernel");
-        SD_LAUNCH(tg::pack_step_kernel, dim3(grid_for((long)n_tok * 2 * d)), dim3(256), 0, st, kvl, (long)n_tok, d, mb + tg::SC_KS, mb + tg::SC_VS,
-                  s.kvs + (size_t)l * s.kvs_layer_halfs, s.scales + l * 16 + tg::SC_KS, s.scales + l * 16 + tg::SC_VS);
-        SD_CHECK_LAUNCH("pack_step_kernel");
+        ka.wkv[l] = w->layers[l].ca_in_w + (size_t)d * d;   // the memory is NOT layer-normed: rows [d, 3 d) of in_proj
+        ka.bkv[l] = w->layers[l].ca_in_b + d;
     }
-    if (Mc == 0) {   // no context rows: their (unused) planes take the step rows' scales (a scale of 1 would drag the common value scale down)
-        SD_LAUNCH(tg::copy_scales_kernel, dim3(1), dim3(64), 0, st, s.scales, L, (int)tg::SC_K, (int)tg::SC_KS, (int)tg::SC_V, (int)tg::SC_VS);
-        SD_CHECK_LAUNCH("copy_scales_kernel");
-    }
+    SD_LAUNCH(tg::step_kv_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, ka, tokens, d, kvstep, (long)n_tok * 2 * d, s.maxbits);
+    SD_CHECK_LAUNCH("step_kv_all_kernel");
+    SD_LAUNCH(tg::pack_step_all_kernel, dim3(grid_for((long)n_tok * 2 * d), (unsigned)L), dim3(256), 0, st, kvstep, (long)n_tok * 2 * d, (long)n_tok, d,
+              s.maxbits, s.kvs, (long)s.kvs_layer_halfs, s.scales, Mc == 0 ? 1 : 0);
+    SD_CHECK_LAUNCH("pack_step_all_kernel");
     return 0;
 }
 
@@ -1092,3 +1175,4 @@ int trajg_step(const sd_denoiser_weights *w, float *gws, float *x, float *eps, i
     SD_CHECK_LAUNCH("traj_step_generic_kernel");
     return 0;
 }
+#endif   // TG_NO_HOST

@@ -154,7 +154,8 @@ class End2EndDiffusionTransformer(nn.Module):
         if step.dtype not in (torch.int64, torch.float32):
             step = step.to(torch.float32 if step.is_floating_point() else torch.int64)
         tokens = ops.step_token(step.contiguous(), self.step_encoding._freq, self.step_encoding.token.detach()).view(n_tok, self.hidden_dim)
-        wkey = (dag._signature(), tuple(p._version for p in dag.parameters()), ops.weights_generation())
+        # (dag.packed() rebuilds its descriptor when a parameter's storage moved: its identity stands for the pointers)
+        wkey = (id(packed), tuple(p._version for p in dag.parameters()), ops.weights_generation())
         return ls.eps(packed, list(context), tokens, x.contiguous(), wkey)
 
     # ---- extras ------------------------------------------------------------------------
