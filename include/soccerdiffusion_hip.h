@@ -508,6 +508,27 @@ int sd_adamw_hyper(double lr, double beta1, double beta2, double eps, double wei
  * changed the word.  Process-wide; NULL switches it off. */
 int sd_set_dropout_epoch(const uint32_t *device_word);
 
+/* ---- image path, TRAINING: torchvision BasicBlock / Bottleneck under autograd with BatchNorm2d in training mode, as the
+ * reference trains its backbone with every step (soccer_diffusion/ml/training/train.py:226-240 -> ml/model/encoder/image.py:38-83).  NHWC fp32
+ * tensors of npix = N * H * W pixels x C channels (C in {64, 128, 256, 512}), 16-byte aligned (soccerdiffusion_amd/csrc/sd_conv_train.hip).
+ *   sd_bn_train_fwd: batch statistics of y (the raw convolution output) -> mean, rstd = 1 / sqrt(biased var + eps) (C floats each);
+ *     z = relu?((y - mean) rstd gamma + beta (+ res)); running_mean / running_var updated as torch.nn.BatchNorm2d does (momentum, unbiased
+ *     variance) unless NULL; z_amax (one uint32, zeroed by the caller) receives the bits of max |z| for the next convolution's fp16 scale.
+ *     acc: 2 C doubles of scratch, ZEROED by the caller.
+ *   sd_bn_train_bwd: g = dz behind the ReLU mask (z > 0; z may be NULL when relu = 0); dgamma = sum g x_hat, dbeta = sum g,
+ *     dy = gamma rstd (g - mean(g) - x_hat mean(g x_hat)); dres (or NULL) receives g, the gradient of the residual operand; dy_amax as above.
+ *   sd_conv_wgrad: dw (Cout, Cin, k, k) (torch layout, ZEROED by the caller) += sum over output pixels of dy[pixel][co] x[pixel * stride + tap - k/2][ci]
+ *     for the k x k (1 or 3), stride 1 or 2, padding k / 2 convolution of x (N,H,W,Cin) with output dy (N,Ho,Wo,Cout); Cin, Cout multiples
+ *     of 64.  Split-fp16 MFMAs with block floating point per 32 pixels, fp32 atomics.
+ * The data gradient is the forward convolution (sd_conv3x3_bn_act / sd_conv1x1_bn_act, identity epilogue) of dy - dilated with zeros for a
+ * stride-2 convolution - with the flipped, transposed weights. */
+int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const float *res, float *z, float *mean, float *rstd,
+                    float *running_mean, float *running_var, double *acc, uint32_t *z_amax, int64_t npix, int C, float eps, float momentum,
+                    int relu, void *stream);
+int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
+                    float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream);
+int sd_conv_wgrad(const float *dy, const float *x, float *dw, int N, int H, int W, int Cin, int Cout, int ksize, int stride, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference's surface) ----
  * While enabled, every kernel launch made by this library is bracketed by a hipEvent pair
  * on the launch stream.  sd_profile_collect waits for them, returns the summed device

@@ -16,7 +16,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "sd_kernels.hip"), os.path.join(PKG, "csrc", "sd_train.hip"),
        os.path.join(PKG, "csrc", "sd_train_chain.hip"), os.path.join(PKG, "csrc", "sd_conv.hip"),
-       os.path.join(PKG, "csrc", "sd_train_traj.hip"), os.path.join(PKG, "csrc", "sd_trajg.hip")]
+       os.path.join(PKG, "csrc", "sd_train_traj.hip"), os.path.join(PKG, "csrc", "sd_trajg.hip"),
+       os.path.join(PKG, "csrc", "sd_conv_train.hip")]
 HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG, "csrc", "sd_common.h"),
        os.path.join(PKG, "csrc", "sd_panel.h"), os.path.join(PKG, "csrc", "sd_f16x3.h"), os.path.join(PKG, "csrc", "sd_traj.h"),
        os.path.join(PKG, "csrc", "sd_trajg.h")]
@@ -46,7 +47,8 @@ def _deps(src: str) -> list:
     hdr = [h for h in HDR if not (h.endswith("sd_f16x3.h") and not src.endswith("sd_kernels.hip"))
            and not (h.endswith("sd_trajg.h") and not (src.endswith("sd_kernels.hip") or src.endswith("sd_trajg.hip")))
            and not (h.endswith("sd_traj.h") and not (src.endswith("sd_kernels.hip") or src.endswith("sd_train_traj.hip")))
-           and not (h.endswith("sd_panel.h") and (src.endswith("sd_train.hip") or src.endswith("sd_conv.hip")))]
+           and not (h.endswith("sd_panel.h") and (src.endswith("sd_train.hip") or src.endswith("sd_conv.hip") or src.endswith("sd_conv_train.hip")
+                                                 or src.endswith("sd_trajg.hip")))]
     return [src] + hdr
 
 

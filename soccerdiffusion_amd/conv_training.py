@@ -1,0 +1,151 @@
+"""Training path of the image backbone on this package's kernels: one ``torch.autograd.Function`` per
+convolution + BatchNorm (+ residual) (+ ReLU) unit of a torchvision BasicBlock / Bottleneck, NHWC tensors.
+
+Reference: the backbone is trained with every step (soccer_diffusion/ml/training/train.py:226-240 calls ``model(batch, ...)`` ->
+ml/model/encoder/image.py:38-52 -> torchvision ResNet under autograd, BatchNorm2d in training mode).
+
+forward   y = conv(h)                      sd_conv3x3_bn_act / sd_conv1x1_bn_act / sd_conv_s2_bn_act with an identity epilogue (csrc/sd_conv.hip)
+          z = relu?(BN_train(y) (+ res))   sd_bn_train_fwd: batch statistics, running statistics as torch updates them, abs-max word of z
+backward  dy, dgamma, dbeta (, dres)       sd_bn_train_bwd
+          dW                               sd_conv_wgrad (csrc/sd_conv_train.hip)
+          dh                               the forward convolution kernel on the flipped, transposed weights; a stride-2 unit's dy is
+                                           dilated with zeros first (exact: dh[j] = sum_t dil[j + t - 1] w[2 - t])
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+Tensor = torch.Tensor
+_const_cache: dict = {}
+
+
+def _ones_zeros(n: int, device):
+    key = (n, torch.device(device))
+    hit = _const_cache.get(key)
+    if hit is None:
+        hit = _const_cache[key] = (torch.ones(n, dtype=torch.float32, device=device), torch.zeros(n, dtype=torch.float32, device=device))
+    return hit
+
+
+def conv_raw(h: Tensor, amax: Tensor, pk: "ops.PackedConv3x3", stride: int) -> Tensor:
+    """The bare convolution (k = pk.ksize, padding k // 2, ``stride`` 1 or 2) of an NHWC tensor: the inference kernels with scale 1, shift 0, no ReLU."""
+    one, zero = _ones_zeros(pk.Cout, h.device)
+    if stride == 1:
+        return ops.conv3x3_bn_act(h, amax, pk, one, zero, relu=False)
+    return ops.conv_s2_bn_act(h, amax, pk, one, zero, relu=False)
+
+
+def bn_train_fwd(y: Tensor, gamma: Tensor, beta: Tensor, res: Optional[Tensor], running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                 eps: float, momentum: float, relu: bool):
+    """-> (z, z_amax word, mean, rstd) for the NHWC tensor y; running statistics updated in place."""
+    lib = _lib.load()
+    Cn = y.shape[-1]
+    npix = y.numel() // Cn
+    z = torch.empty_like(y)
+    mean = torch.empty(Cn, dtype=torch.float32, device=y.device)
+    rstd = torch.empty_like(mean)
+    acc = torch.zeros(2 * Cn, dtype=torch.float64, device=y.device)
+    word = torch.zeros(1, dtype=torch.int32, device=y.device)
+    check(lib.sd_bn_train_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ops._ptr(res), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                              ops._ptr(running_mean), ops._ptr(running_var), acc.data_ptr(), word.data_ptr(), npix, Cn, float(eps), float(momentum),
+                              int(relu), ops._stream()), "sd_bn_train_fwd")
+    return z, word, mean, rstd
+
+
+def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, relu: bool, want_dres: bool):
+    """-> (dy, dy_amax word, dgamma, dbeta, dres or None)."""
+    lib = _lib.load()
+    Cn = y.shape[-1]
+    npix = y.numel() // Cn
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    dgamma = torch.empty(Cn, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    acc = torch.zeros(2 * Cn, dtype=torch.float64, device=y.device)
+    word = torch.zeros(1, dtype=torch.int32, device=y.device)
+    check(lib.sd_bn_train_bwd(dz.data_ptr(), ops._ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dy.data_ptr(), ops._ptr(dres),
+                              dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), word.data_ptr(), npix, Cn, int(relu), ops._stream()), "sd_bn_train_bwd")
+    return dy, word, dgamma, dbeta, dres
+
+
+def conv_wgrad(dy: Tensor, h: Tensor, weight_shape, stride: int) -> Tensor:
+    """dW (Cout, Cin, k, k) of the k x k / padding k // 2 / ``stride`` convolution with input h (N,H,W,Cin) and output gradient dy (N,Ho,Wo,Cout)."""
+    lib = _lib.load()
+    Cout, Cin, k, _ = weight_shape
+    N, H, W, _ = h.shape
+    dw = torch.zeros(Cout, Cin, k, k, dtype=torch.float32, device=h.device)
+    check(lib.sd_conv_wgrad(dy.data_ptr(), h.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, stride, ops._stream()), "sd_conv_wgrad")
+    return dw
+
+
+class PackedPair:
+    """The forward planes of a convolution weight and the planes of its flipped transpose (the data gradient's weight), repacked together when
+    the weight changes (version counter or ``ops.weights_generation()``)."""
+
+    def __init__(self):
+        self.fwd = self.bwd = None
+        self.key = None
+
+    def get(self, weight: Tensor):
+        key = (weight._version, ops.weights_generation(), weight.data_ptr())
+        if self.key != key or self.fwd.planes.device != weight.device:
+            w = weight.detach()
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()
+            self.fwd, self.bwd = ops.PackedConv3x3(w.contiguous()), ops.PackedConv3x3(wt)
+            self.key = key
+        return self.fwd, self.bwd
+
+
+class ConvBNUnit(torch.autograd.Function):
+    """z, z_amax = relu?(BatchNorm_train(conv(h)) (+ res)) on NHWC tensors."""
+
+    @staticmethod
+    def forward(ctx, h, amax, weight, gamma, beta, res, pair: PackedPair, running_mean, running_var, stride: int, relu: bool, eps: float, momentum: float):
+        h = h.contiguous()
+        fwd, bwd = pair.get(weight)
+        y = conv_raw(h, amax, fwd, stride)
+        z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), res, running_mean, running_var, eps, momentum, relu)
+        ctx.save_for_backward(h, y, z if relu else None, mean, rstd, gamma)
+        ctx.cfg = (bwd, tuple(weight.shape), stride, relu, res is not None)
+        ctx.mark_non_differentiable(word)
+        return z, word
+
+    @staticmethod
+    def backward(ctx, dz, _dword):
+        h, y, z, mean, rstd, gamma = ctx.saved_tensors
+        bwd, wshape, stride, relu, has_res = ctx.cfg
+        dy, word, dgamma, dbeta, dres = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), relu, has_res and ctx.needs_input_grad[5])
+        dW = conv_wgrad(dy, h, wshape, stride) if ctx.needs_input_grad[2] else None
+        dh = None
+        if ctx.needs_input_grad[0]:
+            d = dy
+            if stride == 2:   # dilate with zeros: the stride-2 convolution's data gradient is the stride-1 one of the dilated gradient
+                d = torch.zeros(h.shape[0], h.shape[1], h.shape[2], dy.shape[3], dtype=torch.float32, device=dy.device)
+                d[:, ::2, ::2] = dy
+            dh = conv_raw(d, word, bwd, 1)
+        return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def unit(h: Tensor, amax: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, res: Optional[Tensor], relu: bool, pair: PackedPair):
+    """One conv + BatchNorm(train) (+ res) (+ ReLU) unit of a torchvision block on NHWC tensors; bumps ``num_batches_tracked`` like torch."""
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats and bn.running_mean is not None
+    z, word = ConvBNUnit.apply(h, amax, conv.weight, bn.weight, bn.bias, res, pair, bn.running_mean if track else None, bn.running_var if track else None,
+                               conv.stride[0], relu, bn.eps, momentum)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return z, word
+
+
+def supported(conv: torch.nn.Conv2d) -> bool:
+    k, s = conv.kernel_size[0], conv.stride[0]
+    ok = (k in (1, 3) and s in (1, 2) and conv.padding[0] == k // 2 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+          and conv.bias is None and conv.groups == 1 and conv.dilation[0] == 1)
+    return ok and (s == 1 or conv.out_channels % 128 == 0)

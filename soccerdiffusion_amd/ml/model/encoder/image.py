@@ -113,6 +113,31 @@ class _BasicBlock(nn.Module):
         y = ops.conv3x3_bn_act(out, a1, self._packed("_pk2", self.conv2), *self._bn_fold(self.bn2), res=idt, relu=True, y_amax=a2, zero_amax=False)
         return y, a2
 
+    def forward_train_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
+        """Training (BatchNorm on batch statistics, autograd) on the hand-written kernels: h (N, H, W, C) NHWC with its abs-max word ->
+        (h', its abs-max word).  Three conv + BN units: the 1 x 1 shortcut where the block has one, conv1, conv2 (+ identity)."""
+        idt = h if self.downsample is None else _train_unit(h, amax, self.downsample[0], self.downsample[1], None, False)[0]
+        out, a1 = _train_unit(h, amax, self.conv1, self.bn1, None, True)
+        return _train_unit(out, a1, self.conv2, self.bn2, idt, True)
+
+
+def _train_unit(h, amax, conv, bn, res, relu):
+    """conv + BatchNorm(training) (+ res) (+ ReLU) of a torchvision block under autograd on this package's kernels (conv_training.py)."""
+    from .... import conv_training as ct
+
+    store = _derived(conv)
+    pair = store.get("pair")
+    if pair is None:
+        pair = store["pair"] = ct.PackedPair()
+    return ct.unit(h, amax, conv, bn, res, relu, pair)
+
+
+def _train_ok(block) -> bool:
+    from .... import conv_training as ct
+
+    convs = [m for m in block.modules() if isinstance(m, nn.Conv2d)]
+    return all(ct.supported(c) for c in convs)
+
 
 class _Bottleneck(nn.Module):
     expansion = 4
@@ -154,6 +179,13 @@ class _Bottleneck(nn.Module):
         y = ops.conv3x3_bn_act(out, a2, self._packed("_pk3", self.conv3), *fold(self.bn3), res=idt, relu=True, y_amax=a3, zero_amax=False)
         return y, a3
 
+    def forward_train_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
+        """As _BasicBlock.forward_train_nhwc: conv1 1 x 1, conv2 3 x 3 (the block's stride), conv3 1 x 1 (+ identity / 1 x 1 shortcut)."""
+        idt = h if self.downsample is None else _train_unit(h, amax, self.downsample[0], self.downsample[1], None, False)[0]
+        out, a1 = _train_unit(h, amax, self.conv1, self.bn1, None, True)
+        out, a2 = _train_unit(out, a1, self.conv2, self.bn2, None, True)
+        return _train_unit(out, a2, self.conv3, self.bn3, idt, True)
+
 
 class _ResNet(nn.Module):
     """torchvision.models.resnet.ResNet, attribute for attribute (conv1, bn1, layer1-4, avgpool, fc)."""
@@ -181,7 +213,30 @@ class _ResNet(nn.Module):
         return (x.is_cuda and x.dtype == torch.float32 and self.conv1.weight.dtype == torch.float32 and not self.training
                 and not torch.is_grad_enabled() and os.environ.get("SD_CONV", "hip") != "torch")
 
+    def _hip_training(self, x: torch.Tensor) -> bool:
+        """train() mode (BatchNorm on batch statistics) on fp32 CUDA tensors: the blocks run conv_training.ConvBNUnit.  (eval() mode WITH a tape -
+        fine-tuning on frozen statistics - keeps torch.nn, as does SD_CONV=torch.)"""
+        if not (x.is_cuda and x.dtype == torch.float32 and self.conv1.weight.dtype == torch.float32 and self.training
+                and os.environ.get("SD_CONV", "hip") != "torch"):
+            return False
+        ok = self.__dict__.get("_train_ok")
+        if ok is None:
+            ok = self.__dict__["_train_ok"] = all(_train_ok(b) for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer)
+        return ok
+
     def forward(self, x):
+        if self._hip_training(x):
+            # Training: the stem (7 x 7 convolution of 3 input channels, BatchNorm, ReLU, max-pool: ~ 6 % of the backbone's FLOPs) stays on
+            # torch.nn; every block runs on this package's kernels (convolution forward / data gradient / weight gradient, training-mode
+            # BatchNorm forward / backward) behind one autograd.Function per conv + BatchNorm unit, on NHWC tensors.
+            h = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            h = h.permute(0, 2, 3, 1).contiguous()
+            amax = ops.absmax_word(h.detach())
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in layer:
+                    h, amax = blk.forward_train_nhwc(h, amax)
+            x = h.permute(0, 3, 1, 2)
+            return self.fc(torch.flatten(self.avgpool(x), 1))
         if self._hip_inference(x):
             # the whole inference forward on the hand-written kernels: the stem (conv1 / bn1 / relu / maxpool) in one launch from the NCHW
             # frames to an NHWC map, the basic blocks on NHWC tensors, back to an NCHW view for the head

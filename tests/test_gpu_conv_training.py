@@ -1,0 +1,170 @@
+"""SURVEY 8 row f2, TRAINING path of the image backbone (csrc/sd_conv_train.hip, soccerdiffusion_amd/conv_training.py): training-mode
+BatchNorm forward / backward, the convolution weight gradient and the data gradient (the forward kernels on flipped, transposed weights,
+dilated for the stride-2 units) against torch's CPU operators in fp64 - per op, per conv + BN unit, and for EVERY parameter of ResNet-18
+through the module (reference: torchvision BasicBlock under autograd as soccer_diffusion/ml/model/encoder/image.py:55-83 builds it and
+ml/training/train.py:226-240 trains it)."""
+
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,H,W,C,relu,with_res", [(2, 9, 11, 64, True, True), (3, 8, 8, 128, False, False), (1, 5, 7, 512, True, False),
+                                                    (2, 30, 40, 256, True, True)])
+def test_bn_train_forward_and_backward_match_torch_fp64(N, H, W, C, relu, with_res):
+    from soccerdiffusion_amd import conv_training as ct
+
+    g = torch.Generator().manual_seed(C + H)
+    y = (torch.randn(N, H, W, C, generator=g) * 2 + 3.0)   # a mean well away from zero: the shifted sums must not cancel
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    res = torch.randn(N, H, W, C, generator=g) if with_res else None
+    dz = torch.randn(N, H, W, C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    # torch reference in fp64 (NCHW)
+    yd = y.double().permute(0, 3, 1, 2).requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rd = res.double().permute(0, 3, 1, 2).requires_grad_() if with_res else None
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    out = F.batch_norm(yd, rm_ref, rv_ref, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    if with_res:
+        out = out + rd
+    if relu:
+        out = out.relu()
+    out.backward(dz.double().permute(0, 3, 1, 2))
+    # ours
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    z, word, mean, rstd = ct.bn_train_fwd(y.cuda(), gamma.cuda(), beta.cuda(), res.cuda() if with_res else None, rm_g, rv_g, 1e-5, 0.1, relu)
+    assert rel_err(z.permute(0, 3, 1, 2), out) < 2e-6
+    assert rel_err(rm_g, rm_ref) < 1e-6 and rel_err(rv_g, rv_ref) < 1e-6
+    assert abs(float(torch.tensor([int(word.item())], dtype=torch.int32).view(torch.float32)) - float(z.abs().max())) < 1e-6 * float(z.abs().max())
+    dy, dword, dgamma, dbeta, dres = ct.bn_train_bwd(dz.cuda(), z if relu else None, y.cuda(), mean, rstd, gamma.cuda(), relu, with_res)
+    assert rel_err(dy.permute(0, 3, 1, 2), yd.grad) < 1e-5
+    assert rel_err(dgamma, gd.grad) < 1e-5 and rel_err(dbeta, bd.grad) < 1e-5
+    if with_res:
+        assert rel_err(dres.permute(0, 3, 1, 2), rd.grad) < 1e-6
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride", [(2, 9, 11, 64, 64, 3, 1), (1, 17, 33, 64, 128, 3, 2), (2, 8, 8, 128, 64, 1, 1), (1, 10, 12, 64, 128, 1, 2),
+                                                     (1, 7, 70, 128, 256, 3, 2), (3, 6, 5, 256, 64, 3, 1)])
+def test_conv_weight_and_data_gradients_match_torch_fp64(N, H, W, Cin, Cout, k, stride):
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd import ops
+
+    g = torch.Generator().manual_seed(Cin + Cout + k + stride)
+    h = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    hd = h.double().permute(0, 3, 1, 2).requires_grad_()
+    wd = w.double().requires_grad_()
+    out = F.conv2d(hd, wd, stride=stride, padding=k // 2)
+    dy = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dy)
+    dy_nhwc = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = ct.conv_wgrad(dy_nhwc, h.cuda(), (Cout, Cin, k, k), stride)
+    assert rel_err(dw, wd.grad) < 1e-5
+    # forward and data gradient through the packed pair (the data gradient = forward kernel on flipped, transposed weights)
+    pair = ct.PackedPair()
+    fwd, bwd = pair.get(w.cuda())
+    y = ct.conv_raw(h.cuda(), ops.absmax_word(h.cuda()), fwd, stride)
+    assert rel_err(y.permute(0, 3, 1, 2), out) < 2e-6
+    d = dy_nhwc
+    if stride == 2:
+        d = torch.zeros(N, H, W, Cout, device="cuda")
+        d[:, ::2, ::2] = dy_nhwc
+    dh = ct.conv_raw(d, ops.absmax_word(d), bwd, 1)
+    assert rel_err(dh.permute(0, 3, 1, 2), hd.grad) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 3, 480, 640)])
+def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
+    """gradients of every ResNet-18 parameter (and of the input frames) against the same modules on the CPU in fp64,
+    train() mode: batch statistics, running statistics and num_batches_tracked updated as torch does."""
+    import copy
+
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd.ml.model.encoder.image import _BasicBlock, _ResNet
+
+    torch.manual_seed(1)
+    net = _ResNet(_BasicBlock, [2, 2, 2, 2])
+    net.fc = torch.nn.Linear(512, 32)
+    with torch.no_grad():   # non-trivial BatchNorm affine parameters and statistics
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(net).double().train()
+    gpu = copy.deepcopy(net).cuda().train()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(2))
+    xr = x.double().requires_grad_()
+    wr = torch.randn(shape[0], 32, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    out_ref = ref(xr)
+    (out_ref * wr).sum().backward()
+    calls = []
+    orig = ct.ConvBNUnit.apply
+    ct.ConvBNUnit.apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xg = x.cuda().requires_grad_()
+        out = gpu(xg)
+        (out * wr.float().cuda()).sum().backward()
+    finally:
+        ct.ConvBNUnit.apply = orig
+    assert len(calls) == 19   # 16 block convolutions + 3 shortcuts: every unit behind the stem ran on this package's kernels
+    assert rel_err(out, out_ref) < 1e-5
+    pr, pg = dict(ref.named_parameters()), dict(gpu.named_parameters())
+    worst = 0.0
+    for name, p in pr.items():
+        e = rel_err(pg[name].grad, p.grad)
+        worst = max(worst, e)
+        assert e < 2e-4, (name, e)   # (deep fp32 chain with batch statistics; the block-level tests above hold 1e-5)
+    assert rel_err(xg.grad, xr.grad) < 2e-4
+    # running statistics and counters after ONE training forward
+    bg = dict(gpu.named_buffers())
+    for name, b in ref.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(bg[name]) == int(b) == 1, name
+        else:
+            assert rel_err(bg[name], b) < 1e-5, name
+
+
+def test_training_step_of_the_image_conditioned_model_uses_the_unit_kernels():
+    """Through the boundary class: a train_step of the image-conditioned model (configs[4]'s structure at a small size) runs the backbone's
+    blocks on ConvBNUnit and moves every backbone parameter; SD_CONV=torch gives the same loss on the torch.nn route."""
+    from test_gpu_image_path import _model
+
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd.scheduler import DDIMScheduler
+    from soccerdiffusion_amd.training import FusedAdamW, train_step
+
+    dev = torch.device("cuda:0")
+    losses = {}
+    for route in ("hip", "torch"):
+        torch.manual_seed(0)
+        m = _model(dev).train().set_dropout(0.0)
+        opt = FusedAdamW(m.parameters(), lr=1e-3)
+        sch = DDIMScheduler(beta_schedule="squaredcos_cap_v2", clip_sample=False)
+        B, Fr, R = 4, 3, 64
+        g = torch.Generator().manual_seed(3)
+        data = {"joint_command_history": torch.randn(B, 20, 20, generator=g).to(dev), "image_data": torch.rand(B, Fr, 3, R, R, generator=g).to(dev),
+                "game_state": torch.randint(0, 4, (B,), generator=g).to(dev)}
+        target = torch.randn(B, 12, 20, generator=g).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(4)
+        calls = []
+        orig = ct.ConvBNUnit.apply
+        ct.ConvBNUnit.apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        if route == "torch":
+            os.environ["SD_CONV"] = "torch"
+        try:
+            losses[route] = [float(train_step(m, opt, None, sch, target, input_data=data, generator=gen)) for _ in range(2)]
+        finally:
+            ct.ConvBNUnit.apply = orig
+            os.environ.pop("SD_CONV", None)
+        assert len(calls) == (2 * 19 if route == "hip" else 0)
+    assert abs(losses["hip"][0] - losses["torch"][0]) < 1e-4 * abs(losses["torch"][0])
+    assert abs(losses["hip"][1] - losses["torch"][1]) < 5e-3 * abs(losses["torch"][1])   # after one update of both replicas
