@@ -106,24 +106,65 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
     wr = torch.randn(shape[0], 32, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
     out_ref = ref(xr)
     (out_ref * wr).sum().backward()
-    calls = []
-    orig = ct.ConvBNUnit.apply
+    calls, wg_rec, bn_rec = [], [], []
+    orig, orig_wg, orig_bn = ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd
+
+    def wgrad_spy(dy, h, wshape, stride):
+        dw = orig_wg(dy, h, wshape, stride)
+        wg_rec.append((dy, h, wshape, stride, dw))
+        return dw
+
+    def bn_spy(dz, z, y, mean, rstd, gamma, relu, want_dres):
+        res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want_dres)
+        bn_rec.append((dz, z, y, mean, rstd, gamma, relu, res))
+        return res
+
     ct.ConvBNUnit.apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    ct.conv_wgrad, ct.bn_train_bwd = wgrad_spy, bn_spy
     try:
         xg = x.cuda().requires_grad_()
         out = gpu(xg)
         (out * wr.float().cuda()).sum().backward()
     finally:
-        ct.ConvBNUnit.apply = orig
+        ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd = orig, orig_wg, orig_bn
+    # every weight-gradient and BatchNorm-backward launch of this backward against fp64 ON THE SAME TENSORS (the kernels' own error, free of
+    # what fp32 rounding upstream does to ReLU masks and max-pool winners)
+    assert len(wg_rec) == 19 and len(bn_rec) == 19
+    for dy, h, wshape, stride, dw in wg_rec:
+        want = torch.nn.grad.conv2d_weight(h.double().cpu().permute(0, 3, 1, 2), wshape, dy.double().cpu().permute(0, 3, 1, 2), stride=stride,
+                                           padding=wshape[2] // 2)
+        assert rel_err(dw, want) < 1e-5, (wshape, stride, tuple(h.shape))
+    for dz, z, y, mean, rstd, gamma, relu, (dy, _w, dgamma, dbeta, dres) in bn_rec:
+        g = dz.double().cpu() * ((z.double().cpu() > 0) if relu else 1.0)
+        xh = (y.double().cpu() - mean.double().cpu()) * rstd.double().cpu()
+        n = g.numel() // g.shape[-1]
+        s1, s2 = g.reshape(n, -1).sum(0), (g * xh).reshape(n, -1).sum(0)
+        want = gamma.double().cpu() * rstd.double().cpu() * (g - s1 / n - xh * s2 / n)
+        assert rel_err(dy, want) < 1e-5 and rel_err(dgamma, s2) < 1e-5 and rel_err(dbeta, s1) < 1e-5
     assert len(calls) == 19   # 16 block convolutions + 3 shortcuts: every unit behind the stem ran on this package's kernels
     assert rel_err(out, out_ref) < 1e-5
     pr, pg = dict(ref.named_parameters()), dict(gpu.named_parameters())
-    worst = 0.0
-    for name, p in pr.items():
-        e = rel_err(pg[name].grad, p.grad)
-        worst = max(worst, e)
-        assert e < 2e-4, (name, e)   # (deep fp32 chain with batch statistics; the block-level tests above hold 1e-5)
-    assert rel_err(xg.grad, xr.grad) < 2e-4
+    errs = {name: rel_err(pg[name].grad, p.grad) for name, p in pr.items()}
+    errs["input frames"] = rel_err(xg.grad, xr.grad)
+    # the same modules on the GPU's torch.nn route (MIOpen) against the same fp64 reference: how well conditioned this backward is in fp32 at all
+    lib = copy.deepcopy(net).cuda().train()
+    os.environ["SD_CONV"] = "torch"
+    try:
+        xl = x.cuda().requires_grad_()
+        (lib(xl) * wr.float().cuda()).sum().backward()
+    finally:
+        del os.environ["SD_CONV"]
+    pl = dict(lib.named_parameters())
+    lerr = {name: rel_err(pl[name].grad, p.grad) for name, p in pr.items()}
+    lerr["input frames"] = rel_err(xl.grad, xr.grad)
+    print("worst gradient errors:", sorted(errs.items(), key=lambda kv: -kv[1])[:6])
+    print("torch.nn route       :", sorted(lerr.items(), key=lambda kv: -kv[1])[:6])
+    # End to end an fp32 backward of this depth is only as good as its conditioning: at 480 x 640 a handful of ReLU masks / max-pool winners
+    # differ between ANY fp32 forward and the fp64 one and move the early layers' gradients by ~ 5e-3 on both routes alike.  Bar: 2e-5 where
+    # the problem is well conditioned (the small frame), never worse than 1.5 x the library route's worst error on the same problem.
+    bar = max(2e-5, 1.5 * max(lerr.values()))
+    for name, e in errs.items():
+        assert e < bar, (name, e, lerr[name], bar)
     # running statistics and counters after ONE training forward
     bg = dict(gpu.named_buffers())
     for name, b in ref.named_buffers():
