@@ -519,7 +519,8 @@ int sd_set_dropout_epoch(const uint32_t *device_word);
  *     dy = gamma rstd (g - mean(g) - x_hat mean(g x_hat)); dres (or NULL) receives g, the gradient of the residual operand; dy_amax as above.
  *   sd_conv_wgrad: dw (Cout, Cin, k, k) (torch layout, ZEROED by the caller) += sum over output pixels of dy[pixel][co] x[pixel * stride + tap - k/2][ci]
  *     for the k x k (1 or 3), stride 1 or 2, padding k / 2 convolution of x (N,H,W,Cin) with output dy (N,Ho,Wo,Cout); Cin, Cout multiples
- *     of 64.  Split-fp16 MFMAs with block floating point per 32 pixels, fp32 atomics.
+ *     of 64.  Split-fp16 MFMAs, fp32 atomics.  dy_amax / x_amax: the tensors' abs-max words (as sd_bn_train_bwd / sd_bn_train_fwd leave them)
+ *     -> one power-of-two scale per operand for the launch; either NULL -> block floating point per 32 pixels (abs-max taken inside).
  * The data gradient is the forward convolution (sd_conv3x3_bn_act / sd_conv1x1_bn_act, identity epilogue) of dy - dilated with zeros for a
  * stride-2 convolution - with the flipped, transposed weights. */
 int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const float *res, float *z, float *mean, float *rstd,
@@ -527,7 +528,11 @@ int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const
                     int relu, void *stream);
 int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
                     float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream);
-int sd_conv_wgrad(const float *dy, const float *x, float *dw, int N, int H, int W, int Cin, int Cout, int ksize, int stride, void *stream);
+/* scratch (sd_conv_wgrad_scratch_floats floats, or NULL): the 3 x 3 / stride-1 kernel stores per-row-group partial tiles there and a second launch
+ * adds them up (no atomics: thousands of workgroups adding to the same Cout x Cin x 9 floats are bound by the L2's atomic rate) */
+size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H, int W,
+                  int Cin, int Cout, int ksize, int stride, void *stream);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference's surface) ----
  * While enabled, every kernel launch made by this library is bracketed by a hipEvent pair

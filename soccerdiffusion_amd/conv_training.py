@@ -75,13 +75,18 @@ def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd:
     return dy, word, dgamma, dbeta, dres
 
 
-def conv_wgrad(dy: Tensor, h: Tensor, weight_shape, stride: int) -> Tensor:
-    """dW (Cout, Cin, k, k) of the k x k / padding k // 2 / ``stride`` convolution with input h (N,H,W,Cin) and output gradient dy (N,Ho,Wo,Cout)."""
+def conv_wgrad(dy: Tensor, h: Tensor, weight_shape, stride: int, dy_amax: Optional[Tensor] = None, h_amax: Optional[Tensor] = None) -> Tensor:
+    """dW (Cout, Cin, k, k) of the k x k / padding k // 2 / ``stride`` convolution with input h (N,H,W,Cin) and output gradient dy (N,Ho,Wo,Cout).
+    With both abs-max words the kernel uses one fp16 scale per operand; without, block floating point per 32 pixels."""
     lib = _lib.load()
     Cout, Cin, k, _ = weight_shape
     N, H, W, _ = h.shape
     dw = torch.zeros(Cout, Cin, k, k, dtype=torch.float32, device=h.device)
-    check(lib.sd_conv_wgrad(dy.data_ptr(), h.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, k, stride, ops._stream()), "sd_conv_wgrad")
+    both = dy_amax is not None and h_amax is not None
+    n_scratch = lib.sd_conv_wgrad_scratch_floats(N, H, W, Cin, Cout, k, stride) if both else 0
+    scratch = torch.empty(n_scratch, dtype=torch.float32, device=h.device) if n_scratch else None
+    check(lib.sd_conv_wgrad(dy.data_ptr(), h.data_ptr(), ops._ptr(dy_amax) if both else None, ops._ptr(h_amax) if both else None, dw.data_ptr(),
+                            ops._ptr(scratch), N, H, W, Cin, Cout, k, stride, ops._stream()), "sd_conv_wgrad")
     return dw
 
 
@@ -112,17 +117,17 @@ class ConvBNUnit(torch.autograd.Function):
         fwd, bwd = pair.get(weight)
         y = conv_raw(h, amax, fwd, stride)
         z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), res, running_mean, running_var, eps, momentum, relu)
-        ctx.save_for_backward(h, y, z if relu else None, mean, rstd, gamma)
+        ctx.save_for_backward(h, y, z if relu else None, mean, rstd, gamma, amax)
         ctx.cfg = (bwd, tuple(weight.shape), stride, relu, res is not None)
         ctx.mark_non_differentiable(word)
         return z, word
 
     @staticmethod
     def backward(ctx, dz, _dword):
-        h, y, z, mean, rstd, gamma = ctx.saved_tensors
+        h, y, z, mean, rstd, gamma, h_amax = ctx.saved_tensors
         bwd, wshape, stride, relu, has_res = ctx.cfg
         dy, word, dgamma, dbeta, dres = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), relu, has_res and ctx.needs_input_grad[5])
-        dW = conv_wgrad(dy, h, wshape, stride) if ctx.needs_input_grad[2] else None
+        dW = conv_wgrad(dy, h, wshape, stride, word, h_amax) if ctx.needs_input_grad[2] else None
         dh = None
         if ctx.needs_input_grad[0]:
             d = dy
@@ -131,6 +136,34 @@ class ConvBNUnit(torch.autograd.Function):
                 d[:, ::2, ::2] = dy
             dh = conv_raw(d, word, bwd, 1)
         return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+class BNUnit(torch.autograd.Function):
+    """z, z_amax = relu?(BatchNorm_train(y)) on an NHWC tensor (the stem's BatchNorm behind torch's 7 x 7 convolution)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu: bool, eps: float, momentum: float):
+        y = y.contiguous()
+        z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, relu)
+        ctx.save_for_backward(y, z if relu else None, mean, rstd, gamma)
+        ctx.relu = relu
+        ctx.mark_non_differentiable(word)
+        return z, word
+
+    @staticmethod
+    def backward(ctx, dz, _dword):
+        y, z, mean, rstd, gamma = ctx.saved_tensors
+        dy, _word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), ctx.relu, False)
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_unit(y: Tensor, bn: torch.nn.BatchNorm2d, relu: bool):
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats and bn.running_mean is not None
+    z, word = BNUnit.apply(y, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None, relu, bn.eps, momentum)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return z, word
 
 
 def unit(h: Tensor, amax: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, res: Optional[Tensor], relu: bool, pair: PackedPair):

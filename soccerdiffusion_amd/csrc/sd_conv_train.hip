@@ -14,6 +14,7 @@
 // soccerdiffusion_amd/conv_training.py).
 #include "../../include/soccerdiffusion_hip.h"
 #include "sd_common.h"
+#include <stdlib.h>
 
 namespace cvt {
 
@@ -161,16 +162,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
 struct WgradArgs {
     const float *dy;   // [N][Ho][Wo][Cout]
     const float *x;    // [N][H][W][Cin]
+    const unsigned *dy_amax, *x_amax;   // abs-max words of the two tensors, or NULL: block floating point per 32 pixels
     float *dw;         // [Cout][Cin][ks][ks], zeroed by the caller
     int N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad;
     int rows_per_item;   // output image rows per work item
     int n_row_items;     // ceil(N * Ho / rows_per_item)
+    float *part;         // conv_wgrad3_kernel: [n_row_items][Cout][Cin][9] partial sums (plain stores; wgrad_reduce_kernel adds them up), or NULL: atomics
 };
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // Both tensors' abs-max words known (the producing launches left them behind): ONE power-of-two scale per operand for the whole
+    // launch, as the forward convolution does - no per-step reductions, no sub-accumulator (the step is bound by its vector instructions)
+    constexpr bool global_scale = GLOBAL;
+    const float gsy = global_scale ? f16_scale_from_bits(*a.dy_amax) : 1.f, gsx = global_scale ? f16_scale_from_bits(*a.x_amax) : 1.f;
     for (long row = row0; row < row1; ++row) {
         const int n = (int)(row / a.Ho), oy = (int)(row - (long)n * a.Ho);
         const int iy = oy * a.stride + ky - a.pad;
@@ -217,6 +225,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                         mx = fmaxf(mx, fabsf(vb));
                     }
                 }
+            if constexpr (global_scale) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float va = av[st][t][e] * gsy, vb = bv[st][t][e] * gsx;
+                            ah[t][e] = (f16)va;
+                            al[t][e] = (f16)(va - (float)ah[t][e]);
+                            bh[t][e] = (f16)vb;
+                            bl[t][e] = (f16)(vb - (float)bh[t][e]);
+                        }
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        }
+                }
+                continue;
+            }
             const float sy = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(my)));
             const float sx = f16_scale_from_bits(__builtin_bit_cast(unsigned, wave_max(mx)));
             f32x16 sub[2][2];
@@ -259,10 +292,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cot * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v = acc[tm][tn][r];
+                const float v = acc[tm][tn][r] * (global_scale ? 1.0f / (gsy * gsx) : 1.0f);
                 if (v != 0.f) atomicAdd(a.dw + ((long)co * a.Cin + ci) * taps + tap, v);
             }
         }
+}
+
+// ---- 3 x 3, stride 1 (13 of ResNet-18's 16 block convolutions): all nine taps from ONE staging of the operands.  The per-wave kernel above
+// fetches 16 KB per 262 kFLOP - every tap re-reads dY and a shifted X - and sits on the L2's bandwidth (~ 90 TFLOP/s).  Here a workgroup
+// (4 waves) owns a 64 (co) x 64 (ci) tile of dW for ALL nine taps: per 32 output pixels of an image row it stages dY (32 x 64) and the
+// 3 x 34 x 64 halo of X once through LDS as fp16 hi | lo planes (16-byte global loads; one power-of-two scale per tensor from its abs-max
+// word), and wave (co half, ci half) runs 9 taps x 6 MFMAs on fragments from transposing LDS reads (ds_read_b64_tr_b16: 8 consecutive
+// pixels of one channel per lane) - the dY fragments are shared by the nine taps, a tap's X fragments are the same rows shifted by (ky, kx).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int W3_PITCH = 72;                       // halfs per staged pixel (64 channels + 8: 144 bytes, an odd number of 16-byte units)
+constexpr int W3_DY = 32 * W3_PITCH;               // halfs of the dY plane
+constexpr int W3_XROW = 34 * W3_PITCH;             // ... of one halo row of X
+constexpr int W3_PLANE = W3_DY + 3 * W3_XROW;      // one plane (hi or lo): dY, then the three halo rows
+__device__ __forceinline__ f16x8 w3_frag(const f16 *plane, int row0, int col0, int lane) {
+    // as tns_frag of sd_train.hip: lane (l31, half) receives channel col0 + l31, pixels row0 + 0 .. 7 (row0 already holds 8 * half)
+    const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, gc = ((lane >> 4) & 1) * 16;
+    const f16 *at = plane + (row0 + q) * W3_PITCH + col0 + gc + p4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)at);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(at + 4 * W3_PITCH));
+    return __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) f16 sm[2 * W3_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int coh = wave & 1, cih = wave >> 1;     // this wave's 32-channel halves of the tile
+    const int ct = a.Cout / 64, it = a.Cin / 64;
+    long item = blockIdx.x;
+    const int cit = (int)(item % it); item /= it;
+    const int cot = (int)(item % ct); item /= ct;
+    const long row0 = item * a.rows_per_item, row1 = row0 + a.rows_per_item < (long)a.N * a.H ? row0 + a.rows_per_item : (long)a.N * a.H;
+    const float sy = f16_scale_from_bits(*a.dy_amax), sx = f16_scale_from_bits(*a.x_amax);
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // staging assignments: dY 32 x 16 float4 (2 per thread), halo 102 x 16 float4 (up to 7 per thread)
+    const int c4 = (tid & 15) * 4;
+    const float *dyb = a.dy + cot * 64 + c4, *xb = a.x + cit * 64 + c4;
+    const int nsteps = (a.W + 31) / 32;
+    f32x4 yv[2], xv[7];
+    auto load = [&](long row, int x0) __attribute__((always_inline)) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const int n = (int)(row / a.H), oy = (int)(row - (long)n * a.H);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int ox = x0 + (tid >> 4) + 16 * v;
+            yv[v] = ox < a.W ? *reinterpret_cast<const f32x4 *>(dyb + (row * a.W + ox) * (long)a.Cout) : z;
+        }
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const int i = (tid >> 4) + 16 * v;             // halo pixel index 0 .. 101: row i / 34, column i % 34
+            const int hr = i / 34, hx = i - hr * 34, iy = oy + hr - 1, ix = x0 - 1 + hx;
+            const bool ok = i < 102 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            xv[v] = ok ? *reinterpret_cast<const f32x4 *>(xb + (((long)n * a.H + iy) * a.W + ix) * (long)a.Cin) : z;
+        }
+    };
+    const long nwork = (row1 - row0) * nsteps;
+    if (nwork > 0) load(row0, 0);
+    for (long wk = 0; wk < nwork; ++wk) {
+        __syncthreads();   // every wave is done reading the previous step's planes
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            f16x4 h, l;
+            f16_split4(yv[v], sy, h, l);
+            f16 *o = sm + ((tid >> 4) + 16 * v) * W3_PITCH + c4;
+            *reinterpret_cast<f16x4 *>(o) = h;
+            *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
+        }
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const int i = (tid >> 4) + 16 * v;
+            if (i < 102) {
+                f16x4 h, l;
+                f16_split4(xv[v], sx, h, l);
+                f16 *o = sm + W3_DY + i * W3_PITCH + c4;
+                *reinterpret_cast<f16x4 *>(o) = h;
+                *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
+            }
+        }
+        if (wk + 1 < nwork) {   // the next step's global loads are in flight during this step's MFMAs
+            const long nx = wk + 1;
+            load(row0 + nx / nsteps, (int)(nx % nsteps) * 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int r0 = 16 * st + 8 * half;
+            const f16x8 ah = w3_frag(sm, r0, coh * 32, lane), al = w3_frag(sm + W3_PLANE, r0, coh * 32, lane);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                const f16 *xp = sm + W3_DY + ky * W3_XROW;
+                const f16x8 bh = w3_frag(xp, r0 + kx, cih * 32, lane), bl = w3_frag(xp + W3_PLANE, r0 + kx, cih * 32, lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // Every workgroup of a (co, ci) tile adds to the SAME 36 864 floats: with atomics the launch was bound by them (1 477 workgroups x 36 864
+    // adds on 147 KB of addresses at layer 1: 2.0 ms per launch, 10 x the MFMA time).  Each workgroup stores its partial tile instead; a
+    // second launch adds the row groups up (deterministic, too).
+    const float un = 1.0f / (sy * sx);
+    const int ci = cit * 64 + cih * 32 + l31;
+    float *out = a.part ? a.part + item * ((long)a.Cout * a.Cin * 9) : a.dw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cot * 64 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[t][r] * un;
+            if (a.part) out[((long)co * a.Cin + ci) * 9 + t] = v;
+            else if (v != 0.f) atomicAdd(out + ((long)co * a.Cin + ci) * 9 + t, v);
+        }
+}
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts, long n, float *__restrict__ dw) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < n_parts; ++p) s += part[p * n + i];
+        dw[i] = s;
+    }
 }
 
 }   // namespace cvt
@@ -310,21 +466,55 @@ extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, 
     return 0;
 }
 
-extern "C" int sd_conv_wgrad(const float *dy, const float *x, float *dw, int N, int H, int W, int Cin, int Cout, int ksize, int stride, void *stream) {
+// row groups of conv_wgrad3_kernel: ~1024 workgroups per launch (two per CU resident, two rounds), at least one image row each
+static int wgrad3_rows_per_item(long rows, int Cin, int Cout) {
+    const long tiles = (long)(Cout / 64) * (Cin / 64);
+    long groups = (1024 + tiles - 1) / tiles;
+    if (groups > rows) groups = rows;
+    if (groups < 1) groups = 1;
+    return (int)((rows + groups - 1) / groups);
+}
+extern "C" size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride) {
+    if (ksize != 3 || stride != 1 || N <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const long rows = (long)N * H;
+    const int rpi = wgrad3_rows_per_item(rows, Cin, Cout);
+    return (size_t)((rows + rpi - 1) / rpi) * Cout * Cin * 9;
+}
+extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H,
+                             int W, int Cin, int Cout, int ksize, int stride, void *stream) {
     if (!dy || !x || !dw || N <= 0 || H <= 0 || W <= 0) return fail(SD_E_BADARG, "sd_conv_wgrad: null pointer or empty shape");
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return fail(SD_E_BADARG, "sd_conv_wgrad: kernel size 1 or 3, stride 1 or 2");
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv_wgrad: channels must be positive multiples of 64");
     const int pad = ksize / 2, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    cvt::WgradArgs a{dy, x, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0};
+    cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0, nullptr};
     // ~4096 pixels per work item: long enough that a tile's 4096 atomics are a small part of its work, short enough to fill the chip
     a.rows_per_item = (4096 + Wo - 1) / Wo;
     const long rows = (long)N * Ho;
     while (a.rows_per_item > 1 && (rows + a.rows_per_item - 1) / a.rows_per_item * (Cout / 64) * (Cin / 64) * ksize * ksize < 2048) a.rows_per_item = (a.rows_per_item + 1) / 2;
     a.n_row_items = (int)((rows + a.rows_per_item - 1) / a.rows_per_item);
+    static const char *simple = getenv("SD_WGRAD_SIMPLE");   // A/B runs: the per-wave kernel for every shape
+    if (ksize == 3 && stride == 1 && dy_amax && x_amax && !(simple && simple[0] == '1') &&
+        !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15)) {
+        // workgroup items: (row group, co tile, ci tile); with `scratch` (sd_conv_wgrad_scratch_floats) every item stores its partial tile
+        a.rows_per_item = wgrad3_rows_per_item(rows, Cin, Cout);
+        a.n_row_items = (int)((rows + a.rows_per_item - 1) / a.rows_per_item);
+        a.part = scratch;
+        const long wg3 = (long)(Cout / 64) * (Cin / 64) * a.n_row_items;
+        if (wg3 > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
+        SD_LAUNCH(cvt::conv_wgrad3_kernel, dim3((unsigned)wg3), dim3(256), 0, (hipStream_t)stream, a);
+        SD_CHECK_LAUNCH("conv_wgrad3_kernel");
+        if (scratch) {
+            const long n = (long)Cout * Cin * 9;
+            SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, scratch, a.n_row_items, n, dw);
+            SD_CHECK_LAUNCH("wgrad_reduce_kernel");
+        }
+        return 0;
+    }
     const long items = (long)(Cout / 64) * (Cin / 64) * ksize * ksize * a.n_row_items;
     const long wgs = (items + 3) / 4;
     if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
-    SD_LAUNCH(cvt::conv_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    if (dy_amax && x_amax) SD_LAUNCH(cvt::conv_wgrad_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    else SD_LAUNCH(cvt::conv_wgrad_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv_wgrad_kernel");
     return 0;
 }

@@ -229,8 +229,12 @@ class _ResNet(nn.Module):
             # Training: the stem (7 x 7 convolution of 3 input channels, BatchNorm, ReLU, max-pool: ~ 6 % of the backbone's FLOPs) stays on
             # torch.nn; every block runs on this package's kernels (convolution forward / data gradient / weight gradient, training-mode
             # BatchNorm forward / backward) behind one autograd.Function per conv + BatchNorm unit, on NHWC tensors.
-            h = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-            h = h.permute(0, 2, 3, 1).contiguous()
+            from .... import conv_training as ct
+
+            y = self.conv1(x).permute(0, 2, 3, 1).contiguous()           # torch's 7 x 7 convolution; its output as NHWC
+            z, _ = ct.bn_unit(y, self.bn1, relu=True)                    # training-mode BatchNorm + ReLU on this package's kernels
+            h = self.maxpool(z.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)  # ATen's channels-last max-pool: the result is NHWC-contiguous
+            h = h.contiguous()
             amax = ops.absmax_word(h.detach())
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:

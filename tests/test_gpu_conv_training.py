@@ -67,6 +67,9 @@ def test_conv_weight_and_data_gradients_match_torch_fp64(N, H, W, Cin, Cout, k, 
     dy_nhwc = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
     dw = ct.conv_wgrad(dy_nhwc, h.cuda(), (Cout, Cin, k, k), stride)
     assert rel_err(dw, wd.grad) < 1e-5
+    from soccerdiffusion_amd import ops as o
+    dw2 = ct.conv_wgrad(dy_nhwc, h.cuda(), (Cout, Cin, k, k), stride, o.absmax_word(dy_nhwc), o.absmax_word(h.cuda()))   # one scale per operand
+    assert rel_err(dw2, wd.grad) < 1e-5
     # forward and data gradient through the packed pair (the data gradient = forward kernel on flipped, transposed weights)
     pair = ct.PackedPair()
     fwd, bwd = pair.get(w.cuda())
@@ -109,8 +112,8 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
     calls, wg_rec, bn_rec = [], [], []
     orig, orig_wg, orig_bn = ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd
 
-    def wgrad_spy(dy, h, wshape, stride):
-        dw = orig_wg(dy, h, wshape, stride)
+    def wgrad_spy(dy, h, wshape, stride, *words):
+        dw = orig_wg(dy, h, wshape, stride, *words)
         wg_rec.append((dy, h, wshape, stride, dw))
         return dw
 
@@ -129,7 +132,7 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
         ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd = orig, orig_wg, orig_bn
     # every weight-gradient and BatchNorm-backward launch of this backward against fp64 ON THE SAME TENSORS (the kernels' own error, free of
     # what fp32 rounding upstream does to ReLU masks and max-pool winners)
-    assert len(wg_rec) == 19 and len(bn_rec) == 19
+    assert len(wg_rec) == 19 and len(bn_rec) == 20   # (+ the stem's BatchNorm)
     for dy, h, wshape, stride, dw in wg_rec:
         want = torch.nn.grad.conv2d_weight(h.double().cpu().permute(0, 3, 1, 2), wshape, dy.double().cpu().permute(0, 3, 1, 2), stride=stride,
                                            padding=wshape[2] // 2)

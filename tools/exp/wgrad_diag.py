@@ -17,8 +17,8 @@ x = torch.rand(1, 3, 480, 640, generator=torch.Generator().manual_seed(2)).cuda(
 wr = torch.randn(1, 32, generator=torch.Generator().manual_seed(3)).cuda()
 rec = []
 orig_w, orig_raw = ct.conv_wgrad, ct.conv_raw
-def wg(dy, h, shape, stride):
-    dw = orig_w(dy, h, shape, stride)
+def wg(dy, h, shape, stride, *words):
+    dw = orig_w(dy, h, shape, stride, *words)
     rec.append(("wgrad", dy.detach().clone(), h.detach().clone(), shape, stride, dw.detach().clone()))
     return dw
 ct.conv_wgrad = wg
