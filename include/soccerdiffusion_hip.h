@@ -528,6 +528,14 @@ int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const
                     int relu, void *stream);
 int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
                     float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream);
+/* The stem in training: sd_stem_conv_raw = the bare 7 x 7 / stride-2 / padding-3 convolution of sd_stem_conv_bn_relu_pool (same packed planes,
+ * same kernel) -> y_raw (N, Hc, Wc, 64) NHWC, Hc = (H - 1) / 2 + 1; sd_stem_wgrad: its weight gradient dw (64, 3, 7, 7) from dy (N, Hc, Wc, 64)
+ * and the frames x (N, 3, H, W), both with their abs-max words; scratch: sd_stem_wgrad_scratch_floats(N, H, W) floats.  (The frames need no gradient.) */
+int sd_stem_conv_raw(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, float *y_raw, int N, int H, int W,
+                     void *stream);
+size_t sd_stem_wgrad_scratch_floats(int N, int H, int W);
+int sd_stem_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H, int W,
+                  void *stream);
 /* scratch (sd_conv_wgrad_scratch_floats floats, or NULL): the 3 x 3 / stride-1 kernel stores per-row-group partial tiles there and a second launch
  * adds them up (no atomics: thousands of workgroups adding to the same Cout x Cin x 9 floats are bound by the L2's atomic rate) */
 size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride);

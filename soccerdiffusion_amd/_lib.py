@@ -111,6 +111,9 @@ SIGNATURES = {
     "sd_bn_train_bwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "sd_conv_wgrad": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "sd_conv_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 7),
+    "sd_stem_conv_raw": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
+    "sd_stem_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 3),
+    "sd_stem_wgrad": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]),
     "sd_sampler_prepare": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_sampler_eps": (C.c_int, [C.POINTER(DenoiserWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "sd_op_linear": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -138,6 +138,58 @@ class ConvBNUnit(torch.autograd.Function):
         return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+def stem_conv_raw(x: Tensor, x_amax: Tensor, pk: "ops.PackedStem") -> Tensor:
+    """The bare stem convolution (7 x 7, stride 2, padding 3, 3 -> 64) of NCHW frames -> NHWC map (N, Hc, Wc, 64): the inference stem kernel without
+    its BatchNorm / ReLU / max-pool epilogue."""
+    ops._req(x, "x")
+    N, _, H, W = x.shape
+    y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, dtype=torch.float32, device=x.device)
+    check(_lib.load().sd_stem_conv_raw(x.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), x_amax.data_ptr(), y.data_ptr(), N, H, W, ops._stream()),
+          "sd_stem_conv_raw")
+    return y
+
+
+def stem_wgrad(dy: Tensor, x: Tensor, dy_amax: Tensor, x_amax: Tensor) -> Tensor:
+    """dW (64, 3, 7, 7) of the stem convolution from dy (N, Hc, Wc, 64) NHWC and the frames x (N, 3, H, W)."""
+    lib = _lib.load()
+    N, _, H, W = x.shape
+    dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(lib.sd_stem_wgrad_scratch_floats(N, H, W), dtype=torch.float32, device=x.device)
+    check(lib.sd_stem_wgrad(dy.data_ptr(), x.data_ptr(), dy_amax.data_ptr(), x_amax.data_ptr(), dw.data_ptr(), scratch.data_ptr(), N, H, W, ops._stream()),
+          "sd_stem_wgrad")
+    return dw
+
+
+class StemUnit(torch.autograd.Function):
+    """z, z_amax = relu(BatchNorm_train(conv7x7/s2(x))): NCHW frames -> NHWC map.  The frames receive no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, pk: "ops.PackedStem", running_mean, running_var, eps: float, momentum: float):
+        x = x.contiguous()
+        x_amax = ops.absmax_word(x)
+        y = stem_conv_raw(x, x_amax, pk.refresh(weight))
+        z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, True)
+        ctx.save_for_backward(x, x_amax, y, z, mean, rstd, gamma)
+        ctx.mark_non_differentiable(word)
+        return z, word
+
+    @staticmethod
+    def backward(ctx, dz, _dword):
+        x, x_amax, y, z, mean, rstd, gamma = ctx.saved_tensors
+        dy, word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), True, False)
+        dW = stem_wgrad(dy, x, word, x_amax) if ctx.needs_input_grad[1] else None
+        return None, dW, dgamma, dbeta, None, None, None, None, None
+
+
+def stem_unit(x: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, pk: "ops.PackedStem"):
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats and bn.running_mean is not None
+    z, word = StemUnit.apply(x, conv.weight, bn.weight, bn.bias, pk, bn.running_mean if track else None, bn.running_var if track else None, bn.eps, momentum)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return z, word
+
+
 class BNUnit(torch.autograd.Function):
     """z, z_amax = relu?(BatchNorm_train(y)) on an NHWC tensor (the stem's BatchNorm behind torch's 7 x 7 convolution)."""
 

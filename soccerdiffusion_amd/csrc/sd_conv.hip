@@ -450,6 +450,7 @@ struct StemArgs {
     float *y;                 // [N][Hp][Wp][64]
     unsigned *y_amax;
     int N, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
+    float *y_raw;             // training: [N][Hc][Wc][64] receives the bare convolution (no BatchNorm, ReLU, pool; y unused), or NULL
 };
 
 __global__ __launch_bounds__(ST_THREADS) void stem_kernel(StemArgs a) {
@@ -528,9 +529,24 @@ __global__ __launch_bounds__(ST_THREADS) void stem_kernel(StemArgs a) {
             }
         }
     }
+    const float un = 1.0f / (s_in * *a.w_scale);
+    if (a.y_raw) {
+        // training: the bare convolution output.  Neighbouring tiles share a row / column of convolution pixels (the pool's halo): a tile
+        // stores rows / columns 1 .. of its 9 x 17 pixels
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (row >= ST_NPX) continue;
+                const int cy = row / ST_CW, cx = row - cy * ST_CW;
+                const int gy = cy0 + cy, gx = cx0 + cx;
+                if (cy >= 1 && cx >= 1 && gy < a.Hc && gx < a.Wc) a.y_raw[(((long)n * a.Hc + gy) * a.Wc + gx) * 64 + 32 * m + j] = acc[m][r] * un;
+            }
+        return;
+    }
     __syncthreads();   // the input planes are consumed: the region becomes the pooling buffer [153 px][ST_CPITCH]
     float *cbuf = reinterpret_cast<float *>(smem);
-    const float un = 1.0f / (s_in * *a.w_scale);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int co = 32 * m + j;
@@ -675,12 +691,25 @@ extern "C" int sd_stem_pack(const float *w, void *planes, float *scale, uint32_t
     return 0;
 }
 
+static int stem_launch(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                       const float *bn_shift, float *y, uint32_t *y_amax, float *y_raw, int N, int H, int W, void *stream);
 extern "C" int sd_stem_conv_bn_relu_pool(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
                                          const float *bn_shift, float *y, uint32_t *y_amax, int N, int H, int W, void *stream) {
-    if (!x || !w_planes || !w_scale || !x_amax || !bn_scale || !bn_shift || !y || N <= 0 || H <= 0 || W <= 0)
+    if (!bn_scale || !bn_shift || !y) return fail(SD_E_BADARG, "sd_stem_conv_bn_relu_pool: null pointer or empty shape");
+    return stem_launch(x, w_planes, w_scale, x_amax, bn_scale, bn_shift, y, y_amax, nullptr, N, H, W, stream);
+}
+extern "C" int sd_stem_conv_raw(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, float *y_raw, int N, int H, int W,
+                                void *stream) {
+    if (!y_raw) return fail(SD_E_BADARG, "sd_stem_conv_raw: null pointer");
+    return stem_launch(x, w_planes, w_scale, x_amax, nullptr, nullptr, nullptr, nullptr, y_raw, N, H, W, stream);
+}
+static int stem_launch(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,
+                       const float *bn_shift, float *y, uint32_t *y_amax, float *y_raw, int N, int H, int W, void *stream) {
+    if (!x || !w_planes || !w_scale || !x_amax || N <= 0 || H <= 0 || W <= 0)
         return fail(SD_E_BADARG, "sd_stem_conv_bn_relu_pool: null pointer or empty shape");
     cv::StemArgs a;
     a.x = x; a.w = (const f16 *)w_planes; a.w_scale = w_scale; a.x_amax = x_amax; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.y = y; a.y_amax = y_amax;
+    a.y_raw = y_raw;
     a.N = N; a.H = H; a.W = W;
     a.Hc = (H - 1) / 2 + 1; a.Wc = (W - 1) / 2 + 1;          // conv 7 x 7, stride 2, padding 3
     a.Hp = (a.Hc - 1) / 2 + 1; a.Wp = (a.Wc - 1) / 2 + 1;    // max-pool 3 x 3, stride 2, padding 1

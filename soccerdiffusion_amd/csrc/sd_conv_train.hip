@@ -421,6 +421,111 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts,
     }
 }
 
+// ---- weight gradient of the ResNet stem: conv 7 x 7, stride 2, padding 3, 3 -> 64 channels, input frames NCHW.
+// dW[co][ci][ky][kx] = sum over output pixels of dY[pixel][co] x[ci][2 oy + ky - 3][2 ox + kx - 3]: M = 64 output channels, N = 147 columns
+// (ky, kx, ci) padded to 160, K = pixels.  A workgroup walks segments of 32 output pixels of one output row: it stages dY (32 x 64) and the
+// 7 x 69 x 3 input tile - channel-interleaved like the forward kernel's, so that the 21 values (kx, ci) of a kernel row are consecutive
+// halfs - as fp16 hi | lo planes; wave (co half, column-tile parity) takes the dY fragments from transposing reads and GATHERS its column's
+// 8 consecutive pixels (12 bytes apart: stride 2 x 3 channels) with 16-bit LDS reads.  Partial tiles per workgroup, summed by
+// wgrad_reduce_kernel into torch's (64, 3, 7, 7) layout.
+struct StemWgradArgs {
+    const float *dy;     // [N][Hc][Wc][64]
+    const float *x;      // [N][3][H][W]
+    const unsigned *dy_amax, *x_amax;
+    float *part;         // [n_items][64][3][7][7]
+    int N, H, W, Hc, Wc, segs_per_row, steps_per_item;
+    long n_steps;        // N * Hc * segs_per_row
+};
+constexpr int SW_XP = 216;                         // halfs per staged input row: 69 pixels x 3 channels = 207 (+ 9)
+constexpr int SW_DY = 32 * W3_PITCH;               // halfs of the dY plane (as conv_wgrad3_kernel)
+constexpr int SW_PLANE = SW_DY + 7 * SW_XP;
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) f16 sm[2 * SW_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int coh = wave & 1, par = wave >> 1;     // output-channel half; column tiles par, par + 2 (, par + 4)
+    const float sy = f16_scale_from_bits(*a.dy_amax), sx = f16_scale_from_bits(*a.x_amax);
+    constexpr int NT = 3;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // this lane's column of every tile: c = 32 (par + 2 t) + l31 -> (ky, 3 kx + ci); columns >= 147 read the tile's first element with a zero flag
+    int coff[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = 32 * (par + 2 * t) + l31;
+        cok[t] = c < 147 && par + 2 * t < 5;
+        const int ky = cok[t] ? c / 21 : 0, kc = cok[t] ? c - 21 * ky : 0;
+        coff[t] = SW_DY + ky * SW_XP + kc;
+    }
+    const long s0 = (long)blockIdx.x * a.steps_per_item, s1 = s0 + a.steps_per_item < a.n_steps ? s0 + a.steps_per_item : a.n_steps;
+    const int c4 = (tid & 15) * 4;
+    for (long st = s0; st < s1; ++st) {
+        const int seg = (int)(st % a.segs_per_row);
+        const long row = st / a.segs_per_row;          // n * Hc + oy
+        const int n = (int)(row / a.Hc), oy = (int)(row - (long)n * a.Hc), ox0 = 32 * seg;
+        __syncthreads();   // the previous step's readers are done
+        // dY: 32 pixels x 16 float4
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int p = (tid >> 4) + 16 * v, ox = ox0 + p;
+            f32x4 y4 = {0.f, 0.f, 0.f, 0.f};
+            if (ox < a.Wc) y4 = *reinterpret_cast<const f32x4 *>(a.dy + (row * a.Wc + ox) * 64L + c4);
+            f16x4 h, l;
+            f16_split4(y4, sy, h, l);
+            f16 *o = sm + p * W3_PITCH + c4;
+            *reinterpret_cast<f16x4 *>(o) = h;
+            *reinterpret_cast<f16x4 *>(o + SW_PLANE) = l;
+        }
+        // input tile: rows 2 oy - 3 .. + 6, columns 2 ox0 - 3 .. + 68, 3 channels interleaved: half index 3 * col + ci
+        for (int i = tid; i < 7 * 3 * 69; i += 256) {
+            const int rr = i / 207, rem = i - rr * 207, ci = rem / 69, cc = rem - ci * 69;
+            const int iy = 2 * oy - 3 + rr, ix = 2 * ox0 - 3 + cc;
+            const float v = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? a.x[(((long)n * 3 + ci) * a.H + iy) * a.W + ix] * sx : 0.f;
+            const f16 h = (f16)v;
+            f16 *o = sm + SW_DY + rr * SW_XP + 3 * cc + ci;
+            o[0] = h;
+            o[SW_PLANE] = (f16)(v - (float)h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = 16 * ks + 8 * half;
+            const f16x8 ah = w3_frag(sm, r0, coh * 32, lane), al = w3_frag(sm + SW_PLANE, r0, coh * 32, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (par + 2 * t >= 5) continue;   // wave-uniform
+                f16x8 bh, bl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {   // pixel r0 + e: 6 halfs (2 input pixels x 3 channels) further along the row
+                    const f16 *at = sm + coff[t] + 6 * (r0 + e);
+                    bh[e] = cok[t] ? at[0] : (f16)0;
+                    bl[e] = cok[t] ? at[SW_PLANE] : (f16)0;
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // column c = (ky, kx, ci) -> torch's W[co][ci][ky][kx]
+    const float un = 1.0f / (sy * sx);
+    float *out = a.part + (long)blockIdx.x * (64 * 147);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (par + 2 * t >= 5 || !cok[t]) continue;
+        const int c = 32 * (par + 2 * t) + l31, ky = c / 21, kc = c - 21 * ky, kx = kc / 3, ci = kc - 3 * kx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[((co * 3 + ci) * 7 + ky) * 7 + kx] = acc[t][r] * un;
+        }
+    }
+}
+
 }   // namespace cvt
 
 static unsigned blocks_for(long n, long per_block, long cap) {
@@ -516,5 +621,31 @@ extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy
     if (dy_amax && x_amax) SD_LAUNCH(cvt::conv_wgrad_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     else SD_LAUNCH(cvt::conv_wgrad_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv_wgrad_kernel");
+    return 0;
+}
+
+extern "C" size_t sd_stem_wgrad_scratch_floats(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;
+    const long n_steps = (long)N * Hc * ((Wc + 31) / 32);
+    const long items = n_steps < 1024 ? n_steps : 1024;
+    return (size_t)items * 64 * 147;
+}
+extern "C" int sd_stem_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H,
+                             int W, void *stream) {
+    if (!dy || !x || !dy_amax || !x_amax || !dw || !scratch || N <= 0 || H <= 0 || W <= 0) return fail(SD_E_BADARG, "sd_stem_wgrad: null pointer or empty shape");
+    if (reinterpret_cast<uintptr_t>(dy) & 15) return fail(SD_E_BADARG, "sd_stem_wgrad: dy must be 16-byte aligned");
+    cvt::StemWgradArgs a{};
+    a.dy = dy; a.x = x; a.dy_amax = dy_amax; a.x_amax = x_amax; a.part = scratch;
+    a.N = N; a.H = H; a.W = W; a.Hc = (H - 1) / 2 + 1; a.Wc = (W - 1) / 2 + 1;
+    a.segs_per_row = (a.Wc + 31) / 32;
+    a.n_steps = (long)N * a.Hc * a.segs_per_row;
+    const long items = a.n_steps < 1024 ? a.n_steps : 1024;
+    a.steps_per_item = (int)((a.n_steps + items - 1) / items);
+    const long wgs = (a.n_steps + a.steps_per_item - 1) / a.steps_per_item;
+    SD_LAUNCH(cvt::stem_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    SD_CHECK_LAUNCH("stem_wgrad_kernel");
+    SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(64L * 147)), dim3(256), 0, (hipStream_t)stream, scratch, (int)wgs, 64L * 147, dw);
+    SD_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;
 }

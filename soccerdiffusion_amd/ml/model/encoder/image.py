@@ -226,13 +226,20 @@ class _ResNet(nn.Module):
 
     def forward(self, x):
         if self._hip_training(x):
-            # Training: the stem (7 x 7 convolution of 3 input channels, BatchNorm, ReLU, max-pool: ~ 6 % of the backbone's FLOPs) stays on
-            # torch.nn; every block runs on this package's kernels (convolution forward / data gradient / weight gradient, training-mode
-            # BatchNorm forward / backward) behind one autograd.Function per conv + BatchNorm unit, on NHWC tensors.
+            # Training: every convolution and BatchNorm of the backbone on this package's kernels (convolution forward / data gradient / weight
+            # gradient, training-mode BatchNorm forward / backward) behind one autograd.Function per conv + BatchNorm unit, on NHWC tensors;
+            # the max-pool is ATen's channels-last kernel, the head (avgpool + fc) torch.
             from .... import conv_training as ct
 
-            y = self.conv1(x).permute(0, 2, 3, 1).contiguous()           # torch's 7 x 7 convolution; its output as NHWC
-            z, _ = ct.bn_unit(y, self.bn1, relu=True)                    # training-mode BatchNorm + ReLU on this package's kernels
+            if x.requires_grad or os.environ.get("SD_STEM", "hip") == "torch":   # (a differentiable input: torch's convolution has the data gradient)
+                y = self.conv1(x).permute(0, 2, 3, 1).contiguous()
+                z, _ = ct.bn_unit(y, self.bn1, relu=True)
+            else:   # the stem kernel's bare convolution, training-mode BatchNorm + ReLU, and in the backward the stem's own weight-gradient kernel
+                store = _derived(self.conv1)
+                pk = store.get("planes")
+                if pk is None or pk.planes.device != x.device:
+                    pk = store["planes"] = ops.PackedStem(self.conv1.weight)
+                z, _ = ct.stem_unit(x, self.conv1, self.bn1, pk)
             h = self.maxpool(z.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)  # ATen's channels-last max-pool: the result is NHWC-contiguous
             h = h.contiguous()
             amax = ops.absmax_word(h.detach())

@@ -132,7 +132,7 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
         ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd = orig, orig_wg, orig_bn
     # every weight-gradient and BatchNorm-backward launch of this backward against fp64 ON THE SAME TENSORS (the kernels' own error, free of
     # what fp32 rounding upstream does to ReLU masks and max-pool winners)
-    assert len(wg_rec) == 19 and len(bn_rec) == 20   # (+ the stem's BatchNorm)
+    assert len(wg_rec) == 19 and len(bn_rec) == 20   # (+ the stem's BatchNorm; its weight gradient is checked below)
     for dy, h, wshape, stride, dw in wg_rec:
         want = torch.nn.grad.conv2d_weight(h.double().cpu().permute(0, 3, 1, 2), wshape, dy.double().cpu().permute(0, 3, 1, 2), stride=stride,
                                            padding=wshape[2] // 2)
@@ -168,6 +168,18 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
     bar = max(2e-5, 1.5 * max(lerr.values()))
     for name, e in errs.items():
         assert e < bar, (name, e, lerr[name], bar)
+    # the same backward with frames that need no gradient (what training does): the stem runs on StemUnit (sd_stem_conv_raw / sd_stem_wgrad)
+    gpu2 = copy.deepcopy(net).cuda().train()
+    stem_calls = []
+    orig_stem = ct.StemUnit.apply
+    ct.StemUnit.apply = lambda *a, **k: (stem_calls.append(1), orig_stem(*a, **k))[1]
+    try:
+        (gpu2(x.cuda()) * wr.float().cuda()).sum().backward()
+    finally:
+        ct.StemUnit.apply = orig_stem
+    assert len(stem_calls) == 1
+    for name, p in gpu2.named_parameters():
+        assert rel_err(p.grad, pr[name].grad) < bar, name
     # running statistics and counters after ONE training forward
     bg = dict(gpu.named_buffers())
     for name, b in ref.named_buffers():
@@ -175,6 +187,27 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
             assert int(bg[name]) == int(b) == 1, name
         else:
             assert rel_err(bg[name], b) < 1e-5, name
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 96, 128), (1, 61, 77), (3, 32, 40)])
+def test_stem_raw_convolution_and_weight_gradient_match_torch_fp64(N, H, W):
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd import ops
+
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    wd = w.double().requires_grad_()
+    out = F.conv2d(x.double(), wd, stride=2, padding=3)
+    dy = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dy)
+    xg = x.cuda()
+    xa = ops.absmax_word(xg)
+    y = ct.stem_conv_raw(xg, xa, ops.PackedStem(w.cuda()))
+    assert rel_err(y.permute(0, 3, 1, 2), out) < 2e-6
+    dyg = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = ct.stem_wgrad(dyg, xg, ops.absmax_word(dyg), xa)
+    assert rel_err(dw, wd.grad) < 1e-5
 
 
 def test_training_step_of_the_image_conditioned_model_uses_the_unit_kernels():
