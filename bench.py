@@ -31,6 +31,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # only the torch.nn comparison leg of `image_backbone_train` ever reaches MIOpen
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -1015,6 +1017,47 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
         del enc, frames
     except Exception as e:  # noqa: BLE001
         out["image_backbone"] = {"error": repr(e)[:300]}
+    # (e) ... and its TRAINING step (forward + backward of the backbone in train() mode: batch-statistics BatchNorm, every parameter's
+    # gradient) on this repository's kernels (csrc/sd_conv_train.hip, conv_training.py) beside the torch.nn / MIOpen route on the same frames
+    try:
+        from soccerdiffusion_amd.ml.model.encoder.image import ImageEncoderType, image_encoder_factory
+
+        torch.manual_seed(0)
+        enc = image_encoder_factory(ImageEncoderType.RESNET18, 256, True, 480).to(dev).train()
+        frames = torch.rand(16, 10, 3, 480, 640, device=dev)
+
+        def fwd_bwd():
+            for p in enc.parameters():
+                p.grad = None
+            enc(frames).sum().backward()
+
+        rec = {}
+        for route in ("hip", "torch"):
+            if route == "torch":
+                os.environ["SD_CONV"] = "torch"
+            try:
+                fwd_bwd()
+                torch.cuda.synchronize()
+                n = 3
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fwd_bwd()
+                torch.cuda.synchronize()
+                rec[route] = (time.perf_counter() - t0) / n
+            finally:
+                os.environ.pop("SD_CONV", None)
+        flops = 3 * 2 * 1.814e9 * 480 * 640 / (224 * 224)   # forward + data gradient + weight gradient of every convolution
+        out["image_backbone_train"] = {
+            "workload": "BASELINE.json configs[4] per-GPU share, training: ResNet-18 forward + backward on 16 x 10 frames of 480 x 640, train() mode "
+                        "(reference: train.py:226-240 trains the backbone with every step); every convolution (forward, data gradient, weight "
+                        "gradient) and BatchNorm (batch statistics, backward) hand-written, max-pool ATen, no MIOpen kernel",
+            "ms_per_step": round(rec["hip"] * 1e3, 3), "value": round(160 / rec["hip"], 1), "unit": "frames/s",
+            "algorithmic_tflops": round(160 * flops / rec["hip"] / 1e12, 1),
+            "torch_nn_miopen_ms_per_step": round(rec["torch"] * 1e3, 3), "speedup_over_miopen_route": round(rec["torch"] / rec["hip"], 2),
+            "dtype": "f32 (operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate; gradients 1e-5 vs torch CPU fp64 per kernel)"}
+        del enc, frames
+    except Exception as e:  # noqa: BLE001
+        out["image_backbone_train"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -2523,6 +2523,7 @@ struct Scratch {  // carve-up of the caller's workspace (floats)
     f16 *wfc;
     float *scc;
     unsigned *mbc;
+    int *stepmap;   // trajectory kernels, per-trajectory step tokens: block index each trajectory reads (step_map_kernel)
     float *gws;   // region of the generic trajectory kernels (sd_trajg.hip: hidden_dim 128 / 256 / 512, any memory length), or NULL
 };
 
@@ -2578,6 +2579,8 @@ static Scratch carve(float *ws, long R, long RM, int d, int L, int n_steps, long
         s.scc = ws + off; off += align64((size_t)L * 8);
         s.mbc = reinterpret_cast<unsigned *>(ws + off); off += align64((size_t)L * 8);
     }
+    s.stepmap = nullptr;
+    if (n_steps > 0) { s.stepmap = reinterpret_cast<int *>(ws + off); off += align64((size_t)n_steps); }
     s.gws = nullptr;
     if (n_steps > 0 && B > 0 && (d == 128 || d == 256 || d == 512)) s.gws = ws + off;   // trajg_workspace_floats(B, Mc, d, L, n_steps) floats
     return s;
@@ -2596,6 +2599,7 @@ extern "C" size_t sd_workspace_floats(int B, int T, int M, int d, int L, int n_s
         n += align64((size_t)L * 6 * d * d) + 2 * align64((size_t)L * B * kt * 4 * 16 * d) + align64((size_t)L * n_steps * 4 * 16 * d) +
              align64((size_t)L * n_steps * 16 * d) + 2 * align64((size_t)(L + 1) * 8) + align64((size_t)2 * 32 * d);
     if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += align64((size_t)L * 8 * d * d) + 2 * align64((size_t)L * 8);
+    if (n_steps > 0) n += align64((size_t)n_steps);   // step map
     if (n_steps > 0 && (d == 128 || d == 256 || d == 512)) n += trajg_workspace_floats(B, M > 0 ? M : 0, d, L, n_steps);
     return n;
 }
@@ -2974,17 +2978,28 @@ static int traj_prepare_ctx(const sd_denoiser_weights *w, const Scratch &s, cons
 
 // ---- the step tokens' part of the preparation, all layers in one launch each (a forward_with_context call of the reference's loop pays
 // it once per call: four launches instead of four per layer)
+// map[b] = 0 where step token b equals token 0 bit for bit (the usual call of the reference's loop: one timestep for the whole batch, passed
+// as a (B,) tensor), else b: trajectory b reads the folded blocks of token map[b], and only tokens with map[b] == b are folded and packed
+__global__ void step_map_kernel(const float *__restrict__ tokens, int n_tok, int d, int *map) {
+    const int b = blockIdx.x;
+    bool same = true;
+    for (int k = threadIdx.x; k < d; k += blockDim.x)
+        same &= __builtin_bit_cast(unsigned, tokens[(long)b * d + k]) == __builtin_bit_cast(unsigned, tokens[k]);
+    same = __syncthreads_and(same);
+    if (threadIdx.x == 0) map[b] = same ? 0 : b;
+}
 struct StepFoldArgs { const float *wkv[tj::MAX_L], *bkv[tj::MAX_L], *wq[tj::MAX_L], *bq[tj::MAX_L], *woc[tj::MAX_L]; };
 // grid (n_tok, L), 256 threads, hidden_dim 256: K | V = Wkv tok + bkv (memory rows are not layer-normed), then the fold of
 // xattn_fold_kernel for this one row: G_h = Wq_h^T K_h, V'_h = Woc_h V_h, c_h = bq_h . K_h -> gvstep rows [tok * 4 + h][2 D], cstep
 // [tok * 4 + h]; abs-max of G / V' -> words 6 / 7 of the layer's row
 __global__ __launch_bounds__(256) void step_fold_all_kernel(StepFoldArgs a, const float *__restrict__ tokens, float *__restrict__ gvstep,
                                                             long gv_layer_stride, float *__restrict__ cstep, long c_layer_stride,
-                                                            unsigned *maxbits) {
+                                                            unsigned *maxbits, const int *__restrict__ map) {
     constexpr int D = tj::D, HD = tj::HD;
     __shared__ __attribute__((aligned(16))) float st[D], skv[2 * D];
     const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long tok = blockIdx.x;
+    if (map && map[tok] != (int)tok) return;   // a duplicate of token 0: nobody reads its blocks
     st[threadIdx.x] = tokens[tok * D + threadIdx.x];
     __syncthreads();
     const f32x4 t4 = *reinterpret_cast<const f32x4 *>(st + 4 * lane);
@@ -3034,7 +3049,7 @@ __global__ __launch_bounds__(256) void step_fold_all_kernel(StepFoldArgs a, cons
 // abs-max of 0 would drag the common value scale of tj::step_scale down to 1)
 __global__ void pack_step16_all_kernel(const float *__restrict__ gvstep, long gv_layer_stride, long n_tok, const unsigned *maxbits,
                                        f16 *__restrict__ gdst, long g_layer_stride, f16 *__restrict__ vdst, long v_layer_stride, float *scales,
-                                       int no_ctx) {
+                                       int no_ctx, const int *__restrict__ map) {
     constexpr int D = tj::D;
     const int l = blockIdx.y;
     const float sg = f16_scale_from_bits(maxbits[l * 8 + 6]), sv = f16_scale_from_bits(maxbits[l * 8 + 7]);
@@ -3053,6 +3068,7 @@ __global__ void pack_step16_all_kernel(const float *__restrict__ gvstep, long gv
         if (i < ng) {
             const int k8 = (int)(i % (D / 8));
             const long ih = i / (D / 8);
+            if (map && map[ih >> 2] != (int)(ih >> 2)) continue;
             f16x4 h0, l0, h1, l1;
             const float *row = src + ih * 2 * D + tj::kperm(k8, 0);
             f16_split4(*reinterpret_cast<const f32x4 *>(row), sg, h0, l0);
@@ -3066,6 +3082,7 @@ __global__ void pack_step16_all_kernel(const float *__restrict__ gvstep, long gv
             const long j = i - ng;
             const int n = (int)(j % D), head = (int)((j / D) & 3);
             const long item = j / D / 4;
+            if (map && map[item] != (int)item) continue;
             const float v = src[(item * 4 + head) * 2 * D + D + n] * sv;
             const f16 h = (f16)v;
             vd[(item * 2 + 0) * 4 * D + head * D + n] = h;
@@ -3075,12 +3092,19 @@ __global__ void pack_step16_all_kernel(const float *__restrict__ gvstep, long gv
 }
 
 // n_tok step tokens (rows of `tokens`): one per DDIM step of a rollout, or one per trajectory of a single evaluation
-static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, const float *tokens, int n_tok, int Mc, hipStream_t st) {
+static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, const float *tokens, int n_tok, int Mc, hipStream_t st,
+                              bool per_traj = false) {
     const int d = w->d, L = w->L;
     const size_t gvsstride = (size_t)n_tok * 4 * 2 * d, cssstride = (size_t)n_tok * 4;
     const size_t blk = (size_t)32 * d;
     int rc = zero_word_cols(s.maxbits, L, 6, 2, st);
     if (rc) return rc;
+    const int *map = nullptr;
+    if (per_traj) {   // one token per trajectory: fold the distinct ones only (see step_map_kernel)
+        SD_LAUNCH(step_map_kernel, dim3((unsigned)n_tok), dim3(64), 0, st, tokens, n_tok, d, s.stepmap);
+        SD_CHECK_LAUNCH("step_map_kernel");
+        map = s.stepmap;
+    }
     StepFoldArgs fa{};
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
@@ -3088,12 +3112,12 @@ static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, co
         fa.wq[l] = lw.ca_in_w; fa.bq[l] = lw.ca_in_b; fa.woc[l] = lw.ca_out_w;
     }
     SD_LAUNCH(step_fold_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, fa, tokens, s.gvstep, (long)gvsstride, s.cstep, (long)cssstride,
-              s.maxbits);
+              s.maxbits, map);
     SD_CHECK_LAUNCH("step_fold_all_kernel");
     // per-layer regions as carved for mode 2 (n_tok * 4 * blk / n_tok * blk halfs), the step blocks packed densely inside
     unsigned gx = grid_for((long)n_tok * 4 * (d / 8 + d));
     SD_LAUNCH(pack_step16_all_kernel, dim3(gx, (unsigned)L), dim3(256), 0, st, s.gvstep, (long)gvsstride, (long)n_tok, s.maxbits, s.gstep16,
-              (long)((size_t)n_tok * 4 * blk), s.vstep16, (long)((size_t)n_tok * blk), s.scales, Mc == 0 ? 1 : 0);
+              (long)((size_t)n_tok * 4 * blk), s.vstep16, (long)((size_t)n_tok * blk), s.scales, Mc == 0 ? 1 : 0, map);
     SD_CHECK_LAUNCH("pack_step16_all_kernel");
     return 0;
 }
@@ -3122,6 +3146,7 @@ static int decoder_step_traj(const sd_denoiser_weights *w, float *x, const Scrat
     a.scale_log2e = (1.0f / sqrtf((float)(d / w->heads))) * 1.44269504088896340736f;
     a.T = T; a.B = B; a.J = w->J; a.L = L; a.Mk = Mc + 1; a.update_x = coef ? 1 : 0;
     a.step_per_traj = per_traj ? 1 : 0;
+    a.step_map = per_traj ? s.stepmap : nullptr;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
         tj::LayerW &q = a.layer[l];
@@ -3447,10 +3472,14 @@ extern "C" int sd_sampler_eps(const sd_denoiser_weights *w, const float *step_to
         if (int rz = zero_async(status, sizeof(int32_t), st)) return rz;
     }
     if (generic) {
-        if ((rc = trajg_prepare_steps(w, s.gws, step_tokens, s.kvstep, B, Mc, n_tok, st))) return rc;
-        return trajg_step(w, s.gws, const_cast<float *>(x), eps, B, T, Mc, 0, n_tok, nullptr, n_tok > 1, st);
+        if (n_tok > 1) {
+            SD_LAUNCH(step_map_kernel, dim3((unsigned)n_tok), dim3(64), 0, st, step_tokens, n_tok, w->d, s.stepmap);
+            SD_CHECK_LAUNCH("step_map_kernel");
+        }
+        if ((rc = trajg_prepare_steps(w, s.gws, step_tokens, s.kvstep, B, Mc, n_tok, st, n_tok > 1 ? s.stepmap : nullptr))) return rc;
+        return trajg_step(w, s.gws, const_cast<float *>(x), eps, B, T, Mc, 0, n_tok, nullptr, n_tok > 1, st, n_tok > 1 ? s.stepmap : nullptr);
     }
-    if ((rc = traj_prepare_steps(w, s, step_tokens, n_tok, Mc, st))) return rc;
+    if ((rc = traj_prepare_steps(w, s, step_tokens, n_tok, Mc, st, n_tok > 1))) return rc;
     // x is only read (no DDIM coefficients: no update)
     return decoder_step_traj(w, const_cast<float *>(x), s, B, T, Mc, 0, n_tok, nullptr, st, precise, eps, precise ? nullptr : status, n_tok > 1);
 }

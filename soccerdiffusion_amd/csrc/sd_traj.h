@@ -439,6 +439,7 @@ struct StepArgs {
     float scale_log2e;
     int T, B, J, L, Mk, update_x;
     int nkt;                       // key tiles of 16 memory slots (1; 2 .. 4 only for the WIDE instantiations: 17 .. 64 memory rows)
+    const int *step_map;           // step_per_traj: trajectory b reads step block step_map[b] (duplicates of token 0 are folded once), or NULL: block b
     int step_per_traj;             // 0: one step token for the whole batch (the sampler's loop); 1: trajectory b reads block b of gstep / vstep /
                                    // cstep (forward_with_context with a step per sample: sd_sampler_eps)
     int *status;                   // range-guard word (SD_STATUS_SHARP_LOGITS) or NULL
@@ -1532,7 +1533,7 @@ static __device__ __forceinline__ void step_body(const StepArgs &a) {
     layer_norm_to_x<!PRECISE>(c, H, a.n1_w, a.n1_b);
     TJ_STAMP(2);
 #pragma unroll 1
-    for (int l = 0; l < a.L; ++l) decoder_layer<WIDE>(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status, a.nkt, a.step_per_traj ? traj : 0L);
+    for (int l = 0; l < a.L; ++l) decoder_layer<WIDE>(c, a.layer[l], H, traj, a.Mk, a.scale_log2e, a.status, a.nkt, a.step_per_traj ? (a.step_map ? (long)a.step_map[traj] : traj) : 0L);
     // ---- fc_out + DDIM: eps^T = Wout . h^T + b.  h has no a-priori bound: one power-of-two scale per token
     {
         float *stat = reinterpret_cast<float *>(c.smem + LDS_STAT);

@@ -15,8 +15,10 @@ size_t trajg_workspace_floats(int B, int Mc, int d, int L, int n_tok);
 // L * B * Mc * 2 d and L * n_tok * 2 d floats for the projected rows
 int trajg_prepare_weights(const sd_denoiser_weights *w, float *gws, int B, int Mc, int n_tok, hipStream_t st);
 int trajg_prepare_ctx(const sd_denoiser_weights *w, float *gws, const float *ctx, float *kvtmp, int B, int Mc, int n_tok, hipStream_t st);
-int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *tokens, float *kvstep, int B, int Mc, int n_tok, hipStream_t st);
+// map (or NULL): per-trajectory step tokens, trajectory b uses the rows of token map[b] (step_map_kernel: duplicates of token 0 are prepared once)
+int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *tokens, float *kvstep, int B, int Mc, int n_tok, hipStream_t st,
+                        const int *map = nullptr);
 // one denoiser step (+ DDIM update when coef != NULL); step index i of the n_tok prepared step rows, or row b for trajectory b (per_traj)
 int trajg_step(const sd_denoiser_weights *w, float *gws, float *x, float *eps, int B, int T, int Mc, int i, int n_tok, const float *coef,
-               bool per_traj, hipStream_t st);
+               bool per_traj, hipStream_t st, const int *map = nullptr);
 #endif

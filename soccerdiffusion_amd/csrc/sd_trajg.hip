@@ -180,10 +180,11 @@ __global__ void pack_vt_kernel(const float *__restrict__ kv, long items, int row
 // 256 threads: K | V = Wkv tok + bkv -> kvstep [l][tok][2 D] (fp32), abs-max of the K and of the V columns -> words SC_KS / SC_VS of row l
 struct StepKvArgs { const float *wkv[MAX_L], *bkv[MAX_L]; };
 __global__ __launch_bounds__(256) void step_kv_all_kernel(StepKvArgs a, const float *__restrict__ tokens, int D, float *__restrict__ kvstep,
-                                                          long layer_stride, unsigned *maxbits) {
+                                                          long layer_stride, unsigned *maxbits, const int *__restrict__ map) {
     __shared__ __attribute__((aligned(16))) float st[512];
     const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long tok = blockIdx.x;
+    if (map && map[tok] != (int)tok) return;   // a duplicate of token 0 (step_map_kernel of sd_kernels.hip): nobody reads its rows
     for (int k = threadIdx.x; k < D; k += 256) st[k] = tokens[tok * D + k];
     __syncthreads();
     const float *wkv = a.wkv[l], *bkv = a.bkv[l];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void step_kv_all_kernel(StepKvArgs a, const fl
 // the layer's scale row (with no_ctx also into SC_K / SC_V: no context rows - their unused planes take the step rows' scales, a scale of 1
 // would drag the common value scale down)
 __global__ void pack_step_all_kernel(const float *__restrict__ kvstep, long src_layer_stride, long n_tok, int D, const unsigned *maxbits,
-                                     f16 *__restrict__ dst, long dst_layer_stride, float *scales, int no_ctx) {
+                                     f16 *__restrict__ dst, long dst_layer_stride, float *scales, int no_ctx, const int *__restrict__ map) {
     const int l = blockIdx.y;
     const float sk = f16_scale_from_bits(maxbits[l * 16 + SC_KS]), sv = f16_scale_from_bits(maxbits[l * 16 + SC_VS]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -227,6 +228,7 @@ __global__ void pack_step_all_kernel(const float *__restrict__ kvstep, long src_
     const long total = n_tok * 2 * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long tok = i / (2 * D);
+        if (map && map[tok] != (int)tok) continue;
         const int c = (int)(i - tok * 2 * D), isv = c >= D, f = isv ? c - D : c;
         const float v = src[i] * (isv ? sv : sk);
         const f16 h = (f16)v;
@@ -283,6 +285,7 @@ struct StepArgs {
     const float *sc_io;            // scale row L: SC_EMB, SC_OUT
     float c0, c1, c2, c3;
     float scale_log2e;
+    const int *step_map;           // step_per_traj: trajectory b reads step rows step_map[b], or NULL: rows b
     int T, B, J, L, Mc, nkp, update_x, step_per_traj;   // nkp: pairs of 32 context rows, ceil(Mc / 32)
     long kv_traj_halfs;            // halfs of one trajectory's K (= V^T) planes in a layer: nkp * 32 keys * D features * 2 planes
     LayerW layer[MAX_L];
@@ -881,7 +884,7 @@ struct TG {
                 }
             }
         }
-        const long sblk = a.step_per_traj ? traj : 0L;
+        const long sblk = a.step_per_traj ? (a.step_map ? (long)a.step_map[traj] : traj) : 0L;
         layer_norm_to_x(c, H, a.layer[0].n1_w, a.layer[0].n1_b);
 #pragma unroll 1
         for (int l = 0; l < a.L; ++l) {
@@ -1110,7 +1113,8 @@ int trajg_prepare_ctx(const sd_denoiser_weights *w, float *gws, const float *ctx
     return 0;
 }
 
-int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *tokens, float *kvstep, int B, int Mc, int n_tok, hipStream_t st) {
+int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *tokens, float *kvstep, int B, int Mc, int n_tok, hipStream_t st,
+                        const int *map) {
     const int d = w->d, L = w->L;
     const GScratch s = gcarve(gws, B, Mc, d, L, n_tok);
     SD_LAUNCH(tg::zero_word_cols16_kernel, dim3(1), dim3(64), 0, st, s.maxbits, L, (int)tg::SC_KS, 2);
@@ -1120,16 +1124,16 @@ int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *t
         ka.wkv[l] = w->layers[l].ca_in_w + (size_t)d * d;   // the memory is NOT layer-normed: rows [d, 3 d) of in_proj
         ka.bkv[l] = w->layers[l].ca_in_b + d;
     }
-    SD_LAUNCH(tg::step_kv_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, ka, tokens, d, kvstep, (long)n_tok * 2 * d, s.maxbits);
+    SD_LAUNCH(tg::step_kv_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, ka, tokens, d, kvstep, (long)n_tok * 2 * d, s.maxbits, map);
     SD_CHECK_LAUNCH("step_kv_all_kernel");
     SD_LAUNCH(tg::pack_step_all_kernel, dim3(grid_for((long)n_tok * 2 * d), (unsigned)L), dim3(256), 0, st, kvstep, (long)n_tok * 2 * d, (long)n_tok, d,
-              s.maxbits, s.kvs, (long)s.kvs_layer_halfs, s.scales, Mc == 0 ? 1 : 0);
+              s.maxbits, s.kvs, (long)s.kvs_layer_halfs, s.scales, Mc == 0 ? 1 : 0, map);
     SD_CHECK_LAUNCH("pack_step_all_kernel");
     return 0;
 }
 
 int trajg_step(const sd_denoiser_weights *w, float *gws, float *x, float *eps, int B, int T, int Mc, int i, int n_tok, const float *coef,
-               bool per_traj, hipStream_t st) {
+               bool per_traj, hipStream_t st, const int *map) {
     const int d = w->d, L = w->L;
     const GScratch s = gcarve(gws, B, Mc, d, L, n_tok);
     tg::StepArgs a{};
@@ -1145,6 +1149,7 @@ int trajg_step(const sd_denoiser_weights *w, float *gws, float *x, float *eps, i
     a.scale_log2e = (1.0f / sqrtf((float)(d / w->heads))) * 1.44269504088896340736f;
     a.T = T; a.B = B; a.J = w->J; a.L = L; a.Mc = Mc; a.nkp = s.nkp; a.update_x = coef ? 1 : 0;
     a.step_per_traj = per_traj ? 1 : 0;
+    a.step_map = per_traj ? map : nullptr;
     a.kv_traj_halfs = (long)s.nkp * 64 * d;
     for (int l = 0; l < L; ++l) {
         const sd_layer_weights &lw = w->layers[l];
