@@ -56,7 +56,7 @@ def flops_per_traj_step():
 
 def executed_flops_per_traj():
     """FLOPs this implementation executes per trajectory: the sampler caches the memory K/V over the rollout and
-    folds the cross-attention Q and out projections into them, so per step and layer the 16 T d^2 of
+    folds the cross-attention Q and out projections into them (NOTEBOOK.md 5.5), so per step and layer the 16 T d^2 of
     row GEMMs become 12 T d^2 + 4 T d (heads*M); the fold itself is 8 Mc d^2 per layer, once."""
     layer_chain = (L * 12 - 6) * T * D * D + L * 4 * T * D * HEADS * M + 2 * T * D * J   # decoder_layer_kernel, L launches
     head = 2 * T * J * D + 6 * T * D * D                                                 # decoder_head_kernel
@@ -69,7 +69,7 @@ def executed_flops_per_traj():
 def traj_step_flops_per_traj_step(mode: int = 4):
     """Sampler modes 3 / 4 (csrc/sd_traj.h): one launch per DDIM step owns everything of SURVEY 8(d)'s F_step except the memory
     K/V projection (once per rollout).  Executed: 16x16x32 fp16 MFMAs (16 384 FLOP each), three per product - in mode 4 two at the
-    Q | K | V projection - on 7 token tiles of 16 (T = 100 padded to 112), the cross-attention in its folded form."""
+    Q | K | V projection (NOTEBOOK.md 5.11 / 5.12) - on 7 token tiles of 16 (T = 100 padded to 112), the cross-attention in its folded form."""
     f = flops_per_traj_step()
     qkv = 4 * 84 * 8                                                            # products of 16x16x32 tiles: Q | K | V projection, per layer
     rest = 4 * (49 * 2 + 28 * 4 + 112 * 2) + 28 * 8 + 112 * 3 + 2 * 112 * 8    # scores, PV, out-projection; folded cross-attention; W1, W2
@@ -681,7 +681,7 @@ def sample_roofline(ms, cnt, steps, B, elapsed, mode):
     at = names.index("attention_kernel")
     f = flops_per_traj_step()
     ex = executed_flops_per_traj()
-    # mode 2 runs the head of steps 1.. inside the previous step's last layer launch
+    # mode 2 runs the head of steps 1.. inside the previous step's last layer launch (NOTEBOOK.md 5.5)
     merged = mode == 2 and os.environ.get("SD_MERGE_HEAD", "1") != "0"
     launches = max(int(cnt[dl]), 1)
     dl_s = ms[dl] / 1e3

@@ -22,7 +22,7 @@ HDR = [os.path.join(REPO, "include", "soccerdiffusion_hip.h"), os.path.join(PKG,
        os.path.join(PKG, "csrc", "sd_panel.h"), os.path.join(PKG, "csrc", "sd_f16x3.h"), os.path.join(PKG, "csrc", "sd_traj.h"),
        os.path.join(PKG, "csrc", "sd_trajg.h")]
 # The sampler's translation unit is compiled WITHOUT packed fp32 vector instructions (v_pk_fma/mul/add_f32): they do not overlap with
-# MFMAs - neither a wave's own nor its SIMD partner's - while plain fp32 instructions do (tools/exp/coissue3.hip), and
+# MFMAs - neither a wave's own nor its SIMD partner's - while plain fp32 instructions do (tools/exp/coissue3.hip; NOTEBOOK.md 5.11), and
 # the trajectory kernel lives on that overlap: + 1.5 % sampler throughput.  The training units lose 0.6 % with the same flag: packed.
 EXTRA_FLAGS = {"sd_kernels.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
                "sd_trajg.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}

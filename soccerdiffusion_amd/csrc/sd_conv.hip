@@ -76,7 +76,7 @@ __device__ __forceinline__ void publish_amax(unsigned *word, float mx, int lane)
     const unsigned b = __builtin_bit_cast(unsigned, mx);
     if (lane == 0 && b > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, b);
 }
-// (a hipMemsetAsync node replays garbage from a captured graph on this stack - DESIGN.md 5.7: zero fills are kernels)
+// (a hipMemsetAsync node replays garbage from a captured graph on this stack - NOTEBOOK.md 5.7: zero fills are kernels)
 __global__ void zero_words_kernel(unsigned *p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
 }

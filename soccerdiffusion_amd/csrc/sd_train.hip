@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float *__restr
 // Only TWO images are resident at a time now (72 KB, two workgroups per CU, 256 registers): a pass needs the other two images
 // only as "this lane's own row" fragments, which live in registers.  Q, dO are staged first and every lane takes its row
 // fragments; K, V replace them for pass A; before pass B every lane takes its own K, V row fragments and the waves write Q, dO
-// back from the fragments they kept.  An aliasing ablation had promised 116 -> 70 us; measured: see DESIGN.md 5.10.
+// back from the fragments they kept.  An aliasing ablation had promised 116 -> 70 us; measured: see NOTEBOOK.md 5.10.
 // ======================================================================================
 constexpr int AB_P = 136;                 // halfs per image row: hi[64] | lo[64] | 8 pad
 constexpr float AB_QKV = 8.0f, AB_PS = 1024.0f;

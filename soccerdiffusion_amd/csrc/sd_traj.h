@@ -16,7 +16,7 @@
 //     GEMM that accumulates into it.
 // Self-attention, per head: [Q_h | K_h | V_h]^T = 12 n-tiles; wave w computes Q tile w (w < 4) or K tile w-4 for all tokens
 // and a half (by tokens) of V tile w>>1, from ONE fp16 plane of LayerNorm 1's output (2 MFMAs per product: the only site
-// where the measured rollout error allows it).  Q, K, V, O have an LDS buffer each (split planes), so a head is
+// where the measured rollout error allows it, NOTEBOOK.md 5.11).  Q, K, V, O have an LDS buffer each (split planes), so a head is
 // two barrier-delimited phases: W = write Q | K | V of head h (+ out-projection of head h-1 into the residual registers),
 // X = S^T = K Q^T (keys x queries) per query tile on waves 0..6, softmax in registers (a query is a lane column), O^T = V^T P^T
 // with P^T straight from the score accumulators (B operand) and V^T through ds_read_b64_tr_b16, O -> LDS; the projection GEMM
@@ -89,7 +89,7 @@ __device__ __forceinline__ void tj_sync() {
 
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 // c += (ah + al) (bh + bl) without lo.lo, small terms first.
-// Precision experiment (tools/exp/precision_sites.sh): -DTJ_DROP_ALO=<mask> / -DTJ_DROP_BLO=<mask> drop the
+// Precision experiment (tools/exp/precision_sites.sh, NOTEBOOK.md 5.11): -DTJ_DROP_ALO=<mask> / -DTJ_DROP_BLO=<mask> drop the
 // A-lo x B-hi / A-hi x B-lo product at the GEMM sites whose bit is set (A = weights, K, V^T, G, V'^T; B = activations, Q, P).
 #ifndef TJ_DROP_ALO
 #define TJ_DROP_ALO 0
@@ -693,7 +693,7 @@ static __device__ __forceinline__ void gemm_pipe(const Ctx &c, const f16 *pa0, c
 // (tt1 = 4 for odd waves, else 0), K = 256, against the ONE-plane panel: two MFMAs per product (W_lo X_hi + W_hi X_hi).  The
 // lo part of LayerNorm 1's output is dropped here and only here: measured over the 50-step rollout against the fp64 oracle
 // 5.1e-6 (three products: 4.2e-7; bar 1e-4; dropping the WEIGHTS' lo part instead: 2.8e-5 - tools/exp/precision_sites.sh,
-// DESIGN.md).  Same software pipeline as gemm_pipe; the token half of A1 is a wave-uniform run-time predicate so that
+// NOTEBOOK.md 5.11).  Same software pipeline as gemm_pipe; the token half of A1 is a wave-uniform run-time predicate so that
 // the code exists once per parity.
 struct HeadAcc { f32x4 a0[NTT], a1[NH0]; };
 template <bool odd>
