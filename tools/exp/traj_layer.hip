@@ -243,8 +243,8 @@ int main(int argc, char **argv) {
             f16 *g16 = dalloc<f16>((size_t)B * 4 * 8 * 2 * 512), *v16 = dalloc<f16>((size_t)B * 16 * 2 * 2 * 512), *gs = dalloc<f16>(4 * 8 * 2 * 32), *vs = dalloc<f16>(2 * 4 * D);
             hipLaunchKernelGGL(tj::pack_g16_kernel, dim3(2048), dim3(256), 0, 0, d_gv, (long)B, Mc, dmb, g16, sc + 4);
             hipLaunchKernelGGL(tj::pack_v16_kernel, dim3(2048), dim3(256), 0, 0, d_gv, (long)B, Mc, dmb + 1, v16, sc + 5);
-            hipLaunchKernelGGL(tj::pack_gstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb, gs, (float *)nullptr);
-            hipLaunchKernelGGL(tj::pack_vstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb + 1, vs);
+            hipLaunchKernelGGL(tj::pack_gstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb, gs, sc + 6);       // (round 5: the step blocks' own scales)
+            hipLaunchKernelGGL(tj::pack_vstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb + 1, vs, sc + 7);
             CK(hipDeviceSynchronize());
             CK(hipFree(d_gv));
             w.g16 = g16; w.v16 = v16; w.gstep = gs; w.vstep = vs; w.cb = dev(h.cb); w.cstep = dev(h.cstep);
