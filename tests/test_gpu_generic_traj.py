@@ -121,3 +121,22 @@ def test_loop_form_on_the_generic_kernels():
     with torch.no_grad():   # per-sample steps on the generic kernels
         steps = torch.tensor([980, 17])
         assert rel_err(m.forward_with_context(cg, x_T.cuda(), steps.cuda()), ref.forward_with_context(sd, ctxs, x_T, steps)) < TOL
+
+
+def test_generic_rollout_replays_from_a_hipgraph_and_serves_the_robot_batch():
+    """default.yaml's decoder shape at the robot's B = 1: model.sample(use_graph=True) (the rollout captured into a hipGraph, generic kernels
+    inside) equals the eager call bit for bit and the oracle at 1e-4; a second context goes through the same graph."""
+    from test_gpu_loop_form import _model
+
+    d, J, L, T, B, Mc, n = 128, 20, 4, 10, 1, 311, 30
+    m, sd = _model(d, J, L, T)
+    g = torch.Generator().manual_seed(8)
+    for rep in range(2):
+        x_T = torch.randn(B, T, J, generator=g)
+        ctx = torch.randn(B, Mc, d, generator=g)
+        want = ddim_ref.sample(lambda x, t: ref.forward_with_context(sd, [ctx], x, torch.full((B,), t, dtype=torch.int64)), x_T, n,
+                               ddim_ref.alphas_cumprod())[-1]
+        eager = m.sample([ctx.cuda()], x_T.cuda(), n)
+        graphed = m.sample([ctx.cuda()], x_T.cuda(), n, use_graph=True)
+        assert torch.equal(eager, graphed), rep
+        assert rel_err(eager, want) < TOL
