@@ -2858,7 +2858,10 @@ static bool traj_ok(int d, int heads, int T, int Mk, int J, int L) {
     if (env && strcmp(env, "0") == 0) return false;
     // any joint count up to 32 (the embedding's K and fc_out's N are zero-padded to 32 in the packed planes; the reference's database
     // has 22 joints: soccer_diffusion/dataset/models.py:222-247)
-    return f16_env_ok() && d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= 64 && J >= 1 && J <= 32 && L >= 1 && L <= tj::MAX_L;
+    static const char *mr = getenv("SD_TRAJ_MAXROWS");   // A/B runs: memory rows beyond this go to the generic kernels (sd_trajg.hip) instead of the wide instantiation
+    const int max_rows = mr ? atoi(mr) : 64;
+    return f16_env_ok() && d == 256 && heads == 4 && T >= 1 && T <= tj::TMAX && Mk >= 1 && Mk <= (max_rows < 64 ? max_rows : 64) && J >= 1 && J <= 32 && L >= 1 &&
+           L <= tj::MAX_L;
 }
 // key tiles of 16 memory slots in the folded blocks: 1 for the trajectory kernels proper, 2 .. 4 for traj_step_wide_kernel (17 .. 64 rows)
 static int key_tiles(int Mk) { return Mk <= 16 ? 1 : (Mk + 15) / 16; }

@@ -1,0 +1,465 @@
+// Stage-A / Stage-B experiment: the trajectory-owning kernels of soccerdiffusion_amd/csrc/sd_traj.h on random
+// data, checked against an fp64 host restatement of the blocks they replace and timed per 4096 trajectories.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-value -Xclang -target-feature -Xclang -packed-fp32-ops -I include -I soccerdiffusion_amd/csrc tools/exp/traj_layer.hip -o tools/exp/traj_layer
+//   tools/exp/traj_layer [B=4096] [iters=20] [check=2] [L=4]
+// Prints (a) traj_sa_kernel: h + SelfAttention(LN1(h)) alone (Stage A), (b) traj_step_kernel: one whole denoiser step
+// (embedding, L layers with folded cross-attention and FFN, fc_out, DDIM update).  -DTJ_STAMPS adds the phase profile.
+#include "sd_traj.h"
+// -DTL_PRECISE=1: the three-product variant of the step kernel (sa_block_precise)
+#ifndef TL_PRECISE
+#define TL_PRECISE 0
+#endif
+#define TL_STEP_KERNEL tj::traj_step_kernel<7, (TL_PRECISE != 0)>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));  \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+typedef std::vector<float> vf;
+typedef std::vector<double> vd;
+static std::mt19937 rng(1234);
+static vf randu(size_t n, float amp, float off = 0.f) {
+    std::uniform_real_distribution<float> ud(-1.f, 1.f);
+    vf v(n);
+    for (auto &x : v) x = off + amp * ud(rng);
+    return v;
+}
+static vf randn(size_t n) {
+    std::normal_distribution<float> nd(0.f, 1.f);
+    vf v(n);
+    for (auto &x : v) x = nd(rng);
+    return v;
+}
+// bits of the abs-max over n rows of `width` values at p + i * pitch
+static unsigned maxbits(const float *p, size_t n, size_t width, size_t pitch) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < width; ++j) m = fmaxf(m, fabsf(p[i * pitch + j]));
+    unsigned u;
+    memcpy(&u, &m, 4);
+    return u;
+}
+template <class T>
+static T *dev(const std::vector<T> &v) {
+    T *p;
+    CK(hipMalloc(&p, v.size() * sizeof(T)));
+    CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+template <class T>
+static T *dalloc(size_t n) {
+    T *p;
+    CK(hipMalloc(&p, n * sizeof(T)));
+    CK(hipMemset(p, 0, n * sizeof(T)));
+    return p;
+}
+// packs W (N x K) on the device; returns planes, writes the scale to *scale_dev
+static f16 *pack(const vf &W, int N, int K, int Np, int Kp, float *scale_dev) {
+    float *dW = dev(W);
+    unsigned *dmb = dev(std::vector<unsigned>{maxbits(W.data(), 1, W.size(), 0)});
+    f16 *dst = dalloc<f16>((size_t)Np * Kp * 2);
+    hipLaunchKernelGGL(tj::pack_w16_kernel, dim3(256), dim3(256), 0, 0, dW, N, K, Np, Kp, dmb, 0.f, dst, scale_dev);
+    CK(hipDeviceSynchronize());
+    CK(hipFree(dW));
+    return dst;
+}
+
+static void layer_norm(const vd &h, const vf &w, const vf &b, vd &out, int T, int D) {
+    for (int t = 0; t < T; ++t) {
+        double m = 0, v = 0;
+        for (int k = 0; k < D; ++k) m += h[(size_t)t * D + k];
+        m /= D;
+        for (int k = 0; k < D; ++k) v += (h[(size_t)t * D + k] - m) * (h[(size_t)t * D + k] - m);
+        const double rs = 1.0 / sqrt(v / D + 1e-5);
+        for (int k = 0; k < D; ++k) out[(size_t)t * D + k] = (h[(size_t)t * D + k] - m) * rs * w[k] + b[k];
+    }
+}
+// h += SelfAttention(x) Wo^T + bo
+static void self_attention(vd &h, const vd &x, const vf &win, const vf &bin, const vf &wo, const vf &bo, int T, int D, int H) {
+    const int HD = D / H;
+    vd qkv((size_t)T * 3 * D), att((size_t)T * D);
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < 3 * D; ++n) {
+            double s = bin[n];
+            for (int k = 0; k < D; ++k) s += x[(size_t)t * D + k] * win[(size_t)n * D + k];
+            qkv[(size_t)t * 3 * D + n] = s;
+        }
+    for (int hh = 0; hh < H; ++hh)
+        for (int t = 0; t < T; ++t) {
+            vd p(T);
+            double mx = -1e300, sum = 0;
+            for (int s = 0; s < T; ++s) {
+                double d = 0;
+                for (int f = 0; f < HD; ++f) d += qkv[(size_t)t * 3 * D + hh * HD + f] * qkv[(size_t)s * 3 * D + D + hh * HD + f];
+                p[s] = d / sqrt((double)HD);
+                mx = fmax(mx, p[s]);
+            }
+            for (int s = 0; s < T; ++s) { p[s] = exp(p[s] - mx); sum += p[s]; }
+            for (int f = 0; f < HD; ++f) {
+                double o = 0;
+                for (int s = 0; s < T; ++s) o += p[s] * qkv[(size_t)s * 3 * D + 2 * D + hh * HD + f];
+                att[(size_t)t * D + hh * HD + f] = o / sum;
+            }
+        }
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < D; ++n) {
+            double s = bo[n];
+            for (int k = 0; k < D; ++k) s += att[(size_t)t * D + k] * wo[(size_t)n * D + k];
+            h[(size_t)t * D + n] += s;
+        }
+}
+
+struct HostLayer {
+    vf n1w, n1b, n2w, n2b, n3w, n3b, win, bin, wo, bo, w1, b1, w2, b2, boc;
+    vf gv;       // [B][4][16][2 D]
+    vf cb;       // [B][64]
+    vf gvstep;   // [4][2 D]
+    vf cstep;    // [4]
+};
+
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 20, ncheck = argc > 3 ? atoi(argv[3]) : 2;
+    const int L = argc > 4 ? atoi(argv[4]) : 4;
+    const int T = 100, D = 256, H = 4, HD = 64, J = 20, Mc = 10, Mk = Mc + 1;
+    const float scale_log2e = 1.44269504088896340736f / sqrtf((float)HD);
+#ifdef TJ_STAMPS   // the stamp buffer must exist before the first launch of a stamped build
+    unsigned long long *d_st;
+    const size_t n_st = (size_t)tj::TJ_STAMP_WGS * 8 * tj::TJ_NSTAMP;
+    CK(hipMalloc(&d_st, n_st * 8));
+    CK(hipMemset(d_st, 0, n_st * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(tj::g_tj_stamps), &d_st, sizeof(d_st)));
+#endif
+    CK(hipFuncSetAttribute((const void *)tj::traj_sa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *)(TL_STEP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, tj::LDS_BYTES));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    int rc = 0;
+
+    // =============================================================================================== Stage A
+    {
+        vf h = randn((size_t)B * T * D), lnw = randu(D, 0.1f, 1.f), lnb = randu(D, 0.1f), win = randu((size_t)3 * D * D, 1.f / 16), bin = randu(3 * D, 0.1f),
+           wo = randu((size_t)D * D, 1.f / 16), bo = randu(D, 0.1f);
+        float *d_sc = dalloc<float>(2);
+        f16 *d_win16 = pack(win, 3 * D, D, 3 * D, D, d_sc), *d_wo16 = pack(wo, D, D, D, D, d_sc + 1);
+        float sc[2];
+        CK(hipMemcpy(sc, d_sc, 8, hipMemcpyDeviceToHost));
+        float *d_h = dev(h), *d_lnw = dev(lnw), *d_lnb = dev(lnb), *d_bin = dev(bin), *d_bo = dev(bo);
+        float *d_hf = dalloc<float>((size_t)B * tj::HFRAG_FLOATS), *d_of = dalloc<float>((size_t)B * tj::HFRAG_FLOATS), *d_out = dalloc<float>((size_t)B * T * D);
+        hipLaunchKernelGGL(tj::to_hfrag_kernel, dim3(2048), dim3(256), 0, 0, d_h, d_hf, B, T);
+        tj::SaArgs a{d_hf, d_of, d_lnw, d_lnb, d_win16, d_bin, d_wo16, d_bo, sc[0], sc[1], scale_log2e, T, B};
+        hipLaunchKernelGGL(tj::traj_sa_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipGetLastError());
+        hipLaunchKernelGGL(tj::from_hfrag_kernel, dim3(2048), dim3(256), 0, 0, d_of, d_out, B, T);
+        CK(hipDeviceSynchronize());
+        const int nc = ncheck < B ? ncheck : B;
+        vf got((size_t)nc * T * D);
+        CK(hipMemcpy(got.data(), d_out, got.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int b = 0; b < nc; ++b) {
+            vd hh((size_t)T * D), x((size_t)T * D);
+            for (size_t i = 0; i < hh.size(); ++i) hh[i] = h[(size_t)b * T * D + i];
+            layer_norm(hh, lnw, lnb, x, T, D);
+            self_attention(hh, x, win, bin, wo, bo, T, D, H);
+            double num = 0, den = 0;
+            for (size_t i = 0; i < hh.size(); ++i) {
+                const double gvv = got[(size_t)b * T * D + i];
+                num += (gvv - hh[i]) * (gvv - hh[i]);
+                den += hh[i] * hh[i];
+            }
+            worst = fmax(worst, sqrt(num / den));
+        }
+        printf("[A] traj_sa_kernel: worst rel L2 error vs fp64 over %d trajectories %.3e (%s)\n", nc, worst, worst < 2e-5 ? "PASS" : "FAIL");
+        rc |= !(worst < 2e-5);   // (the Q | K | V projection reads one fp16 plane of LN1(h): ~5e-6 here, 4e-7 with both)
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(tj::traj_sa_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(tj::traj_sa_kernel, dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / iters;
+        const double mfma = 4.0 * (84 * 8 + 49 * 2 + 28 * 4 + 112 * 2) * 3.0;   // 16x16x32 MFMAs per trajectory
+        printf("[A] traj_sa_kernel: B=%d  %.1f us per launch = %.1f us per 4096 trajectories, executed %.0f TFLOP/s fp16 MFMA\n", B, us, us * 4096.0 / B,
+               mfma * 16384 * B / us * 1e-6);
+        CK(hipFree(d_h)); CK(hipFree(d_hf)); CK(hipFree(d_of)); CK(hipFree(d_out));
+    }
+
+    // =============================================================================================== Stage B: a whole step
+    {
+        vf x = randn((size_t)B * T * J), wemb = randu((size_t)D * J, 0.2f), bemb = randu(D, 0.1f), pe = randu((size_t)T * D, 1.0f), wout = randu((size_t)J * D, 1.f / 16),
+           bout = randu(J, 0.1f);
+        std::vector<HostLayer> hl(L);
+        for (auto &l : hl) {
+            l.n1w = randu(D, 0.1f, 1.f); l.n1b = randu(D, 0.1f); l.n2w = randu(D, 0.1f, 1.f); l.n2b = randu(D, 0.1f);
+            l.n3w = randu(D, 0.1f, 1.f); l.n3b = randu(D, 0.1f);
+            l.win = randu((size_t)3 * D * D, 1.f / 16); l.bin = randu(3 * D, 0.1f); l.wo = randu((size_t)D * D, 1.f / 16); l.bo = randu(D, 0.1f);
+            l.w1 = randu((size_t)D * D, 1.f / 16); l.b1 = randu(D, 0.1f); l.w2 = randu((size_t)D * D, 1.f / 16); l.b2 = randu(D, 0.1f); l.boc = randu(D, 0.1f);
+            l.gv = randu((size_t)B * 64 * 2 * D, 0.05f);
+            for (int b = 0; b < B; ++b)   // slots >= Mc of the per-trajectory blocks are unused (zero as the fold leaves them)
+                for (int hs = 0; hs < 64; ++hs)
+                    if ((hs & 15) >= Mc) memset(&l.gv[((size_t)b * 64 + hs) * 2 * D], 0, 2 * D * sizeof(float));
+            l.cb = randu((size_t)B * 64, 0.5f);
+            l.gvstep = randu((size_t)4 * 2 * D, 0.05f);
+            l.cstep = randu(4, 0.5f);
+        }
+        const float coef[4] = {0.6f, 0.8f, 0.7f, 0.714f};
+        // device operands
+        float *d_x = dev(x), *d_eps = dalloc<float>((size_t)B * T * J), *d_bemb = dev(bemb), *d_pe = dev(pe), *d_bout = dev(bout);
+        float *d_scio = dalloc<float>(2);
+        f16 *d_wemb = pack(wemb, D, J, D, 32, d_scio), *d_wout = pack(wout, J, D, 32, D, d_scio + 1);
+        tj::StepArgs a{};
+        a.x = d_x; a.eps_out = d_eps; a.w_emb = d_wemb; a.b_emb = d_bemb; a.pe = d_pe; a.w_out = d_wout; a.b_out = d_bout; a.sc_io = d_scio;
+        a.c0 = coef[0]; a.c1 = coef[1]; a.c2 = coef[2]; a.c3 = coef[3];
+        a.scale_log2e = scale_log2e; a.T = T; a.B = B; a.J = J; a.L = L; a.Mk = Mk; a.update_x = 1;
+        a.n1_w = dev(hl[0].n1w); a.n1_b = dev(hl[0].n1b);
+        for (int l = 0; l < L; ++l) {
+            HostLayer &h = hl[l];
+            tj::LayerW &w = a.layer[l];
+            float *sc = dalloc<float>(8);
+            w.sc = sc;
+            w.n2_w = dev(h.n2w); w.n2_b = dev(h.n2b); w.n3_w = dev(h.n3w); w.n3_b = dev(h.n3b);
+            w.w_o = pack(h.wo, D, D, D, D, sc + 0); w.w_1 = pack(h.w1, D, D, D, D, sc + 1); w.w_2 = pack(h.w2, D, D, D, D, sc + 2);
+            w.w_in = pack(h.win, 3 * D, D, 3 * D, D, sc + 3);
+            w.b_in = dev(h.bin); w.b_o = dev(h.bo); w.b_1 = dev(h.b1); w.b_2 = dev(h.b2); w.b_oc = dev(h.boc);
+            // abs-max of G and V' over the per-trajectory rows and the step rows
+            unsigned mg = maxbits(h.gv.data(), (size_t)B * 64, D, 2 * D), mv = maxbits(h.gv.data() + D, (size_t)B * 64, D, 2 * D);
+            mg = std::max(mg, maxbits(h.gvstep.data(), 4, D, 2 * D));
+            mv = std::max(mv, maxbits(h.gvstep.data() + D, 4, D, 2 * D));
+            unsigned *dmb = dev(std::vector<unsigned>{mg, mv});
+            float *d_gv = dev(h.gv), *d_gvs = dev(h.gvstep);
+            f16 *g16 = dalloc<f16>((size_t)B * 4 * 8 * 2 * 512), *v16 = dalloc<f16>((size_t)B * 16 * 2 * 2 * 512), *gs = dalloc<f16>(4 * 8 * 2 * 32), *vs = dalloc<f16>(2 * 4 * D);
+            hipLaunchKernelGGL(tj::pack_g16_kernel, dim3(2048), dim3(256), 0, 0, d_gv, (long)B, Mc, dmb, g16, sc + 4);
+            hipLaunchKernelGGL(tj::pack_v16_kernel, dim3(2048), dim3(256), 0, 0, d_gv, (long)B, Mc, dmb + 1, v16, sc + 5);
+            hipLaunchKernelGGL(tj::pack_gstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb, gs, (float *)nullptr);
+            hipLaunchKernelGGL(tj::pack_vstep16_kernel, dim3(4), dim3(256), 0, 0, d_gvs, 1L, dmb + 1, vs);
+            CK(hipDeviceSynchronize());
+            CK(hipFree(d_gv));
+            w.g16 = g16; w.v16 = v16; w.gstep = gs; w.vstep = vs; w.cb = dev(h.cb); w.cstep = dev(h.cstep);
+            w.nln_w = l + 1 < L ? dev(hl[l + 1].n1w) : nullptr;
+            w.nln_b = l + 1 < L ? dev(hl[l + 1].n1b) : nullptr;
+        }
+        hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        const int nc = ncheck < B ? ncheck : B;
+        vf geps((size_t)nc * T * J), gx((size_t)nc * T * J);
+        CK(hipMemcpy(geps.data(), d_eps, geps.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gx.data(), d_x, gx.size() * 4, hipMemcpyDeviceToHost));
+        double worst_e = 0, worst_x = 0;
+        for (int b = 0; b < nc; ++b) {
+            vd h((size_t)T * D), xn((size_t)T * D);
+            for (int t = 0; t < T; ++t)
+                for (int n = 0; n < D; ++n) {
+                    double s = bemb[n] + pe[(size_t)t * D + n];
+                    for (int j = 0; j < J; ++j) s += (double)wemb[(size_t)n * J + j] * x[((size_t)b * T + t) * J + j];
+                    h[(size_t)t * D + n] = s;
+                }
+            for (int l = 0; l < L; ++l) {
+                const HostLayer &w = hl[l];
+                layer_norm(h, w.n1w, w.n1b, xn, T, D);
+                self_attention(h, xn, w.win, w.bin, w.wo, w.bo, T, D, H);
+                layer_norm(h, w.n2w, w.n2b, xn, T, D);
+                for (int t = 0; t < T; ++t) {
+                    vd add(D, 0.0);
+                    for (int hh = 0; hh < H; ++hh) {
+                        double sc[16], mx = -1e300, sum = 0;
+                        for (int s = 0; s < Mk; ++s) {
+                            const float *g = s < Mc ? &w.gv[(((size_t)b * 4 + hh) * 16 + s) * 2 * D] : &w.gvstep[(size_t)hh * 2 * D];
+                            double d = s < Mc ? w.cb[(size_t)b * 64 + hh * 16 + s] : w.cstep[hh];
+                            for (int k = 0; k < D; ++k) d += xn[(size_t)t * D + k] * g[k];
+                            sc[s] = d / sqrt((double)HD);
+                            mx = fmax(mx, sc[s]);
+                        }
+                        for (int s = 0; s < Mk; ++s) { sc[s] = exp(sc[s] - mx); sum += sc[s]; }
+                        for (int s = 0; s < Mk; ++s) {
+                            const float *v = s < Mc ? &w.gv[(((size_t)b * 4 + hh) * 16 + s) * 2 * D + D] : &w.gvstep[(size_t)hh * 2 * D + D];
+                            for (int n = 0; n < D; ++n) add[n] += sc[s] / sum * v[n];
+                        }
+                    }
+                    for (int n = 0; n < D; ++n) h[(size_t)t * D + n] += add[n] + w.boc[n];
+                }
+                layer_norm(h, w.n3w, w.n3b, xn, T, D);
+                for (int t = 0; t < T; ++t) {
+                    vd u(D);
+                    for (int n = 0; n < D; ++n) {
+                        double s = w.b1[n];
+                        for (int k = 0; k < D; ++k) s += xn[(size_t)t * D + k] * w.w1[(size_t)n * D + k];
+                        u[n] = 0.5 * s * (1.0 + erf(s / sqrt(2.0)));
+                    }
+                    for (int n = 0; n < D; ++n) {
+                        double s = w.b2[n];
+                        for (int k = 0; k < D; ++k) s += u[k] * w.w2[(size_t)n * D + k];
+                        h[(size_t)t * D + n] += s;
+                    }
+                }
+            }
+            double ne = 0, de = 0, nx = 0, dx = 0;
+            for (int t = 0; t < T; ++t)
+                for (int j = 0; j < J; ++j) {
+                    double e = bout[j];
+                    for (int k = 0; k < D; ++k) e += h[(size_t)t * D + k] * wout[(size_t)j * D + k];
+                    const size_t at = ((size_t)b * T + t) * J + j;
+                    const double xw = coef[2] * ((x[at] - coef[1] * e) / coef[0]) + coef[3] * e;
+                    ne += (geps[at] - e) * (geps[at] - e); de += e * e;
+                    nx += (gx[at] - xw) * (gx[at] - xw); dx += xw * xw;
+                }
+            worst_e = fmax(worst_e, sqrt(ne / de));
+            worst_x = fmax(worst_x, sqrt(nx / dx));
+        }
+        const bool ok = worst_e < 1e-4 && worst_x < 1e-5;   // one step on random weights; the rollout bound is tested through the library
+        printf("[B] traj_step_kernel (L=%d): worst rel L2 error vs fp64 over %d trajectories: eps %.3e, x %.3e (%s)\n", L, nc, worst_e, worst_x, ok ? "PASS" : "FAIL");
+        rc |= !ok;
+#ifdef TJ_STAMPS
+        {
+            a.update_x = 0;
+            CK(hipMemset(d_st, 0, n_st * 8));
+            hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> st(n_st);
+            CK(hipMemcpy(st.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
+            const char *names[41] = {"", "embed", "LN1", "(scale)", "QKV gemm head 0", "W0", "X0", "B0", "W1", "X1", "B1", "W2", "X2", "B2", "W3", "X3", "B3",
+                                     "", "", "", "", "", "", "", "", "", "", "", "", "", "", "out-proj(h3)+unscale", "LN2", "xattn scores+softmax", "xattn PV'", "LN3",
+                                     "W1 gemm", "GELU -> panel", "W2 gemm", "LN1'", "fc_out + DDIM (last layer only)"};
+            const int nwg = B < tj::TJ_STAMP_WGS ? B : tj::TJ_STAMP_WGS;
+            auto mean = [&](int w0, int i) {
+                double s = 0;
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long *p = &st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP];
+                    s += (double)(p[i] - p[i - 1]);
+                }
+                return s / nwg;
+            };
+            const char *agg[3] = {"phase W: out-proj(h-1) || write QKV(h)", "phase X: QKV gemm(h+1) || attention(h)", "barrier after phase X"};
+            printf("--- last layer of the step: mean cycles per phase over %d workgroups        wave 0    wave 3    wave 4    wave 7\n", nwg);
+            const int ws[4] = {0, 3, 4, 7};
+            printf("  %-37s", "QKV gemm of head 0");
+            for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], 4));
+            printf("\n");
+            for (int k = 0; k < 3; ++k) {
+                printf("  4 heads: %-28s", agg[k]);
+                for (int wi = 0; wi < 4; ++wi) {
+                    double s = 0;
+                    for (int h = 0; h < 4; ++h) s += mean(ws[wi], 5 + 3 * h + k);
+                    printf(" %9.0f", s);
+                }
+                printf("\n");
+            }
+            {   // inside phase W of heads 1..3 (head 0 has no out-projection)
+                const char *jn[4] = {"  W: out-projection (waves 0-3 first)", "  W: write Q|K|V", "  W: out-projection (waves 4-7 after)", "  W: barrier"};
+                for (int k = 0; k < 4; ++k) {
+                    printf("  heads 1-3 %-27s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            for (int h = 1; h < 4; ++h) {
+                                const unsigned long long t0 = p[7 + 3 * (h - 1)], t1 = p[25 + h], t2 = p[41 + h], t3 = p[45 + h], t4 = p[5 + 3 * h];
+                                sum += (double)(k == 0 ? t1 - t0 : k == 1 ? t2 - t1 : k == 2 ? t3 - t2 : t4 - t3);
+                            }
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
+            {   // inside phase X of heads 0..2 (head 3 has no projection GEMM): first job, attention, second job
+                const char *jn[3] = {"  X: projection GEMM (waves 0-3 first)", "  X: attention", "  X: projection GEMM (waves 4-7 after)"};
+                for (int k = 0; k < 3; ++k) {
+                    printf("  heads 0-2 %-27s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            for (int h = 0; h < 3; ++h) {
+                                const unsigned long long t0 = p[5 + 3 * h], t1 = p[17 + h], t2 = p[21 + h], t3 = p[6 + 3 * h];
+                                sum += (double)(k == 0 ? t1 - t0 : k == 1 ? t2 - t1 : t3 - t2);
+                            }
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
+            printf("  %-37s", "out-proj(h3) + unscale");
+            for (int wi = 0; wi < 4; ++wi) {
+                double s = 0;
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                    s += (double)(p[31] - p[16]);
+                }
+                printf(" %9.0f", s / nwg);
+            }
+            printf("\n");
+            for (int i = 32; i <= 40; ++i) {
+                printf("  %-37s", names[i]);
+                for (int wi = 0; wi < 4; ++wi) printf(" %9.0f", mean(ws[wi], i));
+                printf("\n");
+            }
+            {   // inside the last LayerNorm executed (LN3 of the last layer; stamp 34 precedes it)
+                const char *jn[4] = {"  LN3: per-wave statistics", "  LN3: exchange barrier", "  LN3: combine 8 waves", "  LN3: normalise, split, store"};
+                const int from[4] = {34, 49, 50, 51}, to[4] = {49, 50, 51, 52};
+                for (int k = 0; k < 4; ++k) {
+                    printf("  %-37s", jn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + ws[wi]) * tj::TJ_NSTAMP];
+                            sum += (double)(p[to[k]] - p[from[k]]);
+                        }
+                        printf(" %9.0f", sum / nwg);
+                    }
+                    printf("\n");
+                }
+            }
+            double whole = 0;
+            for (int b = 0; b < nwg; ++b) whole += (double)(st[((size_t)b * 8) * tj::TJ_NSTAMP + 40] - st[((size_t)b * 8) * tj::TJ_NSTAMP]);
+            printf("  whole step (L layers), wave 0: %.0f cycles\n", whole / nwg);
+            const char *sites[11] = {"LayerNorm: statistics exchange", "LayerNorm: panel complete", "self-attention: Q|K|V written (phase W)",
+                                     "self-attention: O written (phase X)", "cross-attention: before P", "cross-attention: P complete",
+                                     "feed-forward: before GELU", "feed-forward: GELU stored", "embedding (1)", "tail: before fc_out", "tail (2)"};
+            printf("--- cycles spent INSIDE barriers over the whole step, mean over %d workgroups   wave:  0      1      2      3      4      5      6      7\n", nwg);
+            double tot[8] = {0};
+            for (int sidx = 0; sidx < 11; ++sidx) {
+                printf("  %-44s", sites[sidx]);
+                for (int w0 = 0; w0 < 8; ++w0) {
+                    double sum = 0;
+                    for (int b = 0; b < nwg; ++b) sum += (double)st[((size_t)b * 8 + w0) * tj::TJ_NSTAMP + 64 + sidx];
+                    printf(" %6.0f", sum / nwg);
+                    tot[w0] += sum / nwg;
+                }
+                printf("\n");
+            }
+            printf("  %-44s", "all barriers");
+            for (int w0 = 0; w0 < 8; ++w0) printf(" %6.0f", tot[w0]);
+            printf("\n");
+            a.update_x = 1;
+        }
+#endif
+        a.update_x = 0;   // timing: x stays put (the same work; only the final store differs)
+        a.eps_out = nullptr;
+        for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((TL_STEP_KERNEL), dim3(B), dim3(tj::NTHREADS), tj::LDS_BYTES, 0, a);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / iters;
+        printf("[B] traj_step_kernel: B=%d L=%d  %.1f us per step = %.1f us per 4096 trajectories;  50 steps -> %.0f trajectories/s\n", B, L, us, us * 4096.0 / B,
+               B / (us * 50e-6));
+    }
+    return rc;
+}
