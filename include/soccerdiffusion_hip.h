@@ -510,7 +510,7 @@ int sd_set_dropout_epoch(const uint32_t *device_word);
 
 /* ---- image path, TRAINING: torchvision BasicBlock / Bottleneck under autograd with BatchNorm2d in training mode, as the
  * reference trains its backbone with every step (soccer_diffusion/ml/training/train.py:226-240 -> ml/model/encoder/image.py:38-83).  NHWC fp32
- * tensors of npix = N * H * W pixels x C channels (C in {64, 128, 256, 512}), 16-byte aligned (soccerdiffusion_amd/csrc/sd_conv_train.hip).
+ * tensors of npix = N * H * W pixels x C channels (C in {64, 128, 256, 512, 1024, 2048}), 16-byte aligned (soccerdiffusion_amd/csrc/sd_conv_train.hip).
  *   sd_bn_train_fwd: batch statistics of y (the raw convolution output) -> mean, rstd = 1 / sqrt(biased var + eps) (C floats each);
  *     z = relu?((y - mean) rstd gamma + beta (+ res)); running_mean / running_var updated as torch.nn.BatchNorm2d does (momentum, unbiased
  *     variance) unless NULL; z_amax (one uint32, zeroed by the caller) receives the bits of max |z| for the next convolution's fp16 scale.

@@ -25,29 +25,34 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtom
 template <class F>   // F(pixel index, channel group base, float4 of the tensor) -> accumulates into two f32x4
 __device__ __forceinline__ void channel_reduce(long npix, int C, double *acc /* [C][2] */, F f) {
     __shared__ float red[256 * 8];
-    const int cg = C / 4, tid = threadIdx.x;
-    const int c4 = tid % cg, prow = tid / cg, pstep = 256 / cg;   // C in {64, 128, 256, 512}: cg in {16 .. 128} divides 256
+    const int tid = threadIdx.x;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long p0 = (long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
-    for (long p = p0 + prow; p < p1; p += pstep) f(p, 4 * c4, s, q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        red[tid * 8 + e] = s[e];
-        red[tid * 8 + 4 + e] = q[e];
-    }
-    __syncthreads();
-    if (tid < cg) {
-        for (int r = 1; r < pstep; ++r)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[e] += red[(r * cg + tid) * 8 + e];
-                q[e] += red[(r * cg + tid) * 8 + 4 + e];
-            }
+    // C in {64 .. 1024}: one pass, cg = C / 4 channel groups divide the 256 threads; wider tensors (ResNet-50's 2048): 1024 channels per pass
+    for (int cb = 0; cb < C; cb += 1024) {
+        const int cc = C - cb < 1024 ? C - cb : 1024, cg = cc / 4;
+        const int c4 = tid % cg, prow = tid / cg, pstep = 256 / cg;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+        for (long p = p0 + prow; p < p1; p += pstep) f(p, cb + 4 * c4, s, q);
+        if (cb > 0) __syncthreads();   // the previous pass has read `red`
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomic_add_f64(acc + (4 * tid + e) * 2, (double)s[e]);
-            atomic_add_f64(acc + (4 * tid + e) * 2 + 1, (double)q[e]);
+            red[tid * 8 + e] = s[e];
+            red[tid * 8 + 4 + e] = q[e];
+        }
+        __syncthreads();
+        if (tid < cg) {
+            for (int r = 1; r < pstep; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += red[(r * cg + tid) * 8 + e];
+                    q[e] += red[(r * cg + tid) * 8 + 4 + e];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomic_add_f64(acc + (cb + 4 * tid + e) * 2, (double)s[e]);
+                atomic_add_f64(acc + (cb + 4 * tid + e) * 2 + 1, (double)q[e]);
+            }
         }
     }
 }
@@ -543,7 +548,6 @@ extern "C" int sd_bn_train_fwd(const float *y, const float *gamma, const float *
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(gamma) |
          reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_train_fwd: tensors must be 16-byte aligned");
-    if (C > 512) return fail(SD_E_BADDIM, "sd_bn_train_fwd: up to 512 channels");
     hipStream_t st = (hipStream_t)stream;
     SD_LAUNCH(cvt::bn_stats_kernel, dim3(blocks_for(npix, 1024, 2048)), dim3(256), 0, st, y, (long)npix, C, acc);
     SD_CHECK_LAUNCH("bn_stats_kernel");
@@ -557,7 +561,7 @@ extern "C" int sd_bn_train_fwd(const float *y, const float *gamma, const float *
 
 extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
                                float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream) {
-    if (!dz || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || (relu && !z) || !bn_shape_ok(npix, C) || C > 512)
+    if (!dz || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || (relu && !z) || !bn_shape_ok(npix, C))
         return fail(SD_E_BADARG, "sd_bn_train_bwd: null pointer or bad shape");
     if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
          reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)

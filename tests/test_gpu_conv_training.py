@@ -210,6 +210,48 @@ def test_stem_raw_convolution_and_weight_gradient_match_torch_fp64(N, H, W):
     assert rel_err(dw, wd.grad) < 1e-5
 
 
+def test_resnet50_bottleneck_gradients_match_torch_cpu_fp64():
+    """The reference's other ResNet option (image_encoder_type "resnet50", ml/model/encoder/image.py:62-66): torchvision Bottleneck blocks under
+    autograd - 1 x 1 / 3 x 3 (stride 1 and 2) / 1 x 1 units and 1 x 1 shortcuts with either stride - on ConvBNUnit: every parameter gradient
+    against the same modules on the CPU in fp64."""
+    import copy
+
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd.ml.model.encoder.image import _Bottleneck, _ResNet
+
+    torch.manual_seed(4)
+    net = _ResNet(_Bottleneck, [2, 1, 1, 1])   # (every block kind of [3, 4, 6, 3] at a quarter of the depth)
+    net.fc = torch.nn.Linear(2048, 16)
+    ref = copy.deepcopy(net).double().train()
+    gpu = copy.deepcopy(net).cuda().train()
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+    wr = torch.randn(2, 16, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    out_ref = ref(x.double())
+    (out_ref * wr).sum().backward()
+    calls = []
+    orig = ct.ConvBNUnit.apply
+    ct.ConvBNUnit.apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = gpu(x.cuda())
+        (out * wr.float().cuda()).sum().backward()
+    finally:
+        ct.ConvBNUnit.apply = orig
+    assert len(calls) == 5 * 3 + 4   # 5 blocks x 3 units + 4 shortcuts
+    assert rel_err(out, out_ref) < 1e-5
+    pr = dict(ref.named_parameters())
+    errs = {name: rel_err(p.grad, pr[name].grad) for name, p in gpu.named_parameters()}
+    # End to end, an fp32 backward is only as good as its conditioning: ONE ReLU-mask element of layer1.0's output sits within fp32 rounding of
+    # zero on this input and flips against the fp64 forward (tools/exp/r50_diag.py: 1 mismatch of 196 608) - a 100 % change of the gradient
+    # at that pixel, which moves layer1.0's and the stem's parameter gradients by ~ 3e-3 while every block behind it stays at 6e-6.  So: the
+    # bulk must be tight, nothing may be far off, and the per-kernel accuracy is asserted on identical tensors elsewhere in this file.
+    vals = sorted(errs.values())
+    assert vals[len(vals) // 2] < 2e-5, vals[len(vals) // 2]
+    assert sum(v < 5e-5 for v in vals) >= 0.7 * len(vals), sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    assert vals[-1] < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    late = [e for name, e in errs.items() if name.startswith(("layer2", "layer3", "layer4", "fc"))]
+    assert max(late) < 5e-5   # behind the flip's reach the kernels' own accuracy shows
+
+
 def test_training_step_of_the_image_conditioned_model_uses_the_unit_kernels():
     """Through the boundary class: a train_step of the image-conditioned model (configs[4]'s structure at a small size) runs the backbone's
     blocks on ConvBNUnit and moves every backbone parameter; SD_CONV=torch gives the same loss on the torch.nn route."""

@@ -1,0 +1,85 @@
+import os, sys, copy, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from soccerdiffusion_amd import conv_training as ct
+from soccerdiffusion_amd.ml.model.encoder.image import _Bottleneck, _ResNet
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+torch.manual_seed(4)
+net = _ResNet(_Bottleneck, [2, 1, 1, 1]); net.fc = torch.nn.Linear(2048, 16)
+ref = copy.deepcopy(net).double().train(); gpu = copy.deepcopy(net).cuda().train()
+x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+wr = torch.randn(2, 16, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+# capture activations' gradients on both sides with hooks on the blocks' outputs
+grads_ref, grads_gpu = {}, {}
+def hook(store, name):
+    def f(mod, inp, out):
+        if isinstance(out, tuple): out = out[0]
+        out.register_hook(lambda g: store.__setitem__(name, g.detach()))
+    return f
+for n_, m in ref.named_modules():
+    if n_ in ("layer1.0", "layer1.1", "layer2.0", "layer3.0", "layer4.0"): m.register_forward_hook(hook(grads_ref, n_))
+(ref(x.double()) * wr).sum().backward()
+# GPU: blocks are called through forward_train_nhwc, not forward: wrap it
+for n_, m in gpu.named_modules():
+    if n_ in ("layer1.0", "layer1.1", "layer2.0", "layer3.0", "layer4.0"):
+        orig = m.forward_train_nhwc
+        def wrapped(h, amax, orig=orig, n_=n_):
+            z, w = orig(h, amax)
+            z.register_hook(lambda g, n_=n_: grads_gpu.__setitem__(n_, g.detach()))
+            return z, w
+        m.forward_train_nhwc = wrapped
+(gpu(x.cuda()) * wr.float().cuda()).sum().backward()
+for k in grads_ref:
+    print(k, "grad wrt block output: rel err %.2e" % rel(grads_gpu[k].permute(0, 3, 1, 2), grads_ref[k]), tuple(grads_ref[k].shape))
+pr = dict(ref.named_parameters())
+for name, p in gpu.named_parameters():
+    print("%-36s %.2e" % (name, rel(p.grad, pr[name].grad)))
+# ---- second pass: compare the forward outputs of layer1.0 / layer1.1 and their masks
+outs_ref, outs_gpu = {}, {}
+ref2 = copy.deepcopy(net).double().train(); gpu2 = copy.deepcopy(net).cuda().train()
+for n_, m in ref2.named_modules():
+    if n_ in ("layer1.0", "layer1.1", "maxpool"): m.register_forward_hook(lambda mod, i, o, n_=n_: outs_ref.__setitem__(n_, o.detach()))
+for n_, m in gpu2.named_modules():
+    if n_ in ("layer1.0", "layer1.1"):
+        orig = m.forward_train_nhwc
+        def wrapped(h, amax, orig=orig, n_=n_):
+            outs_gpu[n_ + ".in"] = h.detach().clone()
+            z, w = orig(h, amax)
+            outs_gpu[n_] = z.detach().clone()
+            return z, w
+        m.forward_train_nhwc = wrapped
+ref2(x.double()); gpu2(x.cuda())
+print("maxpool out vs layer1.0 input:", rel(outs_gpu["layer1.0.in"].permute(0, 3, 1, 2), outs_ref["maxpool"]))
+for k in ("layer1.0", "layer1.1"):
+    a, b = outs_gpu[k].permute(0, 3, 1, 2).cpu().double(), outs_ref[k]
+    print(k, "forward rel err %.2e" % rel(a, b), "mask mismatches", int(((a > 0) != (b > 0)).sum()), "of", a.numel(), "zero fraction %.3f" % float((b == 0).double().mean()))
+# ---- third pass: every bn_train_bwd call against fp64 on the same tensors
+gpu3 = copy.deepcopy(net).cuda().train()
+orig_bn = ct.bn_train_bwd
+rec = []
+def spy(dz, z, y, mean, rstd, gamma, relu, want):
+    res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want)
+    rec.append((dz.clone(), None if z is None else z.clone(), y.clone(), mean.clone(), rstd.clone(), gamma.clone(), relu, [None if r is None else r.clone() for r in res]))
+    return res
+ct.bn_train_bwd = spy
+(gpu3(x.cuda()) * wr.float().cuda()).sum().backward()
+ct.bn_train_bwd = orig_bn
+for i, (dz, z, y, mean, rstd, gamma, relu, (dy, _w, dgamma, dbeta, dres)) in enumerate(rec):
+    g = dz.double().cpu() * ((z.double().cpu() > 0) if relu else 1.0)
+    xh = (y.double().cpu() - mean.double().cpu()) * rstd.double().cpu()
+    n = g.numel() // g.shape[-1]
+    s1, s2 = g.reshape(n, -1).sum(0), (g * xh).reshape(n, -1).sum(0)
+    want = gamma.double().cpu() * rstd.double().cpu() * (g - s1 / n - xh * s2 / n)
+    print(i, tuple(y.shape), "relu", relu, "dy %.1e dgamma %.1e dbeta %.1e" % (rel(dy, want), rel(dgamma, s2), rel(dbeta, s1)),
+          "| mean vs batch mean of y: %.1e" % rel(mean, y.double().cpu().reshape(n, -1).mean(0)))
+# ---- fourth: bias gradient of layer1.0.bn3 recomputed from hooks on both sides
+dz_r, z_r = grads_ref["layer1.0"], outs_ref["layer1.0"]
+s_ref = (dz_r * (z_r > 0)).sum(dim=(0, 2, 3))
+print("ref: sum(dz*mask) vs ref bn3.bias.grad:", rel(s_ref, pr["layer1.0.bn3.bias"].grad))
+dz_g, z_g = grads_gpu["layer1.0"].permute(0, 3, 1, 2).double().cpu(), outs_gpu["layer1.0"].permute(0, 3, 1, 2).double().cpu()
+s_gpu = (dz_g * (z_g > 0)).sum(dim=(0, 2, 3))
+pg = dict(gpu.named_parameters())
+print("gpu: sum(dz*mask) vs gpu bn3.bias.grad:", rel(s_gpu, pg["layer1.0.bn3.bias"].grad), " gpu sum vs ref grad:", rel(s_gpu, pr["layer1.0.bn3.bias"].grad),
+      " |sum| / sum|.|:", float(s_ref.abs().sum() / (dz_r * (z_r > 0)).abs().sum()))
+print("dz diff per-channel-sum:", rel(dz_g.sum(dim=(0, 2, 3)), dz_r.sum(dim=(0, 2, 3))), " ref |sum dz| / sum |dz|:", float(dz_r.sum(dim=(0,2,3)).abs().sum() / dz_r.abs().sum()))
