@@ -173,6 +173,7 @@ struct WgradArgs {
     int rows_per_item;   // output image rows per work item
     int n_row_items;     // ceil(N * Ho / rows_per_item)
     float *part;         // conv_wgrad3_kernel: [n_row_items][Cout][Cin][9] partial sums (plain stores; wgrad_reduce_kernel adds them up), or NULL: atomics
+    int abl;             // diagnostic (SD_W3_ABL): 1 skip the MFMA phase, 2 skip the LDS staging stores, 4 skip the global loads
 };
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int W3_PITCH = 72;                       // halfs per staged pixel (64 channels + 8: 144 bytes, an odd number of 16-byte units)
 constexpr int W3_DY = 32 * W3_PITCH;               // halfs of the dY plane
-constexpr int W3_XROW = 34 * W3_PITCH;             // ... of one halo row of X
+constexpr int W3_XROW = 36 * W3_PITCH;             // ... of one halo row of X (34 pixels + 2 that only the 12-pixel fragment reads touch)
 constexpr int W3_PLANE = W3_DY + 3 * W3_XROW;      // one plane (hi or lo): dY, then the three halo rows
 __device__ __forceinline__ f16x8 w3_frag(const f16 *plane, int row0, int col0, int lane) {
     // as tns_frag of sd_train.hip: lane (l31, half) receives channel col0 + l31, pixels row0 + 0 .. 7 (row0 already holds 8 * half)
@@ -321,6 +322,26 @@ __device__ __forceinline__ f16x8 w3_frag(const f16 *plane, int row0, int col0, i
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)at);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(at + 4 * W3_PITCH));
     return __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// 12 consecutive pixels row0 .. row0 + 11 of channel col0 + l31 (three transposing reads): the three taps of a kernel row use the windows
+// [kx, kx + 8) of them - two LDS reads and four byte-permutes per shifted fragment instead of six LDS reads (the kernel is bound by its LDS
+// reads: 160 transposing reads per wave and 32 pixels against 54 MFMAs before this)
+struct Frag12 { f16x4 a, b, c; };
+__device__ __forceinline__ Frag12 w3_frag12(const f16 *plane, int row0, int col0, int lane) {
+    const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, gc = ((lane >> 4) & 1) * 16;
+    const f16 *at = plane + (row0 + q) * W3_PITCH + col0 + gc + p4;
+    Frag12 f;
+    f.a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)at));
+    f.b = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(at + 4 * W3_PITCH)));
+    f.c = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(at + 8 * W3_PITCH)));
+    return f;
+}
+template <int KX>
+__device__ __forceinline__ f16x8 w3_window(const Frag12 &f) {
+    const f16x8 lo = __builtin_shufflevector(f.a, f.b, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(f.b, f.c, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (KX == 0) return lo;
+    else if constexpr (KX == 1) return __builtin_shufflevector(lo, hi, 1, 2, 3, 4, 5, 6, 7, 12);   // hi = pixels 4 .. 11: element 12 of (lo, hi) = pixel 8
+    else return __builtin_shufflevector(lo, hi, 2, 3, 4, 5, 6, 7, 12, 13);
 }
 __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) f16 sm[2 * W3_PLANE];
@@ -343,9 +364,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
     const float *dyb = a.dy + cot * 64 + c4, *xb = a.x + cit * 64 + c4;
     const int nsteps = (a.W + 31) / 32;
     f32x4 yv[2], xv[7];
-    auto load = [&](long row, int x0) __attribute__((always_inline)) {
+    // (image index n, row oy, column x0 of a step are running counters: a 64-bit division per thread and step cost more than the step's MFMAs)
+    auto load = [&](long row, int n, int oy, int x0) __attribute__((always_inline)) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int n = (int)(row / a.H), oy = (int)(row - (long)n * a.H);
+        if (a.abl & 4) {
+            yv[0] = yv[1] = z;
+#pragma unroll
+            for (int v = 0; v < 7; ++v) xv[v] = z;
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int ox = x0 + (tid >> 4) + 16 * v;
@@ -360,9 +387,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
         }
     };
     const long nwork = (row1 - row0) * nsteps;
-    if (nwork > 0) load(row0, 0);
+    long nrow = row0;
+    int nn = (int)(row0 / a.H), noy = (int)(row0 - (long)nn * a.H), nx0 = 0;   // position of the NEXT load
+    auto advance = [&]() __attribute__((always_inline)) {
+        nx0 += 32;
+        if (nx0 >= a.W) {
+            nx0 = 0;
+            ++nrow;
+            if (++noy == a.H) {
+                noy = 0;
+                ++nn;
+            }
+        }
+    };
+    if (nwork > 0) {
+        load(nrow, nn, noy, nx0);
+        advance();
+    }
     for (long wk = 0; wk < nwork; ++wk) {
         __syncthreads();   // every wave is done reading the previous step's planes
+        if (!(a.abl & 2))
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             f16x4 h, l;
@@ -371,34 +415,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
             *reinterpret_cast<f16x4 *>(o) = h;
             *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
         }
+        if (!(a.abl & 2))
 #pragma unroll
         for (int v = 0; v < 7; ++v) {
             const int i = (tid >> 4) + 16 * v;
             if (i < 102) {
                 f16x4 h, l;
                 f16_split4(xv[v], sx, h, l);
-                f16 *o = sm + W3_DY + i * W3_PITCH + c4;
+                const int hr = i / 34, hx = i - hr * 34;
+                f16 *o = sm + W3_DY + hr * W3_XROW + hx * W3_PITCH + c4;
                 *reinterpret_cast<f16x4 *>(o) = h;
                 *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
             }
         }
         if (wk + 1 < nwork) {   // the next step's global loads are in flight during this step's MFMAs
-            const long nx = wk + 1;
-            load(row0 + nx / nsteps, (int)(nx % nsteps) * 32);
+            load(nrow, nn, noy, nx0);
+            advance();
         }
-        __syncthreads();
+        // An LDS-only barrier (lgkmcnt(0) + s_barrier) instead of __syncthreads(), whose workgroup-scope fence is s_waitcnt vmcnt(0) and would
+        // wait for the loads just issued.  Measured: no difference at layer 1 (1.32 vs 1.30 ms) - a step takes ~ 5 us, longer than the loads'
+        // latency either way; the kernel is bound by the issue of its address arithmetic, splits and MFMAs (NOTEBOOK round-5 addendum).
+        // (builtins, not inline assembly: hipcc flushes every counter before an asm statement with a memory clobber)
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS stores are done; vmcnt / expcnt left alone
+        __builtin_amdgcn_s_barrier();
+        if (!(a.abl & 1))
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int r0 = 16 * st + 8 * half;
             const f16x8 ah = w3_frag(sm, r0, coh * 32, lane), al = w3_frag(sm + W3_PLANE, r0, coh * 32, lane);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t - 3 * ky;
+            for (int ky = 0; ky < 3; ++ky) {
                 const f16 *xp = sm + W3_DY + ky * W3_XROW;
-                const f16x8 bh = w3_frag(xp, r0 + kx, cih * 32, lane), bl = w3_frag(xp + W3_PLANE, r0 + kx, cih * 32, lane);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                const Frag12 fh = w3_frag12(xp, r0, cih * 32, lane), fl = w3_frag12(xp + W3_PLANE, r0, cih * 32, lane);
+                auto tap = [&](f32x16 &c, const f16x8 &bh, const f16x8 &bl) __attribute__((always_inline)) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+                };
+                tap(acc[3 * ky + 0], w3_window<0>(fh), w3_window<0>(fl));
+                tap(acc[3 * ky + 1], w3_window<1>(fh), w3_window<1>(fl));
+                tap(acc[3 * ky + 2], w3_window<2>(fh), w3_window<2>(fl));
             }
         }
     }
@@ -595,7 +651,8 @@ extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return fail(SD_E_BADARG, "sd_conv_wgrad: kernel size 1 or 3, stride 1 or 2");
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv_wgrad: channels must be positive multiples of 64");
     const int pad = ksize / 2, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0, nullptr};
+    static const char *abl_env = getenv("SD_W3_ABL");
+    cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0, nullptr, abl_env ? atoi(abl_env) : 0};
     // ~4096 pixels per work item: long enough that a tile's 4096 atomics are a small part of its work, short enough to fill the chip
     a.rows_per_item = (4096 + Wo - 1) / Wo;
     const long rows = (long)N * Ho;
