@@ -514,8 +514,10 @@ int sd_set_dropout_epoch(const uint32_t *device_word);
  *   sd_bn_train_fwd: batch statistics of y (the raw convolution output) -> mean, rstd = 1 / sqrt(biased var + eps) (C floats each);
  *     z = relu?((y - mean) rstd gamma + beta (+ res)); running_mean / running_var updated as torch.nn.BatchNorm2d does (momentum, unbiased
  *     variance) unless NULL; z_amax (one uint32, zeroed by the caller) receives the bits of max |z| for the next convolution's fp16 scale.
- *     acc: 2 C doubles of scratch, ZEROED by the caller.
- *   sd_bn_train_bwd: g = dz behind the ReLU mask (z > 0; z may be NULL when relu = 0); dgamma = sum g x_hat, dbeta = sum g,
+ *     acc: 2 C doubles (the channel sums, an output); scratch: sd_bn_scratch_floats(npix, C) floats - the workgroups' partial sums (plain
+ *     stores, added up in double by a second launch: no atomics, deterministic).
+ *   sd_bn_train_bwd: g = dz behind the ReLU mask (z > 0; z NULL with relu = 1 and NO residual operand: the mask is recomputed from y, gamma, beta -
+ *     one tensor less to read; beta may be NULL otherwise); dgamma = sum g x_hat, dbeta = sum g,
  *     dy = gamma rstd (g - mean(g) - x_hat mean(g x_hat)); dres (or NULL) receives g, the gradient of the residual operand; dy_amax as above.
  *   sd_conv_wgrad: dw (Cout, Cin, k, k) (torch layout, ZEROED by the caller) += sum over output pixels of dy[pixel][co] x[pixel * stride + tap - k/2][ci]
  *     for the k x k (1 or 3), stride 1 or 2, padding k / 2 convolution of x (N,H,W,Cin) with output dy (N,Ho,Wo,Cout); Cin, Cout multiples
@@ -523,11 +525,14 @@ int sd_set_dropout_epoch(const uint32_t *device_word);
  *     -> one power-of-two scale per operand for the launch; either NULL -> block floating point per 32 pixels (abs-max taken inside).
  * The data gradient is the forward convolution (sd_conv3x3_bn_act / sd_conv1x1_bn_act, identity epilogue) of dy - dilated with zeros for a
  * stride-2 convolution - with the flipped, transposed weights. */
+size_t sd_bn_scratch_floats(int64_t npix, int C);
 int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const float *res, float *z, float *mean, float *rstd,
-                    float *running_mean, float *running_var, double *acc, uint32_t *z_amax, int64_t npix, int C, float eps, float momentum,
-                    int relu, void *stream);
-int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
-                    float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream);
+                    float *running_mean, float *running_var, double *acc, float *scratch, uint32_t *z_amax, int64_t npix, int C, float eps,
+                    float momentum, int relu, void *stream);
+int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                    float *dy,
+                    float *dres, float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int64_t npix, int C, int relu,
+                    void *stream);
 /* The stem in training: sd_stem_conv_raw = the bare 7 x 7 / stride-2 / padding-3 convolution of sd_stem_conv_bn_relu_pool (same packed planes,
  * same kernel) -> y_raw (N, Hc, Wc, 64) NHWC, Hc = (H - 1) / 2 + 1; sd_stem_wgrad: its weight gradient dw (64, 3, 7, 7) from dy (N, Hc, Wc, 64)
  * and the frames x (N, 3, H, W), both with their abs-max words; scratch: sd_stem_wgrad_scratch_floats(N, H, W) floats.  (The frames need no gradient.) */

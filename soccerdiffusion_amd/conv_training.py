@@ -51,16 +51,19 @@ def bn_train_fwd(y: Tensor, gamma: Tensor, beta: Tensor, res: Optional[Tensor], 
     z = torch.empty_like(y)
     mean = torch.empty(Cn, dtype=torch.float32, device=y.device)
     rstd = torch.empty_like(mean)
-    acc = torch.zeros(2 * Cn, dtype=torch.float64, device=y.device)
+    acc = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    scratch = torch.empty(lib.sd_bn_scratch_floats(npix, Cn), dtype=torch.float32, device=y.device)
     word = torch.zeros(1, dtype=torch.int32, device=y.device)
     check(lib.sd_bn_train_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ops._ptr(res), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                              ops._ptr(running_mean), ops._ptr(running_var), acc.data_ptr(), word.data_ptr(), npix, Cn, float(eps), float(momentum),
+                              ops._ptr(running_mean), ops._ptr(running_var), acc.data_ptr(), scratch.data_ptr(), word.data_ptr(), npix, Cn, float(eps), float(momentum),
                               int(relu), ops._stream()), "sd_bn_train_fwd")
     return z, word, mean, rstd
 
 
-def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, relu: bool, want_dres: bool):
-    """-> (dy, dy_amax word, dgamma, dbeta, dres or None)."""
+def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, relu: bool, want_dres: bool,
+                 beta: Optional[Tensor] = None):
+    """-> (dy, dy_amax word, dgamma, dbeta, dres or None).  ``z`` None with ``relu``: a unit WITHOUT residual operand, the ReLU mask is recomputed
+    from y with ``beta`` (the kernels read one tensor less)."""
     lib = _lib.load()
     Cn = y.shape[-1]
     npix = y.numel() // Cn
@@ -68,10 +71,11 @@ def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd:
     dres = torch.empty_like(y) if want_dres else None
     dgamma = torch.empty(Cn, dtype=torch.float32, device=y.device)
     dbeta = torch.empty_like(dgamma)
-    acc = torch.zeros(2 * Cn, dtype=torch.float64, device=y.device)
+    acc = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    scratch = torch.empty(lib.sd_bn_scratch_floats(npix, Cn), dtype=torch.float32, device=y.device)
     word = torch.zeros(1, dtype=torch.int32, device=y.device)
-    check(lib.sd_bn_train_bwd(dz.data_ptr(), ops._ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dy.data_ptr(), ops._ptr(dres),
-                              dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), word.data_ptr(), npix, Cn, int(relu), ops._stream()), "sd_bn_train_bwd")
+    check(lib.sd_bn_train_bwd(dz.data_ptr(), ops._ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), ops._ptr(beta), dy.data_ptr(), ops._ptr(dres),
+                              dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), scratch.data_ptr(), word.data_ptr(), npix, Cn, int(relu), ops._stream()), "sd_bn_train_bwd")
     return dy, word, dgamma, dbeta, dres
 
 
@@ -117,16 +121,18 @@ class ConvBNUnit(torch.autograd.Function):
         fwd, bwd = pair.get(weight)
         y = conv_raw(h, amax, fwd, stride)
         z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), res, running_mean, running_var, eps, momentum, relu)
-        ctx.save_for_backward(h, y, z if relu else None, mean, rstd, gamma, amax)
+        # the ReLU mask of a unit without residual operand is recomputed from y in the backward (z is not read there)
+        ctx.save_for_backward(h, y, z if relu and res is not None else None, mean, rstd, gamma, amax, beta)
         ctx.cfg = (bwd, tuple(weight.shape), stride, relu, res is not None)
         ctx.mark_non_differentiable(word)
         return z, word
 
     @staticmethod
     def backward(ctx, dz, _dword):
-        h, y, z, mean, rstd, gamma, h_amax = ctx.saved_tensors
+        h, y, z, mean, rstd, gamma, h_amax, beta = ctx.saved_tensors
         bwd, wshape, stride, relu, has_res = ctx.cfg
-        dy, word, dgamma, dbeta, dres = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), relu, has_res and ctx.needs_input_grad[5])
+        dy, word, dgamma, dbeta, dres = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), relu, has_res and ctx.needs_input_grad[5],
+                                                     beta.detach())
         dW = conv_wgrad(dy, h, wshape, stride, word, h_amax) if ctx.needs_input_grad[2] else None
         dh = None
         if ctx.needs_input_grad[0]:
@@ -169,14 +175,14 @@ class StemUnit(torch.autograd.Function):
         x_amax = ops.absmax_word(x)
         y = stem_conv_raw(x, x_amax, pk.refresh(weight))
         z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, True)
-        ctx.save_for_backward(x, x_amax, y, z, mean, rstd, gamma)
+        ctx.save_for_backward(x, x_amax, y, mean, rstd, gamma, beta)
         ctx.mark_non_differentiable(word)
         return z, word
 
     @staticmethod
     def backward(ctx, dz, _dword):
-        x, x_amax, y, z, mean, rstd, gamma = ctx.saved_tensors
-        dy, word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), True, False)
+        x, x_amax, y, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy, word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), None, y, mean, rstd, gamma.detach(), True, False, beta.detach())
         dW = stem_wgrad(dy, x, word, x_amax) if ctx.needs_input_grad[1] else None
         return None, dW, dgamma, dbeta, None, None, None, None, None
 
@@ -197,15 +203,15 @@ class BNUnit(torch.autograd.Function):
     def forward(ctx, y, gamma, beta, running_mean, running_var, relu: bool, eps: float, momentum: float):
         y = y.contiguous()
         z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, relu)
-        ctx.save_for_backward(y, z if relu else None, mean, rstd, gamma)
+        ctx.save_for_backward(y, mean, rstd, gamma, beta)
         ctx.relu = relu
         ctx.mark_non_differentiable(word)
         return z, word
 
     @staticmethod
     def backward(ctx, dz, _dword):
-        y, z, mean, rstd, gamma = ctx.saved_tensors
-        dy, _word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), ctx.relu, False)
+        y, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy, _word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), None, y, mean, rstd, gamma.detach(), ctx.relu, False, beta.detach())
         return dy, dgamma, dbeta, None, None, None, None, None
 
 

@@ -18,12 +18,13 @@
 
 namespace cvt {
 
-__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
-
 // ---- per-channel reductions over an NHWC tensor: thread -> 4 consecutive channels (one 16-byte load per pixel), a block walks its
-// pixel range in steps of 256 * 4 / C pixels; lanes with the same channel group are combined through LDS, blocks through double atomics
-template <class F>   // F(pixel index, channel group base, float4 of the tensor) -> accumulates into two f32x4
-__device__ __forceinline__ void channel_reduce(long npix, int C, double *acc /* [C][2] */, F f) {
+// pixel range in steps of 256 * 4 / C pixels; lanes with the same channel group are combined through LDS, workgroups through partial sums in HBM
+// A pixel's contribution is split into LOAD (global reads only) and ADD: four pixels' loads are issued before the first add - with one
+// 16-byte load in flight per thread the reductions ran at 1.8 TB/s (statistics) / 2.9 TB/s (backward sums) against the 5+ TB/s of the
+// element-wise kernels beside them.
+template <class V, class L, class A>   // L(pixel, channel group base) -> V;  A(V, channel group base, s, q) accumulates into two f32x4
+__device__ __forceinline__ void channel_reduce(long npix, int C, float *part /* [gridDim.x][C][2] */, L load, A add) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
@@ -31,9 +32,17 @@ __device__ __forceinline__ void channel_reduce(long npix, int C, double *acc /* 
     // C in {64 .. 1024}: one pass, cg = C / 4 channel groups divide the 256 threads; wider tensors (ResNet-50's 2048): 1024 channels per pass
     for (int cb = 0; cb < C; cb += 1024) {
         const int cc = C - cb < 1024 ? C - cb : 1024, cg = cc / 4;
-        const int c4 = tid % cg, prow = tid / cg, pstep = 256 / cg;
+        const int c4 = tid % cg, prow = tid / cg, pstep = 256 / cg, c0 = cb + 4 * c4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
-        for (long p = p0 + prow; p < p1; p += pstep) f(p, cb + 4 * c4, s, q);
+        long p = p0 + prow;
+        for (; p + 3 * pstep < p1; p += 4 * pstep) {
+            const V v0 = load(p, c0), v1 = load(p + pstep, c0), v2 = load(p + 2 * pstep, c0), v3 = load(p + 3 * pstep, c0);
+            add(v0, c0, s, q);
+            add(v1, c0, s, q);
+            add(v2, c0, s, q);
+            add(v3, c0, s, q);
+        }
+        for (; p < p1; p += pstep) add(load(p, c0), c0, s, q);
         if (cb > 0) __syncthreads();   // the previous pass has read `red`
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -48,23 +57,49 @@ __device__ __forceinline__ void channel_reduce(long npix, int C, double *acc /* 
                     s[e] += red[(r * cg + tid) * 8 + e];
                     q[e] += red[(r * cg + tid) * 8 + 4 + e];
                 }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomic_add_f64(acc + (cb + 4 * tid + e) * 2, (double)s[e]);
-                atomic_add_f64(acc + (cb + 4 * tid + e) * 2 + 1, (double)q[e]);
-            }
+            // the workgroup's partial sums, plain stores: partial_sum_kernel adds the workgroups up in double.  (Double atomics on the 2 C
+            // sums themselves ran at ~ 5 G atomics/s: 2048 workgroups x 128 sums = 50 us per launch, 512 x 1024 at layer 4 = 100 us - for
+            // 20 us of data.)
+            float *o = part + ((long)blockIdx.x * C + cb + 4 * tid) * 2;
+            *reinterpret_cast<f32x4 *>(o) = f32x4{s[0], q[0], s[1], q[1]};
+            *reinterpret_cast<f32x4 *>(o + 4) = f32x4{s[2], q[2], s[3], q[3]};
         }
+    }
+}
+// acc[e] = sum over the partials of part[p][e], e < n (a multiple of 32): a workgroup takes 32 entries, its 8 thread rows every 8th partial
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ part, int nparts, int n, double *acc) {
+    __shared__ double red[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), row = threadIdx.x >> 5;
+    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int p = row;
+    for (; p + 24 < nparts; p += 32) {
+        const float a = part[(long)p * n + e], b = part[(long)(p + 8) * n + e], c = part[(long)(p + 16) * n + e], d = part[(long)(p + 24) * n + e];
+        s += (double)a;
+        s1 += (double)b;
+        s2 += (double)c;
+        s3 += (double)d;
+    }
+    for (; p < nparts; p += 8) s += (double)part[(long)p * n + e];
+    s += s1 + s2 + s3;
+    red[row][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (row == 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) s += red[r][threadIdx.x & 31];
+        acc[e] = s;
     }
 }
 
 // sums of (y - pivot) and (y - pivot)^2 per channel; pivot = the first pixel's value of the channel (keeps the variance formula
 // q / n - (s / n)^2 free of the cancellation a large mean would cause)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ y, long npix, int C, double *acc) {
-    channel_reduce(npix, C, acc, [&](long p, int c0, f32x4 &s, f32x4 &q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(y + p * C + c0) - *reinterpret_cast<const f32x4 *>(y + c0);
-        s = s + v;
-        q = q + v * v;
-    });
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ y, long npix, int C, float *part) {
+    channel_reduce<f32x4>(
+        npix, C, part, [&](long p, int c0) { return *reinterpret_cast<const f32x4 *>(y + p * C + c0); },
+        [&](const f32x4 &yv, int c0, f32x4 &s, f32x4 &q) {
+            const f32x4 v = yv - *reinterpret_cast<const f32x4 *>(y + c0);
+            s = s + v;
+            q = q + v * v;
+        });
 }
 // mean, rstd of the batch; running statistics as torch.nn.BatchNorm2d (momentum m: r = (1 - m) r + m batch, unbiased variance)
 __global__ void bn_finalize_kernel(const double *acc, const float *__restrict__ y, long npix, int C, float eps, float momentum, float *mean,
@@ -79,6 +114,10 @@ __global__ void bn_finalize_kernel(const double *acc, const float *__restrict__ 
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (npix > 1 ? n / (n - 1.0) : 1.0));
     }
 }
+__device__ __forceinline__ f32x4 bn_affine(const f32x4 &y, const float *mean, const float *rstd, const float *gamma, const float *beta, int c0) {
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(rstd + c0) * *reinterpret_cast<const f32x4 *>(gamma + c0);
+    return (y - *reinterpret_cast<const f32x4 *>(mean + c0)) * sc + *reinterpret_cast<const f32x4 *>(beta + c0);
+}
 // z = relu?((y - mean) rstd gamma + beta (+ res)); abs-max of z -> word
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ y, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ res,
@@ -86,8 +125,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)((4 * i) % C);
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(rstd + c0) * *reinterpret_cast<const f32x4 *>(gamma + c0);
-        f32x4 v = (*reinterpret_cast<const f32x4 *>(y + 4 * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * sc + *reinterpret_cast<const f32x4 *>(beta + c0);
+        f32x4 v = bn_affine(*reinterpret_cast<const f32x4 *>(y + 4 * i), mean, rstd, gamma, beta, c0);
         if (res) v = v + *reinterpret_cast<const f32x4 *>(res + 4 * i);
         if (relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         *reinterpret_cast<f32x4 *>(z + 4 * i) = v;
@@ -100,26 +138,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
         if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
     }
 }
-// backward reductions: acc[c] = (sum g, sum g x_hat), g = dz (where z > 0 if relu), x_hat = (y - mean) rstd
+// backward reductions: acc[c] = (sum g, sum g x_hat), g = dz behind the ReLU mask, x_hat = (y - mean) rstd.  The mask is z > 0, or - z NULL, a
+// unit without residual operand - recomputed from y with the forward's own expression (one tensor less to read, here and in the apply kernel)
+struct BnBwdLoad { f32x4 g, z, y; };
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ dz, const float *__restrict__ z, const float *__restrict__ y,
-                                                            const float *__restrict__ mean, const float *__restrict__ rstd, long npix, int C, int relu,
-                                                            double *acc) {
-    channel_reduce(npix, C, acc, [&](long p, int c0, f32x4 &s, f32x4 &q) {
-        f32x4 g = *reinterpret_cast<const f32x4 *>(dz + p * C + c0);
-        if (relu) {
-            const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + p * C + c0);
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta, long npix, int C, int relu,
+                                                            float *part) {
+    channel_reduce<BnBwdLoad>(
+        npix, C, part,
+        [&](long p, int c0) {
+            BnBwdLoad v;
+            v.g = *reinterpret_cast<const f32x4 *>(dz + p * C + c0);
+            v.y = *reinterpret_cast<const f32x4 *>(y + p * C + c0);
+            v.z = (relu && z) ? *reinterpret_cast<const f32x4 *>(z + p * C + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
+            return v;
+        },
+        [&](const BnBwdLoad &v, int c0, f32x4 &s, f32x4 &q) {
+            f32x4 g = v.g;
+            const f32x4 zz = (relu && !z) ? bn_affine(v.y, mean, rstd, gamma, beta, c0) : v.z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
-        }
-        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + p * C + c0) - *reinterpret_cast<const f32x4 *>(mean + c0)) * *reinterpret_cast<const f32x4 *>(rstd + c0);
-        s = s + g;
-        q = q + g * xh;
-    });
+            const f32x4 xh = (v.y - *reinterpret_cast<const f32x4 *>(mean + c0)) * *reinterpret_cast<const f32x4 *>(rstd + c0);
+            s = s + g;
+            q = q + g * xh;
+        });
 }
 // dy = gamma rstd (g - s1 / n - x_hat s2 / n); dgamma = s2, dbeta = s1 (block 0 writes them); g -> dres (the residual branch's gradient) if asked
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dz, const float *__restrict__ z, const float *__restrict__ y,
                                                            const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
-                                                           const double *__restrict__ acc, float *__restrict__ dy, float *__restrict__ dres,
+                                                           const float *__restrict__ beta, const double *__restrict__ acc, float *__restrict__ dy, float *__restrict__ dres,
                                                            float *dgamma, float *dbeta, long npix, int C, int relu, unsigned *amax) {
     const double inv_n = 1.0 / (double)npix;
     if (blockIdx.x == 0)
@@ -132,14 +180,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)((4 * i) % C);
         f32x4 g = *reinterpret_cast<const f32x4 *>(dz + 4 * i);
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + 4 * i);
         if (relu) {
-            const f32x4 zz = *reinterpret_cast<const f32x4 *>(z + 4 * i);
+            const f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + 4 * i) : bn_affine(yv, mean, rstd, gamma, beta, c0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4 *>(dres + 4 * i) = g;
         const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
-        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + 4 * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
+        const f32x4 xh = (yv - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
         f32x4 m1, m2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -595,18 +644,26 @@ static unsigned blocks_for(long n, long per_block, long cap) {
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+// grid of the per-channel reductions: ~ 64 K elements per workgroup (a workgroup of 1024 PIXELS left the 512-channel maps of layer 4 with 47
+// workgroups), at most 2048
+static unsigned reduce_blocks(long npix, int C) { return blocks_for(npix, 65536 / C, 2048); }
 static bool bn_shape_ok(long npix, int C) { return npix > 0 && (C == 64 || C == 128 || C == 256 || C == 512 || C == 1024 || C == 2048); }
 
+extern "C" size_t sd_bn_scratch_floats(int64_t npix, int C) { return bn_shape_ok(npix, C) ? (size_t)reduce_blocks(npix, C) * 2 * C : 0; }
+
 extern "C" int sd_bn_train_fwd(const float *y, const float *gamma, const float *beta, const float *res, float *z, float *mean, float *rstd,
-                               float *running_mean, float *running_var, double *acc, uint32_t *z_amax, int64_t npix, int C, float eps,
-                               float momentum, int relu, void *stream) {
-    if (!y || !gamma || !beta || !z || !mean || !rstd || !acc || !bn_shape_ok(npix, C)) return fail(SD_E_BADARG, "sd_bn_train_fwd: null pointer or bad shape");
+                               float *running_mean, float *running_var, double *acc, float *scratch, uint32_t *z_amax, int64_t npix, int C,
+                               float eps, float momentum, int relu, void *stream) {
+    if (!y || !gamma || !beta || !z || !mean || !rstd || !acc || !scratch || !bn_shape_ok(npix, C)) return fail(SD_E_BADARG, "sd_bn_train_fwd: null pointer or bad shape");
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(gamma) |
          reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_train_fwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    SD_LAUNCH(cvt::bn_stats_kernel, dim3(blocks_for(npix, 1024, 2048)), dim3(256), 0, st, y, (long)npix, C, acc);
+    const unsigned nb = reduce_blocks(npix, C);
+    SD_LAUNCH(cvt::bn_stats_kernel, dim3(nb), dim3(256), 0, st, y, (long)npix, C, scratch);
     SD_CHECK_LAUNCH("bn_stats_kernel");
+    SD_LAUNCH(cvt::partial_sum_kernel, dim3(2 * C / 32), dim3(256), 0, st, scratch, (int)nb, 2 * C, acc);
+    SD_CHECK_LAUNCH("partial_sum_kernel");
     SD_LAUNCH(cvt::bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, y, (long)npix, C, eps, momentum, mean, rstd, running_mean, running_var);
     SD_CHECK_LAUNCH("bn_finalize_kernel");
     const long n4 = npix * C / 4;
@@ -615,17 +672,24 @@ extern "C" int sd_bn_train_fwd(const float *y, const float *gamma, const float *
     return 0;
 }
 
-extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
-                               float *dres, float *dgamma, float *dbeta, double *acc, uint32_t *dy_amax, int64_t npix, int C, int relu, void *stream) {
-    if (!dz || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || (relu && !z) || !bn_shape_ok(npix, C))
+extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float *mean, const float *rstd, const float *gamma,
+                               const float *beta, float *dy,
+                               float *dres, float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int64_t npix, int C, int relu,
+                               void *stream) {
+    if (!dz || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || !scratch || (relu && !z && !beta) || !bn_shape_ok(npix, C))
         return fail(SD_E_BADARG, "sd_bn_train_bwd: null pointer or bad shape");
+    if (relu && !z && dres) return fail(SD_E_BADARG, "sd_bn_train_bwd: a unit with a residual operand needs z for its ReLU mask");
     if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
-         reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
+         reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(mean) |
+         reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_train_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    SD_LAUNCH(cvt::bn_bwd_reduce_kernel, dim3(blocks_for(npix, 1024, 2048)), dim3(256), 0, st, dz, z, y, mean, rstd, (long)npix, C, relu, acc);
+    const unsigned nb = reduce_blocks(npix, C);
+    SD_LAUNCH(cvt::bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, dz, z, y, mean, rstd, gamma, beta, (long)npix, C, relu, scratch);
     SD_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    SD_LAUNCH(cvt::bn_bwd_apply_kernel, dim3(blocks_for(npix * C / 4, 1024, 4096)), dim3(256), 0, st, dz, z, y, mean, rstd, gamma, acc, dy, dres, dgamma,
+    SD_LAUNCH(cvt::partial_sum_kernel, dim3(2 * C / 32), dim3(256), 0, st, scratch, (int)nb, 2 * C, acc);
+    SD_CHECK_LAUNCH("partial_sum_kernel");
+    SD_LAUNCH(cvt::bn_bwd_apply_kernel, dim3(blocks_for(npix * C / 4, 1024, 4096)), dim3(256), 0, st, dz, z, y, mean, rstd, gamma, beta, acc, dy, dres, dgamma,
               dbeta, (long)npix, C, relu, dy_amax);
     SD_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return 0;

@@ -48,6 +48,10 @@ def test_bn_train_forward_and_backward_match_torch_fp64(N, H, W, C, relu, with_r
     assert rel_err(dgamma, gd.grad) < 1e-5 and rel_err(dbeta, bd.grad) < 1e-5
     if with_res:
         assert rel_err(dres.permute(0, 3, 1, 2), rd.grad) < 1e-6
+    if relu and not with_res:
+        # without a residual operand the backward may recompute the ReLU mask from y (z = None: one tensor less to read): the SAME mask, bit for bit
+        dy2, dword2, dgamma2, dbeta2, _ = ct.bn_train_bwd(dz.cuda(), None, y.cuda(), mean, rstd, gamma.cuda(), True, False, beta.cuda())
+        assert torch.equal(dy2, dy) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta) and int(dword2.item()) == int(dword.item())
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride", [(2, 9, 11, 64, 64, 3, 1), (1, 17, 33, 64, 128, 3, 2), (2, 8, 8, 128, 64, 1, 1), (1, 10, 12, 64, 128, 1, 2),
@@ -110,26 +114,32 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
     out_ref = ref(xr)
     (out_ref * wr).sum().backward()
     calls, wg_rec, bn_rec = [], [], []
-    orig, orig_wg, orig_bn = ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd
+    orig, orig_wg, orig_bn, orig_bnf = ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd, ct.bn_train_fwd
+    z_of = {}   # forward outputs by the address of y: the backward of a unit without residual recomputes its ReLU mask instead of reading z
+
+    def bnf_spy(y, *a):
+        out = orig_bnf(y, *a)
+        z_of[y.data_ptr()] = out[0]
+        return out
 
     def wgrad_spy(dy, h, wshape, stride, *words):
         dw = orig_wg(dy, h, wshape, stride, *words)
         wg_rec.append((dy, h, wshape, stride, dw))
         return dw
 
-    def bn_spy(dz, z, y, mean, rstd, gamma, relu, want_dres):
-        res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want_dres)
-        bn_rec.append((dz, z, y, mean, rstd, gamma, relu, res))
+    def bn_spy(dz, z, y, mean, rstd, gamma, relu, want_dres, beta=None):
+        res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want_dres, beta)
+        bn_rec.append((dz, z if z is not None else z_of[y.data_ptr()], y, mean, rstd, gamma, relu, res))
         return res
 
     ct.ConvBNUnit.apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    ct.conv_wgrad, ct.bn_train_bwd = wgrad_spy, bn_spy
+    ct.conv_wgrad, ct.bn_train_bwd, ct.bn_train_fwd = wgrad_spy, bn_spy, bnf_spy
     try:
         xg = x.cuda().requires_grad_()
         out = gpu(xg)
         (out * wr.float().cuda()).sum().backward()
     finally:
-        ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd = orig, orig_wg, orig_bn
+        ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd, ct.bn_train_fwd = orig, orig_wg, orig_bn, orig_bnf
     # every weight-gradient and BatchNorm-backward launch of this backward against fp64 ON THE SAME TENSORS (the kernels' own error, free of
     # what fp32 rounding upstream does to ReLU masks and max-pool winners)
     assert len(wg_rec) == 19 and len(bn_rec) == 20   # (+ the stem's BatchNorm; its weight gradient is checked below)

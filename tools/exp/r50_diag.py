@@ -58,8 +58,10 @@ for k in ("layer1.0", "layer1.1"):
 gpu3 = copy.deepcopy(net).cuda().train()
 orig_bn = ct.bn_train_bwd
 rec = []
-def spy(dz, z, y, mean, rstd, gamma, relu, want):
-    res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want)
+def spy(dz, z, y, mean, rstd, gamma, relu, want, beta=None):
+    res = orig_bn(dz, z, y, mean, rstd, gamma, relu, want, beta)
+    if z is None and relu:   # a unit without residual operand: the kernel recomputed the mask from y
+        z = (y - mean) * (rstd * gamma) + beta
     rec.append((dz.clone(), None if z is None else z.clone(), y.clone(), mean.clone(), rstd.clone(), gamma.clone(), relu, [None if r is None else r.clone() for r in res]))
     return res
 ct.bn_train_bwd = spy
