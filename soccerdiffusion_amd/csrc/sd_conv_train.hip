@@ -221,8 +221,6 @@ struct WgradArgs {
     int N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad;
     int rows_per_item;   // output image rows per work item
     int n_row_items;     // ceil(N * Ho / rows_per_item)
-    float *part;         // conv_wgrad3_kernel: [n_row_items][Cout][Cin][9] partial sums (plain stores; wgrad_reduce_kernel adds them up), or NULL: atomics
-    int abl;             // diagnostic (SD_W3_ABL): 1 skip the MFMA phase, 2 skip the LDS staging stores, 4 skip the global loads
 };
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -355,15 +353,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 // ---- 3 x 3, stride 1 (13 of ResNet-18's 16 block convolutions): all nine taps from ONE staging of the operands.  The per-wave kernel above
 // fetches 16 KB per 262 kFLOP - every tap re-reads dY and a shifted X - and sits on the L2's bandwidth (~ 90 TFLOP/s).  Here a workgroup
-// (4 waves) owns a 64 (co) x 64 (ci) tile of dW for ALL nine taps: per 32 output pixels of an image row it stages dY (32 x 64) and the
-// 3 x 34 x 64 halo of X once through LDS as fp16 hi | lo planes (16-byte global loads; one power-of-two scale per tensor from its abs-max
-// word), and wave (co half, ci half) runs 9 taps x 6 MFMAs on fragments from transposing LDS reads (ds_read_b64_tr_b16: 8 consecutive
-// pixels of one channel per lane) - the dY fragments are shared by the nine taps, a tap's X fragments are the same rows shifted by (ky, kx).
+// (4 waves) owns a 64 (co) x 64 (ci) tile of dW for ALL nine taps and walks 32-pixel COLUMN STRIPS of the images downwards: a step = the 32
+// output pixels (n, oy, x0 .. x0 + 31); its operands are dY's row (32 x 64) and the three halo rows oy - 1 .. oy + 1 of X (34 x 64), of which
+// only row oy + 1 is new - the rows live in a ring of four LDS slots as fp16 hi | lo planes (16-byte global loads; one power-of-two scale per
+// tensor from its abs-max word), dY in two alternating buffers, so ONE barrier per step orders everything (a wave stores step m + 1's
+// operands only after the barrier that every wave reaches after its MFMAs of step m - 1, and those stores touch neither the slots nor the dY
+// buffer step m reads).  Wave (co half, ci half) runs 9 taps x 6 MFMAs per step on fragments from transposing LDS reads (ds_read_b64_tr_b16:
+// 8 consecutive pixels of one channel per lane) - the dY fragments are shared by the nine taps, a kernel row's three taps are windows of
+// one 12-pixel fragment.  (The first version staged dY and the whole 3 x 34 halo per 32 pixels of an image ROW: 134 staged pixels per step
+// instead of 66, X read 3.2 times - more than an XCD's L2 holds across its workgroups - and 1.05 ms per layer-1 launch; NOTEBOOK round 5.)
+// A strip's first step is preceded by two staging-only steps (rows oy - 1, oy).  The grid is persistent: ~ 512 workgroups (two per CU),
+// workgroup (tile, group g) walks steps [g, g + 1) x per_group of the linear order (n, strip, oy) and stores ONE partial tile
+// [tap][co][ci] (128-byte rows); wgrad3_reduce_kernel adds the groups up into torch's (Cout, Cin, 3, 3) layout - no atomics, deterministic.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct Wgrad3Args {
+    const float *dy;   // [N][H][W][Cout]
+    const float *x;    // [N][H][W][Cin]
+    const unsigned *dy_amax, *x_amax;
+    float *part;       // [groups][9][Cout][Cin]
+    int N, H, W, Cin, Cout, nstrips, groups;
+    long steps, per_group;   // N * nstrips * H steps in all
+    int abl;           // diagnostic (SD_W3_ABL): 1 skip the MFMA phase, 2 skip the LDS staging stores, 4 skip the global loads
+};
 constexpr int W3_PITCH = 72;                       // halfs per staged pixel (64 channels + 8: 144 bytes, an odd number of 16-byte units)
-constexpr int W3_DY = 32 * W3_PITCH;               // halfs of the dY plane
+constexpr int W3_DY = 32 * W3_PITCH;               // halfs of one dY buffer
 constexpr int W3_XROW = 36 * W3_PITCH;             // ... of one halo row of X (34 pixels + 2 that only the 12-pixel fragment reads touch)
-constexpr int W3_PLANE = W3_DY + 3 * W3_XROW;      // one plane (hi or lo): dY, then the three halo rows
+constexpr int W3_PLANE = 2 * W3_DY + 4 * W3_XROW;  // one plane (hi or lo): two dY buffers, then the ring of four rows
 __device__ __forceinline__ f16x8 w3_frag(const f16 *plane, int row0, int col0, int lane) {
     // as tns_frag of sd_train.hip: lane (l31, half) receives channel col0 + l31, pixels row0 + 0 .. 7 (row0 already holds 8 * half)
     const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, gc = ((lane >> 4) & 1) * 16;
@@ -373,8 +388,7 @@ __device__ __forceinline__ f16x8 w3_frag(const f16 *plane, int row0, int col0, i
     return __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // 12 consecutive pixels row0 .. row0 + 11 of channel col0 + l31 (three transposing reads): the three taps of a kernel row use the windows
-// [kx, kx + 8) of them - two LDS reads and four byte-permutes per shifted fragment instead of six LDS reads (the kernel is bound by its LDS
-// reads: 160 transposing reads per wave and 32 pixels against 54 MFMAs before this)
+// [kx, kx + 8) of them - two LDS reads and four byte-permutes per shifted fragment instead of six LDS reads
 struct Frag12 { f16x4 a, b, c; };
 __device__ __forceinline__ Frag12 w3_frag12(const f16 *plane, int row0, int col0, int lane) {
     const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, gc = ((lane >> 4) & 1) * 16;
@@ -392,7 +406,7 @@ __device__ __forceinline__ f16x8 w3_window(const Frag12 &f) {
     else if constexpr (KX == 1) return __builtin_shufflevector(lo, hi, 1, 2, 3, 4, 5, 6, 7, 12);   // hi = pixels 4 .. 11: element 12 of (lo, hi) = pixel 8
     else return __builtin_shufflevector(lo, hi, 2, 3, 4, 5, 6, 7, 12, 13);
 }
-__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
     __shared__ __attribute__((aligned(16))) f16 sm[2 * W3_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -400,128 +414,174 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(WgradArgs a) {
     const int ct = a.Cout / 64, it = a.Cin / 64;
     long item = blockIdx.x;
     const int cit = (int)(item % it); item /= it;
-    const int cot = (int)(item % ct); item /= ct;
-    const long row0 = item * a.rows_per_item, row1 = row0 + a.rows_per_item < (long)a.N * a.H ? row0 + a.rows_per_item : (long)a.N * a.H;
+    const int cot = (int)(item % ct); item /= ct;  // item = the group of steps
     const float sy = f16_scale_from_bits(*a.dy_amax), sx = f16_scale_from_bits(*a.x_amax);
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // staging assignments: dY 32 x 16 float4 (2 per thread), halo 102 x 16 float4 (up to 7 per thread)
-    const int c4 = (tid & 15) * 4;
-    const float *dyb = a.dy + cot * 64 + c4, *xb = a.x + cit * 64 + c4;
-    const int nsteps = (a.W + 31) / 32;
-    f32x4 yv[2], xv[7];
-    // (image index n, row oy, column x0 of a step are running counters: a 64-bit division per thread and step cost more than the step's MFMAs)
-    auto load = [&](long row, int n, int oy, int x0) __attribute__((always_inline)) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (a.abl & 4) {
-            yv[0] = yv[1] = z;
+    // staging assignments: thread -> pixel (tid >> 4) + 16 v of a row, 4 channels c4: dY 32 pixels (v < 2), X 34 pixels (v < 3; v = 2: 2 pixels)
+    const int c4 = (tid & 15) * 4, px = tid >> 4;
+    const float *dyb = a.dy + cot * 64, *xb = a.x + cit * 64;   // wave-uniform bases: a load is base (SGPRs) + a 32-bit lane offset
+    // the walk: (n, strip, oy) of the next RUN step, `pre` staging-only steps before it (2 at the head of a strip), `left` run steps to go
+    const long u0 = item * a.per_group, u1 = u0 + a.per_group < a.steps ? u0 + a.per_group : a.steps;
+    long left = u1 > u0 ? u1 - u0 : 0;
+    int oy = (int)(u0 % a.H), strip = (int)((u0 / a.H) % a.nstrips), n = (int)(u0 / a.H / a.nstrips), pre = 2;
+    struct Micro { int n, x0, xrow, oy, run; };
+    auto next = [&]() __attribute__((always_inline)) {
+        Micro m;
+        m.n = n; m.x0 = strip * 32; m.oy = oy;
+        if (pre > 0) {
+            m.xrow = oy + 1 - pre;   // rows oy - 1, oy
+            m.run = 0;
+            --pre;
+        } else {
+            m.xrow = oy + 1;
+            m.run = 1;
+            --left;
+            if (++oy == a.H) {
+                oy = 0;
+                pre = 2;
+                if (++strip == a.nstrips) {
+                    strip = 0;
+                    ++n;
+                }
+            }
+        }
+        return m;
+    };
+    // Two register sets A / B hold the operands of the next two steps: while step m's MFMAs run, the loads of steps m + 1 AND m + 2 are in flight
+    // (one step ahead = 20 KB per workgroup left the loads latency-bound: memory phase and MFMA phase added up, 0.35 + 0.53 ms at layer 1).
+    // Every load is issued unconditionally - a lane outside the image reads the tensor's first bytes and its values are multiplied by a zero
+    // scale at the split - so that hipcc's s_waitcnt for the older set counts exactly the younger set's five loads on every path.
+    struct Stage { f32x4 y[2], x[3]; unsigned ok; Micro m; };
+    auto load = [&](Stage &s) __attribute__((always_inline)) {
+        const Micro &m = s.m;
+        const bool live = !(a.abl & 4);
+        const bool rowok = m.xrow >= 0 && m.xrow < a.H && live;
+        const float *xr = xb + (((long)m.n * a.H + m.xrow) * a.W + (m.x0 - 1)) * (long)a.Cin;   // wave-uniform; only dereferenced inside the image
+        const float *yr = dyb + (((long)m.n * a.H + m.oy) * a.W + m.x0) * (long)a.Cout;
+        s.ok = 0u;
 #pragma unroll
-            for (int v = 0; v < 7; ++v) xv[v] = z;
-            return;
+        for (int v = 0; v < 3; ++v) {
+            const int p = px + 16 * v, ix = m.x0 - 1 + p;
+            const bool ok = rowok && p < 34 && ix >= 0 && ix < a.W;
+            s.x[v] = *reinterpret_cast<const f32x4 *>(ok ? xr + (unsigned)(p * a.Cin + c4) : a.x);
+            s.ok |= (unsigned)ok << v;
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const int ox = x0 + (tid >> 4) + 16 * v;
-            yv[v] = ox < a.W ? *reinterpret_cast<const f32x4 *>(dyb + (row * a.W + ox) * (long)a.Cout) : z;
-        }
-#pragma unroll
-        for (int v = 0; v < 7; ++v) {
-            const int i = (tid >> 4) + 16 * v;             // halo pixel index 0 .. 101: row i / 34, column i % 34
-            const int hr = i / 34, hx = i - hr * 34, iy = oy + hr - 1, ix = x0 - 1 + hx;
-            const bool ok = i < 102 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            xv[v] = ok ? *reinterpret_cast<const f32x4 *>(xb + (((long)n * a.H + iy) * a.W + ix) * (long)a.Cin) : z;
+            const int p = px + 16 * v;
+            const bool ok = m.run > 0 && m.x0 + p < a.W && live;
+            s.y[v] = *reinterpret_cast<const f32x4 *>(ok ? yr + (unsigned)(p * a.Cout + c4) : a.dy);
+            s.ok |= (unsigned)ok << (3 + v);
         }
     };
-    const long nwork = (row1 - row0) * nsteps;
-    long nrow = row0;
-    int nn = (int)(row0 / a.H), noy = (int)(row0 - (long)nn * a.H), nx0 = 0;   // position of the NEXT load
-    auto advance = [&]() __attribute__((always_inline)) {
-        nx0 += 32;
-        if (nx0 >= a.W) {
-            nx0 = 0;
-            ++nrow;
-            if (++noy == a.H) {
-                noy = 0;
-                ++nn;
+    int q = 0, nrun = 0;   // q: rows of X staged so far (row number q lives in slot q & 3); nrun: run steps so far (dY buffer nrun & 1)
+    // one step: stage S's operands, refill S with the step after the other set's, barrier, MFMAs.  Returns false after the last step.
+    auto step = [&](Stage &S) __attribute__((always_inline)) {
+        const bool run = S.m.run > 0, filled = S.m.run >= 0;
+        if (filled && !(a.abl & 2)) {
+            f16 *xs = sm + 2 * W3_DY + (q & 3) * W3_XROW + c4;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int p = px + 16 * v;
+                if (p < 34) {
+                    f16x4 h, l;
+                    f16_split4(S.x[v], (S.ok >> v) & 1u ? sx : 0.f, h, l);
+                    *reinterpret_cast<f16x4 *>(xs + p * W3_PITCH) = h;
+                    *reinterpret_cast<f16x4 *>(xs + p * W3_PITCH + W3_PLANE) = l;
+                }
+            }
+            if (run) {
+                f16 *ys = sm + (nrun & 1) * W3_DY + c4;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    f16x4 h, l;
+                    f16_split4(S.y[v], (S.ok >> (3 + v)) & 1u ? sy : 0.f, h, l);
+                    *reinterpret_cast<f16x4 *>(ys + (px + 16 * v) * W3_PITCH) = h;
+                    *reinterpret_cast<f16x4 *>(ys + (px + 16 * v) * W3_PITCH + W3_PLANE) = l;
+                }
             }
         }
-    };
-    if (nwork > 0) {
-        load(nrow, nn, noy, nx0);
-        advance();
-    }
-    for (long wk = 0; wk < nwork; ++wk) {
-        __syncthreads();   // every wave is done reading the previous step's planes
-        if (!(a.abl & 2))
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            f16x4 h, l;
-            f16_split4(yv[v], sy, h, l);
-            f16 *o = sm + ((tid >> 4) + 16 * v) * W3_PITCH + c4;
-            *reinterpret_cast<f16x4 *>(o) = h;
-            *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
-        }
-        if (!(a.abl & 2))
-#pragma unroll
-        for (int v = 0; v < 7; ++v) {
-            const int i = (tid >> 4) + 16 * v;
-            if (i < 102) {
-                f16x4 h, l;
-                f16_split4(xv[v], sx, h, l);
-                const int hr = i / 34, hx = i - hr * 34;
-                f16 *o = sm + W3_DY + hr * W3_XROW + hx * W3_PITCH + c4;
-                *reinterpret_cast<f16x4 *>(o) = h;
-                *reinterpret_cast<f16x4 *>(o + W3_PLANE) = l;
-            }
-        }
-        if (wk + 1 < nwork) {   // the next step's global loads are in flight during this step's MFMAs
-            load(nrow, nn, noy, nx0);
-            advance();
-        }
-        // An LDS-only barrier (lgkmcnt(0) + s_barrier) instead of __syncthreads(), whose workgroup-scope fence is s_waitcnt vmcnt(0) and would
-        // wait for the loads just issued.  Measured: no difference at layer 1 (1.32 vs 1.30 ms) - a step takes ~ 5 us, longer than the loads'
-        // latency either way; the kernel is bound by the issue of its address arithmetic, splits and MFMAs (NOTEBOOK round-5 addendum).
-        // (builtins, not inline assembly: hipcc flushes every counter before an asm statement with a memory clobber)
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS stores are done; vmcnt / expcnt left alone
+        // refill: the step after next (past the end of the walk: a staging-only step of nothing - its loads hit the tensors' first bytes)
+        if (left > 0) S.m = next();   // (a strip's two staging-only steps come before its first run step: they never end a walk)
+        else S.m = Micro{0, 0, -1, 0, -1};
+        load(S);
+        // LDS-only barrier (lgkmcnt(0) + s_barrier): __syncthreads() would also wait for the loads just issued (vmcnt(0))
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
-        if (!(a.abl & 1))
+        if (run) {
+            if (!(a.abl & 1)) {
+                const f16 *ys = sm + (nrun & 1) * W3_DY;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int r0 = 16 * st + 8 * half;
-            const f16x8 ah = w3_frag(sm, r0, coh * 32, lane), al = w3_frag(sm + W3_PLANE, r0, coh * 32, lane);
+                for (int st = 0; st < 2; ++st) {
+                    const int r0 = 16 * st + 8 * half;
+                    const f16x8 ah = w3_frag(ys, r0, coh * 32, lane), al = w3_frag(ys + W3_PLANE, r0, coh * 32, lane);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const f16 *xp = sm + W3_DY + ky * W3_XROW;
-                const Frag12 fh = w3_frag12(xp, r0, cih * 32, lane), fl = w3_frag12(xp + W3_PLANE, r0, cih * 32, lane);
-                auto tap = [&](f32x16 &c, const f16x8 &bh, const f16x8 &bl) __attribute__((always_inline)) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-                };
-                tap(acc[3 * ky + 0], w3_window<0>(fh), w3_window<0>(fl));
-                tap(acc[3 * ky + 1], w3_window<1>(fh), w3_window<1>(fl));
-                tap(acc[3 * ky + 2], w3_window<2>(fh), w3_window<2>(fl));
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const f16 *xp = sm + 2 * W3_DY + ((q + 2 + ky) & 3) * W3_XROW;   // rows q - 2, q - 1, q = image rows oy - 1, oy, oy + 1
+                        const Frag12 fh = w3_frag12(xp, r0, cih * 32, lane), fl = w3_frag12(xp + W3_PLANE, r0, cih * 32, lane);
+                        auto tap = [&](f32x16 &c, const f16x8 &bh, const f16x8 &bl) __attribute__((always_inline)) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+                        };
+                        tap(acc[3 * ky + 0], w3_window<0>(fh), w3_window<0>(fl));
+                        tap(acc[3 * ky + 1], w3_window<1>(fh), w3_window<1>(fl));
+                        tap(acc[3 * ky + 2], w3_window<2>(fh), w3_window<2>(fl));
+                    }
+                }
             }
+            ++nrun;
         }
+        q += filled;
+    };
+    // Both sets start EMPTY (run = -2) and are filled by step() itself: every global load of the kernel is issued from the one loop body, so
+    // the vmcnt hipcc derives for "set A's five loads, with B's five younger ones in flight" is exact (with a prologue that loaded A and B, the
+    // merge of the entry path with the back edge made it wait for everything: vmcnt(0) at the head of every step).  run = -1: end of the walk.
+    Stage A, B;
+    A.m = B.m = Micro{0, 0, -1, 0, left > 0 ? -2 : -1};
+    A.ok = B.ok = 0u;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) A.x[v] = B.x[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    A.y[0] = A.y[1] = B.y[0] = B.y[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        if (A.m.run == -1) break;
+        step(A);
+        if (B.m.run == -1) break;
+        step(B);
     }
-    // Every workgroup of a (co, ci) tile adds to the SAME 36 864 floats: with atomics the launch was bound by them (1 477 workgroups x 36 864
-    // adds on 147 KB of addresses at layer 1: 2.0 ms per launch, 10 x the MFMA time).  Each workgroup stores its partial tile instead; a
-    // second launch adds the row groups up (deterministic, too).
+    // the workgroup's partial tile [tap][co][ci]: a half-wave stores 32 consecutive ci = 128 bytes
     const float un = 1.0f / (sy * sx);
     const int ci = cit * 64 + cih * 32 + l31;
-    float *out = a.part ? a.part + item * ((long)a.Cout * a.Cin * 9) : a.dw;
+    float *out = a.part + item * (9L * a.Cout * a.Cin);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cot * 64 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = acc[t][r] * un;
-            if (a.part) out[((long)co * a.Cin + ci) * 9 + t] = v;
-            else if (v != 0.f) atomicAdd(out + ((long)co * a.Cin + ci) * 9 + t, v);
+            out[((long)t * a.Cout + co) * a.Cin + ci] = acc[t][r] * un;
         }
+}
+// dw[co][ci][tap] = sum over the groups of part[g][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float *__restrict__ part, int groups, int Cout, int Cin, float *__restrict__ dw) {
+    const long n = 9L * Cout * Cin, cc = (long)Cout * Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = 0;
+        for (; g + 3 < groups; g += 4) {
+            const float a0 = part[g * n + i], a1 = part[(g + 1) * n + i], a2 = part[(g + 2) * n + i], a3 = part[(g + 3) * n + i];
+            s0 += a0;
+            s1 += a1;
+            s2 += a2;
+            s3 += a3;
+        }
+        for (; g < groups; ++g) s0 += part[g * n + i];
+        const long t = i / cc, rem = i - t * cc;
+        dw[rem * 9 + t] = (s0 + s1) + (s2 + s3);
+    }
 }
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts, long n, float *__restrict__ dw) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -695,19 +755,17 @@ extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, 
     return 0;
 }
 
-// row groups of conv_wgrad3_kernel: ~1024 workgroups per launch (two per CU resident, two rounds), at least one image row each
-static int wgrad3_rows_per_item(long rows, int Cin, int Cout) {
+// conv_wgrad3_kernel's persistent grid: ~ 512 workgroups (two per CU) = (co tile, ci tile) x groups of steps
+static int wgrad3_groups(long steps, int Cin, int Cout) {
     const long tiles = (long)(Cout / 64) * (Cin / 64);
-    long groups = (1024 + tiles - 1) / tiles;
-    if (groups > rows) groups = rows;
+    long groups = 512 / tiles;
+    if (groups > steps) groups = steps;
     if (groups < 1) groups = 1;
-    return (int)((rows + groups - 1) / groups);
+    return (int)groups;
 }
 extern "C" size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride) {
-    if (ksize != 3 || stride != 1 || N <= 0 || H <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    const long rows = (long)N * H;
-    const int rpi = wgrad3_rows_per_item(rows, Cin, Cout);
-    return (size_t)((rows + rpi - 1) / rpi) * Cout * Cin * 9;
+    if (ksize != 3 || stride != 1 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)wgrad3_groups((long)N * H * ((W + 31) / 32), Cin, Cout) * 9 * Cout * Cin;
 }
 extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H,
                              int W, int Cin, int Cout, int ksize, int stride, void *stream) {
@@ -715,31 +773,28 @@ extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return fail(SD_E_BADARG, "sd_conv_wgrad: kernel size 1 or 3, stride 1 or 2");
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv_wgrad: channels must be positive multiples of 64");
     const int pad = ksize / 2, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
-    static const char *abl_env = getenv("SD_W3_ABL");
-    cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0, nullptr, abl_env ? atoi(abl_env) : 0};
+    static const char *simple = getenv("SD_WGRAD_SIMPLE");   // A/B runs: the per-wave kernel for every shape
+    if (ksize == 3 && stride == 1 && dy_amax && x_amax && scratch && !(simple && simple[0] == '1') &&
+        !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15)) {
+        static const char *abl_env = getenv("SD_W3_ABL");
+        cvt::Wgrad3Args w{dy, x, dy_amax, x_amax, scratch, N, H, W, Cin, Cout, (W + 31) / 32, 0, 0, 0, abl_env ? atoi(abl_env) : 0};
+        w.steps = (long)N * H * w.nstrips;
+        w.groups = wgrad3_groups(w.steps, Cin, Cout);
+        w.per_group = (w.steps + w.groups - 1) / w.groups;
+        const long wg3 = (long)(Cout / 64) * (Cin / 64) * w.groups;
+        if (wg3 > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
+        SD_LAUNCH(cvt::conv_wgrad3_kernel, dim3((unsigned)wg3), dim3(256), 0, (hipStream_t)stream, w);
+        SD_CHECK_LAUNCH("conv_wgrad3_kernel");
+        SD_LAUNCH(cvt::wgrad3_reduce_kernel, dim3(grid_for(9L * Cout * Cin)), dim3(256), 0, (hipStream_t)stream, scratch, w.groups, Cout, Cin, dw);
+        SD_CHECK_LAUNCH("wgrad3_reduce_kernel");
+        return 0;
+    }
+    cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0};
     // ~4096 pixels per work item: long enough that a tile's 4096 atomics are a small part of its work, short enough to fill the chip
     a.rows_per_item = (4096 + Wo - 1) / Wo;
     const long rows = (long)N * Ho;
     while (a.rows_per_item > 1 && (rows + a.rows_per_item - 1) / a.rows_per_item * (Cout / 64) * (Cin / 64) * ksize * ksize < 2048) a.rows_per_item = (a.rows_per_item + 1) / 2;
     a.n_row_items = (int)((rows + a.rows_per_item - 1) / a.rows_per_item);
-    static const char *simple = getenv("SD_WGRAD_SIMPLE");   // A/B runs: the per-wave kernel for every shape
-    if (ksize == 3 && stride == 1 && dy_amax && x_amax && !(simple && simple[0] == '1') &&
-        !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15)) {
-        // workgroup items: (row group, co tile, ci tile); with `scratch` (sd_conv_wgrad_scratch_floats) every item stores its partial tile
-        a.rows_per_item = wgrad3_rows_per_item(rows, Cin, Cout);
-        a.n_row_items = (int)((rows + a.rows_per_item - 1) / a.rows_per_item);
-        a.part = scratch;
-        const long wg3 = (long)(Cout / 64) * (Cin / 64) * a.n_row_items;
-        if (wg3 > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
-        SD_LAUNCH(cvt::conv_wgrad3_kernel, dim3((unsigned)wg3), dim3(256), 0, (hipStream_t)stream, a);
-        SD_CHECK_LAUNCH("conv_wgrad3_kernel");
-        if (scratch) {
-            const long n = (long)Cout * Cin * 9;
-            SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, scratch, a.n_row_items, n, dw);
-            SD_CHECK_LAUNCH("wgrad_reduce_kernel");
-        }
-        return 0;
-    }
     const long items = (long)(Cout / 64) * (Cin / 64) * ksize * ksize * a.n_row_items;
     const long wgs = (items + 3) / 4;
     if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
