@@ -533,6 +533,16 @@ int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float
                     float *dy,
                     float *dres, float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int64_t npix, int C, int relu,
                     void *stream);
+/* The stem's BatchNorm (batch statistics) + ReLU + max-pool 3 x 3 / stride 2 / padding 1 (torchvision ResNet.forward: maxpool(relu(bn1(conv1 x)))) fused:
+ * y (N, Hc, Wc, C) -> p (N, Hp, Wp, C), Hp = (Hc - 1) / 2 + 1, and idx (N, Hp, Wp, C / 4 words: one byte per element = the winner's position 0 .. 8
+ * in its window, first maximum in scan order as ATen's kernel, 9 = no positive value); z = relu(BN(y)) is never materialised.  The backward gathers
+ * the pool's gradient from dp and idx (no dz tensor) inside the two BatchNorm-backward launches: dy, dgamma, dbeta as sd_bn_train_bwd.
+ * acc / scratch / the abs-max words as sd_bn_train_fwd (scratch: sd_bn_scratch_floats(N * Hc * Wc, C)). */
+int sd_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta, float *p, uint32_t *idx, float *mean, float *rstd, float *running_mean,
+                        float *running_var, double *acc, float *scratch, uint32_t *p_amax, int N, int Hc, int Wc, int C, float eps, float momentum,
+                        void *stream);
+int sd_bn_relu_pool_bwd(const float *dp, const uint32_t *idx, const float *y, const float *mean, const float *rstd, const float *gamma, float *dy,
+                        float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int N, int Hc, int Wc, int C, void *stream);
 /* The stem in training: sd_stem_conv_raw = the bare 7 x 7 / stride-2 / padding-3 convolution of sd_stem_conv_bn_relu_pool (same packed planes,
  * same kernel) -> y_raw (N, Hc, Wc, 64) NHWC, Hc = (H - 1) / 2 + 1; sd_stem_wgrad: its weight gradient dw (64, 3, 7, 7) from dy (N, Hc, Wc, 64)
  * and the frames x (N, 3, H, W), both with their abs-max words; scratch: sd_stem_wgrad_scratch_floats(N, H, W) floats.  (The frames need no gradient.) */

@@ -10,6 +10,8 @@ backward  dy, dgamma, dbeta (, dres)       sd_bn_train_bwd
           dW                               sd_conv_wgrad (csrc/sd_conv_train.hip)
           dh                               the forward convolution kernel on the flipped, transposed weights; a stride-2 unit's dy is
                                            dilated with zeros first (exact: dh[j] = sum_t dil[j + t - 1] w[2 - t])
+stem      p = maxpool(relu(BN_train(conv7x7(x))))   sd_stem_conv_raw, sd_bn_relu_pool_fwd (BatchNorm + ReLU + max-pool in one pass, relu(BN(.))
+                                           never written), sd_bn_relu_pool_bwd, sd_stem_wgrad  (StemPoolUnit / BNPoolUnit)
 """
 
 from __future__ import annotations
@@ -77,6 +79,41 @@ def bn_train_bwd(dz: Tensor, z: Optional[Tensor], y: Tensor, mean: Tensor, rstd:
     check(lib.sd_bn_train_bwd(dz.data_ptr(), ops._ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), ops._ptr(beta), dy.data_ptr(), ops._ptr(dres),
                               dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), scratch.data_ptr(), word.data_ptr(), npix, Cn, int(relu), ops._stream()), "sd_bn_train_bwd")
     return dy, word, dgamma, dbeta, dres
+
+
+def bn_relu_pool_fwd(y: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float, momentum: float):
+    """max_pool2d(relu(BatchNorm_train(y)), 3, 2, 1) of the NHWC tensor y in one pass -> (p, p_amax word, idx, mean, rstd); relu(BN(y)) is never
+    written.  idx: one byte per pooled element (the winner's position in its window) for the backward."""
+    lib = _lib.load()
+    N, Hc, Wc, Cn = y.shape
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    p = torch.empty(N, Hp, Wp, Cn, dtype=torch.float32, device=y.device)
+    idx = torch.empty(N, Hp, Wp, Cn // 4, dtype=torch.int32, device=y.device)
+    mean = torch.empty(Cn, dtype=torch.float32, device=y.device)
+    rstd = torch.empty_like(mean)
+    acc = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    scratch = torch.empty(lib.sd_bn_scratch_floats(N * Hc * Wc, Cn), dtype=torch.float32, device=y.device)
+    word = torch.zeros(1, dtype=torch.int32, device=y.device)
+    check(lib.sd_bn_relu_pool_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), p.data_ptr(), idx.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                  ops._ptr(running_mean), ops._ptr(running_var), acc.data_ptr(), scratch.data_ptr(), word.data_ptr(), N, Hc, Wc, Cn,
+                                  float(eps), float(momentum), ops._stream()), "sd_bn_relu_pool_fwd")
+    return p, word, idx, mean, rstd
+
+
+def bn_relu_pool_bwd(dp: Tensor, idx: Tensor, y: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor):
+    """-> (dy, dy_amax word, dgamma, dbeta): the max-pool's, the ReLU's and the BatchNorm's backward in two launches over y (no dz tensor)."""
+    lib = _lib.load()
+    N, Hc, Wc, Cn = y.shape
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(Cn, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    acc = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    scratch = torch.empty(lib.sd_bn_scratch_floats(N * Hc * Wc, Cn), dtype=torch.float32, device=y.device)
+    word = torch.zeros(1, dtype=torch.int32, device=y.device)
+    check(lib.sd_bn_relu_pool_bwd(dp.data_ptr(), idx.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dy.data_ptr(),
+                                  dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), scratch.data_ptr(), word.data_ptr(), N, Hc, Wc, Cn, ops._stream()),
+          "sd_bn_relu_pool_bwd")
+    return dy, word, dgamma, dbeta
 
 
 def conv_wgrad(dy: Tensor, h: Tensor, weight_shape, stride: int, dy_amax: Optional[Tensor] = None, h_amax: Optional[Tensor] = None) -> Tensor:
@@ -166,62 +203,66 @@ def stem_wgrad(dy: Tensor, x: Tensor, dy_amax: Tensor, x_amax: Tensor) -> Tensor
     return dw
 
 
-class StemUnit(torch.autograd.Function):
-    """z, z_amax = relu(BatchNorm_train(conv7x7/s2(x))): NCHW frames -> NHWC map.  The frames receive no gradient."""
+class StemPoolUnit(torch.autograd.Function):
+    """p, p_amax = maxpool3x3/s2(relu(BatchNorm_train(conv7x7/s2(x)))): NCHW frames -> pooled NHWC map (torchvision ResNet's whole stem).  The
+    frames receive no gradient; relu(BN(.)) (3 GB at 160 frames of 480 x 640) is never written, in either direction."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, pk: "ops.PackedStem", running_mean, running_var, eps: float, momentum: float):
         x = x.contiguous()
         x_amax = ops.absmax_word(x)
         y = stem_conv_raw(x, x_amax, pk.refresh(weight))
-        z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, True)
-        ctx.save_for_backward(x, x_amax, y, mean, rstd, gamma, beta)
+        p, word, idx, mean, rstd = bn_relu_pool_fwd(y, gamma.detach(), beta.detach(), running_mean, running_var, eps, momentum)
+        ctx.save_for_backward(x, x_amax, y, idx, mean, rstd, gamma)
         ctx.mark_non_differentiable(word)
-        return z, word
+        return p, word
 
     @staticmethod
-    def backward(ctx, dz, _dword):
-        x, x_amax, y, mean, rstd, gamma, beta = ctx.saved_tensors
-        dy, word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), None, y, mean, rstd, gamma.detach(), True, False, beta.detach())
+    def backward(ctx, dp, _dword):
+        x, x_amax, y, idx, mean, rstd, gamma = ctx.saved_tensors
+        dy, word, dgamma, dbeta = bn_relu_pool_bwd(dp.contiguous(), idx, y, mean, rstd, gamma.detach())
         dW = stem_wgrad(dy, x, word, x_amax) if ctx.needs_input_grad[1] else None
         return None, dW, dgamma, dbeta, None, None, None, None, None
 
 
-def stem_unit(x: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, pk: "ops.PackedStem"):
-    momentum = 0.1 if bn.momentum is None else bn.momentum
-    track = bn.track_running_stats and bn.running_mean is not None
-    z, word = StemUnit.apply(x, conv.weight, bn.weight, bn.bias, pk, bn.running_mean if track else None, bn.running_var if track else None, bn.eps, momentum)
-    if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return z, word
-
-
-class BNUnit(torch.autograd.Function):
-    """z, z_amax = relu?(BatchNorm_train(y)) on an NHWC tensor (the stem's BatchNorm behind torch's 7 x 7 convolution)."""
+class BNPoolUnit(torch.autograd.Function):
+    """p, p_amax = maxpool3x3/s2(relu(BatchNorm_train(y))) of an NHWC tensor (behind torch's stem convolution when the frames need a gradient)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, relu: bool, eps: float, momentum: float):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps: float, momentum: float):
         y = y.contiguous()
-        z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), None, running_mean, running_var, eps, momentum, relu)
-        ctx.save_for_backward(y, mean, rstd, gamma, beta)
-        ctx.relu = relu
+        p, word, idx, mean, rstd = bn_relu_pool_fwd(y, gamma.detach(), beta.detach(), running_mean, running_var, eps, momentum)
+        ctx.save_for_backward(y, idx, mean, rstd, gamma)
         ctx.mark_non_differentiable(word)
-        return z, word
+        return p, word
 
     @staticmethod
-    def backward(ctx, dz, _dword):
-        y, mean, rstd, gamma, beta = ctx.saved_tensors
-        dy, _word, dgamma, dbeta, _ = bn_train_bwd(dz.contiguous(), None, y, mean, rstd, gamma.detach(), ctx.relu, False, beta.detach())
-        return dy, dgamma, dbeta, None, None, None, None, None
+    def backward(ctx, dp, _dword):
+        y, idx, mean, rstd, gamma = ctx.saved_tensors
+        dy, _word, dgamma, dbeta = bn_relu_pool_bwd(dp.contiguous(), idx, y, mean, rstd, gamma.detach())
+        return dy, dgamma, dbeta, None, None, None, None
 
 
-def bn_unit(y: Tensor, bn: torch.nn.BatchNorm2d, relu: bool):
+def _bn_args(bn: torch.nn.BatchNorm2d):
     momentum = 0.1 if bn.momentum is None else bn.momentum
     track = bn.track_running_stats and bn.running_mean is not None
-    z, word = BNUnit.apply(y, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None, relu, bn.eps, momentum)
+    return momentum, track
+
+
+def stem_pool_unit(x: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, pk: "ops.PackedStem"):
+    momentum, track = _bn_args(bn)
+    p, word = StemPoolUnit.apply(x, conv.weight, bn.weight, bn.bias, pk, bn.running_mean if track else None, bn.running_var if track else None, bn.eps, momentum)
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return z, word
+    return p, word
+
+
+def bn_pool_unit(y: Tensor, bn: torch.nn.BatchNorm2d):
+    momentum, track = _bn_args(bn)
+    p, word = BNPoolUnit.apply(y, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None, bn.eps, momentum)
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return p, word
 
 
 def unit(h: Tensor, amax: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, res: Optional[Tensor], relu: bool, pair: PackedPair):

@@ -207,6 +207,135 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     }
 }
 
+// ---- the stem's BatchNorm + ReLU + max-pool (3 x 3, stride 2, padding 1) as ONE forward launch and two backward launches, without the
+// 3-GB tensor z = relu(BN(y)) in between (160 frames of 480 x 640: y and z are 3.15 GB each; torch's route writes z, reads it for the pool,
+// writes the pool's gradient dz and reads it twice in the BatchNorm backward).  Forward: a thread owns 4 channels of a pooled pixel, takes
+// the maximum of relu(BN(y)) over its window and remembers WHERE it was (one byte per element: 0 .. 8 in scan order, first maximum wins like
+// ATen's kernel; 9 = the window holds no positive value, its gradient dies in the ReLU).  Backward: the gradient of convolution pixel (r, c)
+// is g = sum of dp over the <= 4 windows whose winner it is - gathered from dp and the index bytes, no dz tensor - and feeds the same two
+// BatchNorm launches as bn_bwd_reduce / bn_bwd_apply.
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__restrict__ y, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ p,
+                                                               unsigned *__restrict__ idx, int N, int Hc, int Wc, int Hp, int Wp, int C, unsigned *amax) {
+    const int cg = C / 4;
+    const long n4 = (long)N * Hp * Wp * cg;
+    float mx = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % cg) * 4;
+        long t = e / cg;
+        const int j = (int)(t % Wp); t /= Wp;
+        const int i = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};
+        unsigned k[4] = {9u, 9u, 9u, 9u};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int r = 2 * i - 1 + ky;
+            if (r < 0 || r >= Hc) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int c = 2 * j - 1 + kx;
+                if (c < 0 || c >= Wc) continue;
+                const f32x4 v = bn_affine(*reinterpret_cast<const f32x4 *>(y + (((long)n * Hc + r) * Wc + c) * C + c0), mean, rstd, gamma, beta, c0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (v[q] > m[q]) {
+                        m[q] = v[q];
+                        k[q] = (unsigned)(ky * 3 + kx);
+                    }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(p + 4 * e) = m;
+        idx[e] = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24);
+        mx = fmaxf(mx, fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const unsigned b = __builtin_bit_cast(unsigned, mx);
+        if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
+    }
+}
+// g of the 4 channels c0 .. of convolution pixel `pix` = (n, r, c): row r lies in the windows i = r / 2 (r even) or (r - 1) / 2, (r + 1) / 2
+struct PoolGeom { int Hc, Wc, Hp, Wp, C; };
+__device__ __forceinline__ f32x4 pool_gather(const float *__restrict__ dp, const unsigned *__restrict__ idx, const PoolGeom &G, long pix, int c0) {
+    const int c = (int)(pix % G.Wc);
+    const long t = pix / G.Wc;
+    const int r = (int)(t % G.Hc), n = (int)(t / G.Hc);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int i0 = r >> 1, ni = (r & 1) ? 2 : 1, j0 = c >> 1, nj = (c & 1) ? 2 : 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int i = i0 + a;
+        if (a >= ni || i >= G.Hp) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + b;
+            if (b >= nj || j >= G.Wp) continue;
+            const unsigned pos = (unsigned)((r - (2 * i - 1)) * 3 + (c - (2 * j - 1)));
+            const long w = (((long)n * G.Hp + i) * G.Wp + j) * G.C + c0;
+            const unsigned k4 = idx[w >> 2];
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dp + w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] += ((k4 >> (8 * q)) & 255u) == pos ? d[q] : 0.f;
+        }
+    }
+    return g;
+}
+struct BnPoolLoad { f32x4 g, y; };
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float *__restrict__ dp, const unsigned *__restrict__ idx, const float *__restrict__ y,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd, long npix, PoolGeom G,
+                                                                 float *part) {
+    channel_reduce<BnPoolLoad>(
+        npix, G.C, part,
+        [&](long p, int c0) {
+            BnPoolLoad v;
+            v.y = *reinterpret_cast<const f32x4 *>(y + p * G.C + c0);
+            v.g = pool_gather(dp, idx, G, p, c0);
+            return v;
+        },
+        [&](const BnPoolLoad &v, int c0, f32x4 &s, f32x4 &q) {
+            const f32x4 xh = (v.y - *reinterpret_cast<const f32x4 *>(mean + c0)) * *reinterpret_cast<const f32x4 *>(rstd + c0);
+            s = s + v.g;
+            q = q + v.g * xh;
+        });
+}
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__restrict__ dp, const unsigned *__restrict__ idx, const float *__restrict__ y,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                const float *__restrict__ gamma, const double *__restrict__ acc, float *__restrict__ dy,
+                                                                float *dgamma, float *dbeta, long npix, PoolGeom G, unsigned *amax) {
+    const double inv_n = 1.0 / (double)npix;
+    const int C = G.C, cg = C / 4;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dgamma[c] = (float)acc[2 * c + 1];
+            dbeta[c] = (float)acc[2 * c];
+        }
+    float mx = 0.f;
+    const long n4 = npix * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * 4;
+        const f32x4 g = pool_gather(dp, idx, G, i / cg, c0);
+        const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
+        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + 4 * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
+        f32x4 m1, m2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m1[e] = (float)(acc[2 * (c0 + e)] * inv_n);
+            m2[e] = (float)(acc[2 * (c0 + e) + 1] * inv_n);
+        }
+        const f32x4 v = (g - m1 - xh * m2) * (rs * *reinterpret_cast<const f32x4 *>(gamma + c0));
+        *reinterpret_cast<f32x4 *>(dy + 4 * i) = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const unsigned b = __builtin_bit_cast(unsigned, mx);
+        if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
+    }
+}
+
 // ---- convolution weight gradient.  One WAVE owns a 64 (co) x 64 (ci) tile of dW for ONE tap and a group of `rows_per_item` output image
 // rows (n, oy); it walks their pixels 32 at a time: A[i = co][k = pixel] = dY[pixel][co0 + lane & 31 (+ 32)], B[k = pixel][j = ci] =
 // X[pixel * stride + tap - pad][ci0 + lane & 31 (+ 32)] (zero outside the image), both read as they lie in memory (NHWC: a pixel's channels
@@ -752,6 +881,51 @@ extern "C" int sd_bn_train_bwd(const float *dz, const float *z, const float *y, 
     SD_LAUNCH(cvt::bn_bwd_apply_kernel, dim3(blocks_for(npix * C / 4, 1024, 4096)), dim3(256), 0, st, dz, z, y, mean, rstd, gamma, beta, acc, dy, dres, dgamma,
               dbeta, (long)npix, C, relu, dy_amax);
     SD_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" int sd_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta, float *p, uint32_t *idx, float *mean, float *rstd,
+                                   float *running_mean, float *running_var, double *acc, float *scratch, uint32_t *p_amax, int N, int Hc, int Wc,
+                                   int C, float eps, float momentum, void *stream) {
+    const long npix = (long)N * Hc * Wc;
+    if (!y || !gamma || !beta || !p || !idx || !mean || !rstd || !acc || !scratch || N <= 0 || Hc <= 0 || Wc <= 0 || !bn_shape_ok(npix, C))
+        return fail(SD_E_BADARG, "sd_bn_relu_pool_fwd: null pointer or bad shape");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+         reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
+        return fail(SD_E_BADARG, "sd_bn_relu_pool_fwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = reduce_blocks(npix, C);
+    SD_LAUNCH(cvt::bn_stats_kernel, dim3(nb), dim3(256), 0, st, y, npix, C, scratch);
+    SD_CHECK_LAUNCH("bn_stats_kernel");
+    SD_LAUNCH(cvt::partial_sum_kernel, dim3(2 * C / 32), dim3(256), 0, st, scratch, (int)nb, 2 * C, acc);
+    SD_CHECK_LAUNCH("partial_sum_kernel");
+    SD_LAUNCH(cvt::bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, y, npix, C, eps, momentum, mean, rstd, running_mean, running_var);
+    SD_CHECK_LAUNCH("bn_finalize_kernel");
+    const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+    SD_LAUNCH(cvt::bn_relu_pool_fwd_kernel, dim3(blocks_for((long)N * Hp * Wp * (C / 4), 512, 8192)), dim3(256), 0, st, y, mean, rstd, gamma, beta, p, idx, N, Hc,
+              Wc, Hp, Wp, C, p_amax);
+    SD_CHECK_LAUNCH("bn_relu_pool_fwd_kernel");
+    return 0;
+}
+extern "C" int sd_bn_relu_pool_bwd(const float *dp, const uint32_t *idx, const float *y, const float *mean, const float *rstd, const float *gamma,
+                                   float *dy, float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int N, int Hc, int Wc, int C,
+                                   void *stream) {
+    const long npix = (long)N * Hc * Wc;
+    if (!dp || !idx || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || !scratch || N <= 0 || Hc <= 0 || Wc <= 0 || !bn_shape_ok(npix, C))
+        return fail(SD_E_BADARG, "sd_bn_relu_pool_bwd: null pointer or bad shape");
+    if ((reinterpret_cast<uintptr_t>(dp) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma) |
+         reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
+        return fail(SD_E_BADARG, "sd_bn_relu_pool_bwd: tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const cvt::PoolGeom G{Hc, Wc, (Hc - 1) / 2 + 1, (Wc - 1) / 2 + 1, C};
+    const unsigned nb = reduce_blocks(npix, C);
+    SD_LAUNCH(cvt::bn_pool_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, dp, idx, y, mean, rstd, npix, G, scratch);
+    SD_CHECK_LAUNCH("bn_pool_bwd_reduce_kernel");
+    SD_LAUNCH(cvt::partial_sum_kernel, dim3(2 * C / 32), dim3(256), 0, st, scratch, (int)nb, 2 * C, acc);
+    SD_CHECK_LAUNCH("partial_sum_kernel");
+    SD_LAUNCH(cvt::bn_pool_bwd_apply_kernel, dim3(blocks_for(npix * C / 4, 1024, 4096)), dim3(256), 0, st, dp, idx, y, mean, rstd, gamma, acc, dy, dgamma, dbeta,
+              npix, G, dy_amax);
+    SD_CHECK_LAUNCH("bn_pool_bwd_apply_kernel");
     return 0;
 }
 

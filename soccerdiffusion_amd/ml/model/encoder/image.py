@@ -227,22 +227,21 @@ class _ResNet(nn.Module):
     def forward(self, x):
         if self._hip_training(x):
             # Training: every convolution and BatchNorm of the backbone on this package's kernels (convolution forward / data gradient / weight
-            # gradient, training-mode BatchNorm forward / backward) behind one autograd.Function per conv + BatchNorm unit, on NHWC tensors;
-            # the max-pool is ATen's channels-last kernel, the head (avgpool + fc) torch.
+            # gradient, training-mode BatchNorm forward / backward, the stem's max-pool) behind one autograd.Function per conv + BatchNorm
+            # unit, on NHWC tensors; the head (avgpool + fc) is torch.
             from .... import conv_training as ct
 
+            # the stem: BatchNorm (batch statistics) + ReLU + max-pool are ONE forward launch and two backward launches (sd_bn_relu_pool_*):
+            # relu(bn1(.)) - 3 GB at 160 frames of 480 x 640 - is never written
             if x.requires_grad or os.environ.get("SD_STEM", "hip") == "torch":   # (a differentiable input: torch's convolution has the data gradient)
                 y = self.conv1(x).permute(0, 2, 3, 1).contiguous()
-                z, _ = ct.bn_unit(y, self.bn1, relu=True)
-            else:   # the stem kernel's bare convolution, training-mode BatchNorm + ReLU, and in the backward the stem's own weight-gradient kernel
+                h, amax = ct.bn_pool_unit(y, self.bn1)
+            else:   # the stem kernel's bare convolution, and in the backward the stem's own weight-gradient kernel
                 store = _derived(self.conv1)
                 pk = store.get("planes")
                 if pk is None or pk.planes.device != x.device:
                     pk = store["planes"] = ops.PackedStem(self.conv1.weight)
-                z, _ = ct.stem_unit(x, self.conv1, self.bn1, pk)
-            h = self.maxpool(z.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)  # ATen's channels-last max-pool: the result is NHWC-contiguous
-            h = h.contiguous()
-            amax = ops.absmax_word(h.detach())
+                h, amax = ct.stem_pool_unit(x, self.conv1, self.bn1, pk)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in layer:
                     h, amax = blk.forward_train_nhwc(h, amax)

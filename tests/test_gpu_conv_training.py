@@ -142,7 +142,7 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
         ct.ConvBNUnit.apply, ct.conv_wgrad, ct.bn_train_bwd, ct.bn_train_fwd = orig, orig_wg, orig_bn, orig_bnf
     # every weight-gradient and BatchNorm-backward launch of this backward against fp64 ON THE SAME TENSORS (the kernels' own error, free of
     # what fp32 rounding upstream does to ReLU masks and max-pool winners)
-    assert len(wg_rec) == 19 and len(bn_rec) == 20   # (+ the stem's BatchNorm; its weight gradient is checked below)
+    assert len(wg_rec) == 19 and len(bn_rec) == 19   # (the stem's BatchNorm + ReLU + max-pool run on the fused sd_bn_relu_pool_* kernels: own test below)
     for dy, h, wshape, stride, dw in wg_rec:
         want = torch.nn.grad.conv2d_weight(h.double().cpu().permute(0, 3, 1, 2), wshape, dy.double().cpu().permute(0, 3, 1, 2), stride=stride,
                                            padding=wshape[2] // 2)
@@ -178,15 +178,15 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
     bar = max(2e-5, 1.5 * max(lerr.values()))
     for name, e in errs.items():
         assert e < bar, (name, e, lerr[name], bar)
-    # the same backward with frames that need no gradient (what training does): the stem runs on StemUnit (sd_stem_conv_raw / sd_stem_wgrad)
+    # the same backward with frames that need no gradient (what training does): the stem runs on StemPoolUnit (sd_stem_conv_raw / sd_bn_relu_pool_* / sd_stem_wgrad)
     gpu2 = copy.deepcopy(net).cuda().train()
     stem_calls = []
-    orig_stem = ct.StemUnit.apply
-    ct.StemUnit.apply = lambda *a, **k: (stem_calls.append(1), orig_stem(*a, **k))[1]
+    orig_stem = ct.StemPoolUnit.apply
+    ct.StemPoolUnit.apply = lambda *a, **k: (stem_calls.append(1), orig_stem(*a, **k))[1]
     try:
         (gpu2(x.cuda()) * wr.float().cuda()).sum().backward()
     finally:
-        ct.StemUnit.apply = orig_stem
+        ct.StemPoolUnit.apply = orig_stem
     assert len(stem_calls) == 1
     for name, p in gpu2.named_parameters():
         assert rel_err(p.grad, pr[name].grad) < bar, name
@@ -197,6 +197,36 @@ def test_every_resnet18_parameter_gradient_matches_torch_cpu_fp64(shape):
             assert int(bg[name]) == int(b) == 1, name
         else:
             assert rel_err(bg[name], b) < 1e-5, name
+
+
+@pytest.mark.parametrize("N,Hc,Wc,C", [(2, 48, 64, 64), (1, 31, 39, 64), (3, 7, 9, 64), (2, 1, 1, 64), (1, 2, 5, 128), (1, 240, 320, 64)])
+def test_fused_bn_relu_maxpool_matches_torch_fp64(N, Hc, Wc, C):
+    """The stem's bn1 -> relu -> maxpool(3, 2, 1) (torchvision ResNet.forward) as sd_bn_relu_pool_fwd / _bwd: pooled map, running statistics, dy,
+    dgamma, dbeta against torch in fp64; even / odd maps, the borders of the pool's padding, a single pixel, the stem's own shape."""
+    from soccerdiffusion_amd import conv_training as ct
+
+    g = torch.Generator().manual_seed(N * 100 + Hc + Wc)
+    y = torch.randn(N, Hc, Wc, C, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    yd = y.double().permute(0, 3, 1, 2).requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    out = F.max_pool2d(F.batch_norm(yd, rm_ref, rv_ref, gd, bd, training=True, momentum=0.1, eps=1e-5).relu(), 3, 2, 1)
+    dp = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dp)
+    rm_g, rv_g = rm.cuda(), rv.cuda()
+    p, word, idx, mean, rstd = ct.bn_relu_pool_fwd(y.cuda(), gamma.cuda(), beta.cuda(), rm_g, rv_g, 1e-5, 0.1)
+    assert tuple(p.shape) == (N, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, C)
+    assert rel_err(p.permute(0, 3, 1, 2), out) < 2e-6
+    assert rel_err(rm_g, rm_ref) < 1e-6 and rel_err(rv_g, rv_ref) < 1e-6
+    pmax = float(p.abs().max())
+    assert abs(float(torch.tensor([int(word.item())], dtype=torch.int32).view(torch.float32)) - pmax) <= 1e-6 * pmax
+    dy, dword, dgamma, dbeta = ct.bn_relu_pool_bwd(dp.float().permute(0, 2, 3, 1).contiguous().cuda(), idx, y.cuda(), mean, rstd, gamma.cuda())
+    # (a window whose two largest values differ by less than fp32 rounding could pick another winner than fp64: not with these sizes and seeds)
+    assert rel_err(dy.permute(0, 3, 1, 2), yd.grad) < 1e-5
+    assert rel_err(dgamma, gd.grad) < 1e-5 and rel_err(dbeta, bd.grad) < 1e-5
+    assert abs(float(torch.tensor([int(dword.item())], dtype=torch.int32).view(torch.float32)) - float(dy.abs().max())) <= 1e-6 * float(dy.abs().max())
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 96, 128), (1, 61, 77), (3, 32, 40)])

@@ -3,7 +3,8 @@
 denoiser (d=256, L=4, horizon 100), B trajectories x image_context_length frames of 480x640 RGB, image_use_final_avgpool
 True (the no-avgpool head assumes square frames: reference encoder/image.py:69-83).  Reports trajectories/s, frames/s
 and the share of the step spent in the backbone (its forward + backward timed alone on the same frames).
-The backbone is torch.nn / MIOpen (restated torchvision ResNet-18: parity unpinned vs torchvision)."""
+The backbone trains on this package's kernels (conv_training.py; SD_CONV=torch: torch.nn / MIOpen, for the A/B); it restates torchvision's
+ResNet-18 (architecture parity unpinned vs torchvision)."""
 import argparse, json, os, sys, threading, time
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # the exhaustive convolution search at 1 280 x 3 x 480 x 640 takes many minutes
 import torch
