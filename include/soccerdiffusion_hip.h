@@ -533,6 +533,12 @@ int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float
                     float *dy,
                     float *dres, float *dgamma, float *dbeta, double *acc, float *scratch, uint32_t *dy_amax, int64_t npix, int C, int relu,
                     void *stream);
+/* Data gradient of a 3 x 3 / stride-2 / padding-1 convolution (conv1 of ResNet layers 2 - 4): dx (N, H, W, Cout) = the transposed convolution of
+ * dy (N, (H + 1) / 2, (W + 1) / 2, Cin) with w_planes = sd_conv3x3_pack of the FLIPPED, TRANSPOSED weights (Cout = the forward's input channels) -
+ * what sd_conv3x3_bn_act computes on dy dilated with zeros, without the zeros: one launch per parity class of the output pixels, each with
+ * its 1 / 2 / 2 / 4 live taps (csrc/sd_conv.hip: convt3x3_s2_kernel).  Epilogue as sd_conv3x3_bn_act without ReLU: dx = acc * bn_scale + bn_shift (+ res). */
+int sd_convt3x3_s2(const float *dy, const void *w_planes, const float *w_scale, const uint32_t *dy_amax, const float *bn_scale, const float *bn_shift,
+                   const float *res, float *dx, uint32_t *dx_amax, int N, int H, int W, int Cin, int Cout, void *stream);
 /* The stem's BatchNorm (batch statistics) + ReLU + max-pool 3 x 3 / stride 2 / padding 1 (torchvision ResNet.forward: maxpool(relu(bn1(conv1 x)))) fused:
  * y (N, Hc, Wc, C) -> p (N, Hp, Wp, C), Hp = (Hc - 1) / 2 + 1, and idx (N, Hp, Wp, C / 4 words: one byte per element = the winner's position 0 .. 8
  * in its window, first maximum in scan order as ATen's kernel, 9 = no positive value); z = relu(BN(y)) is never materialised.  The backward gathers

@@ -8,8 +8,8 @@ forward   y = conv(h)                      sd_conv3x3_bn_act / sd_conv1x1_bn_act
           z = relu?(BN_train(y) (+ res))   sd_bn_train_fwd: batch statistics, running statistics as torch updates them, abs-max word of z
 backward  dy, dgamma, dbeta (, dres)       sd_bn_train_bwd
           dW                               sd_conv_wgrad (csrc/sd_conv_train.hip)
-          dh                               the forward convolution kernel on the flipped, transposed weights; a stride-2 unit's dy is
-                                           dilated with zeros first (exact: dh[j] = sum_t dil[j + t - 1] w[2 - t])
+          dh                               the forward convolution kernel on the flipped, transposed weights; 3 x 3 / stride 2: sd_convt3x3_s2 (the
+                                           transposed convolution by output parity classes); the 1 x 1 / stride-2 shortcut: dy dilated with zeros
 stem      p = maxpool(relu(BN_train(conv7x7(x))))   sd_stem_conv_raw, sd_bn_relu_pool_fwd (BatchNorm + ReLU + max-pool in one pass, relu(BN(.))
                                            never written), sd_bn_relu_pool_bwd, sd_stem_wgrad  (StemPoolUnit / BNPoolUnit)
 """
@@ -42,6 +42,20 @@ def conv_raw(h: Tensor, amax: Tensor, pk: "ops.PackedConv3x3", stride: int) -> T
     if stride == 1:
         return ops.conv3x3_bn_act(h, amax, pk, one, zero, relu=False)
     return ops.conv_s2_bn_act(h, amax, pk, one, zero, relu=False)
+
+
+def convt3x3_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W: int) -> Tensor:
+    """Data gradient of a 3 x 3 / stride-2 / padding-1 convolution with input (N, H, W, pk.Cout): dy (N, (H + 1) // 2, (W + 1) // 2, pk.Cin), pk = the
+    flipped, transposed weights - the stride-1 convolution of the zero-dilated dy without the zeros (sd_convt3x3_s2: four parity classes)."""
+    ops._req(dy, "dy")
+    N, Ho, Wo, Cin = dy.shape
+    if Cin != pk.Cin or pk.ksize != 3 or Ho != (H + 1) // 2 or Wo != (W + 1) // 2:
+        raise ValueError("convt3x3_s2: shape mismatch")
+    one, zero = _ones_zeros(pk.Cout, dy.device)
+    dx = torch.empty(N, H, W, pk.Cout, dtype=torch.float32, device=dy.device)
+    check(_lib.load().sd_convt3x3_s2(dy.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), dy_amax.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
+                                     dx.data_ptr(), None, N, H, W, Cin, pk.Cout, ops._stream()), "sd_convt3x3_s2")
+    return dx
 
 
 def bn_train_fwd(y: Tensor, gamma: Tensor, beta: Tensor, res: Optional[Tensor], running_mean: Optional[Tensor], running_var: Optional[Tensor],
@@ -173,11 +187,14 @@ class ConvBNUnit(torch.autograd.Function):
         dW = conv_wgrad(dy, h, wshape, stride, word, h_amax) if ctx.needs_input_grad[2] else None
         dh = None
         if ctx.needs_input_grad[0]:
-            d = dy
-            if stride == 2:   # dilate with zeros: the stride-2 convolution's data gradient is the stride-1 one of the dilated gradient
-                d = torch.zeros(h.shape[0], h.shape[1], h.shape[2], dy.shape[3], dtype=torch.float32, device=dy.device)
-                d[:, ::2, ::2] = dy
-            dh = conv_raw(d, word, bwd, 1)
+            if stride == 2 and wshape[2] == 3:   # the transposed convolution by parity classes (no zero-dilated tensor)
+                dh = convt3x3_s2(dy, word, bwd, h.shape[1], h.shape[2])
+            else:
+                d = dy
+                if stride == 2:   # the 1 x 1 shortcut: dilate with zeros (its data gradient is the stride-1 one of the dilated gradient)
+                    d = torch.zeros(h.shape[0], h.shape[1], h.shape[2], dy.shape[3], dtype=torch.float32, device=dy.device)
+                    d[:, ::2, ::2] = dy
+                dh = conv_raw(d, word, bwd, 1)
         return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 

@@ -254,6 +254,126 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Data gradient of the 3 x 3 / stride-2 / padding-1 convolution (conv1 of layers 2 - 4 in training): the transposed convolution
+//   dx[n][y][x][ci] = sum over (t, u) of dil[y + t - 1][x + u - 1] . wt[ci][:][t][u],   dil[2 i][2 j] = dy[i][j], zero elsewhere
+// (wt = the flipped, transposed weights, packed like a forward convolution's).  Run on the dilated tensor, conv3x3_kernel multiplies three
+// zeros for every value.  Here a launch takes ONE parity class (PY, PX) of the output pixels (y, x) = (2 i + PY, 2 j + PX): only the taps with
+// t = PY + 1 (mod 2), u = PX + 1 (mod 2) meet a non-zero - 1, 2, 2 or 4 of the nine - and they read dy itself at (i + a, j + b), a, b in {0, 1}:
+// the tile, the split-fp16 staging, the weight ring and the epilogue are conv3x3_kernel's with a (TH + PY) x (TW + PX) halo of dy, no
+// padding, and an output pixel pitch of two.  Four launches = 9 tap-passes over the quarter-resolution map instead of 36.
+template <int PY, int PX>
+__global__ __launch_bounds__(256, 3) void convt3x3_s2_kernel(ConvArgs a, int Ho, int Wo) {
+    constexpr int HHt = TH + PY, HWt = TW + PX, NTY = 1 + PY, NTX = 1 + PX, TAPS = NTY * NTX, NSTEP = TAPS * 4, PLANEt = HHt * HWt * PIX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kg = lane >> 5;
+    const int ph = w & 1, ch = w >> 1;
+    int t, yblk;
+    xcd_tile(a.Cout / COT, a.ygroup, a.tiles_x * a.tiles_y * a.N, t, yblk);
+    if (t >= a.tiles_x * a.tiles_y * a.N) return;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int i0 = ty * TH, j0 = tx * TW;              // the tile's first (i, j): output pixel (2 i + PY, 2 j + PX), dy pixels (i + a, j + b)
+    const int co0 = yblk * COT + ch * 32;
+    const float s_in = f16_scale_from_bits(*a.x_amax);
+    const int nks = a.Cin / 16;
+    const f16 *wbase = a.w + (long)(co0 >> 5) * 9 * nks * 1024 + lane * 8;   // the forward layout: [tap 0 .. 8][ks][plane]
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    unsigned abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) abase[m] = (unsigned)(((4 * ph + 2 * m + row32(j)) * HWt + (j & 15)) * PIX + 16 * kg);
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0 > 0) __syncthreads();
+        constexpr int NST = (HHt * HWt * (CK / 4) + 255) / 256;
+        f32x4 hv[NST];
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            const int hy = p / HWt, hx = p - hy * HWt;
+            const int gy = i0 + hy, gx = j0 + hx;
+            hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < HHt * HWt && gy < Ho && gx < Wo) hv[q] = *reinterpret_cast<const f32x4 *>(a.x + (((long)n * Ho + gy) * Wo + gx) * a.Cin + c0 + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int i = tid + 256 * q, c4 = i & (CK / 4 - 1), p = i / (CK / 4);
+            if (p >= HHt * HWt) continue;
+            f16x4 h, l;
+            f16_split4(hv[q], s_in, h, l);
+            char *at = smem + p * PIX + 8 * c4;
+            *reinterpret_cast<f16x4 *>(at) = h;
+            *reinterpret_cast<f16x4 *>(at + PLANEt) = l;
+        }
+        __syncthreads();
+        const f16 *wp = wbase + (long)(c0 / 16) * 1024;
+        f16x8 bw[WD][2], af[2][2][2];
+        // step s = (tap index q = s >> 2, k-step s & 3); tap q = (qy, qx): weight tap (t, u) = (PY ? 2 qy : 1, PX ? 2 qx : 1), dy offset (a, b) = (qy, qx)
+        auto load_w = [&](int s) __attribute__((always_inline)) {
+            const int q = s >> 2, ks = s & 3, qy = q / NTX, qx = q % NTX;
+            const int tap = (PY ? 2 * qy : 1) * 3 + (PX ? 2 * qx : 1);
+            const f16 *pq = wp + ((long)tap * nks + ks) * 1024;
+            bw[s % WD][0] = *reinterpret_cast<const f16x8 *>(pq);
+            bw[s % WD][1] = *reinterpret_cast<const f16x8 *>(pq + 512);
+        };
+        auto load_a = [&](int s, int st) __attribute__((always_inline)) {
+            const int q = s >> 2, ks = s & 3, qy = q / NTX, qx = q % NTX;
+            const unsigned toff = (unsigned)((qy * HWt + qx) * PIX + 32 * ks);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                af[st][m][0] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff);
+                af[st][m][1] = *reinterpret_cast<const f16x8 *>(smem + abase[m] + toff + PLANEt);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < WD - 1 && s < NSTEP; ++s) load_w(s);
+        load_a(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int st = s & 1;
+            if (s + WD - 1 < NSTEP) load_w(s + WD - 1);
+            if (s + 1 < NSTEP) load_a(s + 1, st ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = mfma32(bw[s % WD][0], af[st][m][1], acc[m]);
+                acc[m] = mfma32(bw[s % WD][1], af[st][m][0], acc[m]);
+                acc[m] = mfma32(bw[s % WD][0], af[st][m][0], acc[m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float un = 1.0f / (s_in * *a.w_scale);
+    f32x4 bs[4], bt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bs[q] = *reinterpret_cast<const f32x4 *>(a.bn_scale + co0 + 8 * q + 4 * kg) * un;
+        bt[q] = *reinterpret_cast<const f32x4 *>(a.bn_shift + co0 + 8 * q + 4 * kg);
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = 2 * (i0 + 4 * ph + 2 * m + row32(j)) + PY, gx = 2 * (j0 + (j & 15)) + PX;
+        if (gy >= a.H || gx >= a.W) continue;
+        const long at = (((long)n * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * kg;
+        f32x4 rv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = a.res ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.res + at + 8 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = f32x4{acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]} * bs[q] + bt[q] + rv[q];
+            *reinterpret_cast<f32x4 *>(a.y + at + 8 * q) = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    if (a.y_amax) publish_amax(a.y_amax, mx, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The striding convolutions of a ResNet stage entry: 3 x 3 stride 2 padding 1 (conv1 of layers 2 - 4) and the 1 x 1 stride 2 shortcut,
 // with the inference BatchNorm (+ ReLU) in the epilogue.  Same arithmetic and operand layouts as conv3x3_kernel; the output maps are
 // small (60 x 80 ... 15 x 20), so a workgroup takes a 4 x 8 pixel tile (one 32-row MFMA tile) x 128 output channels, wave w = channel
@@ -651,6 +771,38 @@ static int conv_s1_bn_act(int ksize, const float *x, const void *w_planes, const
     else SD_LAUNCH(cv::conv3x3_kernel<1>, dim3((unsigned)wgs), dim3(256), (size_t)(2 * cv::TH * cv::TW * cv::PIX), (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("conv3x3_kernel");
     return 0;
+}
+
+template <int PY, int PX>
+static int convt_class(cv::ConvArgs a, int Ho, int Wo, hipStream_t st) {
+    const int ni = (a.H - PY + 1) / 2, nj = (a.W - PX + 1) / 2;   // output pixels of this parity class per column / row
+    if (ni <= 0 || nj <= 0) return 0;
+    a.tiles_x = (nj + cv::TW - 1) / cv::TW;
+    a.tiles_y = (ni + cv::TH - 1) / cv::TH;
+    const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
+    const long wgs = (tiles + 7) / 8 * 8 * (a.Cout / cv::COT);
+    if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_convt3x3_s2: too many tiles");
+    SD_LAUNCH((cv::convt3x3_s2_kernel<PY, PX>), dim3((unsigned)wgs), dim3(256), (size_t)(2 * (cv::TH + PY) * (cv::TW + PX) * cv::PIX), st, a, Ho, Wo);
+    SD_CHECK_LAUNCH("convt3x3_s2_kernel");
+    return 0;
+}
+extern "C" int sd_convt3x3_s2(const float *dy, const void *w_planes, const float *w_scale, const uint32_t *dy_amax, const float *bn_scale,
+                              const float *bn_shift, const float *res, float *dx, uint32_t *dx_amax, int N, int H, int W, int Cin, int Cout,
+                              void *stream) {
+    if (!dy || !w_planes || !w_scale || !dy_amax || !bn_scale || !bn_shift || !dx || N <= 0 || H <= 0 || W <= 0)
+        return fail(SD_E_BADARG, "sd_convt3x3_s2: null pointer or empty shape");
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_convt3x3_s2: channels must be positive multiples of 64");
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(bn_scale) |
+         reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+        return fail(SD_E_BADARG, "sd_convt3x3_s2: tensors must be 16-byte aligned");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    cv::ConvArgs a{dy, (const f16 *)w_planes, w_scale, dy_amax, bn_scale, bn_shift, res, dx, dx_amax, N, H, W, Cin, Cout, 0, 0, 0,
+                   cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * 9 * 4)};
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = convt_class<1, 1>(a, Ho, Wo, st)) return rc;   // (the four-tap class first: the longest workgroups)
+    if (int rc = convt_class<1, 0>(a, Ho, Wo, st)) return rc;
+    if (int rc = convt_class<0, 1>(a, Ho, Wo, st)) return rc;
+    return convt_class<0, 0>(a, Ho, Wo, st);
 }
 
 extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,

@@ -1,6 +1,6 @@
 """SURVEY 8 row f2, TRAINING path of the image backbone (csrc/sd_conv_train.hip, soccerdiffusion_amd/conv_training.py): training-mode
-BatchNorm forward / backward, the convolution weight gradient and the data gradient (the forward kernels on flipped, transposed weights,
-dilated for the stride-2 units) against torch's CPU operators in fp64 - per op, per conv + BN unit, and for EVERY parameter of ResNet-18
+BatchNorm forward / backward, the convolution weight gradient and the data gradient (the forward kernels on flipped, transposed weights;
+3 x 3 / stride 2: the transposed convolution by parity classes) against torch's CPU operators in fp64 - per op, per conv + BN unit, and for EVERY parameter of ResNet-18
 through the module (reference: torchvision BasicBlock under autograd as soccer_diffusion/ml/model/encoder/image.py:55-83 builds it and
 ml/training/train.py:226-240 trains it)."""
 
@@ -85,6 +85,30 @@ def test_conv_weight_and_data_gradients_match_torch_fp64(N, H, W, Cin, Cout, k, 
         d[:, ::2, ::2] = dy_nhwc
     dh = ct.conv_raw(d, ops.absmax_word(d), bwd, 1)
     assert rel_err(dh.permute(0, 3, 1, 2), hd.grad) < 2e-6
+    if stride == 2 and k == 3:   # what ConvBNUnit.backward runs: the transposed convolution without the zero-dilated tensor
+        dh2 = ct.convt3x3_s2(dy_nhwc, ops.absmax_word(dy_nhwc), bwd, H, W)
+        assert rel_err(dh2.permute(0, 3, 1, 2), hd.grad) < 2e-6
+        assert rel_err(dh2, dh) < 1e-6
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 1, 1, 64, 64), (2, 2, 3, 64, 128), (1, 16, 32, 128, 64), (1, 17, 33, 64, 64), (2, 31, 20, 64, 128),
+                                            (1, 120, 160, 64, 128)])
+def test_transposed_stride2_convolution_matches_torch_fp64(N, H, W, Cin, Cout):
+    """sd_convt3x3_s2 = the input gradient of conv2d(3 x 3, stride 2, padding 1): even / odd maps, maps smaller than a tile, one pixel, the
+    layer-2 entry's own shape."""
+    from soccerdiffusion_amd import conv_training as ct
+    from soccerdiffusion_amd import ops
+
+    g = torch.Generator().manual_seed(H * 7 + W)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn(N, Cout, Ho, Wo, generator=g, dtype=torch.float64)
+    want = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy, stride=2, padding=1)
+    _, bwd = ct.PackedPair().get(w.cuda())
+    dy_nhwc = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    got = ct.convt3x3_s2(dy_nhwc, ops.absmax_word(dy_nhwc), bwd, H, W)
+    assert tuple(got.shape) == (N, H, W, Cin)
+    assert rel_err(got.permute(0, 3, 1, 2), want) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 3, 480, 640)])
