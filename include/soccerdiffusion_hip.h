@@ -539,6 +539,10 @@ int sd_bn_train_bwd(const float *dz, const float *z, const float *y, const float
  * its 1 / 2 / 2 / 4 live taps (csrc/sd_conv.hip: convt3x3_s2_kernel).  Epilogue as sd_conv3x3_bn_act without ReLU: dx = acc * bn_scale + bn_shift (+ res). */
 int sd_convt3x3_s2(const float *dy, const void *w_planes, const float *w_scale, const uint32_t *dy_amax, const float *bn_scale, const float *bn_shift,
                    const float *res, float *dx, uint32_t *dx_amax, int N, int H, int W, int Cin, int Cout, void *stream);
+/* ... and of the 1 x 1 / stride-2 shortcut (w_planes = sd_conv_pack(ksize 1) of the transposed weights): dx[2 i][2 j] = dy[i][j] . w; the other
+ * three quarters of dx are NOT written - the caller zeroes dx first. */
+int sd_convt1x1_s2(const float *dy, const void *w_planes, const float *w_scale, const uint32_t *dy_amax, const float *bn_scale, const float *bn_shift,
+                   float *dx, int N, int H, int W, int Cin, int Cout, void *stream);
 /* The stem's BatchNorm (batch statistics) + ReLU + max-pool 3 x 3 / stride 2 / padding 1 (torchvision ResNet.forward: maxpool(relu(bn1(conv1 x)))) fused:
  * y (N, Hc, Wc, C) -> p (N, Hp, Wp, C), Hp = (Hc - 1) / 2 + 1, and idx (N, Hp, Wp, C / 4 words: one byte per element = the winner's position 0 .. 8
  * in its window, first maximum in scan order as ATen's kernel, 9 = no positive value); z = relu(BN(y)) is never materialised.  The backward gathers

@@ -110,6 +110,7 @@ SIGNATURES = {
     "sd_bn_scratch_floats": (C.c_size_t, [C.c_int64, C.c_int]),
     "sd_bn_train_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "sd_convt3x3_s2": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 5 + [C.c_void_p]),
+    "sd_convt1x1_s2": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]),
     "sd_bn_relu_pool_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "sd_bn_relu_pool_bwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sd_bn_train_bwd": (C.c_int, [C.c_void_p] * 14 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),

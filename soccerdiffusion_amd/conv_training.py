@@ -9,7 +9,7 @@ forward   y = conv(h)                      sd_conv3x3_bn_act / sd_conv1x1_bn_act
 backward  dy, dgamma, dbeta (, dres)       sd_bn_train_bwd
           dW                               sd_conv_wgrad (csrc/sd_conv_train.hip)
           dh                               the forward convolution kernel on the flipped, transposed weights; 3 x 3 / stride 2: sd_convt3x3_s2 (the
-                                           transposed convolution by output parity classes); the 1 x 1 / stride-2 shortcut: dy dilated with zeros
+                                           transposed convolution by output parity classes); the 1 x 1 / stride-2 shortcut: sd_convt1x1_s2
 stem      p = maxpool(relu(BN_train(conv7x7(x))))   sd_stem_conv_raw, sd_bn_relu_pool_fwd (BatchNorm + ReLU + max-pool in one pass, relu(BN(.))
                                            never written), sd_bn_relu_pool_bwd, sd_stem_wgrad  (StemPoolUnit / BNPoolUnit)
 """
@@ -55,6 +55,19 @@ def convt3x3_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W:
     dx = torch.empty(N, H, W, pk.Cout, dtype=torch.float32, device=dy.device)
     check(_lib.load().sd_convt3x3_s2(dy.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), dy_amax.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
                                      dx.data_ptr(), None, N, H, W, Cin, pk.Cout, ops._stream()), "sd_convt3x3_s2")
+    return dx
+
+
+def convt1x1_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W: int) -> Tensor:
+    """Data gradient of a 1 x 1 / stride-2 convolution (the stage entries' shortcut): dx[:, ::2, ::2] = dy . w^T, zero elsewhere."""
+    ops._req(dy, "dy")
+    N, Ho, Wo, Cin = dy.shape
+    if Cin != pk.Cin or pk.ksize != 1 or Ho != (H + 1) // 2 or Wo != (W + 1) // 2:
+        raise ValueError("convt1x1_s2: shape mismatch")
+    one, zero = _ones_zeros(pk.Cout, dy.device)
+    dx = torch.zeros(N, H, W, pk.Cout, dtype=torch.float32, device=dy.device)
+    check(_lib.load().sd_convt1x1_s2(dy.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), dy_amax.data_ptr(), one.data_ptr(), zero.data_ptr(),
+                                     dx.data_ptr(), N, H, W, Cin, pk.Cout, ops._stream()), "sd_convt1x1_s2")
     return dx
 
 
@@ -189,12 +202,10 @@ class ConvBNUnit(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride == 2 and wshape[2] == 3:   # the transposed convolution by parity classes (no zero-dilated tensor)
                 dh = convt3x3_s2(dy, word, bwd, h.shape[1], h.shape[2])
+            elif stride == 2:                    # the 1 x 1 shortcut: one parity class, the rest of dh is zero
+                dh = convt1x1_s2(dy, word, bwd, h.shape[1], h.shape[2])
             else:
-                d = dy
-                if stride == 2:   # the 1 x 1 shortcut: dilate with zeros (its data gradient is the stride-1 one of the dilated gradient)
-                    d = torch.zeros(h.shape[0], h.shape[1], h.shape[2], dy.shape[3], dtype=torch.float32, device=dy.device)
-                    d[:, ::2, ::2] = dy
-                dh = conv_raw(d, word, bwd, 1)
+                dh = conv_raw(dy, word, bwd, 1)
         return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_kernel(ConvArgs a) {
 // the tile, the split-fp16 staging, the weight ring and the epilogue are conv3x3_kernel's with a (TH + PY) x (TW + PX) halo of dy, no
 // padding, and an output pixel pitch of two.  Four launches = 9 tap-passes over the quarter-resolution map instead of 36.
 template <int PY, int PX>
-__global__ __launch_bounds__(256, 3) void convt3x3_s2_kernel(ConvArgs a, int Ho, int Wo) {
+__global__ __launch_bounds__(256, 3) void convt3x3_s2_kernel(ConvArgs a, int Ho, int Wo, int wtaps) {
     constexpr int HHt = TH + PY, HWt = TW + PX, NTY = 1 + PY, NTX = 1 + PX, TAPS = NTY * NTX, NSTEP = TAPS * 4, PLANEt = HHt * HWt * PIX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void convt3x3_s2_kernel(ConvArgs a, int Ho,
     const int co0 = yblk * COT + ch * 32;
     const float s_in = f16_scale_from_bits(*a.x_amax);
     const int nks = a.Cin / 16;
-    const f16 *wbase = a.w + (long)(co0 >> 5) * 9 * nks * 1024 + lane * 8;   // the forward layout: [tap 0 .. 8][ks][plane]
+    const f16 *wbase = a.w + (long)(co0 >> 5) * wtaps * nks * 1024 + lane * 8;   // the forward layout: [tap 0 .. 8][ks][plane] (wtaps = 1: a 1 x 1 weight)
     f32x16 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 3) void convt3x3_s2_kernel(ConvArgs a, int Ho,
         // step s = (tap index q = s >> 2, k-step s & 3); tap q = (qy, qx): weight tap (t, u) = (PY ? 2 qy : 1, PX ? 2 qx : 1), dy offset (a, b) = (qy, qx)
         auto load_w = [&](int s) __attribute__((always_inline)) {
             const int q = s >> 2, ks = s & 3, qy = q / NTX, qx = q % NTX;
-            const int tap = (PY ? 2 * qy : 1) * 3 + (PX ? 2 * qx : 1);
+            const int tap = wtaps == 1 ? 0 : (PY ? 2 * qy : 1) * 3 + (PX ? 2 * qx : 1);
             const f16 *pq = wp + ((long)tap * nks + ks) * 1024;
             bw[s % WD][0] = *reinterpret_cast<const f16x8 *>(pq);
             bw[s % WD][1] = *reinterpret_cast<const f16x8 *>(pq + 512);
@@ -774,7 +774,7 @@ static int conv_s1_bn_act(int ksize, const float *x, const void *w_planes, const
 }
 
 template <int PY, int PX>
-static int convt_class(cv::ConvArgs a, int Ho, int Wo, hipStream_t st) {
+static int convt_class(cv::ConvArgs a, int Ho, int Wo, int wtaps, hipStream_t st) {
     const int ni = (a.H - PY + 1) / 2, nj = (a.W - PX + 1) / 2;   // output pixels of this parity class per column / row
     if (ni <= 0 || nj <= 0) return 0;
     a.tiles_x = (nj + cv::TW - 1) / cv::TW;
@@ -782,7 +782,7 @@ static int convt_class(cv::ConvArgs a, int Ho, int Wo, hipStream_t st) {
     const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
     const long wgs = (tiles + 7) / 8 * 8 * (a.Cout / cv::COT);
     if (wgs > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_convt3x3_s2: too many tiles");
-    SD_LAUNCH((cv::convt3x3_s2_kernel<PY, PX>), dim3((unsigned)wgs), dim3(256), (size_t)(2 * (cv::TH + PY) * (cv::TW + PX) * cv::PIX), st, a, Ho, Wo);
+    SD_LAUNCH((cv::convt3x3_s2_kernel<PY, PX>), dim3((unsigned)wgs), dim3(256), (size_t)(2 * (cv::TH + PY) * (cv::TW + PX) * cv::PIX), st, a, Ho, Wo, wtaps);
     SD_CHECK_LAUNCH("convt3x3_s2_kernel");
     return 0;
 }
@@ -799,10 +799,22 @@ extern "C" int sd_convt3x3_s2(const float *dy, const void *w_planes, const float
     cv::ConvArgs a{dy, (const f16 *)w_planes, w_scale, dy_amax, bn_scale, bn_shift, res, dx, dx_amax, N, H, W, Cin, Cout, 0, 0, 0,
                    cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * 9 * 4)};
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = convt_class<1, 1>(a, Ho, Wo, st)) return rc;   // (the four-tap class first: the longest workgroups)
-    if (int rc = convt_class<1, 0>(a, Ho, Wo, st)) return rc;
-    if (int rc = convt_class<0, 1>(a, Ho, Wo, st)) return rc;
-    return convt_class<0, 0>(a, Ho, Wo, st);
+    if (int rc = convt_class<1, 1>(a, Ho, Wo, 9, st)) return rc;   // (the four-tap class first: the longest workgroups)
+    if (int rc = convt_class<1, 0>(a, Ho, Wo, 9, st)) return rc;
+    if (int rc = convt_class<0, 1>(a, Ho, Wo, 9, st)) return rc;
+    return convt_class<0, 0>(a, Ho, Wo, 9, st);
+}
+// the 1 x 1 / stride-2 shortcut's data gradient: dx[2 i][2 j] = dy[i][j] . wt, every other pixel of dx stays as the caller left it (ZEROED)
+extern "C" int sd_convt1x1_s2(const float *dy, const void *w_planes, const float *w_scale, const uint32_t *dy_amax, const float *bn_scale,
+                              const float *bn_shift, float *dx, int N, int H, int W, int Cin, int Cout, void *stream) {
+    if (!dy || !w_planes || !w_scale || !dy_amax || !bn_scale || !bn_shift || !dx || N <= 0 || H <= 0 || W <= 0)
+        return fail(SD_E_BADARG, "sd_convt1x1_s2: null pointer or empty shape");
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_convt1x1_s2: channels must be positive multiples of 64");
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+        return fail(SD_E_BADARG, "sd_convt1x1_s2: tensors must be 16-byte aligned");
+    cv::ConvArgs a{dy, (const f16 *)w_planes, w_scale, dy_amax, bn_scale, bn_shift, nullptr, dx, nullptr, N, H, W, Cin, Cout, 0, 0, 0,
+                   cv::y_group(Cout / cv::COT, (long)cv::COT * Cin * 4)};
+    return convt_class<0, 0>(a, (H + 1) / 2, (W + 1) / 2, 1, (hipStream_t)stream);
 }
 
 extern "C" int sd_conv_s2_bn_act(const float *x, const void *w_planes, const float *w_scale, const uint32_t *x_amax, const float *bn_scale,

@@ -89,6 +89,9 @@ def test_conv_weight_and_data_gradients_match_torch_fp64(N, H, W, Cin, Cout, k, 
         dh2 = ct.convt3x3_s2(dy_nhwc, ops.absmax_word(dy_nhwc), bwd, H, W)
         assert rel_err(dh2.permute(0, 3, 1, 2), hd.grad) < 2e-6
         assert rel_err(dh2, dh) < 1e-6
+    if stride == 2 and k == 1:   # the shortcut's data gradient: one parity class written, zeros elsewhere
+        dh2 = ct.convt1x1_s2(dy_nhwc, ops.absmax_word(dy_nhwc), bwd, H, W)
+        assert rel_err(dh2.permute(0, 3, 1, 2), hd.grad) < 2e-6
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 1, 1, 64, 64), (2, 2, 3, 64, 128), (1, 16, 32, 128, 64), (1, 17, 33, 64, 64), (2, 31, 20, 64, 128),
