@@ -36,15 +36,18 @@ def _ones_zeros(n: int, device):
     return hit
 
 
-def conv_raw(h: Tensor, amax: Tensor, pk: "ops.PackedConv3x3", stride: int) -> Tensor:
-    """The bare convolution (k = pk.ksize, padding k // 2, ``stride`` 1 or 2) of an NHWC tensor: the inference kernels with scale 1, shift 0, no ReLU."""
+def conv_raw(h: Tensor, amax: Tensor, pk: "ops.PackedConv3x3", stride: int, add: Optional[Tensor] = None) -> Tensor:
+    """The bare convolution (k = pk.ksize, padding k // 2, ``stride`` 1 or 2) of an NHWC tensor: the inference kernels with scale 1, shift 0, no ReLU
+    (+ ``add`` in the epilogue, stride 1: a data gradient joins the residual branch's gradient there)."""
     one, zero = _ones_zeros(pk.Cout, h.device)
     if stride == 1:
-        return ops.conv3x3_bn_act(h, amax, pk, one, zero, relu=False)
+        return ops.conv3x3_bn_act(h, amax, pk, one, zero, res=add, relu=False)
+    if add is not None:
+        raise ValueError("conv_raw: add needs stride 1")
     return ops.conv_s2_bn_act(h, amax, pk, one, zero, relu=False)
 
 
-def convt3x3_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W: int) -> Tensor:
+def convt3x3_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W: int, add: Optional[Tensor] = None) -> Tensor:
     """Data gradient of a 3 x 3 / stride-2 / padding-1 convolution with input (N, H, W, pk.Cout): dy (N, (H + 1) // 2, (W + 1) // 2, pk.Cin), pk = the
     flipped, transposed weights - the stride-1 convolution of the zero-dilated dy without the zeros (sd_convt3x3_s2: four parity classes)."""
     ops._req(dy, "dy")
@@ -53,8 +56,12 @@ def convt3x3_s2(dy: Tensor, dy_amax: Tensor, pk: "ops.PackedConv3x3", H: int, W:
         raise ValueError("convt3x3_s2: shape mismatch")
     one, zero = _ones_zeros(pk.Cout, dy.device)
     dx = torch.empty(N, H, W, pk.Cout, dtype=torch.float32, device=dy.device)
-    check(_lib.load().sd_convt3x3_s2(dy.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), dy_amax.data_ptr(), one.data_ptr(), zero.data_ptr(), None,
-                                     dx.data_ptr(), None, N, H, W, Cin, pk.Cout, ops._stream()), "sd_convt3x3_s2")
+    if add is not None:
+        ops._req(add, "add")
+        if add.shape != dx.shape:
+            raise ValueError("convt3x3_s2: add shape mismatch")
+    check(_lib.load().sd_convt3x3_s2(dy.data_ptr(), pk.planes.data_ptr(), pk.scale.data_ptr(), dy_amax.data_ptr(), one.data_ptr(), zero.data_ptr(),
+                                     ops._ptr(add), dx.data_ptr(), None, N, H, W, Cin, pk.Cout, ops._stream()), "sd_convt3x3_s2")
     return dx
 
 
@@ -177,36 +184,47 @@ class PackedPair:
 
 
 class ConvBNUnit(torch.autograd.Function):
-    """z, z_amax = relu?(BatchNorm_train(conv(h)) (+ res)) on NHWC tensors."""
+    """z, z_amax = relu?(BatchNorm_train(conv(h)) (+ res)) on NHWC tensors.  With ``pass_input`` the unit also returns h itself (an alias): a block
+    hands THAT to its residual branch (the identity or the 1 x 1 shortcut), so the branch's gradient arrives in this unit's backward and is added in
+    the data-gradient kernel's epilogue instead of by a separate element-wise launch over the whole tensor."""
 
     @staticmethod
-    def forward(ctx, h, amax, weight, gamma, beta, res, pair: PackedPair, running_mean, running_var, stride: int, relu: bool, eps: float, momentum: float):
-        h = h.contiguous()
+    def forward(ctx, h, amax, weight, gamma, beta, res, pair: PackedPair, running_mean, running_var, stride: int, relu: bool, eps: float, momentum: float,
+                pass_input: bool = False):
+        hc = h.contiguous()
         fwd, bwd = pair.get(weight)
-        y = conv_raw(h, amax, fwd, stride)
+        y = conv_raw(hc, amax, fwd, stride)
         z, word, mean, rstd = bn_train_fwd(y, gamma.detach(), beta.detach(), res, running_mean, running_var, eps, momentum, relu)
         # the ReLU mask of a unit without residual operand is recomputed from y in the backward (z is not read there)
-        ctx.save_for_backward(h, y, z if relu and res is not None else None, mean, rstd, gamma, amax, beta)
+        ctx.save_for_backward(hc, y, z if relu and res is not None else None, mean, rstd, gamma, amax, beta)
         ctx.cfg = (bwd, tuple(weight.shape), stride, relu, res is not None)
         ctx.mark_non_differentiable(word)
+        ctx.set_materialize_grads(False)
+        if pass_input:
+            return z, word, h
         return z, word
 
     @staticmethod
-    def backward(ctx, dz, _dword):
+    def backward(ctx, dz, _dword=None, dpass=None):
         h, y, z, mean, rstd, gamma, h_amax, beta = ctx.saved_tensors
         bwd, wshape, stride, relu, has_res = ctx.cfg
+        if dz is None:   # only the passed-through input was used downstream
+            return dpass, None, None, None, None, None, None, None, None, None, None, None, None, None
         dy, word, dgamma, dbeta, dres = bn_train_bwd(dz.contiguous(), z, y, mean, rstd, gamma.detach(), relu, has_res and ctx.needs_input_grad[5],
                                                      beta.detach())
         dW = conv_wgrad(dy, h, wshape, stride, word, h_amax) if ctx.needs_input_grad[2] else None
         dh = None
         if ctx.needs_input_grad[0]:
+            add = None if dpass is None else dpass.contiguous()
             if stride == 2 and wshape[2] == 3:   # the transposed convolution by parity classes (no zero-dilated tensor)
-                dh = convt3x3_s2(dy, word, bwd, h.shape[1], h.shape[2])
+                dh = convt3x3_s2(dy, word, bwd, h.shape[1], h.shape[2], add)
             elif stride == 2:                    # the 1 x 1 shortcut: one parity class, the rest of dh is zero
                 dh = convt1x1_s2(dy, word, bwd, h.shape[1], h.shape[2])
+                if add is not None:
+                    dh = dh + add
             else:
-                dh = conv_raw(dy, word, bwd, 1)
-        return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None
+                dh = conv_raw(dy, word, bwd, 1, add)
+        return dh, None, dW, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 def stem_conv_raw(x: Tensor, x_amax: Tensor, pk: "ops.PackedStem") -> Tensor:
@@ -293,15 +311,17 @@ def bn_pool_unit(y: Tensor, bn: torch.nn.BatchNorm2d):
     return p, word
 
 
-def unit(h: Tensor, amax: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, res: Optional[Tensor], relu: bool, pair: PackedPair):
-    """One conv + BatchNorm(train) (+ res) (+ ReLU) unit of a torchvision block on NHWC tensors; bumps ``num_batches_tracked`` like torch."""
+def unit(h: Tensor, amax: Tensor, conv: torch.nn.Conv2d, bn: torch.nn.BatchNorm2d, res: Optional[Tensor], relu: bool, pair: PackedPair,
+         pass_input: bool = False):
+    """One conv + BatchNorm(train) (+ res) (+ ReLU) unit of a torchvision block on NHWC tensors; bumps ``num_batches_tracked`` like torch.
+    ``pass_input``: -> (z, word, h) with h an alias of the input for the block's residual branch (see ConvBNUnit)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     track = bn.track_running_stats and bn.running_mean is not None
-    z, word = ConvBNUnit.apply(h, amax, conv.weight, bn.weight, bn.bias, res, pair, bn.running_mean if track else None, bn.running_var if track else None,
-                               conv.stride[0], relu, bn.eps, momentum)
+    out = ConvBNUnit.apply(h, amax, conv.weight, bn.weight, bn.bias, res, pair, bn.running_mean if track else None, bn.running_var if track else None,
+                           conv.stride[0], relu, bn.eps, momentum, pass_input)
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return z, word
+    return out
 
 
 def supported(conv: torch.nn.Conv2d) -> bool:

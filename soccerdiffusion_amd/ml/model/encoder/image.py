@@ -116,12 +116,14 @@ class _BasicBlock(nn.Module):
     def forward_train_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
         """Training (BatchNorm on batch statistics, autograd) on the hand-written kernels: h (N, H, W, C) NHWC with its abs-max word ->
         (h', its abs-max word).  Three conv + BN units: the 1 x 1 shortcut where the block has one, conv1, conv2 (+ identity)."""
-        idt = h if self.downsample is None else _train_unit(h, amax, self.downsample[0], self.downsample[1], None, False)[0]
-        out, a1 = _train_unit(h, amax, self.conv1, self.bn1, None, True)
+        # conv1's unit hands its input on (an alias): the residual branch hangs off THAT, so its gradient reaches conv1's backward and is added in
+        # the data-gradient kernel's epilogue (no separate element-wise launch at the join)
+        out, a1, hp = _train_unit(h, amax, self.conv1, self.bn1, None, True, pass_input=True)
+        idt = hp if self.downsample is None else _train_unit(hp, amax, self.downsample[0], self.downsample[1], None, False)[0]
         return _train_unit(out, a1, self.conv2, self.bn2, idt, True)
 
 
-def _train_unit(h, amax, conv, bn, res, relu):
+def _train_unit(h, amax, conv, bn, res, relu, pass_input=False):
     """conv + BatchNorm(training) (+ res) (+ ReLU) of a torchvision block under autograd on this package's kernels (conv_training.py)."""
     from .... import conv_training as ct
 
@@ -129,7 +131,7 @@ def _train_unit(h, amax, conv, bn, res, relu):
     pair = store.get("pair")
     if pair is None:
         pair = store["pair"] = ct.PackedPair()
-    return ct.unit(h, amax, conv, bn, res, relu, pair)
+    return ct.unit(h, amax, conv, bn, res, relu, pair, pass_input)
 
 
 def _train_ok(block) -> bool:
@@ -181,8 +183,8 @@ class _Bottleneck(nn.Module):
 
     def forward_train_nhwc(self, h: torch.Tensor, amax: torch.Tensor):
         """As _BasicBlock.forward_train_nhwc: conv1 1 x 1, conv2 3 x 3 (the block's stride), conv3 1 x 1 (+ identity / 1 x 1 shortcut)."""
-        idt = h if self.downsample is None else _train_unit(h, amax, self.downsample[0], self.downsample[1], None, False)[0]
-        out, a1 = _train_unit(h, amax, self.conv1, self.bn1, None, True)
+        out, a1, hp = _train_unit(h, amax, self.conv1, self.bn1, None, True, pass_input=True)   # (the residual branch: as _BasicBlock)
+        idt = hp if self.downsample is None else _train_unit(hp, amax, self.downsample[0], self.downsample[1], None, False)[0]
         out, a2 = _train_unit(out, a1, self.conv2, self.bn2, None, True)
         return _train_unit(out, a2, self.conv3, self.bn3, idt, True)
 
