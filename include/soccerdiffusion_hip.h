@@ -561,9 +561,10 @@ int sd_stem_conv_raw(const float *x, const void *w_planes, const float *w_scale,
 size_t sd_stem_wgrad_scratch_floats(int N, int H, int W);
 int sd_stem_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H, int W,
                   void *stream);
-/* scratch (sd_conv_wgrad_scratch_floats floats, or NULL): the 3 x 3 / stride-1 kernel (LDS-staged column strips, all nine taps per staging) stores
- * one partial tile per workgroup there and a second launch adds them up (no atomics: hundreds of workgroups adding to the same Cout x Cin x 9
- * floats are bound by the L2's atomic rate; deterministic).  Without scratch (or abs-max words) the per-wave kernel with atomics runs. */
+/* scratch (sd_conv_wgrad_scratch_floats floats, or NULL): the 3 x 3 kernel (LDS-staged column strips, all taps of a staging; stride 2: one launch
+ * per row / column parity class of x) stores one partial tile per workgroup there and a second launch adds them up (no atomics: hundreds of
+ * workgroups adding to the same Cout x Cin x 9 floats are bound by the L2's atomic rate; deterministic).  Without scratch (or abs-max words), and for
+ * 1 x 1 convolutions, the per-wave kernel with atomics runs. */
 size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride);
 int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H, int W,
                   int Cin, int Cout, int ksize, int stride, void *stream);

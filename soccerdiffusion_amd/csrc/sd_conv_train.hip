@@ -497,10 +497,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 struct Wgrad3Args {
     const float *dy;   // [N][H][W][Cout]
-    const float *x;    // [N][H][W][Cin]
+    const float *x;    // [N][Hx][Wx][Cin]; the kernel sees the (H, W) image x'[r][c] = x[xs r + xr][xs c + xc] (zero outside x): xs = 1: x itself;
+                       // xs = 2: one row / column parity class of a stride-2 convolution's input
     const unsigned *dy_amax, *x_amax;
-    float *part;       // [groups][9][Cout][Cin]
+    float *part;       // [groups][taps of this instantiation][Cout][Cin]
     int N, H, W, Cin, Cout, nstrips, groups;
+    int Hx, Wx, xs, xr, xc;
     long steps, per_group;   // N * nstrips * H steps in all
     int abl;           // diagnostic (SD_W3_ABL): 1 skip the MFMA phase, 2 skip the LDS staging stores, 4 skip the global loads
 };
@@ -535,7 +537,12 @@ __device__ __forceinline__ f16x8 w3_window(const Frag12 &f) {
     else if constexpr (KX == 1) return __builtin_shufflevector(lo, hi, 1, 2, 3, 4, 5, 6, 7, 12);   // hi = pixels 4 .. 11: element 12 of (lo, hi) = pixel 8
     else return __builtin_shufflevector(lo, hi, 2, 3, 4, 5, 6, 7, 12, 13);
 }
+// KYM / KXM: bit ky' / kx' set = the shift (ky' - 1, kx' - 1) between dY and x' is computed (all nine for the 3 x 3 / stride-1 convolution).  A 3 x 3 /
+// stride-2 convolution is four launches, one per parity class (pr, pc) of x: tap ky reads row 2 oy + ky - 1 = row oy - 1 of the odd class (ky = 0), row oy
+// of the even class (ky = 1) or row oy of the odd class (ky = 2) - the odd class computes shifts {-1, 0}, the even class shift {0}: 4 + 2 + 2 + 1 taps.
+template <int KYM, int KXM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
+    constexpr int NKX = ((KXM >> 0) & 1) + ((KXM >> 1) & 1) + ((KXM >> 2) & 1), NKY = ((KYM >> 0) & 1) + ((KYM >> 1) & 1) + ((KYM >> 2) & 1), NT = NKY * NKX;
     __shared__ __attribute__((aligned(16))) f16 sm[2 * W3_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -545,9 +552,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
     const int cit = (int)(item % it); item /= it;
     const int cot = (int)(item % ct); item /= ct;  // item = the group of steps
     const float sy = f16_scale_from_bits(*a.dy_amax), sx = f16_scale_from_bits(*a.x_amax);
-    f32x16 acc[9];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // staging assignments: thread -> pixel (tid >> 4) + 16 v of a row, 4 channels c4: dY 32 pixels (v < 2), X 34 pixels (v < 3; v = 2: 2 pixels)
@@ -588,15 +595,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
     auto load = [&](Stage &s) __attribute__((always_inline)) {
         const Micro &m = s.m;
         const bool live = !(a.abl & 4);
-        const bool rowok = m.xrow >= 0 && m.xrow < a.H && live;
-        const float *xr = xb + (((long)m.n * a.H + m.xrow) * a.W + (m.x0 - 1)) * (long)a.Cin;   // wave-uniform; only dereferenced inside the image
+        const int rr = a.xs * m.xrow + a.xr;   // the row of x behind row m.xrow of x'
+        const bool rowok = m.xrow >= 0 && rr < a.Hx && live;
+        const float *xr = xb + (((long)m.n * a.Hx + rr) * a.Wx + (a.xs * (m.x0 - 1) + a.xc)) * (long)a.Cin;   // wave-uniform; only dereferenced inside the image
         const float *yr = dyb + (((long)m.n * a.H + m.oy) * a.W + m.x0) * (long)a.Cout;
         s.ok = 0u;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const int p = px + 16 * v, ix = m.x0 - 1 + p;
-            const bool ok = rowok && p < 34 && ix >= 0 && ix < a.W;
-            s.x[v] = *reinterpret_cast<const f32x4 *>(ok ? xr + (unsigned)(p * a.Cin + c4) : a.x);
+            const bool ok = rowok && p < 34 && ix >= 0 && a.xs * ix + a.xc < a.Wx;
+            s.x[v] = *reinterpret_cast<const f32x4 *>(ok ? xr + (unsigned)(p * a.xs * a.Cin + c4) : a.x);
             s.ok |= (unsigned)ok << v;
         }
 #pragma unroll
@@ -650,6 +658,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
                     const f16x8 ah = w3_frag(ys, r0, coh * 32, lane), al = w3_frag(ys + W3_PLANE, r0, coh * 32, lane);
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
+                        if (!((KYM >> ky) & 1)) continue;
+                        constexpr int below[3] = {0, KYM & 1, (KYM & 1) + ((KYM >> 1) & 1)};   // computed rows before ky
+                        const int t0 = below[ky] * NKX;
                         const f16 *xp = sm + 2 * W3_DY + ((q + 2 + ky) & 3) * W3_XROW;   // rows q - 2, q - 1, q = image rows oy - 1, oy, oy + 1
                         const Frag12 fh = w3_frag12(xp, r0, cih * 32, lane), fl = w3_frag12(xp + W3_PLANE, r0, cih * 32, lane);
                         auto tap = [&](f32x16 &c, const f16x8 &bh, const f16x8 &bl) __attribute__((always_inline)) {
@@ -657,9 +668,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
                             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
                         };
-                        tap(acc[3 * ky + 0], w3_window<0>(fh), w3_window<0>(fl));
-                        tap(acc[3 * ky + 1], w3_window<1>(fh), w3_window<1>(fl));
-                        tap(acc[3 * ky + 2], w3_window<2>(fh), w3_window<2>(fl));
+                        if constexpr (KXM & 1) tap(acc[t0], w3_window<0>(fh), w3_window<0>(fl));
+                        if constexpr (KXM & 2) tap(acc[t0 + (KXM & 1)], w3_window<1>(fh), w3_window<1>(fl));
+                        if constexpr (KXM & 4) tap(acc[t0 + (KXM & 1) + ((KXM >> 1) & 1)], w3_window<2>(fh), w3_window<2>(fl));
                     }
                 }
             }
@@ -685,18 +696,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_kernel(Wgrad3Args a) {
     // the workgroup's partial tile [tap][co][ci]: a half-wave stores 32 consecutive ci = 128 bytes
     const float un = 1.0f / (sy * sx);
     const int ci = cit * 64 + cih * 32 + l31;
-    float *out = a.part + item * (9L * a.Cout * a.Cin);
+    float *out = a.part + item * ((long)NT * a.Cout * a.Cin);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cot * 64 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             out[((long)t * a.Cout + co) * a.Cin + ci] = acc[t][r] * un;
         }
 }
-// dw[co][ci][tap] = sum over the groups of part[g][tap][co][ci]
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float *__restrict__ part, int groups, int Cout, int Cin, float *__restrict__ dw) {
-    const long n = 9L * Cout * Cin, cc = (long)Cout * Cin;
+// dw[co][ci][tap] = sum over the groups of part[g][t][co][ci], tap = nibble t of tapmap; kk taps per (co, ci) in dw (9 or 1)
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float *__restrict__ part, int groups, int Cout, int Cin, float *__restrict__ dw, int nt,
+                                                            unsigned long tapmap, int kk) {
+    const long n = (long)nt * Cout * Cin, cc = (long)Cout * Cin;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int g = 0;
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float *__restr
         }
         for (; g < groups; ++g) s0 += part[g * n + i];
         const long t = i / cc, rem = i - t * cc;
-        dw[rem * 9 + t] = (s0 + s1) + (s2 + s3);
+        dw[rem * kk + (long)((tapmap >> (4 * t)) & 15ul)] = (s0 + s1) + (s2 + s3);
     }
 }
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts, long n, float *__restrict__ dw) {
@@ -938,8 +950,22 @@ static int wgrad3_groups(long steps, int Cin, int Cout) {
     return (int)groups;
 }
 extern "C" size_t sd_conv_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int ksize, int stride) {
-    if (ksize != 3 || stride != 1 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (size_t)wgrad3_groups((long)N * H * ((W + 31) / 32), Cin, Cout) * 9 * Cout * Cin;
+    if (ksize != 3 || (stride != 1 && stride != 2) || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int nt = stride == 1 ? 9 : 4;   // the most taps one launch computes
+    return (size_t)wgrad3_groups((long)N * Ho * ((Wo + 31) / 32), Cin, Cout) * nt * Cout * Cin;
+}
+// one launch of the strip-walking kernel + its reduction: shifts (KYM, KXM) of dY against the class (xs, xr, xc) of x; tapmap: compact tap t -> tap of dw
+template <int KYM, int KXM>
+static int wgrad3_launch(cvt::Wgrad3Args w, float *dw, unsigned long tapmap, int kk, hipStream_t st) {
+    constexpr int NT = (((KYM >> 0) & 1) + ((KYM >> 1) & 1) + ((KYM >> 2) & 1)) * (((KXM >> 0) & 1) + ((KXM >> 1) & 1) + ((KXM >> 2) & 1));
+    const long wg3 = (long)(w.Cout / 64) * (w.Cin / 64) * w.groups;
+    if (wg3 > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
+    SD_LAUNCH((cvt::conv_wgrad3_kernel<KYM, KXM>), dim3((unsigned)wg3), dim3(256), 0, st, w);
+    SD_CHECK_LAUNCH("conv_wgrad3_kernel");
+    SD_LAUNCH(cvt::wgrad3_reduce_kernel, dim3(grid_for((long)NT * w.Cout * w.Cin)), dim3(256), 0, st, w.part, w.groups, w.Cout, w.Cin, dw, NT, tapmap, kk);
+    SD_CHECK_LAUNCH("wgrad3_reduce_kernel");
+    return 0;
 }
 extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H,
                              int W, int Cin, int Cout, int ksize, int stride, void *stream) {
@@ -948,20 +974,25 @@ extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy
     if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return fail(SD_E_BADDIM, "sd_conv_wgrad: channels must be positive multiples of 64");
     const int pad = ksize / 2, Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     static const char *simple = getenv("SD_WGRAD_SIMPLE");   // A/B runs: the per-wave kernel for every shape
-    if (ksize == 3 && stride == 1 && dy_amax && x_amax && scratch && !(simple && simple[0] == '1') &&
-        !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15)) {
+    // (1 x 1 convolutions stay on the per-wave kernel below: one tap per staging does not pay - 0.17 against 0.19 ms for the stride-2 shortcuts)
+    if (ksize == 3 && dy_amax && x_amax && scratch && !(simple && simple[0] == '1') && !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15)) {
+        // the strip-walking kernel over dY's (Ho, Wo) pixels; x through the class (xs, xr, xc)
         static const char *abl_env = getenv("SD_W3_ABL");
-        cvt::Wgrad3Args w{dy, x, dy_amax, x_amax, scratch, N, H, W, Cin, Cout, (W + 31) / 32, 0, 0, 0, abl_env ? atoi(abl_env) : 0};
-        w.steps = (long)N * H * w.nstrips;
+        hipStream_t st = (hipStream_t)stream;
+        cvt::Wgrad3Args w{dy, x, dy_amax, x_amax, scratch, N, Ho, Wo, Cin, Cout, (Wo + 31) / 32, 0, H, W, stride, 0, 0, 0, 0, abl_env ? atoi(abl_env) : 0};
+        w.steps = (long)N * Ho * w.nstrips;
         w.groups = wgrad3_groups(w.steps, Cin, Cout);
         w.per_group = (w.steps + w.groups - 1) / w.groups;
-        const long wg3 = (long)(Cout / 64) * (Cin / 64) * w.groups;
-        if (wg3 > 0x7fffffffL) return fail(SD_E_TOOBIG, "sd_conv_wgrad: too many work items");
-        SD_LAUNCH(cvt::conv_wgrad3_kernel, dim3((unsigned)wg3), dim3(256), 0, (hipStream_t)stream, w);
-        SD_CHECK_LAUNCH("conv_wgrad3_kernel");
-        SD_LAUNCH(cvt::wgrad3_reduce_kernel, dim3(grid_for(9L * Cout * Cin)), dim3(256), 0, (hipStream_t)stream, scratch, w.groups, Cout, Cin, dw);
-        SD_CHECK_LAUNCH("wgrad3_reduce_kernel");
-        return 0;
+        if (stride == 1) return wgrad3_launch<7, 7>(w, dw, 0x876543210ul, 9, st);
+        // stride 2: tap (ky, kx) of dw = shift (ky' - 1, kx' - 1) of class (pr, pc): odd class ky' = 0, 1 -> ky = 0, 2; even class ky' = 1 -> ky = 1
+        w.xr = 1; w.xc = 1;
+        if (int rc = wgrad3_launch<3, 3>(w, dw, 0x8620ul, 9, st)) return rc;                  // (0,0) (0,2) (2,0) (2,2)
+        w.xr = 1; w.xc = 0;
+        if (int rc = wgrad3_launch<3, 2>(w, dw, 0x71ul, 9, st)) return rc;                    // (0,1) (2,1)
+        w.xr = 0; w.xc = 1;
+        if (int rc = wgrad3_launch<2, 3>(w, dw, 0x53ul, 9, st)) return rc;                    // (1,0) (1,2)
+        w.xr = 0; w.xc = 0;
+        return wgrad3_launch<2, 2>(w, dw, 0x4ul, 9, st);                                      // (1,1)
     }
     cvt::WgradArgs a{dy, x, dy_amax, x_amax, dw, N, H, W, Ho, Wo, Cin, Cout, ksize, stride, pad, 0, 0};
     // ~4096 pixels per work item: long enough that a tile's 4096 atomics are a small part of its work, short enough to fill the chip
