@@ -217,15 +217,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__restrict__ y, const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ p,
                                                                unsigned *__restrict__ idx, int N, int Hc, int Wc, int Hp, int Wp, int C, unsigned *amax) {
-    const int cg = C / 4;
-    const long n4 = (long)N * Hp * Wp * cg;
+    // (32-bit index arithmetic: the host refuses tensors of 2^31 float4 or more; three 64-bit divisions per element cost more than its nine loads)
+    const unsigned cg = C / 4;
+    const unsigned n4 = (unsigned)N * Hp * Wp * cg;
     float mx = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
         const int c0 = (int)(e % cg) * 4;
-        long t = e / cg;
-        const int j = (int)(t % Wp); t /= Wp;
-        const int i = (int)(t % Hp);
-        const int n = (int)(t / Hp);
+        unsigned t = e / cg;
+        const int j = (int)(t % (unsigned)Wp); t /= (unsigned)Wp;
+        const int i = (int)(t % (unsigned)Hp);
+        const int n = (int)(t / (unsigned)Hp);
         f32x4 m = {0.f, 0.f, 0.f, 0.f};
         unsigned k[4] = {9u, 9u, 9u, 9u};
 #pragma unroll
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__re
                     }
             }
         }
-        *reinterpret_cast<f32x4 *>(p + 4 * e) = m;
+        *reinterpret_cast<f32x4 *>(p + 4l * e) = m;
         idx[e] = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24);
         mx = fmaxf(mx, fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
     }
@@ -259,9 +260,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__re
 // g of the 4 channels c0 .. of convolution pixel `pix` = (n, r, c): row r lies in the windows i = r / 2 (r even) or (r - 1) / 2, (r + 1) / 2
 struct PoolGeom { int Hc, Wc, Hp, Wp, C; };
 __device__ __forceinline__ f32x4 pool_gather(const float *__restrict__ dp, const unsigned *__restrict__ idx, const PoolGeom &G, long pix, int c0) {
-    const int c = (int)(pix % G.Wc);
-    const long t = pix / G.Wc;
-    const int r = (int)(t % G.Hc), n = (int)(t / G.Hc);
+    const unsigned pu = (unsigned)pix;   // (fewer than 2^31 pixels: checked on the host)
+    const int c = (int)(pu % (unsigned)G.Wc);
+    const unsigned t = pu / (unsigned)G.Wc;
+    const int r = (int)(t % (unsigned)G.Hc), n = (int)(t / (unsigned)G.Hc);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     const int i0 = r >> 1, ni = (r & 1) ? 2 : 1, j0 = c >> 1, nj = (c & 1) ? 2 : 1;
 #pragma unroll
@@ -312,12 +314,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__r
             dbeta[c] = (float)acc[2 * c];
         }
     float mx = 0.f;
-    const long n4 = npix * cg;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cg) * 4;
-        const f32x4 g = pool_gather(dp, idx, G, i / cg, c0);
+    const unsigned n4 = (unsigned)(npix * cg);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % (unsigned)cg) * 4;
+        const f32x4 g = pool_gather(dp, idx, G, (long)(i / (unsigned)cg), c0);
         const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
-        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + 4 * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
+        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + 4l * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
         f32x4 m1, m2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__r
             m2[e] = (float)(acc[2 * (c0 + e) + 1] * inv_n);
         }
         const f32x4 v = (g - m1 - xh * m2) * (rs * *reinterpret_cast<const f32x4 *>(gamma + c0));
-        *reinterpret_cast<f32x4 *>(dy + 4 * i) = v;
+        *reinterpret_cast<f32x4 *>(dy + 4l * i) = v;
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
     if (amax) {
@@ -902,6 +904,7 @@ extern "C" int sd_bn_relu_pool_fwd(const float *y, const float *gamma, const flo
     const long npix = (long)N * Hc * Wc;
     if (!y || !gamma || !beta || !p || !idx || !mean || !rstd || !acc || !scratch || N <= 0 || Hc <= 0 || Wc <= 0 || !bn_shape_ok(npix, C))
         return fail(SD_E_BADARG, "sd_bn_relu_pool_fwd: null pointer or bad shape");
+    if (npix * (C / 4) >= (1l << 31)) return fail(SD_E_TOOBIG, "sd_bn_relu_pool_fwd: 2^31 or more 16-byte elements");
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
          reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_relu_pool_fwd: tensors must be 16-byte aligned");
@@ -925,6 +928,7 @@ extern "C" int sd_bn_relu_pool_bwd(const float *dp, const uint32_t *idx, const f
     const long npix = (long)N * Hc * Wc;
     if (!dp || !idx || !y || !mean || !rstd || !gamma || !dy || !dgamma || !dbeta || !acc || !scratch || N <= 0 || Hc <= 0 || Wc <= 0 || !bn_shape_ok(npix, C))
         return fail(SD_E_BADARG, "sd_bn_relu_pool_bwd: null pointer or bad shape");
+    if (npix * (C / 4) >= (1l << 31)) return fail(SD_E_TOOBIG, "sd_bn_relu_pool_bwd: 2^31 or more 16-byte elements");
     if ((reinterpret_cast<uintptr_t>(dp) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma) |
          reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_relu_pool_bwd: tensors must be 16-byte aligned");
