@@ -967,6 +967,7 @@ static __device__ __forceinline__ void sa_head_precise(const Ctx &c0, const SaW 
     const int w = c.w, g = c.g, t = c.t;
     HeadAcc acc;
     head_zero(acc);
+    if (h == 1) TJ_STAMP(17);   // (diagnostic build: the phases of head 1)
     {
         const int nt0 = (w < 4 ? 0 : 16) + 4 * h + (w & 3);     // Q tile (waves 0..3) or K tile (waves 4..7)
         const int nt1 = 32 + 4 * h + (w >> 1);                   // V tile, token half w & 1
@@ -986,6 +987,7 @@ static __device__ __forceinline__ void sa_head_precise(const Ctx &c0, const SaW 
         else run(std::false_type{});
     }
     const float c_in = 1.0f / a.s_in;   // accumulator -> ACT * value
+    if (h == 1) TJ_STAMP(18);
     TJ_SYNC(2);            // B1: the previous head's readers of Q / O and K / V are done
     {   // Q or K tile -> LDS planes (features 16 (w & 3) + 4 g + r of the head, natural order on both operands of the scores)
         const int w3 = w & 3;
@@ -1000,10 +1002,12 @@ static __device__ __forceinline__ void sa_head_precise(const Ctx &c0, const SaW 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (h == 1) TJ_STAMP(19);
     TJ_SYNC(2);            // B2: Q, K complete
     f32x4 S[NTT];
     float psum = 1.f;
     if (w < NTT) att_scores(ctx_local(c0), a, Qb, Kb, S, psum);
+    if (h == 1) TJ_STAMP(20);
     TJ_SYNC(3);            // B3: K is dead
     {   // V piece -> rows [token][hi 64 | lo 64] (features 16 (w >> 1) + 4 g + r) over K
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b_in + 2 * D + HD * h + 16 * (w >> 1) + 4 * g) * ACT;
@@ -1017,13 +1021,16 @@ static __device__ __forceinline__ void sa_head_precise(const Ctx &c0, const SaW 
             split_store(at, at + 128, acc.a1[i] * c_in + bv);
         }
     }
+    if (h == 1) TJ_STAMP(21);
     TJ_SYNC(3);            // B4: V complete (every wave has read its Q fragments: O may overwrite Q)
     AK64 wo;
     if (w < NTT) att_pv(ctx_local(c0), S, psum, Kb, Qb);
     // the out-projection's weight fragments: their L2 round trip passes under the barrier
     head_out_load(c, a, h, wo);
+    if (h == 1) TJ_STAMP(22);
     TJ_SYNC(3);            // B5: O complete
     gemm_k64(ctx_local(c0), H, wo, Qb);
+    if (h == 1) TJ_STAMP(23);
 }
 static __device__ __forceinline__ void sa_block_precise(const Ctx &c, const SaW &a, f32x4 (&H)[2][NTT], const float *b_o, Bias2 &bo) {
     bo = bias_load(c, b_o);

@@ -342,6 +342,27 @@ int main(int argc, char **argv) {
                 }
                 return s / nwg;
             };
+#if TL_PRECISE
+            {   // mode 3: the phases of head 1 (stamps 17 .. 23 of sa_head_precise; each interval ends BEFORE the barrier named after it, so a
+                // phase's number includes the wait at the barrier that precedes it)
+                const char *pn[6] = {"Q|K|V projection GEMM", "B1 + write Q, K", "B2 + scores + softmax", "B3 + write V", "B4 + P V -> O", "B5 + out-projection"};
+                printf("--- mode 3, head 1 of the last layer: mean cycles per phase over %d workgroups   wave 0    wave 3    wave 4    wave 7\n", B < tj::TJ_STAMP_WGS ? B : tj::TJ_STAMP_WGS);
+                const int wsp[4] = {0, 3, 4, 7};
+                for (int k = 0; k < 6; ++k) {
+                    printf("  %-45s", pn[k]);
+                    for (int wi = 0; wi < 4; ++wi) {
+                        double sum = 0;
+                        const int nw = B < tj::TJ_STAMP_WGS ? B : tj::TJ_STAMP_WGS;
+                        for (int b = 0; b < nw; ++b) {
+                            const unsigned long long *p = &st[((size_t)b * 8 + wsp[wi]) * tj::TJ_NSTAMP];
+                            sum += (double)(p[18 + k] - p[17 + k]);
+                        }
+                        printf(" %9.0f", sum / nw);
+                    }
+                    printf("\n");
+                }
+            }
+#endif
             const char *agg[3] = {"phase W: out-proj(h-1) || write QKV(h)", "phase X: QKV gemm(h+1) || attention(h)", "barrier after phase X"};
             printf("--- last layer of the step: mean cycles per phase over %d workgroups        wave 0    wave 3    wave 4    wave 7\n", nwg);
             const int ws[4] = {0, 3, 4, 7};
