@@ -1050,7 +1050,7 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
         out["image_backbone_train"] = {
             "workload": "BASELINE.json configs[4] per-GPU share, training: ResNet-18 forward + backward on 16 x 10 frames of 480 x 640, train() mode "
                         "(reference: train.py:226-240 trains the backbone with every step); every convolution (forward, data gradient, weight "
-                        "gradient) and BatchNorm (batch statistics, backward) hand-written, max-pool ATen, no MIOpen kernel",
+                        "gradient) and BatchNorm (batch statistics, backward) hand-written, the stem's BatchNorm + ReLU + max-pool fused (sd_bn_relu_pool_*), no MIOpen kernel",
             "ms_per_step": round(rec["hip"] * 1e3, 3), "value": round(160 / rec["hip"], 1), "unit": "frames/s",
             "algorithmic_tflops": round(160 * flops / rec["hip"] / 1e12, 1),
             "torch_nn_miopen_ms_per_step": round(rec["torch"] * 1e3, 3), "speedup_over_miopen_route": round(rec["torch"] / rec["hip"], 2),
