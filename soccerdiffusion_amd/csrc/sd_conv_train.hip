@@ -726,21 +726,35 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float *__restr
         dw[rem * kk + (long)((tapmap >> (4 * t)) & 15ul)] = (s0 + s1) + (s2 + s3);
     }
 }
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts, long n, float *__restrict__ dw) {
+// out[slice][i] = sum of part[p][i] over the parts p of slice blockIdx.y (gridDim.y slices of `per` parts): called twice (parts -> 32 slices -> 1),
+// so that no thread adds more than 32 values in sequence (one launch over 1024 parts took 0.28 ms for 38 MB)
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int n_parts, int per, long n, float *__restrict__ out) {
+    const int p0 = blockIdx.y * per, p1 = p0 + per < n_parts ? p0 + per : n_parts;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < n_parts; ++p) s += part[p * n + i];
-        dw[i] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = p0;
+        for (; p + 3 < p1; p += 4) {
+            const float a0 = part[p * n + i], a1 = part[(p + 1) * n + i], a2 = part[(p + 2) * n + i], a3 = part[(p + 3) * n + i];
+            s0 += a0;
+            s1 += a1;
+            s2 += a2;
+            s3 += a3;
+        }
+        for (; p < p1; ++p) s0 += part[p * n + i];
+        out[(long)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
     }
 }
 
 // ---- weight gradient of the ResNet stem: conv 7 x 7, stride 2, padding 3, 3 -> 64 channels, input frames NCHW.
 // dW[co][ci][ky][kx] = sum over output pixels of dY[pixel][co] x[ci][2 oy + ky - 3][2 ox + kx - 3]: M = 64 output channels, N = 147 columns
 // (ky, kx, ci) padded to 160, K = pixels.  A workgroup walks segments of 32 output pixels of one output row: it stages dY (32 x 64) and the
-// 7 x 69 x 3 input tile - channel-interleaved like the forward kernel's, so that the 21 values (kx, ci) of a kernel row are consecutive
-// halfs - as fp16 hi | lo planes; wave (co half, column-tile parity) takes the dY fragments from transposing reads and GATHERS its column's
-// 8 consecutive pixels (12 bytes apart: stride 2 x 3 channels) with 16-bit LDS reads.  Partial tiles per workgroup, summed by
-// wgrad_reduce_kernel into torch's (64, 3, 7, 7) layout.
+// TRANSPOSED im2col block of the 7 x 69 x 3 input tile, IM[column (ky, kx, ci)][pixel 0 .. 31], as fp16 hi | lo planes - an input value
+// x[ky][cc][ci] is column (ky, kx, ci) of pixel (cc - kx) / 2 for the <= 4 kx of its parity: up to four 2-byte LDS stores per value and plane,
+// offsets and masks fixed per thread - so that a lane's B fragment (its column's 8 consecutive pixels) is ONE 16-byte LDS read (80-byte row
+// pitch: the rows of a ds_read_b128 group fall into distinct 16-byte slots).  Wave (co half, column-tile parity) takes the dY fragments from
+// transposing reads.  (The first version kept the tile channel-interleaved and GATHERED the 8 pixels, 12 bytes apart, with 16-bit reads: 96
+// reads + packing per lane and step for 18 MFMAs - 2.6 ms per 160 frames.)  Partial tiles per workgroup, summed by wgrad_reduce_kernel into
+// torch's (64, 3, 7, 7) layout.
 struct StemWgradArgs {
     const float *dy;     // [N][Hc][Wc][64]
     const float *x;      // [N][3][H][W]
@@ -749,9 +763,9 @@ struct StemWgradArgs {
     int N, H, W, Hc, Wc, segs_per_row, steps_per_item;
     long n_steps;        // N * Hc * segs_per_row
 };
-constexpr int SW_XP = 216;                         // halfs per staged input row: 69 pixels x 3 channels = 207 (+ 9)
+constexpr int SW_RP = 40;                          // halfs per im2col row: 32 pixels + 8 (80 bytes)
 constexpr int SW_DY = 32 * W3_PITCH;               // halfs of the dY plane (as conv_wgrad3_kernel)
-constexpr int SW_PLANE = SW_DY + 7 * SW_XP;
+constexpr int SW_PLANE = SW_DY + 147 * SW_RP;
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradArgs a) {
     __shared__ __attribute__((aligned(16))) f16 sm[2 * SW_PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -771,38 +785,74 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradArgs a) {
     for (int t = 0; t < NT; ++t) {
         const int c = 32 * (par + 2 * t) + l31;
         cok[t] = c < 147 && par + 2 * t < 5;
-        const int ky = cok[t] ? c / 21 : 0, kc = cok[t] ? c - 21 * ky : 0;
-        coff[t] = SW_DY + ky * SW_XP + kc;
+        coff[t] = SW_DY + (cok[t] ? c : 0) * SW_RP;
     }
     const long s0 = (long)blockIdx.x * a.steps_per_item, s1 = s0 + a.steps_per_item < a.n_steps ? s0 + a.steps_per_item : a.n_steps;
     const int c4 = (tid & 15) * 4;
-    for (long st = s0; st < s1; ++st) {
+    // this thread's six elements of the 7 x 3 x 69 input tile (the same for every step): row rr, channel ci, column cc; xo = the half index of
+    // its first im2col copy (kx = cc & 1, pixel (cc - kx) / 2), the next kx of that parity is 6 rows further and one pixel back; xm = which of the
+    // four copies exist (kx <= 6, pixel in 0 .. 31)
+    constexpr int NX = (7 * 3 * 69 + 255) / 256;
+    int xrr[NX], xci[NX], xcc[NX], xo[NX];
+    unsigned xm[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = tid + 256 * k, rr = i / 207, rem = i - rr * 207;
+        xrr[k] = i < 7 * 3 * 69 ? rr : -100;   // (-100: never inside the frame)
+        xci[k] = rem / 69;
+        xcc[k] = rem - xci[k] * 69;
+        const int q = xcc[k] & 1, p0 = (xcc[k] - q) >> 1;
+        xo[k] = SW_DY + (rr * 21 + q * 3 + xci[k]) * SW_RP + p0;
+        xm[k] = 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (xrr[k] >= 0 && q + 2 * m <= 6 && p0 - m >= 0 && p0 - m < 32) xm[k] |= 1u << m;
+    }
+    // the operands of step st, in registers one step ahead: the global loads of step st + 1 are in flight during step st's gathers and MFMAs
+    // (loaded at their point of use, every step paid an HBM round trip: 3.5 us per step for 0.24 us of MFMAs)
+    f32x4 yv[2];
+    float xv[NX];
+    auto load = [&](long st) __attribute__((always_inline)) {
         const int seg = (int)(st % a.segs_per_row);
         const long row = st / a.segs_per_row;          // n * Hc + oy
         const int n = (int)(row / a.Hc), oy = (int)(row - (long)n * a.Hc), ox0 = 32 * seg;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int ox = ox0 + (tid >> 4) + 16 * v;
+            yv[v] = ox < a.Wc ? *reinterpret_cast<const f32x4 *>(a.dy + (row * a.Wc + ox) * 64L + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int iy = 2 * oy - 3 + xrr[k], ix = 2 * ox0 - 3 + xcc[k];
+            xv[k] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? a.x[(((long)n * 3 + xci[k]) * a.H + iy) * a.W + ix] : 0.f;
+        }
+    };
+    if (s0 < s1) load(s0);
+    for (long st = s0; st < s1; ++st) {
         __syncthreads();   // the previous step's readers are done
         // dY: 32 pixels x 16 float4
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const int p = (tid >> 4) + 16 * v, ox = ox0 + p;
-            f32x4 y4 = {0.f, 0.f, 0.f, 0.f};
-            if (ox < a.Wc) y4 = *reinterpret_cast<const f32x4 *>(a.dy + (row * a.Wc + ox) * 64L + c4);
             f16x4 h, l;
-            f16_split4(y4, sy, h, l);
-            f16 *o = sm + p * W3_PITCH + c4;
+            f16_split4(yv[v], sy, h, l);
+            f16 *o = sm + ((tid >> 4) + 16 * v) * W3_PITCH + c4;
             *reinterpret_cast<f16x4 *>(o) = h;
             *reinterpret_cast<f16x4 *>(o + SW_PLANE) = l;
         }
         // input tile: rows 2 oy - 3 .. + 6, columns 2 ox0 - 3 .. + 68, 3 channels interleaved: half index 3 * col + ci
-        for (int i = tid; i < 7 * 3 * 69; i += 256) {
-            const int rr = i / 207, rem = i - rr * 207, ci = rem / 69, cc = rem - ci * 69;
-            const int iy = 2 * oy - 3 + rr, ix = 2 * ox0 - 3 + cc;
-            const float v = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? a.x[(((long)n * 3 + ci) * a.H + iy) * a.W + ix] * sx : 0.f;
-            const f16 h = (f16)v;
-            f16 *o = sm + SW_DY + rr * SW_XP + 3 * cc + ci;
-            o[0] = h;
-            o[SW_PLANE] = (f16)(v - (float)h);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const float v = xv[k] * sx;
+            const f16 h = (f16)v, l = (f16)(v - (float)h);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if ((xm[k] >> m) & 1u) {
+                    f16 *o = sm + xo[k] + m * (6 * SW_RP - 1);
+                    o[0] = h;
+                    o[SW_PLANE] = l;
+                }
         }
+        if (st + 1 < s1) load(st + 1);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -811,13 +861,9 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWgradArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (par + 2 * t >= 5) continue;   // wave-uniform
-                f16x8 bh, bl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {   // pixel r0 + e: 6 halfs (2 input pixels x 3 channels) further along the row
-                    const f16 *at = sm + coff[t] + 6 * (r0 + e);
-                    bh[e] = cok[t] ? at[0] : (f16)0;
-                    bl[e] = cok[t] ? at[SW_PLANE] : (f16)0;
-                }
+                const f16x8 z8 = {(f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0};
+                const f16 *at = sm + coff[t] + r0;   // this lane's column, pixels r0 .. r0 + 7
+                const f16x8 bh = cok[t] ? *reinterpret_cast<const f16x8 *>(at) : z8, bl = cok[t] ? *reinterpret_cast<const f16x8 *>(at + SW_PLANE) : z8;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
@@ -1013,12 +1059,12 @@ extern "C" int sd_conv_wgrad(const float *dy, const float *x, const uint32_t *dy
     return 0;
 }
 
+static long stem_wgrad_items(long n_steps) { return n_steps < 512 ? n_steps : 512; }   // two workgroups per CU, one round
 extern "C" size_t sd_stem_wgrad_scratch_floats(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;
     const long n_steps = (long)N * Hc * ((Wc + 31) / 32);
-    const long items = n_steps < 1024 ? n_steps : 1024;
-    return (size_t)items * 64 * 147;
+    return (size_t)(stem_wgrad_items(n_steps) + 32) * 64 * 147;   // the workgroups' partial tiles + 32 slices of the first reduction
 }
 extern "C" int sd_stem_wgrad(const float *dy, const float *x, const uint32_t *dy_amax, const uint32_t *x_amax, float *dw, float *scratch, int N, int H,
                              int W, void *stream) {
@@ -1029,12 +1075,17 @@ extern "C" int sd_stem_wgrad(const float *dy, const float *x, const uint32_t *dy
     a.N = N; a.H = H; a.W = W; a.Hc = (H - 1) / 2 + 1; a.Wc = (W - 1) / 2 + 1;
     a.segs_per_row = (a.Wc + 31) / 32;
     a.n_steps = (long)N * a.Hc * a.segs_per_row;
-    const long items = a.n_steps < 1024 ? a.n_steps : 1024;
+    const long items = stem_wgrad_items(a.n_steps);
     a.steps_per_item = (int)((a.n_steps + items - 1) / items);
     const long wgs = (a.n_steps + a.steps_per_item - 1) / a.steps_per_item;
     SD_LAUNCH(cvt::stem_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     SD_CHECK_LAUNCH("stem_wgrad_kernel");
-    SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(64L * 147)), dim3(256), 0, (hipStream_t)stream, scratch, (int)wgs, 64L * 147, dw);
+    const long n = 64L * 147;
+    const int per = (int)((wgs + 31) / 32), slices = (int)((wgs + per - 1) / per);
+    float *tmp = scratch + items * n;
+    SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(n), slices), dim3(256), 0, (hipStream_t)stream, scratch, (int)wgs, per, n, tmp);
+    SD_CHECK_LAUNCH("wgrad_reduce_kernel");
+    SD_LAUNCH(cvt::wgrad_reduce_kernel, dim3(grid_for(n), 1), dim3(256), 0, (hipStream_t)stream, tmp, slices, slices, n, dw);
     SD_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;
 }
