@@ -354,3 +354,16 @@ def test_training_step_of_the_image_conditioned_model_uses_the_unit_kernels():
         assert len(calls) == (2 * 19 if route == "hip" else 0)
     assert abs(losses["hip"][0] - losses["torch"][0]) < 1e-4 * abs(losses["torch"][0])
     assert abs(losses["hip"][1] - losses["torch"][1]) < 5e-3 * abs(losses["torch"][1])   # after one update of both replicas
+
+
+def test_randomised_soak_of_the_image_training_kernels():
+    """30 random shapes (maps of 1 .. 44 x 1 .. 70 pixels, 64 - 256 channels, 1 x 1 / 3 x 3, stride 1 / 2, activations of 0.01 .. 30, gradients of
+    1e-3 .. 100): the weight gradient on both scale paths, the data gradient (transposed convolutions for stride 2) and the fused BatchNorm + ReLU +
+    max-pool forward / backward against torch CPU fp64 (tools/exp/soak_conv_train.py holds the bars)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("soak_conv_train", os.path.join(os.path.dirname(__file__), "..", "tools", "exp", "soak_conv_train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst = mod.soak(30, 7, verbose=False)
+    assert max(worst.values()) < 5e-6, worst
