@@ -18,6 +18,13 @@
 
 namespace cvt {
 
+// Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  A kernel whose neighbouring workgroups read overlapping rows (the
+// 3 x 3 pooling windows) wants neighbours on ONE XCD: logical id = (id % 8) * (n / 8) + id / 8 gives every XCD a contiguous band (n a multiple of 8).
+__device__ __forceinline__ unsigned xcd_band_id() {
+    const unsigned b = blockIdx.x, n = gridDim.x;
+    return (n & 7u) ? b : (b & 7u) * (n >> 3) + (b >> 3);
+}
+
 // ---- per-channel reductions over an NHWC tensor: thread -> 4 consecutive channels (one 16-byte load per pixel), a block walks its
 // pixel range in steps of 256 * 4 / C pixels; lanes with the same channel group are combined through LDS, workgroups through partial sums in HBM
 // A pixel's contribution is split into LOAD (global reads only) and ADD: four pixels' loads are issued before the first add - with one
@@ -221,7 +228,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__re
     const unsigned cg = C / 4;
     const unsigned n4 = (unsigned)N * Hp * Wp * cg;
     float mx = 0.f;
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
+    // (bands of consecutive pooled rows per XCD: pooled rows i and i + 1 share convolution row 2 i + 1 - with round-robin ids the two reads went to
+    // different L2s and the counters showed 1.57 x y's bytes fetched from HBM)
+    for (unsigned e = xcd_band_id() * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
         const int c0 = (int)(e % cg) * 4;
         unsigned t = e / cg;
         const int j = (int)(t % (unsigned)Wp); t /= (unsigned)Wp;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__r
         }
     float mx = 0.f;
     const unsigned n4 = (unsigned)(npix * cg);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    for (unsigned i = xcd_band_id() * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
         const int c0 = (int)(i % (unsigned)cg) * 4;
         const f32x4 g = pool_gather(dp, idx, G, (long)(i / (unsigned)cg), c0);
         const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
