@@ -238,18 +238,29 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__re
         const int n = (int)(t / (unsigned)Hp);
         f32x4 m = {0.f, 0.f, 0.f, 0.f};
         unsigned k[4] = {9u, 9u, 9u, 9u};
+        // all nine loads first, from clamped coordinates (a window position outside the map re-reads a border pixel and is masked below): with a
+        // branch per position the loads went out one at a time and the launch ran at the rate of ONE 16-byte load in flight per thread
+        f32x4 yv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int r = 2 * i - 1 + ky, rc = r < 0 ? 0 : (r >= Hc ? Hc - 1 : r);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int c = 2 * j - 1 + kx, cc = c < 0 ? 0 : (c >= Wc ? Wc - 1 : c);
+                yv[ky * 3 + kx] = *reinterpret_cast<const f32x4 *>(y + (((long)n * Hc + rc) * Wc + cc) * C + c0);
+            }
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int r = 2 * i - 1 + ky;
-            if (r < 0 || r >= Hc) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int c = 2 * j - 1 + kx;
-                if (c < 0 || c >= Wc) continue;
-                const f32x4 v = bn_affine(*reinterpret_cast<const f32x4 *>(y + (((long)n * Hc + r) * Wc + c) * C + c0), mean, rstd, gamma, beta, c0);
+                const bool in = r >= 0 && r < Hc && c >= 0 && c < Wc;
+                const f32x4 v = bn_affine(yv[ky * 3 + kx], mean, rstd, gamma, beta, c0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (v[q] > m[q]) {
+                    if (in && v[q] > m[q]) {
                         m[q] = v[q];
                         k[q] = (unsigned)(ky * 3 + kx);
                     }
@@ -275,6 +286,8 @@ __device__ __forceinline__ f32x4 pool_gather(const float *__restrict__ dp, const
     const int r = (int)(t % (unsigned)G.Hc), n = (int)(t / (unsigned)G.Hc);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     const int i0 = r >> 1, ni = (r & 1) ? 2 : 1, j0 = c >> 1, nj = (c & 1) ? 2 : 1;
+    // (loading all four candidate windows unconditionally, as the forward kernel loads its nine positions, was slower here: 3.6 -> 4.6 ms for the two
+    // backward launches - three quarters of the pixels sit in one or two windows)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int i = i0 + a;
