@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned xcd_band_id() {
 // A pixel's contribution is split into LOAD (global reads only) and ADD: four pixels' loads are issued before the first add - with one
 // 16-byte load in flight per thread the reductions ran at 1.8 TB/s (statistics) / 2.9 TB/s (backward sums) against the 5+ TB/s of the
 // element-wise kernels beside them.
-template <class V, class L, class A>   // L(pixel, channel group base) -> V;  A(V, channel group base, s, q) accumulates into two f32x4
+template <class V, int UNROLL = 4, class L, class A>   // L(item, channel group base) -> V;  A(V, channel group base, s, q) accumulates into two f32x4
 __device__ __forceinline__ void channel_reduce(long npix, int C, float *part /* [gridDim.x][C][2] */, L load, A add) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
@@ -42,12 +42,14 @@ __device__ __forceinline__ void channel_reduce(long npix, int C, float *part /* 
         const int c4 = tid % cg, prow = tid / cg, pstep = 256 / cg, c0 = cb + 4 * c4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
         long p = p0 + prow;
-        for (; p + 3 * pstep < p1; p += 4 * pstep) {
-            const V v0 = load(p, c0), v1 = load(p + pstep, c0), v2 = load(p + 2 * pstep, c0), v3 = load(p + 3 * pstep, c0);
-            add(v0, c0, s, q);
-            add(v1, c0, s, q);
-            add(v2, c0, s, q);
-            add(v3, c0, s, q);
+        if constexpr (UNROLL == 4) {
+            for (; p + 3 * pstep < p1; p += 4 * pstep) {
+                const V v0 = load(p, c0), v1 = load(p + pstep, c0), v2 = load(p + 2 * pstep, c0), v3 = load(p + 3 * pstep, c0);
+                add(v0, c0, s, q);
+                add(v1, c0, s, q);
+                add(v2, c0, s, q);
+                add(v3, c0, s, q);
+            }
         }
         for (; p < p1; p += pstep) add(load(p, c0), c0, s, q);
         if (cb > 0) __syncthreads();   // the previous pass has read `red`
@@ -277,57 +279,63 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float *__re
         if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, b);
     }
 }
-// g of the 4 channels c0 .. of convolution pixel `pix` = (n, r, c): row r lies in the windows i = r / 2 (r even) or (r - 1) / 2, (r + 1) / 2
-struct PoolGeom { int Hc, Wc, Hp, Wp, C; };
-__device__ __forceinline__ f32x4 pool_gather(const float *__restrict__ dp, const unsigned *__restrict__ idx, const PoolGeom &G, long pix, int c0) {
-    const unsigned pu = (unsigned)pix;   // (fewer than 2^31 pixels: checked on the host)
-    const int c = (int)(pu % (unsigned)G.Wc);
-    const unsigned t = pu / (unsigned)G.Wc;
-    const int r = (int)(t % (unsigned)G.Hc), n = (int)(t / (unsigned)G.Hc);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    const int i0 = r >> 1, ni = (r & 1) ? 2 : 1, j0 = c >> 1, nj = (c & 1) ? 2 : 1;
-    // (loading all four candidate windows unconditionally, as the forward kernel loads its nine positions, was slower here: 3.6 -> 4.6 ms for the two
-    // backward launches - three quarters of the pixels sit in one or two windows)
+// The backward works on 2 x 2 BLOCKS of convolution pixels (2 i' + a, 2 j' + b): together they lie in exactly the four windows (i', j'), (i', j' + 1),
+// (i' + 1, j'), (i' + 1, j' + 1) - pixel (even, even) in the first only, at its centre (position 4); (even, odd) in the first two (5, 3); (odd, even)
+// in the first and third (7, 1); (odd, odd) in all four (8, 6, 2, 0) - so one thread loads four index words and four gradients for four pixels
+// (a thread per PIXEL loaded 2.25 windows on average, behind branches that depend on the pixel's parity).
+struct PoolGeom { int Hc, Wc, Hp, Wp, C, Hb, Wb; };   // Hb x Wb blocks per image
+struct PoolBlock { f32x4 g[4], y[4]; bool in[4]; long at[4]; };
+__device__ __forceinline__ PoolBlock pool_block(const float *__restrict__ dp, const unsigned *__restrict__ idx, const float *__restrict__ y, const PoolGeom &G,
+                                                unsigned item, int c0) {
+    const int jb = (int)(item % (unsigned)G.Wb);
+    const unsigned t = item / (unsigned)G.Wb;
+    const int ib = (int)(t % (unsigned)G.Hb), n = (int)(t / (unsigned)G.Hb);
+    PoolBlock B;
+    unsigned k4[4];
+    f32x4 d[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int i = i0 + a;
-        if (a >= ni || i >= G.Hp) continue;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int j = j0 + b;
-            if (b >= nj || j >= G.Wp) continue;
-            const unsigned pos = (unsigned)((r - (2 * i - 1)) * 3 + (c - (2 * j - 1)));
-            const long w = (((long)n * G.Hp + i) * G.Wp + j) * G.C + c0;
-            const unsigned k4 = idx[w >> 2];
-            const f32x4 d = *reinterpret_cast<const f32x4 *>(dp + w);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] += ((k4 >> (8 * q)) & 255u) == pos ? d[q] : 0.f;
+            const int r = 2 * ib + a, c = 2 * jb + b, rc = r < G.Hc ? r : G.Hc - 1, cc = c < G.Wc ? c : G.Wc - 1;
+            B.in[2 * a + b] = r < G.Hc && c < G.Wc;
+            B.at[2 * a + b] = (((long)n * G.Hc + rc) * G.Wc + cc) * G.C + c0;
+            B.y[2 * a + b] = *reinterpret_cast<const f32x4 *>(y + B.at[2 * a + b]);
+            const int i = ib + a, j = jb + b, ic = i < G.Hp ? i : G.Hp - 1, jc = j < G.Wp ? j : G.Wp - 1;
+            const long w = (((long)n * G.Hp + ic) * G.Wp + jc) * G.C + c0;
+            const bool wok = i < G.Hp && j < G.Wp;
+            k4[2 * a + b] = wok ? idx[w >> 2] : 0x09090909u;   // (9 matches no position)
+            d[2 * a + b] = *reinterpret_cast<const f32x4 *>(dp + w);
         }
+    auto pick = [&](int win, unsigned pos, int q) __attribute__((always_inline)) { return ((k4[win] >> (8 * q)) & 255u) == pos ? d[win][q] : 0.f; };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        B.g[0][q] = pick(0, 4u, q);
+        B.g[1][q] = pick(0, 5u, q) + pick(1, 3u, q);
+        B.g[2][q] = pick(0, 7u, q) + pick(2, 1u, q);
+        B.g[3][q] = (pick(0, 8u, q) + pick(1, 6u, q)) + (pick(2, 2u, q) + pick(3, 0u, q));
     }
-    return g;
+    return B;
 }
-struct BnPoolLoad { f32x4 g, y; };
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float *__restrict__ dp, const unsigned *__restrict__ idx, const float *__restrict__ y,
-                                                                 const float *__restrict__ mean, const float *__restrict__ rstd, long npix, PoolGeom G,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd, long nitems, PoolGeom G,
                                                                  float *part) {
-    channel_reduce<BnPoolLoad>(
-        npix, G.C, part,
-        [&](long p, int c0) {
-            BnPoolLoad v;
-            v.y = *reinterpret_cast<const f32x4 *>(y + p * G.C + c0);
-            v.g = pool_gather(dp, idx, G, p, c0);
-            return v;
-        },
-        [&](const BnPoolLoad &v, int c0, f32x4 &s, f32x4 &q) {
-            const f32x4 xh = (v.y - *reinterpret_cast<const f32x4 *>(mean + c0)) * *reinterpret_cast<const f32x4 *>(rstd + c0);
-            s = s + v.g;
-            q = q + v.g * xh;
+    channel_reduce<PoolBlock, 1>(
+        nitems, G.C, part, [&](long p, int c0) { return pool_block(dp, idx, y, G, (unsigned)p, c0); },
+        [&](const PoolBlock &v, int c0, f32x4 &s, f32x4 &q) {
+            const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c0), rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!v.in[k]) continue;
+                s = s + v.g[k];
+                q = q + v.g[k] * ((v.y[k] - mu) * rs);
+            }
         });
 }
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__restrict__ dp, const unsigned *__restrict__ idx, const float *__restrict__ y,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 const float *__restrict__ gamma, const double *__restrict__ acc, float *__restrict__ dy,
-                                                                float *dgamma, float *dbeta, long npix, PoolGeom G, unsigned *amax) {
+                                                                float *dgamma, float *dbeta, long npix, long nitems, PoolGeom G, unsigned *amax) {
     const double inv_n = 1.0 / (double)npix;
     const int C = G.C, cg = C / 4;
     if (blockIdx.x == 0)
@@ -336,21 +344,25 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float *__r
             dbeta[c] = (float)acc[2 * c];
         }
     float mx = 0.f;
-    const unsigned n4 = (unsigned)(npix * cg);
+    const unsigned n4 = (unsigned)(nitems * cg);
     for (unsigned i = xcd_band_id() * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
         const int c0 = (int)(i % (unsigned)cg) * 4;
-        const f32x4 g = pool_gather(dp, idx, G, (long)(i / (unsigned)cg), c0);
-        const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0);
-        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(y + 4l * i) - *reinterpret_cast<const f32x4 *>(mean + c0)) * rs;
+        const PoolBlock B = pool_block(dp, idx, y, G, i / (unsigned)cg, c0);
+        const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c0), mu = *reinterpret_cast<const f32x4 *>(mean + c0);
+        const f32x4 sc = rs * *reinterpret_cast<const f32x4 *>(gamma + c0);
         f32x4 m1, m2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             m1[e] = (float)(acc[2 * (c0 + e)] * inv_n);
             m2[e] = (float)(acc[2 * (c0 + e) + 1] * inv_n);
         }
-        const f32x4 v = (g - m1 - xh * m2) * (rs * *reinterpret_cast<const f32x4 *>(gamma + c0));
-        *reinterpret_cast<f32x4 *>(dy + 4l * i) = v;
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!B.in[k]) continue;
+            const f32x4 v = (B.g[k] - m1 - ((B.y[k] - mu) * rs) * m2) * sc;
+            *reinterpret_cast<f32x4 *>(dy + B.at[k]) = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
     }
     if (amax) {
 #pragma unroll
@@ -1001,14 +1013,15 @@ extern "C" int sd_bn_relu_pool_bwd(const float *dp, const uint32_t *idx, const f
          reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15)
         return fail(SD_E_BADARG, "sd_bn_relu_pool_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const cvt::PoolGeom G{Hc, Wc, (Hc - 1) / 2 + 1, (Wc - 1) / 2 + 1, C};
-    const unsigned nb = reduce_blocks(npix, C);
-    SD_LAUNCH(cvt::bn_pool_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, dp, idx, y, mean, rstd, npix, G, scratch);
+    const cvt::PoolGeom G{Hc, Wc, (Hc - 1) / 2 + 1, (Wc - 1) / 2 + 1, C, (Hc + 1) / 2, (Wc + 1) / 2};
+    const long nitems = (long)N * G.Hb * G.Wb;   // 2 x 2 blocks of convolution pixels
+    const unsigned nb = reduce_blocks(npix, C);    // (also what sd_bn_scratch_floats sized the scratch for)
+    SD_LAUNCH(cvt::bn_pool_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, dp, idx, y, mean, rstd, nitems, G, scratch);
     SD_CHECK_LAUNCH("bn_pool_bwd_reduce_kernel");
     SD_LAUNCH(cvt::partial_sum_kernel, dim3(2 * C / 32), dim3(256), 0, st, scratch, (int)nb, 2 * C, acc);
     SD_CHECK_LAUNCH("partial_sum_kernel");
-    SD_LAUNCH(cvt::bn_pool_bwd_apply_kernel, dim3(blocks_for(npix * C / 4, 1024, 4096)), dim3(256), 0, st, dp, idx, y, mean, rstd, gamma, acc, dy, dgamma, dbeta,
-              npix, G, dy_amax);
+    SD_LAUNCH(cvt::bn_pool_bwd_apply_kernel, dim3(blocks_for(nitems * C / 4, 512, 4096)), dim3(256), 0, st, dp, idx, y, mean, rstd, gamma, acc, dy, dgamma, dbeta,
+              npix, nitems, G, dy_amax);
     SD_CHECK_LAUNCH("bn_pool_bwd_apply_kernel");
     return 0;
 }
