@@ -2992,50 +2992,68 @@ __global__ void step_map_kernel(const float *__restrict__ tokens, int n_tok, int
     if (threadIdx.x == 0) map[b] = same ? 0 : b;
 }
 struct StepFoldArgs { const float *wkv[tj::MAX_L], *bkv[tj::MAX_L], *wq[tj::MAX_L], *bq[tj::MAX_L], *woc[tj::MAX_L]; };
-// grid (n_tok, L), 256 threads, hidden_dim 256: K | V = Wkv tok + bkv (memory rows are not layer-normed), then the fold of
-// xattn_fold_kernel for this one row: G_h = Wq_h^T K_h, V'_h = Woc_h V_h, c_h = bq_h . K_h -> gvstep rows [tok * 4 + h][2 D], cstep
-// [tok * 4 + h]; abs-max of G / V' -> words 6 / 7 of the layer's row
-__global__ __launch_bounds__(256) void step_fold_all_kernel(StepFoldArgs a, const float *__restrict__ tokens, float *__restrict__ gvstep,
-                                                            long gv_layer_stride, float *__restrict__ cstep, long c_layer_stride,
-                                                            unsigned *maxbits, const int *__restrict__ map) {
-    constexpr int D = tj::D, HD = tj::HD;
-    __shared__ __attribute__((aligned(16))) float st[D], skv[2 * D];
+// hidden_dim 256.  step_kv_kernel, grid (n_tok, L, 8), 256 threads: rows 64 z .. 64 z + 63 of K | V = Wkv tok + bkv (memory rows are not
+// layer-normed) -> kvstep[l][tok][2 D].  step_fold_all_kernel, grid (n_tok, L, 4 heads): the fold of xattn_fold_kernel for this one row and head:
+// G_h = Wq_h^T K_h, V'_h = Woc_h V_h, c_h = bq_h . K_h -> gvstep row [tok * 4 + h][2 D], cstep [tok * 4 + h]; abs-max of G / V' -> words 6 / 7 of
+// the layer's row.  (One workgroup per (token, layer) did all of it as a chain of dependent weight loads: 130 us for ONE token - what every
+// forward_with_context call of the reference's loop pays, 27 % of a B = 256 rollout; 16 rows in flight per wave: 100 us; the work of a token
+// and layer spread over 8 + 4 workgroups: see NOTEBOOK round 5.)
+__global__ __launch_bounds__(256) void step_kv_kernel(StepFoldArgs a, const float *__restrict__ tokens, float *__restrict__ kvstep, long n_tok,
+                                                      const int *__restrict__ map) {
+    constexpr int D = tj::D;
     const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long tok = blockIdx.x;
     if (map && map[tok] != (int)tok) return;   // a duplicate of token 0: nobody reads its blocks
-    st[threadIdx.x] = tokens[tok * D + threadIdx.x];
-    __syncthreads();
-    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(st + 4 * lane);
+    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(tokens + tok * D + 4 * lane);
     const float *wkv = a.wkv[l], *bkv = a.bkv[l];
-    for (int o = wv; o < 2 * D; o += 4) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wkv + (long)o * D + 4 * lane);
-        const float s = wave_sum((w4[0] * t4[0] + w4[1] * t4[1]) + (w4[2] * t4[2] + w4[3] * t4[3]));
-        if (lane == 0) skv[o] = s + bkv[o];
+    const int o0 = blockIdx.z * 64 + wv * 16;
+    f32x4 w4[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w4[u] = *reinterpret_cast<const f32x4 *>(wkv + (long)(o0 + u) * D + 4 * lane);
+    float *out = kvstep + ((long)l * n_tok + tok) * 2 * D;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float s = wave_sum((w4[u][0] * t4[0] + w4[u][1] * t4[1]) + (w4[u][2] * t4[2] + w4[u][3] * t4[3]));
+        if (lane == 0) out[o0 + u] = s + bkv[o0 + u];
     }
-    __syncthreads();
-    {   // wave h: the score bias of head h
-        const float c = wave_sum(a.bq[l][wv * HD + lane] * skv[wv * HD + lane]);
-        if (lane == 0) cstep[l * c_layer_stride + tok * 4 + wv] = c;
-    }
+}
+__global__ __launch_bounds__(256) void step_fold_all_kernel(StepFoldArgs a, const float *__restrict__ kvstep, long n_tok, float *__restrict__ gvstep,
+                                                            long gv_layer_stride, float *__restrict__ cstep, long c_layer_stride,
+                                                            unsigned *maxbits, const int *__restrict__ map) {
+    constexpr int D = tj::D, HD = tj::HD;
+    __shared__ __attribute__((aligned(16))) float sk[HD], sv[HD];
+    const int l = blockIdx.y, h = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long tok = blockIdx.x;
+    if (map && map[tok] != (int)tok) return;
     const int n = threadIdx.x;
     const float *wq = a.wq[l], *woc = a.woc[l] + (long)n * D;
-    float *out = gvstep + l * gv_layer_stride + tok * 4 * 2 * D;
-    float mg = 0.f, mv = 0.f;
-#pragma unroll 1
-    for (int h = 0; h < 4; ++h) {
-        float g = 0.f, v = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < HD; ++j) g += wq[(long)(h * HD + j) * D + n] * skv[h * HD + j];
-#pragma unroll 4
-        for (int j = 0; j < HD; j += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(woc + h * HD + j), v4 = *reinterpret_cast<const f32x4 *>(skv + D + h * HD + j);
-            v += (w4[0] * v4[0] + w4[1] * v4[1]) + (w4[2] * v4[2] + w4[3] * v4[3]);
-        }
-        out[(long)h * 2 * D + n] = g;
-        out[(long)h * 2 * D + D + n] = v;
-        mg = fmaxf(mg, fabsf(g));
-        mv = fmaxf(mv, fabsf(v));
+    // the head's weights first (64 + 16 loads per thread in flight), then its K / V slice
+    float wqv[HD];
+    f32x4 wov[HD / 4];
+#pragma unroll
+    for (int j = 0; j < HD; ++j) wqv[j] = wq[(long)(h * HD + j) * D + n];
+#pragma unroll
+    for (int j = 0; j < HD / 4; ++j) wov[j] = *reinterpret_cast<const f32x4 *>(woc + h * HD + 4 * j);
+    const float *kv = kvstep + ((long)l * n_tok + tok) * 2 * D;
+    if (threadIdx.x < HD) sk[threadIdx.x] = kv[h * HD + threadIdx.x];
+    else if (threadIdx.x < 2 * HD) sv[threadIdx.x - HD] = kv[D + h * HD + threadIdx.x - HD];
+    __syncthreads();
+    if (wv == 0) {   // the score bias of head h
+        const float c = wave_sum(a.bq[l][h * HD + lane] * sk[lane]);
+        if (lane == 0) cstep[l * c_layer_stride + tok * 4 + h] = c;
     }
+    float g = 0.f, v = 0.f;
+#pragma unroll
+    for (int j = 0; j < HD; ++j) g += wqv[j] * sk[j];
+#pragma unroll
+    for (int j = 0; j < HD / 4; ++j) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(sv + 4 * j);
+        v += (wov[j][0] * v4[0] + wov[j][1] * v4[1]) + (wov[j][2] * v4[2] + wov[j][3] * v4[3]);
+    }
+    float *out = gvstep + l * gv_layer_stride + tok * 4 * 2 * D;
+    out[(long)h * 2 * D + n] = g;
+    out[(long)h * 2 * D + D + n] = v;
+    float mg = fabsf(g), mv = fabsf(v);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mg = fmaxf(mg, __shfl_xor(mg, o, 64));
@@ -3114,8 +3132,10 @@ static int traj_prepare_steps(const sd_denoiser_weights *w, const Scratch &s, co
         fa.wkv[l] = lw.ca_in_w + (size_t)d * d; fa.bkv[l] = lw.ca_in_b + d;
         fa.wq[l] = lw.ca_in_w; fa.bq[l] = lw.ca_in_b; fa.woc[l] = lw.ca_out_w;
     }
-    SD_LAUNCH(step_fold_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, fa, tokens, s.gvstep, (long)gvsstride, s.cstep, (long)cssstride,
-              s.maxbits, map);
+    SD_LAUNCH(step_kv_kernel, dim3((unsigned)n_tok, (unsigned)L, 8), dim3(256), 0, st, fa, tokens, s.kvstep, (long)n_tok, map);
+    SD_CHECK_LAUNCH("step_kv_kernel");
+    SD_LAUNCH(step_fold_all_kernel, dim3((unsigned)n_tok, (unsigned)L, 4), dim3(256), 0, st, fa, s.kvstep, (long)n_tok, s.gvstep, (long)gvsstride, s.cstep,
+              (long)cssstride, s.maxbits, map);
     SD_CHECK_LAUNCH("step_fold_all_kernel");
     // per-layer regions as carved for mode 2 (n_tok * 4 * blk / n_tok * blk halfs), the step blocks packed densely inside
     unsigned gx = grid_for((long)n_tok * 4 * (d / 8 + d));
