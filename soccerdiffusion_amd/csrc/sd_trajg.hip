@@ -176,36 +176,44 @@ __global__ void pack_vt_kernel(const float *__restrict__ kv, long items, int row
         }
     }
 }
-// The step tokens, all layers in one launch (a forward_with_context call of the reference's loop pays this once per call).  grid (n_tok, L),
-// 256 threads: K | V = Wkv tok + bkv -> kvstep [l][tok][2 D] (fp32), abs-max of the K and of the V columns -> words SC_KS / SC_VS of row l
+// The step tokens, all layers in one launch (a forward_with_context call of the reference's loop pays this once per call).  grid (n_tok, L,
+// 2 D / 64), 256 threads: rows 64 z .. 64 z + 63 of K | V = Wkv tok + bkv -> kvstep [l][tok][2 D] (fp32), abs-max of the K and of the V columns
+// -> words SC_KS / SC_VS of row l.  A wave has its 16 rows' weight loads in flight together (one workgroup per (token, layer) walking the rows one
+// by one was a chain of 2 D / 4 dependent round trips: ~ 180 us at hidden_dim 512 for ONE token).
 struct StepKvArgs { const float *wkv[MAX_L], *bkv[MAX_L]; };
-__global__ __launch_bounds__(256) void step_kv_all_kernel(StepKvArgs a, const float *__restrict__ tokens, int D, float *__restrict__ kvstep,
-                                                          long layer_stride, unsigned *maxbits, const int *__restrict__ map) {
-    __shared__ __attribute__((aligned(16))) float st[512];
+template <int D>
+__global__ __launch_bounds__(256) void step_kv_all_kernel(StepKvArgs a, const float *__restrict__ tokens, float *__restrict__ kvstep, long layer_stride,
+                                                          unsigned *maxbits, const int *__restrict__ map) {
+    constexpr int NK = (D + 255) / 256;   // float4 pieces of a row per lane
     const int l = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long tok = blockIdx.x;
     if (map && map[tok] != (int)tok) return;   // a duplicate of token 0 (step_map_kernel of sd_kernels.hip): nobody reads its rows
-    for (int k = threadIdx.x; k < D; k += 256) st[k] = tokens[tok * D + k];
-    __syncthreads();
+    f32x4 t4[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) t4[k] = 4 * lane + 256 * k < D ? *reinterpret_cast<const f32x4 *>(tokens + tok * D + 4 * lane + 256 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float *wkv = a.wkv[l], *bkv = a.bkv[l];
     float *out = kvstep + l * layer_stride + tok * 2 * D;
-    float mk = 0.f, mv = 0.f;
-    for (int o = wv; o < 2 * D; o += 4) {
+    const int o0 = blockIdx.z * 64 + wv * 16;
+    f32x4 w4[16][NK];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            w4[u][k] = 4 * lane + 256 * k < D ? *reinterpret_cast<const f32x4 *>(wkv + (long)(o0 + u) * D + 4 * lane + 256 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
         float p = 0.f;
-        for (int k = 4 * lane; k < D; k += 256) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wkv + (long)o * D + k), t4 = *reinterpret_cast<const f32x4 *>(st + k);
-            p += (w4[0] * t4[0] + w4[1] * t4[1]) + (w4[2] * t4[2] + w4[3] * t4[3]);
-        }
-        const float v = wave_sum(p) + bkv[o];
-        if (lane == 0) out[o] = v;
-        if (o < D) mk = fmaxf(mk, fabsf(v));
-        else mv = fmaxf(mv, fabsf(v));
+#pragma unroll
+        for (int k = 0; k < NK; ++k) p += (w4[u][k][0] * t4[k][0] + w4[u][k][1] * t4[k][1]) + (w4[u][k][2] * t4[k][2] + w4[u][k][3] * t4[k][3]);
+        const float v = wave_sum(p) + bkv[o0 + u];
+        if (lane == 0) out[o0 + u] = v;
+        m = fmaxf(m, fabsf(v));
     }
-    if (lane == 0) {
-        unsigned *wk = maxbits + l * 16 + SC_KS, *wv2 = maxbits + l * 16 + SC_VS;
-        const unsigned bk = __builtin_bit_cast(unsigned, mk), bv = __builtin_bit_cast(unsigned, mv);
-        if (bk > __atomic_load_n(wk, __ATOMIC_RELAXED)) atomicMax(wk, bk);
-        if (bv > __atomic_load_n(wv2, __ATOMIC_RELAXED)) atomicMax(wv2, bv);
+    if (lane == 0) {   // (a workgroup's 64 rows lie on one side of D: 64 divides 128, 256 and 512)
+        unsigned *word = maxbits + l * 16 + (o0 < D ? SC_KS : SC_VS);
+        const unsigned b = __builtin_bit_cast(unsigned, m);
+        if (b > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, b);
     }
 }
 // grid (blocks, L): kvstep [l][n_tok][2 D] -> compact split rows [l][n_tok][4][D]: K hi, K lo, V hi, V lo; scales from words SC_KS / SC_VS ->
@@ -1124,7 +1132,10 @@ int trajg_prepare_steps(const sd_denoiser_weights *w, float *gws, const float *t
         ka.wkv[l] = w->layers[l].ca_in_w + (size_t)d * d;   // the memory is NOT layer-normed: rows [d, 3 d) of in_proj
         ka.bkv[l] = w->layers[l].ca_in_b + d;
     }
-    SD_LAUNCH(tg::step_kv_all_kernel, dim3((unsigned)n_tok, (unsigned)L), dim3(256), 0, st, ka, tokens, d, kvstep, (long)n_tok * 2 * d, s.maxbits, map);
+    const dim3 kvgrid((unsigned)n_tok, (unsigned)L, (unsigned)(2 * d / 64));
+    if (d == 128) SD_LAUNCH(tg::step_kv_all_kernel<128>, kvgrid, dim3(256), 0, st, ka, tokens, kvstep, (long)n_tok * 2 * d, s.maxbits, map);
+    else if (d == 256) SD_LAUNCH(tg::step_kv_all_kernel<256>, kvgrid, dim3(256), 0, st, ka, tokens, kvstep, (long)n_tok * 2 * d, s.maxbits, map);
+    else SD_LAUNCH(tg::step_kv_all_kernel<512>, kvgrid, dim3(256), 0, st, ka, tokens, kvstep, (long)n_tok * 2 * d, s.maxbits, map);
     SD_CHECK_LAUNCH("step_kv_all_kernel");
     SD_LAUNCH(tg::pack_step_all_kernel, dim3(grid_for((long)n_tok * 2 * d), (unsigned)L), dim3(256), 0, st, kvstep, (long)n_tok * 2 * d, (long)n_tok, d,
               s.maxbits, s.kvs, (long)s.kvs_layer_halfs, s.scales, Mc == 0 ? 1 : 0, map);
