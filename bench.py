@@ -1036,7 +1036,8 @@ def sample_extras(ops, packed, toks, coef, x_T, ctx, x, sd, dev, mode=4, guard=N
             if route == "torch":
                 os.environ["SD_CONV"] = "torch"
             try:
-                fwd_bwd()
+                for _ in range(3):   # (three warm-up passes: MIOpen picks its backward kernels and the allocator settles over the first two)
+                    fwd_bwd()
                 torch.cuda.synchronize()
                 n = 3
                 t0 = time.perf_counter()
