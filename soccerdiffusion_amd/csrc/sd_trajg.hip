@@ -463,14 +463,22 @@ struct TG {
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f;
     }
+    // this lane's slice of a bias vector (features 16 (NA w + a) + 4 g + r).  Requested BEFORE the GEMM whose result it completes: loaded at its
+    // point of use, behind the pipeline's scheduling fences, every bias cost an exposed L2 round trip - at the robot's B = 1 (one workgroup, nothing
+    // else to run) a dozen of them per layer
+    struct BiasV { f32x4 v[NA]; };
+    static __device__ __forceinline__ BiasV bias_load(const Ctx &c, const float *bias) {
+        BiasV b;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) b.v[a] = *reinterpret_cast<const f32x4 *>(bias + 16 * (NA * c.w + a) + 4 * c.g);
+        return b;
+    }
     // H = H * f + bias[feature]
-    static __device__ __forceinline__ void unscale_h(const Ctx &c, f32x4 (&H)[NA][NTT], float f, const float *bias) {
+    static __device__ __forceinline__ void unscale_h(f32x4 (&H)[NA][NTT], float f, const BiasV &b) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 16 * (NA * c.w + a) + 4 * c.g);
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + bv;
-        }
+            for (int tt = 0; tt < NTT; ++tt) H[a][tt] = H[a][tt] * f + b.v[a];
     }
 
     // ---- self-attention of head h on the residual accumulators (pre-scaled by ACT * s_o): H += Wo[:, head] . O_head^T.
@@ -492,6 +500,14 @@ struct TG {
             const int job = min(w + 8 * j, 3 * NQ - 1), which = job / NQ, tile = job % NQ;
             pa[j] = L.w_in + (long)(which * (D / 16) + h * NQ + tile) * (KS * 2 * 512);
         }
+        // the jobs' bias slices and the input scale, requested before the GEMM (see bias_load)
+        f32x4 bjob[NJOB];
+#pragma unroll
+        for (int j = 0; j < NJOB; ++j) {
+            const int job = min(w + 8 * j, 3 * NQ - 1), which = job / NQ, tile = job % NQ;
+            bjob[j] = *reinterpret_cast<const f32x4 *>(L.b_in + which * D + HD * h + 16 * tile + 4 * g) * ACT;
+        }
+        const float c_in = 1.0f / L.sc[SC_IN];   // accumulator -> ACT * value
         // (a wave has NJOB or NJOB - 1 jobs: the choice is made once, outside the pipeline - a wave-uniform branch inside every one of its
         // unrolled steps made hipcc keep the whole prefetch state live across all of them: 277 spilled registers at hidden_dim 128, T = 100)
         auto body = [&](int j, int tt, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) __attribute__((always_inline)) { mma3(acc[j][tt], ah, al, bh, bl); };
@@ -503,14 +519,13 @@ struct TG {
             for (int j = 0; j < NJOB - 1; ++j) pb[j] = pa[j];
             gemm_panel<NJOB - 1>(c, pb, body);
         }
-        const float c_in = 1.0f / L.sc[SC_IN];   // accumulator -> ACT * value
         __syncthreads();   // B1: the previous head's readers of Q / O and K / V are done
         c = ctx_local(c0); g = c.g; t = c.t;
 #pragma unroll
         for (int j = 0; j < NJOB; ++j) {
             const int job = w + 8 * j, which = job / NQ, tile = job % NQ;
             if (job >= 2 * NQ) continue;   // (V tiles wait for K to die)
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_in + which * D + HD * h + 16 * tile + 4 * g) * ACT;
+            const f32x4 bv = bjob[j];
             char *dst = which == 0 ? Qb : Kb;
             const int ch = 2 * tile + (g >> 1);
 #pragma unroll
@@ -569,7 +584,7 @@ struct TG {
         for (int j = 0; j < NJOB; ++j) {
             const int job = w + 8 * j, tile = job % NQ;
             if (job < 2 * NQ || job >= 3 * NQ) continue;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_in + 2 * D + HD * h + 16 * tile + 4 * g) * ACT;
+            const f32x4 bv = bjob[j];
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) {
                 if (!tok_ok(c, tt)) continue;
@@ -660,14 +675,14 @@ struct TG {
             for (int aa = 0; aa < NA; ++aa)
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) U[aa][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_own(c, U, L.w_q);
+            const BiasV bq = bias_load(c, L.b_q);
             const float cq = 1.0f / L.sc[SC_Q];
+            gemm_own(c, U, L.w_q);
             __syncthreads();   // every wave has read LN2(h)
 #pragma unroll
             for (int aa = 0; aa < NA; ++aa) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(L.b_q + 16 * (NA * w + aa) + 4 * g) * ACT;
 #pragma unroll
-                for (int tt = 0; tt < NTT; ++tt) store_x(c, tt, NA * w + aa, U[aa][tt] * cq + bv);
+                for (int tt = 0; tt < NTT; ++tt) store_x(c, tt, NA * w + aa, U[aa][tt] * cq + bq.v[aa] * ACT);
             }
             __syncthreads();
         }
@@ -798,9 +813,10 @@ struct TG {
         }
         __syncthreads();   // the attention output is complete in the panel
         const float up = ACT * L.sc[SC_OC];
+        const BiasV boc = bias_load(c, L.b_oc);
         scale_h(H, up);
         gemm_own(c, H, L.w_oc);
-        unscale_h(c, H, 1.0f / up, L.b_oc);
+        unscale_h(H, 1.0f / up, boc);
     }
 
     static __device__ __forceinline__ void decoder_layer(const Ctx &c0, const LayerW &L, f32x4 (&H)[NA][NTT], long traj, const StepArgs &a, long sblk) {
@@ -808,12 +824,13 @@ struct TG {
         // ---- self-attention block: h += Wo . SA(LN1(h)) + bo   (the panel holds LN1(h))
         {
             const float up = ACT * L.sc[SC_O];
+            const BiasV bo = bias_load(c, L.b_o);
             scale_h(H, up);
 #if !(defined(TG_ABL) && (TG_ABL & 1))
 #pragma unroll 1
             for (int h = 0; h < 4; ++h) sa_head(c, L, h, H, a.scale_log2e);
 #endif
-            unscale_h(c, H, 1.0f / up, L.b_o);
+            unscale_h(H, 1.0f / up, bo);
         }
         layer_norm_to_x(c, H, L.n2_w, L.n2_b);
 #if !(defined(TG_ABL) && (TG_ABL & 2))
@@ -828,13 +845,14 @@ struct TG {
             for (int aa = 0; aa < NA; ++aa)
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) U[aa][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const BiasV bb1 = bias_load(c0, L.b_1), bb2 = bias_load(c0, L.b_2);
+            const float c1 = 1.0f / (ACT * L.sc[SC_1]), up = ACT * L.sc[SC_2];
             gemm_own(c0, U, L.w_1);
-            const float c1 = 1.0f / (ACT * L.sc[SC_1]);
             __syncthreads();   // every wave has read LN3(h): the panel receives gelu(u)
             const Ctx c = ctx_local(c0);
 #pragma unroll
             for (int aa = 0; aa < NA; ++aa) {
-                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(L.b_1 + 16 * (NA * c.w + aa) + 4 * c.g);
+                const f32x4 b1 = bb1.v[aa];
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) {
                     const f32x4 pre = U[aa][tt] * c1 + b1;
@@ -843,10 +861,9 @@ struct TG {
                 }
             }
             __syncthreads();
-            const float up = ACT * L.sc[SC_2];
             scale_h(H, up);
             gemm_own(c0, H, L.w_2);
-            unscale_h(c0, H, 1.0f / up, L.b_2);
+            unscale_h(H, 1.0f / up, bb2);
         }
 #endif
     }
